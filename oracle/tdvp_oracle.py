@@ -1,0 +1,517 @@
+"""CPU oracle for the one-site TDVP sweep hot path (NumPy restatement).
+
+TEST INFRASTRUCTURE -- NOT THE PRODUCT.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module, and only as the checker / the timed CPU baseline.  The
+product path (``pytdscf_amd`` -> ``libmitdvp.so``) never routes through it.
+
+Parity status: PINNED.  Every function below is checked in
+``tests/test_oracle_golden.py`` against golden vectors that were produced by
+running the reference itself (``/root/reference``, PyTDSCF v1.3.3, NumPy
+backend) in the development container with ``tests/golden/make_golden.py``.
+
+All ``file:line`` citations are relative to ``/root/reference/pytdscf``.
+
+Conventions:
+    site tensor  psi[b, j, s]     shape (D_l, d, D_r), complex128, C order
+    left env     L[a, c, b]       (bra D_l, MPO bond M_l, ket D_l)
+    right env    R[r, t, s]       (bra D_r, MPO bond M_r, ket D_r)
+    MPO core     W[c, i, j, t]    (M_l, d_out(bra), d_in(ket), M_r)
+The oracle only knows ONE full-chain 4-leg MPO; the shell in
+``pytdscf_amd.operators`` reduces the reference's operator dictionaries
+(several keys, diagonal 3-leg cores, identity fill-ins, coupleJ) to that form
+by an exact MPO direct sum, see DESIGN.md.
+"""
+
+from __future__ import annotations
+
+import cmath
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.linalg
+
+EPS = 1e-12  # _integrator.py:20-ish: breakdown threshold "EPS"
+MAX_KRYLOV = 20  # _integrator.py:182
+
+
+# --------------------------------------------------------------------------
+# a1: bond dimensions and initial canonical form
+# --------------------------------------------------------------------------
+def bond_dims(dims: list[int], m_aux_max: int) -> list[tuple[int, int]]:
+    """(D_l, D_r) per site, ``LatticeInfo.get_bond_dim`` (_mps_cls.py:2616-2631)."""
+    nsite = len(dims)
+    out = []
+    for isite in range(nsite):
+        dim_left = 1 if isite == 0 else min(m_aux_max, math.prod(dims[:isite]))
+        dim_right = (
+            1 if isite == nsite - 1 else min(m_aux_max, math.prod(dims[isite + 1 :]))
+        )
+        dc = dims[isite]
+        out.append(
+            (min(dim_left, dc * dim_right, m_aux_max), min(dim_left * dc, dim_right, m_aux_max))
+        )
+    return out
+
+
+def qr_psi2Asigma(psi: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """"Psi2Asigma": psi.reshape(D_l*d, D_r) = Q R; A = Q, sigma = R.
+
+    _site_cls.py:278-291 (scipy.linalg.qr, mode="economic").
+    """
+    dl, d, dr = psi.shape
+    q, r = scipy.linalg.qr(psi.reshape(dl * d, dr), mode="economic")
+    return q.reshape(dl, d, -1), r
+
+
+def qr_psi2sigmaB(psi: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """"Psi2sigmaB": QR of psi.transpose(2,1,0).reshape(D_r*d, D_l).
+
+    sigma = R^T, B = Q.reshape(D_r, d, k).transpose(2,1,0); _site_cls.py:257-273.
+    Returns (sigma, B).
+    """
+    dl, d, dr = psi.shape
+    q, r = scipy.linalg.qr(
+        np.ascontiguousarray(psi.transpose(2, 1, 0).reshape(dr * d, dl)), mode="economic"
+    )
+    return r.T, q.reshape(dr, d, -1).transpose(2, 1, 0)
+
+
+def canonicalize_site0(cores: list[np.ndarray], scale: float = 1.0) -> list[np.ndarray]:
+    """Right->left QR sweep so sites 1.. are "B" and site 0 is "Psi".
+
+    Tail of ``alloc_superblock_random`` (_mps_cls.py:2684-2699): C2sigmaB on
+    every site from the right, sigma absorbed into the left neighbour, site 0
+    scaled to ``scale`` (Hilbert space).
+    """
+    cores = [np.array(c, dtype=np.complex128) for c in cores]
+    for isite in range(len(cores) - 1, 0, -1):
+        sval, matB = qr_psi2sigmaB(cores[isite])
+        cores[isite] = np.ascontiguousarray(matB)
+        cores[isite - 1] = np.tensordot(cores[isite - 1], sval, axes=(2, 0))
+    cores[0] = cores[0] * (scale / np.linalg.norm(cores[0]))
+    return cores
+
+
+# --------------------------------------------------------------------------
+# a3: environment update
+# --------------------------------------------------------------------------
+def env_update_left(L: np.ndarray, A: np.ndarray, W: np.ndarray) -> np.ndarray:
+    """L'[i,q,j] = sum conj(A)[m,r,i] A[n,s,j] L[m,p,n] W[p,r,s,q].
+
+    "mri,nsj,mpn,prsq->iqj", _contraction.py:286-297 (gauge "A", modes 3,2),
+    called from renormalize_op_psite (_mps_mpo.py:554).  GEMM order
+    L.A -> W -> conj(A) so that it is also a fair zgemm CPU baseline.
+    """
+    Dl, M, _ = L.shape
+    _, d, Dr = A.shape
+    Mr = W.shape[3]
+    # X[m,p,s,j] = sum_n L[m,p,n] A[n,s,j]
+    X = (L.reshape(Dl * M, Dl) @ A.reshape(Dl, d * Dr)).reshape(Dl, M * d, Dr)
+    # Y[m,(r,q),j] = sum_(p,s) W2[(r,q),(p,s)] X[m,(p,s),j]
+    W2 = W.transpose(1, 3, 0, 2).reshape(d * Mr, M * d)
+    Y = np.matmul(W2, X)  # (Dl, d*Mr, Dr)
+    # L'[i,(q,j)] = sum_(m,r) conj(A)[(m,r),i] Y[(m,r),(q,j)]
+    out = A.reshape(Dl * d, Dr).conj().T @ Y.reshape(Dl * d, Mr * Dr)
+    return out.reshape(Dr, Mr, Dr)
+
+
+def env_update_right(R: np.ndarray, B: np.ndarray, W: np.ndarray) -> np.ndarray:
+    """R'[i,p,j] = sum conj(B)[i,r,m] B[j,s,n] R[m,q,n] W[p,r,s,q].
+
+    "irm,jsn,mqn,prsq->ipj", _contraction.py:376-388 (gauge "B" mirror case).
+    Evaluated as the mirror image of :func:`env_update_left`.
+    """
+    Bt = np.ascontiguousarray(B.transpose(2, 1, 0))  # [n,s,j]
+    Wt = np.ascontiguousarray(W.transpose(3, 1, 2, 0))  # [q,r,s,p]
+    return env_update_left(R, Bt, Wt)
+
+
+# --------------------------------------------------------------------------
+# a4 / a5: effective Hamiltonian applies
+# --------------------------------------------------------------------------
+def heff_apply(L: np.ndarray, W: np.ndarray, R: np.ndarray, psi: np.ndarray) -> np.ndarray:
+    """sigma[a,i,r] = sum L[a,c,b] W[c,i,j,t] R[r,t,s] psi[b,j,s].
+
+    "bjs,acb,cijt,rts->air", _contraction.py:1154-1161 via
+    multiplyH_MPS_direct_MPO.dot (_contraction.py:1182-1243).
+    """
+    Dl, Ml, _ = L.shape
+    Dr, Mr, _ = R.shape
+    d = psi.shape[1]
+    X = (L.reshape(Dl * Ml, Dl) @ psi.reshape(Dl, d * Dr)).reshape(Dl, Ml * d, Dr)
+    W2 = W.transpose(1, 3, 0, 2).reshape(d * Mr, Ml * d)
+    Y = np.matmul(W2, X)  # [a,(i,t),s]
+    out = Y.reshape(Dl * d, Mr * Dr) @ R.reshape(Dr, Mr * Dr).T
+    return out.reshape(Dl, d, Dr)
+
+
+def keff_apply(L: np.ndarray, R: np.ndarray, sigma: np.ndarray) -> np.ndarray:
+    """sigma'[a,r] = sum L[a,c,b] sigma[b,s] R[r,c,s].
+
+    "bs,acb,rcs->ar", _contraction.py:1339-1352 via multiplyK_MPS_direct_MPO.dot.
+    """
+    Dl, M, _ = L.shape
+    Dr = R.shape[0]
+    X = L.reshape(Dl * M, Dl) @ sigma  # [(a,c),s]
+    return X.reshape(Dl, M * Dr) @ R.reshape(Dr, M * Dr).T
+
+
+# --------------------------------------------------------------------------
+# a6 / a7: local propagators
+# --------------------------------------------------------------------------
+def _n_warmup(size: int, k_prev: int) -> int:
+    """_iter_info, _integrator.py:178-186."""
+    return min(size, min(max(0, k_prev - 2), 15))
+
+
+def sil_lanczos(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
+    """exp(scale*H) psi by the reference's short-iterative Lanczos.
+
+    Follows _integrator.py:453-655 statement by statement, including the
+    reference's non-textbook alpha_l = <v0|H|v_l> (``v0_conj`` fixed,
+    :535, :556), the warm-up that skips eigen-decompositions
+    (:578-579), host ``eigh_tridiagonal`` for real alpha (:617-621), dense
+    ``eig``+``solve`` otherwise (:622-633), the successive-approximant
+    convergence test (:644-652) and ``_normalize/_rescale`` (:189-213).
+    Returns (psi_new, k) where k is the Krylov dimension stored in
+    ``_Debug.niter_krylov`` (:641, :649).  Raises ValueError like :653.
+    """
+    shape = psi.shape
+    v0 = np.array(psi, dtype=np.complex128).reshape(-1)
+    size = v0.size
+    ndim = min(size, MAX_KRYLOV)
+    n_warm = _n_warmup(size, k_prev)
+    if conserve_norm:
+        beta0 = 1.0
+    else:
+        beta0 = float(np.linalg.norm(v0))
+        if beta0 == 0.0:
+            raise ValueError("Initial psi has zero norm.")
+        v0 = v0 / beta0
+    v0_conj = np.conj(v0)
+    V = [v0]
+    alpha: list[complex] = []
+    beta: list[float] = []
+    alpha_is_real = True
+    psi_sv = None
+    beta_l = 0.0
+    for ldim in range(ndim):
+        trial = psi if ldim == 0 else V[-1].reshape(shape)
+        v_l = np.array(matvec(trial)).reshape(-1)
+        if not conserve_norm and ldim == 0:
+            v_l = v_l / beta0
+        a_l = complex(np.inner(v0_conj, v_l))
+        alpha.append(a_l)
+        v_l = v_l - V[-1] * a_l
+        if ldim > 0:
+            v_l = v_l - V[-2] * beta_l
+        beta_l = float(np.linalg.norm(v_l))
+        beta.append(beta_l)
+        if beta_l >= EPS:
+            v_l = v_l / beta_l
+        V.append(v_l)
+        is_converged = beta_l < EPS or ldim + 1 == size
+        if alpha_is_real and abs(a_l.imag) > 1e-10:
+            alpha_is_real = False
+        if ldim < n_warm and not is_converged:
+            continue
+        if ldim == 0:
+            psi_next = v0 * cmath.exp(scale * alpha[-1])
+        else:
+            if alpha_is_real:
+                lam, phi = scipy.linalg.eigh_tridiagonal(np.real(alpha), beta[:-1])
+                coef = phi @ (np.exp(scale * lam) * np.conjugate(phi).T[:, 0])
+            else:
+                mat = (
+                    np.diag(alpha, 0)
+                    + np.diag(beta[:-1], -1).astype(np.complex128)
+                    + np.diag(beta[:-1], 1).astype(np.complex128)
+                )
+                lam, phi = scipy.linalg.eig(mat)
+                e0 = np.zeros(ldim + 1, dtype=mat.dtype)
+                e0[0] = 1
+                coef = phi @ (np.exp(scale * lam) * np.linalg.solve(phi, e0))
+            psi_next = np.dot(coef, np.array(V[:-1]))
+        done = is_converged
+        if not done:
+            if psi_sv is not None and float(np.linalg.norm(psi_next - psi_sv)) < thresh:
+                done = True
+            psi_sv = psi_next
+        if done:
+            if conserve_norm:
+                psi_next = psi_next / float(np.linalg.norm(psi_next))
+            else:
+                psi_next = psi_next * beta0
+            return psi_next.reshape(shape), ldim + 1
+    raise ValueError(
+        f"Short Iterative Lanczos is not converged in {ndim} basis. Try shorter time interval."
+    )
+
+
+def sil_arnoldi(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
+    """exp(scale*H) psi by short-iterative Arnoldi, _integrator.py:287-432.
+
+    Classical Gram-Schmidt against all previous vectors (_orth_step_np,
+    :247-260), (k+1) x k Hessenberg, ``eig`` + ``solve(eigvecs, e0)``
+    (:401-409), same warm-up / convergence / rescale rules as Lanczos.
+    """
+    shape = psi.shape
+    v0 = np.array(psi, dtype=np.complex128).reshape(-1)
+    size = v0.size
+    ndim = min(size, MAX_KRYLOV)
+    n_warm = _n_warmup(size, k_prev)
+    hessen = np.zeros((ndim + 1, ndim), dtype=np.complex128)
+    if conserve_norm:
+        beta0 = 1.0
+    else:
+        beta0 = float(np.linalg.norm(v0))
+        if beta0 == 0.0:
+            raise ValueError("Initial psi has zero norm.")
+        v0 = v0 / beta0
+    V = [v0]
+    psi_sv = None
+    v = v0
+    for ldim in range(ndim):
+        trial = psi if ldim == 0 else v.reshape(shape)
+        v_l = np.array(matvec(trial)).reshape(-1)
+        if not conserve_norm and ldim == 0:
+            v_l = v_l / beta0
+        Vm = np.array(V)
+        hcol = np.sum(np.conj(Vm) * v_l[np.newaxis, :], axis=1)
+        v_l = v_l - np.sum(hcol[:, np.newaxis] * Vm, axis=0)
+        beta = float(np.linalg.norm(v_l))
+        hessen[: ldim + 1, ldim] = hcol
+        if beta > EPS:
+            v_l = v_l / beta
+            V.append(v_l)
+            if hessen.shape[0] > ldim + 1:
+                hessen[ldim + 1, ldim] = beta
+        v = v_l
+        is_converged = beta < EPS or ldim + 1 == size
+        if ldim < n_warm and not is_converged:
+            continue
+        if ldim == 0:
+            psi_next = v0 * cmath.exp(scale * hessen[0, 0])
+        else:
+            subH = hessen[: ldim + 1, : ldim + 1]
+            lam, vec = np.linalg.eig(subH)
+            e0 = np.zeros(ldim + 1, dtype=subH.dtype)
+            e0[0] = 1
+            coef = vec @ (np.exp(scale * lam) * np.linalg.solve(vec, e0))
+            psi_next = np.tensordot(coef, np.array(V[: ldim + 1]), axes=(0, 0))
+        done = is_converged
+        if not done:
+            if psi_sv is not None and float(np.linalg.norm(psi_next - psi_sv)) < thresh:
+                done = True
+            psi_sv = psi_next
+        if done:
+            if conserve_norm:
+                psi_next = psi_next / float(np.linalg.norm(psi_next))
+            else:
+                psi_next = psi_next * beta0
+            return psi_next.reshape(shape), ldim + 1
+    raise ValueError("Short Iterative Arnoldi is not converged in 20 basis.")
+
+
+# --------------------------------------------------------------------------
+# a8-a10: sweep
+# --------------------------------------------------------------------------
+@dataclass
+class OracleMPS:
+    """Site-0-centred MPS + MPO + the environment cache handed between sweeps.
+
+    ``cores[0]`` is "Psi", the rest "B" (_mps_cls.py:2684-2703).  ``envs`` is
+    the reference's ``op_sys_sites`` (_mps_cls.py:848-861, :1006-1012) stored
+    by bond: ``left[p]`` acts on bond (p-1|p), ``right[p]`` on bond (p|p+1).
+    ``kprev`` mirrors ``_Debug.niter_krylov`` keyed by site (_helper.py:29).
+    """
+
+    cores: list[np.ndarray]
+    mpo: list[np.ndarray]
+    integrator: str = "lanczos"
+    thresh: float = 1e-9
+    conserve_norm: bool = True
+    shift: complex = 0.0  # coupleJ[0][0] * ovlp term, _contraction.py:1200-1216
+    left: dict = field(default_factory=dict)
+    right: dict = field(default_factory=dict)
+    kprev: dict = field(default_factory=dict)
+    n_apply: int = 0
+    center: int = 0
+
+    def __post_init__(self):
+        self.cores = [np.array(c, dtype=np.complex128) for c in self.cores]
+        self.mpo = [np.array(w, dtype=np.complex128) for w in self.mpo]
+        self.nsite = len(self.cores)
+        one = np.ones((1, 1, 1), dtype=np.complex128)  # construct_op_zerosite, _mps_mpo.py:364
+        self.left[0] = one
+        self.right[self.nsite - 1] = one
+
+    # ---- environment construction (construct_op_sites, _mps_cls.py:1738-1796)
+    def build_right_envs(self):
+        for p in range(self.nsite - 1, 0, -1):
+            self.right[p - 1] = env_update_right(self.right[p], self.cores[p], self.mpo[p])
+
+    def _exp(self, scale, matvec, x, site):
+        fn = sil_lanczos if self.integrator == "lanczos" else sil_arnoldi
+        out, k = fn(
+            scale, matvec, x, self.thresh, self.kprev.get(site, 0), self.conserve_norm
+        )
+        self.kprev[site] = k
+        return out
+
+    def _heff(self, p):
+        L, W, R = self.left[p], self.mpo[p], self.right[p]
+
+        def mv(x):
+            self.n_apply += 1
+            y = heff_apply(L, W, R, x)
+            if self.shift != 0.0:
+                y = y + self.shift * x
+            return y
+
+        return mv
+
+    def _keff(self, L, R):
+        def mv(x):
+            y = keff_apply(L, R, x)
+            if self.shift != 0.0:
+                y = y + self.shift * x
+            return y
+
+        return mv
+
+    def sweep(self, dt: float, forward: bool):
+        """One half-sweep, propagate_along_sweep (_mps_cls.py:798-1014)."""
+        n = self.nsite
+        sites = range(0, n) if forward else range(n - 1, -1, -1)
+        end = n - 1 if forward else 0
+        for p in sites:
+            # exp_superH_propagation_direct, _mps_cls.py:1016-1100 (:1070)
+            self.cores[p] = self._exp(-1.0j * dt / 2, self._heff(p), self.cores[p], p)
+            if p == end:
+                break
+            if forward:
+                # trans_next_psite_AsigmaB, _mps_cls.py:1798-1850
+                A, sval = qr_psi2Asigma(self.cores[p])
+                self.cores[p] = A
+                self.left[p + 1] = env_update_left(self.left[p], A, self.mpo[p])
+                # exp_superK_propagation_direct, _mps_cls.py:1102-1170 (:1151)
+                sval = self._exp(
+                    +1.0j * dt / 2, self._keff(self.left[p + 1], self.right[p]), sval, p
+                )
+                # trans_next_psite_APsiB, _mps_cls.py:1172-1206
+                self.cores[p + 1] = np.tensordot(sval, self.cores[p + 1], axes=(1, 0))
+            else:
+                sval, B = qr_psi2sigmaB(self.cores[p])
+                self.cores[p] = np.ascontiguousarray(B)
+                self.right[p - 1] = env_update_right(self.right[p], self.cores[p], self.mpo[p])
+                sval = self._exp(
+                    +1.0j * dt / 2, self._keff(self.left[p], self.right[p - 1]), sval, p
+                )
+                self.cores[p - 1] = np.tensordot(self.cores[p - 1], sval, axes=(2, 0))
+        self.center = end
+
+    def propagate(self, dt: float):
+        """One time step = forward + backward half-sweep, MPSCoef.propagate
+        (_mps_cls.py:452-503).  The first call builds all right environments
+        (:835-843)."""
+        if len(self.right) < self.nsite:
+            self.build_right_envs()
+        self.sweep(dt, True)
+        self.sweep(dt, False)
+
+    # ---- a11: observables -------------------------------------------------
+    def norm(self) -> float:
+        """pop_states / norm (_mps_cls.py:682-716): ||Psi(site 0)||."""
+        return float(np.linalg.norm(self.cores[0]))
+
+    def expectation(self, mpo: list[np.ndarray] | None = None) -> complex:
+        """<Psi|O|Psi> at site 0 with fresh right environments
+        (MPSCoef.expectation, _mps_cls.py:540-612; expectation_Op,
+        _integrator.py:41-71)."""
+        mpo = self.mpo if mpo is None else [np.asarray(w, dtype=np.complex128) for w in mpo]
+        R = np.ones((1, 1, 1), dtype=np.complex128)
+        for p in range(self.nsite - 1, 0, -1):
+            R = env_update_right(R, self.cores[p], mpo[p])
+        L = np.ones((1, 1, 1), dtype=np.complex128)
+        sig = heff_apply(L, mpo[0], R, self.cores[0])
+        if mpo is self.mpo and self.shift != 0.0:
+            sig = sig + self.shift * self.cores[0]
+        return complex(np.vdot(self.cores[0].reshape(-1), sig.reshape(-1)))
+
+    def autocorr(self) -> complex:
+        """<Psi^*|Psi> (no conjugation of the bra), the t/2 trick
+        (wavefunction.py:226-257, properties.py:211-220)."""
+        return overlap(self.cores, self.cores, conj_bra=False)
+
+
+def overlap(bra: list[np.ndarray], ket: list[np.ndarray], conj_bra: bool = True) -> complex:
+    """Transfer-matrix overlap of two MPS, left to right."""
+    T = np.ones((1, 1), dtype=np.complex128)
+    for b, k in zip(bra, ket):
+        bb = np.conj(b) if conj_bra else b
+        # T'[i,j] = sum_{m,n,s} bb[m,s,i] T[m,n] k[n,s,j]
+        tmp = np.tensordot(T, k, axes=(1, 0))  # [m,s,j]
+        T = np.tensordot(bb, tmp, axes=([0, 1], [0, 1]))
+    return complex(T[0, 0])
+
+
+def site_rdm(cores: list[np.ndarray], site: int) -> np.ndarray:
+    """One-site reduced density matrix rho[j,j'] of a site-0-centred MPS
+    (what ``get_reduced_densities`` returns for key (site, site),
+    _mps_cls.py:1208-1436): move the centre to ``site`` by QR, trace bonds."""
+    cs = [np.array(c) for c in cores]
+    for p in range(site):
+        A, s = qr_psi2Asigma(cs[p])
+        cs[p] = A
+        cs[p + 1] = np.tensordot(s, cs[p + 1], axes=(1, 0))
+    c = cs[site]
+    return np.einsum("ajs,aks->jk", c, np.conj(c))
+
+
+# --------------------------------------------------------------------------
+# synthetic inputs -- used by tests and bench
+# --------------------------------------------------------------------------
+def synthetic_mpo(L: int, d: int, M: int, seed: int = 0, dtype=np.complex128):
+    """Hermitian nearest-neighbour-like MPO with bond M = K+2."""
+    rng = np.random.default_rng(seed)
+    K = M - 2
+    cores = []
+    for p in range(L):
+        W = np.zeros((M, d, d, M), dtype=dtype)
+        eye = np.eye(d)
+
+        def herm(scale):
+            G = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+            return scale * (G + G.conj().T) / 2
+
+        W[0, :, :, 0] = eye
+        W[M - 1, :, :, M - 1] = eye
+        for k in range(1, K + 1):
+            A = herm(0.01)
+            W[0, :, :, k] = A
+            W[k, :, :, M - 1] = A
+        W[0, :, :, M - 1] = herm(0.05)
+        if p == 0:
+            W = W[0:1]
+        if p == L - 1:
+            W = W[:, :, :, M - 1 : M]
+        cores.append(np.ascontiguousarray(W))
+    return cores
+
+
+def synthetic_mps(dims: list[int], D: int, seed: int = 1):
+    """Full-rank random MPS, canonicalised to site 0 and normalised."""
+    rng = np.random.default_rng(seed)
+    bd = bond_dims(dims, D)
+    cores = []
+    for (dl, dr), d in zip(bd, dims):
+        cores.append(rng.standard_normal((dl, d, dr)) + 1j * rng.standard_normal((dl, d, dr)))
+    return canonicalize_site0(cores)
+
+
+def flops_heff(Dl, d, Dr, Ml, Mr) -> float:
+    """F_H of SURVEY 8(d): complex MAC = 8 flop."""
+    return 8.0 * (Dl * Dl * Ml * d * Dr + Dl * Dr * Ml * Mr * d * d + Dl * Dr * Dr * Mr * d)

@@ -1,0 +1,454 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE.
+
+Run only in the development container (``/root/reference`` must exist):
+
+    python tests/golden/make_golden.py
+
+The reference (PyTDSCF v1.3.3) is imported from ``/root/reference`` with its
+NumPy backend.  Its *third-party* imports that are absent from this image
+(jax, loguru, discvar, opt_einsum, polars, netCDF4 -- none of them part of the
+reference's own source) are replaced by throw-away stand-ins written to a
+temporary directory; see SURVEY.md section 8(c).  No reference source is copied:
+the fixtures hold inputs (tensors, time step) and the reference's outputs.
+
+Every fixture is a small ``.npz``; the parity tests load them without the
+reference being present.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import textwrap
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def _write(path, text):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write(textwrap.dedent(text))
+
+
+def make_third_party_stubs(root: str) -> None:
+    """Stand-ins for third-party packages only (never for reference code)."""
+    _write(
+        f"{root}/jax/__init__.py",
+        """
+        class Array:  # never instantiated on the NumPy path
+            pass
+        def jit(f=None, **kw):
+            if f is None:
+                return lambda g: g
+            return f
+        class _Cfg:
+            def update(self, *a, **k): pass
+        config = _Cfg()
+        from . import numpy, scipy  # noqa
+        """,
+    )
+    _write(
+        f"{root}/jax/numpy/__init__.py",
+        """
+        import numpy as _np
+        from jax import Array as ndarray
+        complex128 = _np.complex128
+        float64 = _np.float64
+        """,
+    )
+    _write(f"{root}/jax/scipy/__init__.py", "from . import linalg\n")
+    _write(f"{root}/jax/scipy/linalg.py", "")
+    _write(
+        f"{root}/loguru/__init__.py",
+        """
+        class _L:
+            def bind(self, **k): return self
+            def add(self, *a, **k): return 0
+            def remove(self, *a, **k): pass
+            def debug(self, *a, **k): pass
+            def info(self, *a, **k): pass
+            def warning(self, *a, **k): pass
+            def error(self, *a, **k): pass
+            def critical(self, *a, **k): pass
+        logger = _L()
+        """,
+    )
+    # discvar v0.0.2 is the upstream home of the HO-DVR classes; the reference
+    # ships in-tree twins (pytdscf/basis/__init__.py:1-4) which we re-export.
+    _write(
+        f"{root}/discvar/__init__.py",
+        """
+        from pytdscf.basis.ho import HarmonicOscillator, PrimBas_HO
+        from pytdscf.basis.abc import DVRPrimitivesMixin
+        from pytdscf.basis import ho
+        from pytdscf.basis import abc
+        """,
+    )
+    _write(f"{root}/discvar/abc.py", "from pytdscf.basis.abc import DVRPrimitivesMixin\n")
+    _write(
+        f"{root}/opt_einsum/__init__.py",
+        """
+        import numpy as np
+        _cache = {}
+        def _path(sub, ops):
+            key = (sub, tuple(o.shape for o in ops))
+            if key not in _cache:
+                _cache[key] = np.einsum_path(sub, *ops, optimize=("optimal", 2**44))[0]
+            return _cache[key]
+        def contract(sub, *ops, **kw):
+            ops = [np.asarray(o) for o in ops]
+            return np.einsum(sub, *ops, optimize=_path(sub, ops))
+        class _Expr:
+            def __init__(self, sub, args, constants):
+                self.sub = sub; self.args = list(args); self.constants = list(constants)
+            def __call__(self, *ops, **kw):
+                full = list(self.args); it = iter(ops)
+                for i in range(len(full)):
+                    if i not in self.constants:
+                        full[i] = next(it)
+                return contract(self.sub, *full)
+        def contract_expression(sub, *args, constants=(), **kw):
+            return _Expr(sub, args, constants)
+        """,
+    )
+    _write(f"{root}/polars/__init__.py", "")
+    _write(
+        f"{root}/netCDF4/__init__.py",
+        """
+        class Dataset:
+            def __init__(self, *a, **k): raise RuntimeError("netCDF4 absent")
+        """,
+    )
+    _write(
+        f"{root}/pytdscf-1.3.3.dist-info/METADATA",
+        "Metadata-Version: 2.1\nName: pytdscf\nVersion: 1.3.3\n",
+    )
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference not present; fixtures can only be regenerated in the dev container")
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    stubs = os.path.join(tmp, "stubs")
+    make_third_party_stubs(stubs)
+    sys.path.insert(0, REF)
+    sys.path.insert(0, stubs)
+    sys.path.insert(0, REPO)
+    os.chdir(tmp)  # the reference writes {jobname}_prop/ and wf_*.pkl into cwd
+
+    import numpy as np
+    import pytdscf  # noqa: F401  (must come before anything imports discvar)
+    from pytdscf import Model, Simulator, units
+    from pytdscf import _helper as helper
+    from pytdscf._const_cls import const
+    from pytdscf._contraction import (
+        SplitStack,
+        contract_with_site_mpo,
+        multiplyH_MPS_direct_MPO,
+        multiplyK_MPS_direct_MPO,
+    )
+    from pytdscf import _integrator
+    from pytdscf._mpo_cls import OperatorCore
+    from pytdscf._site_cls import SiteCoef
+    from pytdscf.basis import Exciton
+    from pytdscf.dvr_operator_cls import (
+        TensorOperator,
+        construct_kinetic_mpo,
+        construct_nMR_recursive,
+    )
+    from pytdscf.hamiltonian_cls import TensorHamiltonian
+    from discvar import HarmonicOscillator as HO
+
+    from oracle import tdvp_oracle as orc  # only for the synthetic input builders
+
+    au_in_fs = float(units.au_in_fs)
+    rng = np.random.default_rng(20260503)
+
+    def crandn(*shape):
+        return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+    def save(name, **kw):
+        np.savez_compressed(os.path.join(HERE, name), **kw)
+        print("wrote", name, {k: np.shape(v) for k, v in kw.items()})
+
+    # ------------------------------------------------------------------ unit
+    const.use_jax = False  # the global run-type flags the unit-level calls read
+    const.conserve_norm = True
+    const.verbose = 0
+    # a3: environment updates through contract_with_site_mpo
+    Dl, d, Dr, Ml, Mr = 5, 3, 4, 3, 2
+    A = crandn(Dl, d, Dr)
+    Lb = crandn(Dl, Ml, Dl)
+    W = crandn(Ml, d, d, Mr)
+    core = OperatorCore([0, 1, 2], ((0, 0), (1, 1), (2, 2)), 1, W, "numpy")
+    outA = contract_with_site_mpo(SiteCoef(A, "A", 1), SiteCoef(A, "A", 1), Lb, core)
+    B = crandn(Dr, d, Dl)  # (D_l', d, D_r') with D_r' = Dl to reuse Lb as right block
+    Rb = crandn(Dl, Mr, Dl)
+    outB = contract_with_site_mpo(SiteCoef(B, "B", 1), SiteCoef(B, "B", 1), Rb, core)
+    save("unit_env.npz", A=A, L=Lb, W=W, outA=outA, B=B, R=Rb, outB=outB)
+
+    # a4 / a5: H_eff and K_eff applies through _op_lcr_dot / _op_lr_dot
+    psi = crandn(Dl, d, Dr)
+    R3 = crandn(Dr, Mr, Dr)
+    mh = multiplyH_MPS_direct_MPO.__new__(multiplyH_MPS_direct_MPO)
+    mh._op_lcr_dot_cached = {}
+    sig = mh._op_lcr_dot(Lb, core, R3, psi, key="k")
+    sv = crandn(Dl, Dr)
+    Rk = crandn(Dr, Ml, Dr)
+    mk = multiplyK_MPS_direct_MPO.__new__(multiplyK_MPS_direct_MPO)
+    mk._op_lr_dot_cached = {}
+    sigk = mk._op_lr_dot(Lb, Rk, sv, key="k")
+    save("unit_apply.npz", L=Lb, W=W, R=R3, psi=psi, sigma=sig, Rk=Rk, sval=sv, sigma_k=sigk)
+
+    # a6 / a7: local propagators on a dense operator through the SplitStack seam
+    class Dense(SplitStack):
+        def __init__(self, mat, shape):
+            super().__init__(shape)
+            self.mat = mat
+
+        def dot(self, states):
+            return [(self.mat @ states[0].reshape(-1)).reshape(states[0].shape)]
+
+    n = 36
+    G = crandn(n, n)
+    Hh = (G + G.conj().T) / 2
+    Hn = Hh - 0.3j * np.diag(rng.random(n))  # non-Hermitian (absorbing)
+    x0 = crandn(3, 4, 3)
+    x0 /= np.linalg.norm(x0)
+    out = {}
+    for tag, integ, mat, cn, scale in [
+        ("lan_dt001", "lanczos", Hh, True, -0.01j),
+        ("lan_dt01", "lanczos", Hh, True, -0.1j),
+        ("lan_real", "lanczos", Hh, False, -0.05),
+        ("arn_dt001", "arnoldi", Hn, False, -0.01j),
+        ("arn_dt01", "arnoldi", Hn, False, -0.1j),
+    ]:
+        const.conserve_norm = cn
+        const.use_jax = False
+        helper._Debug.niter_krylov.clear()
+        helper._Debug.site_now = 0
+        fn = (
+            _integrator.short_iterative_lanczos
+            if integ == "lanczos"
+            else _integrator.short_iterative_arnoldi
+        )
+        xin = x0 * (1.0 if cn else 1.7)
+        y1 = fn(scale, Dense(mat, x0.shape), [xin.copy()], 1e-9)[0]
+        k1 = helper._Debug.niter_krylov[0]
+        # second call: warm-up from the stored iteration count
+        y2 = fn(scale, Dense(mat, x0.shape), [y1.copy()], 1e-9)[0]
+        k2 = helper._Debug.niter_krylov[0]
+        out[tag + "_in"] = xin
+        out[tag + "_y1"] = y1
+        out[tag + "_y2"] = y2
+        out[tag + "_k"] = np.array([k1, k2])
+        out[tag + "_scale"] = np.array(scale, dtype=np.complex128)
+        out[tag + "_cn"] = np.array(cn)
+    save("unit_krylov.npz", Hh=Hh, Hn=Hn, **out)
+
+    # a8: gauge moves
+    psi_g = crandn(4, 3, 5)
+    a_site, sA = SiteCoef(psi_g.copy(), "Psi", 1).gauge_trf("Psi2Asigma")
+    b_site, sB = SiteCoef(psi_g.copy(), "Psi", 1).gauge_trf("Psi2sigmaB")
+    save(
+        "unit_gauge.npz", psi=psi_g, A=np.array(a_site.data), sigA=sA, B=np.array(b_site.data), sigB=sB
+    )
+
+    # ------------------------------------------------------------ end-to-end
+    def run_ref(basis, operators, cores, D, dt_fs, nstep, **kw):
+        """Reference Simulator.propagate from explicit (full-rank) cores."""
+        model = Model(basis, operators=operators, bond_dim=D)
+        model.init_HartreeProduct = [[np.array(c) for c in cores]]
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold", model, backend="numpy", verbose=0)
+        ener, wf = sim.propagate(stepsize=dt_fs, maxstep=nstep, **kw)
+        fin = [np.array(s.data) for s in wf.ci_coef.superblock_states[0]]
+        return dict(
+            energy_last=np.array(ener),
+            final=fin,
+            autocorr=np.array(wf._ints_wf_ovlp_mpssm(wf.ci_coef, conj=False)),
+            norm=np.array(wf.norm()),
+            energy_final=np.array(wf.expectation(model.hamiltonian)),
+            krylov=np.array(
+                [helper._Debug.niter_krylov[i] for i in range(len(cores))]
+            ),
+        )
+
+    def pack(prefix, res):
+        o = {}
+        for k, v in res.items():
+            if k == "final":
+                for i, c in enumerate(v):
+                    o[f"{prefix}_final{i}"] = c
+            else:
+                o[f"{prefix}_{k}"] = v
+        return o
+
+    # (i) synthetic Hermitian chain, Lanczos, full-rank start (SURVEY 8d inputs)
+    L, d, M, D = 6, 3, 4, 6
+    mpo = orc.synthetic_mpo(L, d, M, seed=0)
+    bd = orc.bond_dims([d] * L, D)
+    cores = [crandn(dl, d, dr) for (dl, dr) in bd]
+    basis = [Exciton(nstate=d) for _ in range(L)]
+    dt = 0.05
+    o = {f"mpo{i}": w for i, w in enumerate(mpo)}
+    o.update({f"init{i}": c for i, c in enumerate(cores)})
+    for n in (1, 4):
+        o.update(pack(f"n{n}", run_ref(basis, {"hamiltonian": [w.copy() for w in mpo]}, cores, D, dt, n)))
+    save("chain_lanczos.npz", dt_au=np.array(dt / au_in_fs), nsite=np.array(L), **o)
+
+    # (ii) non-Hermitian chain, Arnoldi, conserve_norm=False
+    mpo_n = [w.copy() for w in mpo]
+    for p in range(L):
+        g = 0.02 * rng.random(d)
+        # -i * gamma_j |j><j| on the "local" slot of the MPO
+        row = 0
+        col = mpo_n[p].shape[3] - 1
+        mpo_n[p][row, :, :, col] += -1j * np.diag(g)
+    o = {f"mpo{i}": w for i, w in enumerate(mpo_n)}
+    o.update({f"init{i}": c for i, c in enumerate(cores)})
+    for n in (1, 3):
+        o.update(
+            pack(
+                f"n{n}",
+                run_ref(
+                    basis,
+                    {"hamiltonian": [w.copy() for w in mpo_n]},
+                    cores,
+                    D,
+                    dt,
+                    n,
+                    integrator="arnoldi",
+                    conserve_norm=False,
+                ),
+            )
+        )
+    save("chain_arnoldi.npz", dt_au=np.array(dt / au_in_fs), nsite=np.array(L), **o)
+
+    # (iii) the reference's own exciton pin (tests/test_exiciton_propagate.py):
+    # potential = diagonal 3-leg cores + one 4-leg core, kinetic on sites 0-2 only.
+    au_in_cm1 = float(units.au_in_cm1)
+    freqs = [1000, 2000, 3000]
+    omega2 = [(f / au_in_cm1) ** 2 for f in freqs]
+    nprim = 8
+    prim = [HO(nprim, f, units="cm-1") for f in freqs] + [Exciton(nstate=2, names=["S0", "S1"])]
+    dE, J, lamb, kappa = 0.01, 0.001, 0.0001, 0.0001
+    W0 = np.zeros((1, nprim, 3), dtype=np.complex128)
+    W1 = np.zeros((3, nprim, 4), dtype=np.complex128)
+    W2 = np.zeros((4, nprim, 3), dtype=np.complex128)
+    W3 = np.zeros((3, 2, 2, 1), dtype=np.complex128)
+    q1 = [np.array(ho.get_grids()) for ho in prim[:3]]
+    q2 = [q * q for q in q1]
+    one = [np.ones_like(q) for q in q1]
+    a = prim[3].get_annihilation_matrix()
+    ad = prim[3].get_creation_matrix()
+    W0[0, :, 0] = one[0]
+    W0[0, :, 1] = q1[0]
+    W0[0, :, 2] = omega2[0] / 2 * q2[0]
+    W1[0, :, 0] = J * one[1] + lamb * q1[1]
+    W1[0, :, 1] = one[1]
+    W1[0, :, 2] = kappa * q1[1] + omega2[1] ** 2 / 2 * q2[1]
+    W1[0, :, 3] = omega2[1] / 2 * q2[1]
+    W1[1, :, 0] = lamb * one[1]
+    W1[1, :, 2] = kappa * one[1]
+    W1[2, :, 2] = one[1]
+    W1[2, :, 3] = one[1]
+    W2[0, :, 2] = one[2]
+    W2[1, :, 0] = dE * one[2] + kappa * q1[2] + omega2[2] / 2 * q2[2]
+    W2[1, :, 1] = omega2[2] / 2 * q2[2]
+    W2[1, :, 2] = lamb * q1[2]
+    W2[2, :, 0] = one[2]
+    W2[3, :, 1] = one[2]
+    W3[0, :, :, 0] = ad @ a
+    W3[1, :, :, 0] = a @ ad
+    W3[2, :, :, 0] = ad + a
+    pot = [W0, W1, W2, W3]
+    kin = []
+    for idof in range(3):
+        t = prim[idof].get_2nd_derivative_matrix_dvr() / 2
+        if idof == 0:
+            c = np.zeros((1, nprim, nprim, 2), dtype=np.complex128)
+            c[0, :, :, 0] = t
+            c[0, :, :, 1] = np.eye(nprim)
+        elif idof == 2:
+            c = np.zeros((2, nprim, nprim, 1), dtype=np.complex128)
+            c[0, :, :, 0] = np.eye(nprim)
+            c[1, :, :, 0] = t
+        else:
+            c = np.zeros((2, nprim, nprim, 2), dtype=np.complex128)
+            c[0, :, :, 0] = np.eye(nprim)
+            c[1, :, :, 1] = np.eye(nprim)
+            c[0, :, :, 1] = t
+        kin.append(c)
+
+    def exciton_model():
+        ham = TensorHamiltonian(
+            ndof=4,
+            potential=[[{(0, 1, 2, (3, 3)): TensorOperator(mpo=[w.copy() for w in pot], legs=(0, 1, 2, 3, 3))}]],
+            kinetic=[[{((0, 0), (1, 1), (2, 2)): TensorOperator(mpo=[w.copy() for w in kin], legs=(0, 0, 1, 1, 2, 2))}]],
+            backend="numpy",
+        )
+        m = Model(prim, {"hamiltonian": ham}, bond_dim=2)
+        m.init_HartreeProduct = [
+            [ho.get_unitary()[0].tolist() for ho in prim[:3]] + [np.array([0.0, 1.0]).tolist()]
+        ]
+        return m
+
+    o = {f"pot{i}": w for i, w in enumerate(pot)}
+    o.update({f"kin{i}": w for i, w in enumerate(kin)})
+    o.update({f"w{i}": np.array(ho.get_unitary()[0]) for i, ho in enumerate(prim[:3])})
+    for n in (19, 20):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_exc", exciton_model(), backend="numpy", verbose=0)
+        ener, wf = sim.propagate(stepsize=0.1, maxstep=n)
+        o[f"n{n}_energy_last"] = np.array(ener)
+        # key (3, 3) -> remain_legs (0, 0, 0, 2), properties.py:69-82
+        rd = wf.get_reduced_densities((0, 0, 0, 2))
+        o[f"n{n}_rdm33"] = np.array(rd[0])
+        for i, s in enumerate(wf.ci_coef.superblock_states[0]):
+            o[f"n{n}_final{i}"] = np.array(s.data)
+    # the reference's own known answers (tests/test_exiciton_propagate.py:178-184)
+    assert abs(o["n20_energy_last"] - 0.010000180312707298) < 1e-6 * 0.01
+    pin = np.array(
+        [
+            [1.86417721e-02 + 1.60379680e-20j, 2.87367863e-02 - 6.91095824e-02j],
+            [2.87367863e-02 + 6.91095824e-02j, 9.81358228e-01 - 7.40721885e-18j],
+        ]
+    )
+    np.testing.assert_allclose(o["n19_rdm33"], pin, atol=1e-9)
+    save("exciton.npz", dt_au=np.array(0.1 / au_in_fs), ref_pin_rdm33=pin,
+         ref_pin_energy=np.array(0.010000180312707298), **o)
+
+    # (iv) the reference's Henon-Heiles NumPy pin (tests/test_henon_heiles.py:23)
+    w_cm, lam, f, N, m, dt_h = 2000, 1.0e-03, 2, 5, 4, 0.001
+    dvr = [HO(N, w_cm) for _ in range(f)]
+    w_au = w_cm / au_in_cm1
+    func = {
+        (0,): lambda Q1: pow(w_au, 2) / 2 * Q1**2,
+        (0, 1): lambda Q1, Q2: lam * pow(w_au, 3 / 2) * (Q1**2 * Q2),
+        (1,): lambda Qf: pow(w_au, 2) / 2 * Qf**2 - lam * pow(w_au, 3 / 2) / 3 * Qf**3,
+    }
+    pmpo = construct_nMR_recursive(dvr, nMR=2, func=func, rate=0.99999999999)
+    kmpo = construct_kinetic_mpo(dvr)
+    o = {f"pot{i}": np.array(w) for i, w in enumerate(pmpo)}
+    o.update({f"kin{i}": np.array(w) for i, w in enumerate(kmpo)})
+    o.update({f"unitary{i}": np.array(h.get_unitary()) for i, h in enumerate(dvr)})
+    model = Model(dvr, operators={"potential": [np.array(w) for w in pmpo], "kinetic": [np.array(w) for w in kmpo]}, bond_dim=m)
+    model.init_weight_VIBSTATE = [[[0.0, 1.0] + [0.0] * (N - 2)] + [[1.0] + [0.0] * (N - 1)] * (f - 1)]
+    helper._Debug.niter_krylov.clear()
+    sim = Simulator("gold_hh", model, backend="numpy", verbose=0)
+    ener, wf = sim.propagate(maxstep=3, stepsize=dt_h)
+    assert abs(ener - 0.018225341011652626) < 1e-6 * 0.02
+    o["n3_energy_last"] = np.array(ener)
+    for i, s in enumerate(wf.ci_coef.superblock_states[0]):
+        o[f"n3_final{i}"] = np.array(s.data)
+    save("henon_heiles.npz", dt_au=np.array(dt_h / au_in_fs), ref_pin_energy=np.array(0.018225341011652626),
+         au_in_fs=np.array(au_in_fs), au_in_cm1=np.array(au_in_cm1), **o)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""CPU: pin the NumPy oracle against golden vectors produced by the reference
+(tests/golden/make_golden.py).  Every comparison is on the reference's own
+function outputs or on gauge-invariant end-to-end quantities."""
+
+import numpy as np
+import pytest
+
+from oracle import tdvp_oracle as orc
+
+
+def test_env_update(golden):
+    g = golden("unit_env.npz")
+    np.testing.assert_allclose(orc.env_update_left(g["L"], g["A"], g["W"]), g["outA"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(orc.env_update_right(g["R"], g["B"], g["W"]), g["outB"], rtol=1e-13, atol=1e-13)
+
+
+def test_heff_keff_apply(golden):
+    g = golden("unit_apply.npz")
+    np.testing.assert_allclose(orc.heff_apply(g["L"], g["W"], g["R"], g["psi"]), g["sigma"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(orc.keff_apply(g["L"], g["Rk"], g["sval"]), g["sigma_k"], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("tag", ["lan_dt001", "lan_dt01", "lan_real", "arn_dt001", "arn_dt01"])
+def test_local_propagators(golden, tag):
+    g = golden("unit_krylov.npz")
+    mat = g["Hh"] if tag.startswith("lan") else g["Hn"]
+    fn = orc.sil_lanczos if tag.startswith("lan") else orc.sil_arnoldi
+    cn = bool(g[tag + "_cn"])
+    scale = complex(g[tag + "_scale"])
+    x = g[tag + "_in"]
+    mv = lambda t: (mat @ t.reshape(-1)).reshape(t.shape)
+    y1, k1 = fn(scale, mv, x, 1e-9, 0, cn)
+    y2, k2 = fn(scale, mv, y1, 1e-9, k1, cn)
+    assert [k1, k2] == list(g[tag + "_k"])  # same algorithm => same iteration counts
+    np.testing.assert_allclose(y1, g[tag + "_y1"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(y2, g[tag + "_y2"], rtol=0, atol=1e-12)
+
+
+def test_gauge(golden):
+    g = golden("unit_gauge.npz")
+    A, s = orc.qr_psi2Asigma(g["psi"])
+    np.testing.assert_allclose(A, g["A"], atol=1e-13)
+    np.testing.assert_allclose(s, g["sigA"], atol=1e-13)
+    s, B = orc.qr_psi2sigmaB(g["psi"])
+    np.testing.assert_allclose(B, g["B"], atol=1e-13)
+    np.testing.assert_allclose(s, g["sigB"], atol=1e-13)
+    np.testing.assert_allclose(np.tensordot(s, B, axes=(1, 0)), g["psi"], atol=1e-13)
+
+
+def _load_chain(g):
+    n = int(g["nsite"])
+    mpo = [g[f"mpo{i}"] for i in range(n)]
+    init = [g[f"init{i}"] for i in range(n)]
+    return n, mpo, init
+
+
+@pytest.mark.parametrize(
+    "name,integ,cn,steps",
+    [("chain_lanczos.npz", "lanczos", True, (1, 4)), ("chain_arnoldi.npz", "arnoldi", False, (1, 3))],
+)
+def test_chain_end_to_end(golden, name, integ, cn, steps):
+    g = golden(name)
+    n, mpo, init = _load_chain(g)
+    dt = float(g["dt_au"])
+    for ns in steps:
+        st = orc.OracleMPS(orc.canonicalize_site0(init), mpo, integrator=integ, conserve_norm=cn)
+        e_last = None
+        for i in range(ns):
+            e_last = st.expectation()  # observables before the step (Appendix B.1)
+            st.propagate(dt)
+        ref = [g[f"n{ns}_final{i}"] for i in range(n)]
+        assert list(g[f"n{ns}_krylov"]) == [st.kprev[i] for i in range(n)]
+        np.testing.assert_allclose(e_last.real, float(g[f"n{ns}_energy_last"]), rtol=1e-10)
+        np.testing.assert_allclose(st.norm(), float(g[f"n{ns}_norm"]), rtol=1e-12)
+        np.testing.assert_allclose(st.autocorr(), complex(g[f"n{ns}_autocorr"]), rtol=1e-9, atol=1e-12)
+        # WFunc.expectation returns the real part (wavefunction.py:112)
+        np.testing.assert_allclose(st.expectation().real, float(g[f"n{ns}_energy_final"].real), rtol=1e-9, atol=1e-13)
+        nrm = st.norm()
+        fid = abs(orc.overlap(ref, st.cores)) / (nrm * np.sqrt(abs(orc.overlap(ref, ref))))
+        assert abs(fid - 1) < 1e-10
+        for a, b in zip(ref, st.cores):  # same LAPACK => even the tensors agree
+            np.testing.assert_allclose(a, b, atol=1e-9)
+
+
+def test_synthetic_inputs_shapes():
+    mpo = orc.synthetic_mpo(5, 3, 4)
+    assert [w.shape for w in mpo] == [(1, 3, 3, 4)] + [(4, 3, 3, 4)] * 3 + [(4, 3, 3, 1)]
+    mps = orc.synthetic_mps([3] * 5, 6)
+    assert abs(np.linalg.norm(mps[0]) - 1) < 1e-14
+    # Hermitian MPO => real energy
+    st = orc.OracleMPS(mps, mpo)
+    assert abs(st.expectation().imag) < 1e-14
+    assert orc.bond_dims([3] * 5, 6) == [(1, 3), (3, 6), (6, 6), (6, 3), (3, 1)]
