@@ -1,0 +1,156 @@
+/*
+ * mitdvp.h -- C ABI of the MI355X-native one-site TDVP sweep engine.
+ *
+ * This is the drop-in boundary for PyTDSCF's hot path.  Every entry point
+ * names the reference interface it replaces (paths relative to
+ * /root/reference/pytdscf).  The coarse seam is
+ *     MPSCoef.propagate(stepsize_au, ints_spf, matH)      _mps_cls.py:452-503
+ * called once per time step from WFunc.propagate_SM        wavefunction.py:408-412
+ * plus the observables MPSCoef.expectation / autocorr / norm / pop_states
+ * (_mps_cls.py:540-716, wavefunction.py:226-257).
+ *
+ * Conventions
+ *   - all tensors are complex128, C order, passed as interleaved (re, im)
+ *     doubles; host buffers are copied in/out, the handle owns device memory;
+ *   - site tensor psi[b][j][s]      shape (D_l, d, D_r)   _site_cls.py:27-60
+ *   - MPO core    W[c][i][j][t]     shape (M_l, d, d, M_r) _mpo_cls.py:166-198
+ *   - every function returns 0 on success, a negative MITDVP_E* code on error;
+ *     mitdvp_last_error() gives the message.  The Python shell maps
+ *     MITDVP_ENOTCONV to ValueError like _integrator.py:430,653.
+ *   - a handle is bound to one GPU and one HIP stream and is not thread safe.
+ */
+#ifndef MITDVP_H
+#define MITDVP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mitdvp_engine mitdvp_engine;
+
+enum {
+  MITDVP_OK = 0,
+  MITDVP_EINVAL = -1,   /* bad argument / shape                        */
+  MITDVP_EHIP = -2,     /* HIP runtime error                           */
+  MITDVP_ENOTCONV = -3, /* Krylov not converged in 20 vectors          */
+  MITDVP_ESTATE = -4,   /* call sequence error (e.g. missing tensors)  */
+  MITDVP_ENOMEM = -5
+};
+
+enum { MITDVP_LANCZOS = 0, MITDVP_ARNOLDI = 1 };
+enum { MITDVP_GAUGE_PSI = 0, MITDVP_GAUGE_A = 1, MITDVP_GAUGE_B = 2 };
+
+/* const.set_runtype(...) flags that reach the sweep (_const_cls.py:102-252). */
+typedef struct {
+  int nsite;            /* chain length L                                   */
+  int device;           /* HIP device ordinal                               */
+  int integrator;       /* MITDVP_LANCZOS | MITDVP_ARNOLDI  (:integrator)   */
+  int conserve_norm;    /* const.conserve_norm, _integrator.py:189-213      */
+  int relax;            /* 0 real time; 1 imaginary time (const.doRelax)    */
+  double thresh;        /* const.thresh_exp, default 1e-9                   */
+  int max_krylov;       /* 20, _integrator.py:182                           */
+  int lanczos_variant;  /* 0: reference alpha_l=<v0|H|v_l> (_integrator.py:556)
+                           1: orthodox alpha_l=<v_l|H|v_l>                  */
+  int reserved[8];
+} mitdvp_config;
+
+/* -- lifetime ---------------------------------------------------------- */
+int mitdvp_create(const mitdvp_config* cfg, mitdvp_engine** out);
+void mitdvp_destroy(mitdvp_engine* h);
+const char* mitdvp_last_error(const mitdvp_engine* h); /* h may be NULL */
+const char* mitdvp_version(void);
+
+/* -- state: superblock_states[0][isite] (SiteCoef), _site_cls.py:27-60 --- */
+int mitdvp_set_site(mitdvp_engine* h, int isite, const double* reim, int l, int n, int r, int gauge);
+int mitdvp_get_site_shape(mitdvp_engine* h, int isite, int* l, int* n, int* r, int* gauge);
+int mitdvp_get_site(mitdvp_engine* h, int isite, double* reim_out);
+/* Device-side full-rank random MPS with LatticeInfo.get_bond_dim bond
+ * dimensions (_mps_cls.py:2616-2631), canonicalised right->left like
+ * alloc_superblock_random (:2684-2699).  For workloads too large to stage
+ * through the host. */
+int mitdvp_init_random(mitdvp_engine* h, const int* dims, int bond_dim, uint64_t seed);
+/* alloc_superblock_random's C2sigmaB sweep for tensors given by set_site
+ * with gauge "C": site 0 becomes "Psi", scaled to norm `scale`. */
+int mitdvp_canonicalize(mitdvp_engine* h, double scale);
+
+/* -- operators: TensorHamiltonian.mpo[0][0] after reduction to one
+ *    full-chain 4-leg MPO (hamiltonian_cls.py:618-752, _mpo_cls.py:44-234).
+ *    op_id 0 is the Hamiltonian used by mitdvp_step; others are observables. */
+int mitdvp_set_mpo_core(mitdvp_engine* h, int op_id, int isite, const double* reim,
+                        int ml, int d_out, int d_in, int mr);
+/* coupleJ[0][0] * ovlp term (_contraction.py:1200-1216): adds shift*psi. */
+int mitdvp_set_shift(mitdvp_engine* h, int op_id, double re, double im);
+
+/* -- the hot path ------------------------------------------------------- */
+/* MPSCoef.propagate: forward + backward half-sweep with dt/2 each
+ * (_mps_cls.py:482-500).  First call builds all right environments
+ * (:835-843); the cache is reused afterwards (:848-861). */
+int mitdvp_step(mitdvp_engine* h, double dt_au);
+/* propagate_along_sweep (_mps_cls.py:798-1014), one direction only. */
+int mitdvp_sweep(mitdvp_engine* h, double dt_au, int forward);
+/* op_sys_sites = None (_mps_cls.py:2311,2371,2417, wavefunction.py:64-65). */
+int mitdvp_invalidate_env(mitdvp_engine* h);
+
+/* -- observables -------------------------------------------------------- */
+int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */
+int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */
+int mitdvp_norm(mitdvp_engine* h, double* out);                      /* _mps_cls.py:706-716 */
+int mitdvp_site_rdm(mitdvp_engine* h, int isite, double* reim_out);  /* _mps_cls.py:1208-1436, key (isite,isite) */
+int mitdvp_krylov_stats(mitdvp_engine* h, int* per_site);            /* _Debug.niter_krylov, _helper.py:29 */
+
+/* -- counters: _ElpTime / _NFlops equivalents (_helper.py:33-101) ------- */
+typedef struct {
+  double heff_flops;     /* algorithmic flops in H_eff applies (SURVEY 8d F_H)  */
+  double heff_ms;        /* HIP-event time of those applies (profiling on)      */
+  double env_flops, env_ms;
+  double keff_flops, keff_ms;
+  double qr_flops, qr_ms;
+  double krylov_vec_ms;  /* Krylov vector kernels                               */
+  long long n_heff, n_keff, n_env, n_qr;
+  long long n_exp_site, n_exp_bond;
+  long long n_launch;    /* kernel launches issued                              */
+  double reserved[8];
+} mitdvp_counters;
+int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out);
+int mitdvp_counters_reset(mitdvp_engine* h);
+int mitdvp_set_profiling(mitdvp_engine* h, int on); /* HIP-event timing per phase */
+
+/* -- fine seam for unit-level parity tests (SURVEY 8b "internal seam 1"):
+ *    one H_eff / K_eff apply and one environment update on caller data.
+ *    contract_with_site_mpo (_contraction.py:148-397),
+ *    multiplyH_MPS_direct_MPO._op_lcr_dot (:1038-1173),
+ *    multiplyK_MPS_direct_MPO._op_lr_dot (:1297-1352). */
+int mitdvp_heff_apply(int device, const double* L, const double* W, const double* R, const double* psi,
+                      int dl, int d, int dr, int ml, int mr, double* sigma_out, int reps, double* ms_out);
+int mitdvp_keff_apply(int device, const double* L, const double* R, const double* sval,
+                      int dl, int dr, int m, double* out);
+int mitdvp_env_update(int device, int left, const double* env, const double* site, const double* W,
+                      int dl, int d, int dr, int ml, int mr, double* out);
+/* SiteCoef.gauge_trf (_site_cls.py:138-292): key 0 "Psi2Asigma", 1 "Psi2sigmaB". */
+int mitdvp_gauge_trf(int device, int key, const double* psi, int dl, int d, int dr,
+                     double* site_out, double* sigma_out);
+/* short_iterative_lanczos / _arnoldi on a dense operator (_integrator.py:287-655). */
+int mitdvp_expm_dense(int device, int integrator, int conserve_norm, int lanczos_variant,
+                      const double* mat, int n, const double* x, double scale_re, double scale_im,
+                      double thresh, int k_prev, double* y_out, int* k_out);
+
+/* -- kernel-level test / bench hooks (no reference counterpart) --------- */
+/* C = alpha*op(A)*op(B) + beta*C on the MFMA zgemm kernel, row-major. */
+int mitdvp_zgemm(int device, int transA, int conjA, int transB, int conjB, int m, int n, int k,
+                 const double* A, const double* B, double* C, const double alpha[2], const double beta[2],
+                 int tile_cfg, int reps, double* ms_out);
+/* Device-resident timing of the three-stage H_eff apply at a given shape
+ * with random operands (bench roofline leg).  Returns avg ms per apply. */
+int mitdvp_bench_heff(int device, int dl, int d, int dr, int ml, int mr, int reps, int warmup, double* ms_out);
+/* raw v_mfma_f64_16x16x4_f64 issue-rate probe: returns TFLOP/s */
+int mitdvp_mfma_peak_probe(int device, double* tflops_out);
+/* dumps the C/D lane map of v_mfma_f64_16x16x4_f64: out[64*4*2] = (row, col) */
+int mitdvp_mfma_layout_probe(int device, int* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MITDVP_H */

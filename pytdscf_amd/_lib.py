@@ -1,0 +1,139 @@
+"""ctypes binding of ``libmitdvp.so`` (C ABI declared in ``include/mitdvp.h``).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU
+is visible every compute entry point raises.  Loading the library itself does
+not touch the GPU, so symbol checks can run on a CPU-only box.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmitdvp.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mitdvp.h")
+
+OK, EINVAL, EHIP, ENOTCONV, ESTATE, ENOMEM = 0, -1, -2, -3, -4, -5
+LANCZOS, ARNOLDI = 0, 1
+GAUGE_PSI, GAUGE_A, GAUGE_B, GAUGE_C = 0, 1, 2, -1
+
+
+class MitdvpError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("nsite", C.c_int),
+        ("device", C.c_int),
+        ("integrator", C.c_int),
+        ("conserve_norm", C.c_int),
+        ("relax", C.c_int),
+        ("thresh", C.c_double),
+        ("max_krylov", C.c_int),
+        ("lanczos_variant", C.c_int),
+        ("reserved", C.c_int * 8),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("heff_flops", C.c_double),
+        ("heff_ms", C.c_double),
+        ("env_flops", C.c_double),
+        ("env_ms", C.c_double),
+        ("keff_flops", C.c_double),
+        ("keff_ms", C.c_double),
+        ("qr_flops", C.c_double),
+        ("qr_ms", C.c_double),
+        ("krylov_vec_ms", C.c_double),
+        ("n_heff", C.c_longlong),
+        ("n_keff", C.c_longlong),
+        ("n_env", C.c_longlong),
+        ("n_qr", C.c_longlong),
+        ("n_exp_site", C.c_longlong),
+        ("n_exp_bond", C.c_longlong),
+        ("n_launch", C.c_longlong),
+        ("reserved", C.c_double * 8),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/mitdvp.h."""
+    with open(HEADER_PATH) as f:
+        txt = f.read()
+    return sorted(set(re.findall(r"\b(mitdvp_[a-z_0-9]+)\s*\(", txt)))
+
+
+def load() -> C.CDLL:
+    """Load the library (no GPU needed for loading). Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MitdvpError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pytdscf_amd/csrc`.  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    i, d = C.c_int, C.c_double
+    sig = {
+        "mitdvp_create": (i, [C.POINTER(Config), C.POINTER(vp)]),
+        "mitdvp_destroy": (None, [vp]),
+        "mitdvp_last_error": (C.c_char_p, [vp]),
+        "mitdvp_version": (C.c_char_p, []),
+        "mitdvp_set_site": (i, [vp, i, dp, i, i, i, i]),
+        "mitdvp_get_site_shape": (i, [vp, i, ip, ip, ip, ip]),
+        "mitdvp_get_site": (i, [vp, i, dp]),
+        "mitdvp_init_random": (i, [vp, ip, i, C.c_uint64]),
+        "mitdvp_canonicalize": (i, [vp, d]),
+        "mitdvp_set_mpo_core": (i, [vp, i, i, dp, i, i, i, i]),
+        "mitdvp_set_shift": (i, [vp, i, d, d]),
+        "mitdvp_step": (i, [vp, d]),
+        "mitdvp_sweep": (i, [vp, d, i]),
+        "mitdvp_invalidate_env": (i, [vp]),
+        "mitdvp_expect": (i, [vp, i, dp]),
+        "mitdvp_autocorr": (i, [vp, dp]),
+        "mitdvp_norm": (i, [vp, dp]),
+        "mitdvp_site_rdm": (i, [vp, i, dp]),
+        "mitdvp_krylov_stats": (i, [vp, ip]),
+        "mitdvp_counters_get": (i, [vp, C.POINTER(Counters)]),
+        "mitdvp_counters_reset": (i, [vp]),
+        "mitdvp_set_profiling": (i, [vp, i]),
+        "mitdvp_heff_apply": (i, [i, dp, dp, dp, dp, i, i, i, i, i, dp, i, dp]),
+        "mitdvp_keff_apply": (i, [i, dp, dp, dp, i, i, i, dp]),
+        "mitdvp_env_update": (i, [i, i, dp, dp, dp, i, i, i, i, i, dp]),
+        "mitdvp_gauge_trf": (i, [i, i, dp, i, i, i, dp, dp]),
+        "mitdvp_expm_dense": (i, [i, i, i, i, dp, i, dp, d, d, d, i, dp, ip]),
+        "mitdvp_zgemm": (i, [i, i, i, i, i, i, i, i, dp, dp, dp, dp, dp, i, i, dp]),
+        "mitdvp_bench_heff": (i, [i, i, i, i, i, i, i, i, dp]),
+        "mitdvp_mfma_peak_probe": (i, [i, dp]),
+        "mitdvp_mfma_layout_probe": (i, [i, ip]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, handle=None):
+    if rc == OK:
+        return
+    msg = load().mitdvp_last_error(handle).decode(errors="replace")
+    if rc == ENOTCONV:
+        # same exception type as the reference (_integrator.py:430, :653)
+        raise ValueError(msg)
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise MitdvpError(f"mitdvp error {rc}: {msg}")

@@ -1,0 +1,74 @@
+// common.h -- shared types for the MI355X TDVP engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace mitdvp {
+
+typedef double2 zc;  // complex128, (x, y) = (re, im), interleaved like NumPy
+typedef std::complex<double> hzc;
+
+struct HipError : std::runtime_error {
+  explicit HipError(const std::string& s) : std::runtime_error(s) {}
+};
+struct ArgError : std::runtime_error {
+  explicit ArgError(const std::string& s) : std::runtime_error(s) {}
+};
+struct NotConverged : std::runtime_error {
+  explicit NotConverged(const std::string& s) : std::runtime_error(s) {}
+};
+
+#define HIP_CHECK(expr)                                                                   \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      char _b[512];                                                                       \
+      snprintf(_b, sizeof(_b), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,              \
+               hipGetErrorString(_e));                                                    \
+      throw ::mitdvp::HipError(_b);                                                       \
+    }                                                                                     \
+  } while (0)
+
+__host__ __device__ inline zc zmake(double re, double im) { return make_double2(re, im); }
+__host__ __device__ inline zc zmul(zc a, zc b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__host__ __device__ inline zc zconj(zc a) { return make_double2(a.x, -a.y); }
+__host__ __device__ inline zc zadd(zc a, zc b) { return make_double2(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline zc zsub(zc a, zc b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+// ---------------------------------------------------------------- zgemm.hip
+struct ZgemmDesc {
+  const zc* A;
+  const zc* B;
+  zc* C;
+  int M, N, K;
+  long lda, ldb, ldc;              // leading dimensions in complex elements
+  long strideA, strideB, strideC;  // batch strides (0 = shared operand)
+  int batch;
+  int transA;  // 0: A stored [M][K]; 1: A stored [K][M]
+  int conjA;
+  int transB;  // 0: B stored [K][N]; 1: B stored [N][K]
+  int conjB;
+  zc alpha, beta;
+  int tile_cfg;  // -1 auto; 0: 128x128, 1: 64x64, 2: 32x32
+};
+// C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
+void zgemm(hipStream_t st, const ZgemmDesc& d);
+inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K) {
+  ZgemmDesc d{};
+  d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K;
+  d.lda = K; d.ldb = N; d.ldc = N; d.batch = 1;
+  d.alpha = make_double2(1.0, 0.0); d.beta = make_double2(0.0, 0.0);
+  d.tile_cfg = -1;
+  return d;
+}
+double mfma_peak_probe(hipStream_t st);
+void mfma_layout_probe(hipStream_t st, int* host_out);
+
+}  // namespace mitdvp

@@ -1,0 +1,149 @@
+// engine.h -- device-resident one-site TDVP engine (host orchestration).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mitdvp.h"
+#include "common.h"
+#include "qr.h"
+#include "vecops.h"
+
+namespace mitdvp {
+
+// growable device buffer (complex elements)
+struct DevBuf {
+  zc* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void reserve(size_t elems) {
+    if (elems <= n) return;
+    release();
+    if (elems == 0) return;
+    HIP_CHECK(hipMalloc(&p, elems * sizeof(zc)));
+    n = elems;
+  }
+};
+
+struct MpoSite {
+  int ml = 0, d = 0, mr = 0;
+  DevBuf w2l;  // W2L[(i,t)][(c,j)] = W[c,i,j,t]   (d*mr) x (ml*d)
+  DevBuf w2r;  // W2R[(i,c)][(t,j)] = W[c,i,j,t]   (d*ml) x (mr*d)
+  bool set = false;
+};
+struct Operator {
+  std::vector<MpoSite> sites;
+  hzc shift{0.0, 0.0};
+};
+
+struct PhaseTimer {
+  hipEvent_t a, b;
+  int kind;
+};
+
+class Engine {
+ public:
+  explicit Engine(const mitdvp_config& cfg);
+  ~Engine();
+
+  // state
+  void set_site(int isite, const double* reim, int l, int n, int r, int gauge);
+  void get_site_shape(int isite, int* l, int* n, int* r, int* gauge) const;
+  void get_site(int isite, double* out);
+  void init_random(const int* dims, int bond_dim, uint64_t seed);
+  void canonicalize(double scale);
+  void set_mpo_core(int op_id, int isite, const double* reim, int ml, int dout, int din, int mr);
+  void set_shift(int op_id, double re, double im);
+
+  // hot path
+  void step(double dt);
+  void sweep(double dt, bool forward);
+  void invalidate_env();
+
+  // observables
+  hzc expect(int op_id);
+  hzc autocorr();
+  double norm();
+  void site_rdm(int isite, double* out);
+  void krylov_stats(int* per_site) const;
+
+  void counters_get(mitdvp_counters* out);
+  void counters_reset();
+  void set_profiling(bool on) { profiling_ = on; }
+
+  std::string last_error;
+
+  // ---- building blocks (also used by the unit-level C entry points) -------
+  void heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
+                  hzc shift);
+  void keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift);
+  // generic environment update: env_in (din, min, din), T (din, d, dout),
+  // W2 ((d*mout) x (min*d)) -> env_out (dout, mout, dout)
+  void env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
+                  int mout);
+  // x <- exp(scale * Op) x ; returns Krylov dimension used
+  template <class MV>
+  int krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev);
+  void gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* sigma_out);   // Psi2Asigma
+  void gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc* Bt_out, zc* sigma_out);  // Psi2sigmaB
+  void ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n);
+  hipStream_t stream() const { return st_; }
+  const MpoSite& mpo(int op_id, int isite);
+  mitdvp_config cfg;
+
+ private:
+  int L_;
+  hipStream_t st_ = nullptr;
+  std::vector<int> dl_, dd_, dr_, gauge_;
+  std::vector<DevBuf> site_;
+  std::map<int, Operator> ops_;
+  int center_ = -1;
+
+  // environment cache: bond b is left of site b, b = 0..L
+  std::vector<DevBuf> envL_, envR_;
+  std::vector<char> envL_ok_, envR_ok_;
+  std::vector<DevBuf> pool_;
+  DevBuf pool_get(size_t elems);
+  void pool_put(DevBuf&& b);
+
+  // workspaces
+  DevBuf X_, Y_, V_, tmp1_, tmp2_, sig_, sig2_, qrwork_, red_;
+  zc* h_red_ = nullptr;  // pinned host mirror of red_
+  size_t red_elems_ = 0;
+  std::vector<int> kprev_;
+
+  // counters
+  mitdvp_counters cnt_{};
+  bool profiling_ = false;
+  std::vector<PhaseTimer> pending_;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool_;
+  void timer_begin(int kind);
+  void timer_end();
+  void resolve_timers();
+  int cur_timer_ = -1;
+
+  Operator& op(int id);
+  void size_workspaces();
+  void build_right_envs();
+  void local_site_exp(int p, double dt);
+  void require_ready();
+  hzc scale_site(double dt) const;
+  hzc scale_bond(double dt) const;
+  void read_partials(size_t off_elems, size_t count);
+};
+
+}  // namespace mitdvp

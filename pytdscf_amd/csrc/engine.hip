@@ -1,0 +1,816 @@
+// engine.hip -- host orchestration of the device-resident one-site TDVP sweep.
+//
+// Reference path being replaced (paths relative to /root/reference/pytdscf):
+//   MPSCoef.propagate / propagate_along_sweep      _mps_cls.py:452-503, :798-1014
+//   exp_superH/K_propagation_direct                _mps_cls.py:1016-1170
+//   trans_next_psite_AsigmaB / APsiB               _mps_cls.py:1798-1850, :1172-1206
+//   renormalize_op_psite / contract_with_site_mpo  _mps_mpo.py:421-696, _contraction.py:148-397
+//   multiplyH/K_MPS_direct_MPO.dot                 _contraction.py:1182-1243, :1358-1407
+//   short_iterative_lanczos / _arnoldi             _integrator.py:453-655, :287-432
+//   SiteCoef.gauge_trf                             _site_cls.py:138-292
+//
+// All tensors live in HBM for the whole run; one HIP stream; the host only sees
+// the O(k) Krylov scalars (k <= 20) at the points where the reference evaluates
+// its convergence test.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "small_linalg.h"
+
+namespace mitdvp {
+
+static const double KRYLOV_EPS = 1e-12;  // _integrator.py:22
+
+// layout of the reduction scratch (units: zc)
+static constexpr size_t RED_ALPHA = 0;                                   // [MAXK][NPART] zc
+static constexpr size_t RED_NRM = RED_ALPHA + (size_t)MAXK * NPART;      // [MAXK][NPART] double
+static constexpr size_t RED_H = RED_NRM + (size_t)MAXK * NPART / 2 + 1;  // [MAXK][MAXK][NPART] zc
+static constexpr size_t RED_MISC = RED_H + (size_t)MAXK * MAXK * NPART;  // [4][NPART] zc
+static constexpr size_t RED_TOTAL = RED_MISC + 4 * (size_t)NPART;
+
+Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
+  if (c.nsite < 1) throw ArgError("nsite must be >= 1");
+  if (c.max_krylov < 1 || c.max_krylov > MAXK - 1) throw ArgError("max_krylov must be in [1, 20]");
+  if (c.integrator != MITDVP_LANCZOS && c.integrator != MITDVP_ARNOLDI) throw ArgError("bad integrator");
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
+  if (c.device < 0 || c.device >= ndev) throw ArgError("bad device ordinal");
+  HIP_CHECK(hipSetDevice(c.device));
+  HIP_CHECK(hipStreamCreate(&st_));
+  dl_.assign(L_, 0); dd_.assign(L_, 0); dr_.assign(L_, 0); gauge_.assign(L_, -1);
+  site_.resize(L_);
+  envL_.resize(L_ + 1); envR_.resize(L_ + 1);
+  envL_ok_.assign(L_ + 1, 0); envR_ok_.assign(L_ + 1, 0);
+  kprev_.assign(L_, 0);
+  red_.reserve(RED_TOTAL);
+  red_elems_ = RED_TOTAL;
+  HIP_CHECK(hipHostMalloc((void**)&h_red_, RED_TOTAL * sizeof(zc)));
+  // trivial boundary blocks, construct_op_zerosite (_mps_mpo.py:364-419)
+  const zc one = make_double2(1.0, 0.0);
+  envL_[0].reserve(1); envR_[L_].reserve(1);
+  HIP_CHECK(hipMemcpyAsync(envL_[0].p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipMemcpyAsync(envR_[L_].p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  envL_ok_[0] = 1; envR_ok_[L_] = 1;
+}
+
+Engine::~Engine() {
+  if (st_) (void)hipStreamSynchronize(st_);
+  for (auto& t : pending_) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto& e : evpool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (h_red_) (void)hipHostFree(h_red_);
+  if (st_) (void)hipStreamDestroy(st_);
+}
+
+// ---------------------------------------------------------------------------
+DevBuf Engine::pool_get(size_t elems) {
+  for (size_t i = 0; i < pool_.size(); ++i)
+    if (pool_[i].n >= elems && pool_[i].n <= elems + elems / 2 + 64) {
+      DevBuf b = std::move(pool_[i]);
+      pool_.erase(pool_.begin() + i);
+      return b;
+    }
+  DevBuf b;
+  b.reserve(elems);
+  return b;
+}
+void Engine::pool_put(DevBuf&& b) {
+  if (b.p) pool_.push_back(std::move(b));
+}
+
+void Engine::timer_begin(int kind) {
+  if (!profiling_) return;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!evpool_.empty()) { ev = evpool_.back(); evpool_.pop_back(); }
+  else { HIP_CHECK(hipEventCreate(&ev.first)); HIP_CHECK(hipEventCreate(&ev.second)); }
+  HIP_CHECK(hipEventRecord(ev.first, st_));
+  pending_.push_back(PhaseTimer{ev.first, ev.second, kind});
+  cur_timer_ = (int)pending_.size() - 1;
+}
+void Engine::timer_end() {
+  if (!profiling_ || cur_timer_ < 0) return;
+  HIP_CHECK(hipEventRecord(pending_[cur_timer_].b, st_));
+  cur_timer_ = -1;
+  if (pending_.size() > 8192) resolve_timers();
+}
+void Engine::resolve_timers() {
+  if (pending_.empty()) return;
+  HIP_CHECK(hipStreamSynchronize(st_));
+  for (auto& t : pending_) {
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, t.a, t.b));
+    switch (t.kind) {
+      case 0: cnt_.heff_ms += ms; break;
+      case 1: cnt_.env_ms += ms; break;
+      case 2: cnt_.keff_ms += ms; break;
+      case 3: cnt_.qr_ms += ms; break;
+      default: cnt_.krylov_vec_ms += ms; break;
+    }
+    evpool_.emplace_back(t.a, t.b);
+  }
+  pending_.clear();
+}
+void Engine::counters_get(mitdvp_counters* out) {
+  resolve_timers();
+  *out = cnt_;
+}
+void Engine::counters_reset() {
+  resolve_timers();
+  std::memset(&cnt_, 0, sizeof(cnt_));
+}
+
+void Engine::read_partials(size_t off, size_t count) {
+  HIP_CHECK(hipMemcpyAsync(h_red_ + off, red_.p + off, count * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+// ---------------------------------------------------------------------------
+// state
+// ---------------------------------------------------------------------------
+void Engine::set_site(int i, const double* reim, int l, int n, int r, int gauge) {
+  if (i < 0 || i >= L_) throw ArgError("set_site: bad site index");
+  if (l < 1 || n < 1 || r < 1) throw ArgError("set_site: bad shape");
+  const size_t e = (size_t)l * n * r;
+  site_[i].reserve(e);
+  HIP_CHECK(hipMemcpyAsync(site_[i].p, reim, e * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  dl_[i] = l; dd_[i] = n; dr_[i] = r; gauge_[i] = gauge;
+  if (gauge == MITDVP_GAUGE_PSI) center_ = i;
+  invalidate_env();
+}
+void Engine::get_site_shape(int i, int* l, int* n, int* r, int* gauge) const {
+  if (i < 0 || i >= L_) throw ArgError("get_site_shape: bad site index");
+  *l = dl_[i]; *n = dd_[i]; *r = dr_[i]; *gauge = gauge_[i];
+}
+void Engine::get_site(int i, double* out) {
+  if (i < 0 || i >= L_ || !site_[i].p) throw ArgError("get_site: bad or unset site");
+  const size_t e = (size_t)dl_[i] * dd_[i] * dr_[i];
+  HIP_CHECK(hipMemcpyAsync(out, site_[i].p, e * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+Operator& Engine::op(int id) {
+  auto it = ops_.find(id);
+  if (it == ops_.end()) {
+    Operator o;
+    o.sites.resize(L_);
+    it = ops_.emplace(id, std::move(o)).first;
+  }
+  return it->second;
+}
+const MpoSite& Engine::mpo(int op_id, int isite) {
+  auto it = ops_.find(op_id);
+  if (it == ops_.end() || !it->second.sites[isite].set) throw ArgError("operator core not set for this site");
+  return it->second.sites[isite];
+}
+
+void Engine::set_mpo_core(int op_id, int isite, const double* reim, int ml, int dout, int din, int mr) {
+  if (isite < 0 || isite >= L_) throw ArgError("set_mpo_core: bad site index");
+  if (ml < 1 || mr < 1 || dout < 1 || dout != din) throw ArgError("set_mpo_core: need a square 4-leg core");
+  const int d = dout;
+  const hzc* W = reinterpret_cast<const hzc*>(reim);
+  std::vector<hzc> w2l((size_t)d * mr * ml * d), w2r((size_t)d * ml * mr * d);
+  for (int c = 0; c < ml; ++c)
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j)
+        for (int t = 0; t < mr; ++t) {
+          const hzc v = W[(((size_t)c * d + i) * d + j) * mr + t];
+          w2l[((size_t)i * mr + t) * ((size_t)ml * d) + (size_t)c * d + j] = v;
+          w2r[((size_t)i * ml + c) * ((size_t)mr * d) + (size_t)t * d + j] = v;
+        }
+  MpoSite& s = op(op_id).sites[isite];
+  s.ml = ml; s.d = d; s.mr = mr;
+  s.w2l.reserve(w2l.size());
+  s.w2r.reserve(w2r.size());
+  HIP_CHECK(hipMemcpyAsync(s.w2l.p, w2l.data(), w2l.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipMemcpyAsync(s.w2r.p, w2r.data(), w2r.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  s.set = true;
+  if (op_id == 0) invalidate_env();
+}
+void Engine::set_shift(int op_id, double re, double im) { op(op_id).shift = hzc(re, im); }
+
+void Engine::invalidate_env() {
+  for (int b = 1; b < L_; ++b) {
+    envL_ok_[b] = 0; envR_ok_[b] = 0;
+    pool_put(std::move(envL_[b]));
+    pool_put(std::move(envR_[b]));
+  }
+}
+
+void Engine::ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n) {
+  X_.reserve(max_x);
+  Y_.reserve(max_y);
+  V_.reserve((size_t)MAXK * max_site);
+  tmp1_.reserve(max_site);
+  tmp2_.reserve(max_site);
+  const size_t dd = (size_t)max_qr_n * max_qr_n;
+  sig_.reserve(std::max<size_t>(dd, 1));
+  sig2_.reserve(std::max<size_t>(dd, 1));
+  qrwork_.reserve(qr_work_elems(max_qr_m, max_qr_n));
+}
+
+void Engine::size_workspaces() {
+  long ms = 1, mx = 1, my = 1;
+  int qm = 1, qn = 1;
+  for (int p = 0; p < L_; ++p) {
+    const long s = (long)dl_[p] * dd_[p] * dr_[p];
+    ms = std::max(ms, s);
+    qm = std::max(qm, std::max(dl_[p], dr_[p]) * dd_[p]);
+    qn = std::max(qn, std::max(dl_[p], dr_[p]));
+    for (auto& kv : ops_) {
+      const MpoSite& w = kv.second.sites[p];
+      if (!w.set) continue;
+      const long mm = std::max(w.ml, w.mr);
+      mx = std::max(mx, (long)dl_[p] * dr_[p] * dd_[p] * mm);
+      my = std::max(my, (long)dl_[p] * dr_[p] * dd_[p] * mm);
+    }
+  }
+  ensure_work(ms, mx, my, qm, qn);
+}
+
+void Engine::require_ready() {
+  for (int p = 0; p < L_; ++p) {
+    if (!site_[p].p) throw ArgError("site tensor not set");
+    if (p + 1 < L_ && dr_[p] != dl_[p + 1]) throw ArgError("bond dimension mismatch between neighbouring sites");
+  }
+  if (dl_[0] != 1 || dr_[L_ - 1] != 1) throw ArgError("open boundary bonds must be 1");
+  size_workspaces();
+}
+
+// ---------------------------------------------------------------------------
+// contractions
+// ---------------------------------------------------------------------------
+void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
+                        hzc shift) {
+  const int ml = w.ml, mr = w.mr;
+  timer_begin(0);
+  {  // X[(a,c)][(j,s)] = L[(a,c)][b] psi[b][(j,s)]
+    ZgemmDesc g = zgemm_desc(L, psi, X_.p, dl * ml, d * dr, dl);
+    zgemm(st_, g);
+  }
+  {  // Y_a[(i,t)][s] = W2L[(i,t)][(c,j)] X_a[(c,j)][s]
+    ZgemmDesc g = zgemm_desc(w.w2l.p, X_.p, Y_.p, d * mr, dr, ml * d);
+    g.batch = dl; g.strideA = 0; g.strideB = (long)ml * d * dr; g.strideC = (long)d * mr * dr;
+    zgemm(st_, g);
+  }
+  {  // out[(a,i)][r] = Y[(a,i)][(t,s)] R[r][(t,s)]
+    ZgemmDesc g = zgemm_desc(Y_.p, R, out, dl * d, dr, mr * dr);
+    g.transB = 1; g.ldb = (long)mr * dr;
+    zgemm(st_, g);
+  }
+  if (shift != hzc(0.0, 0.0))
+    vec_axpby(st_, out, psi, (long)dl * d * dr, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
+  timer_end();
+  cnt_.n_launch += 3;
+  cnt_.n_heff += 1;
+  cnt_.heff_flops += 8.0 * ((double)dl * dl * ml * d * dr + (double)dl * dr * ml * mr * d * d + (double)dl * dr * dr * mr * d);
+}
+
+void Engine::keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift) {
+  timer_begin(2);
+  {  // X[(a,c)][s] = L[(a,c)][b] sig[b][s]
+    ZgemmDesc g = zgemm_desc(L, sig, X_.p, d1 * m, d2, d1);
+    zgemm(st_, g);
+  }
+  {  // out[a][r] = X[a][(c,s)] R[r][(c,s)]
+    ZgemmDesc g = zgemm_desc(X_.p, R, out, d1, d2, m * d2);
+    g.transB = 1; g.ldb = (long)m * d2;
+    zgemm(st_, g);
+  }
+  if (shift != hzc(0.0, 0.0))
+    vec_axpby(st_, out, sig, (long)d1 * d2, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
+  timer_end();
+  cnt_.n_launch += 2;
+  cnt_.n_keff += 1;
+  cnt_.keff_flops += 8.0 * ((double)d1 * d1 * m * d2 + (double)d1 * d2 * d2 * m);
+}
+
+void Engine::env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
+                        int mout) {
+  timer_begin(1);
+  {  // X[(m,p)][(s,j)] = env[(m,p)][n] T[n][(s,j)]
+    ZgemmDesc g = zgemm_desc(env_in, T, X_.p, din * min_, d * dout, din);
+    zgemm(st_, g);
+  }
+  {  // Y_m[(r,q)][j] = W2[(r,q)][(p,s)] X_m[(p,s)][j]
+    ZgemmDesc g = zgemm_desc(w2, X_.p, Y_.p, d * mout, dout, min_ * d);
+    g.batch = din; g.strideA = 0; g.strideB = (long)min_ * d * dout; g.strideC = (long)d * mout * dout;
+    zgemm(st_, g);
+  }
+  {  // env'[i][(q,j)] = conj(T)[(m,r)][i] Y[(m,r)][(q,j)]
+    ZgemmDesc g = zgemm_desc(T, Y_.p, env_out, dout, mout * dout, din * d);
+    g.transA = 1; g.conjA = 1; g.lda = dout;
+    zgemm(st_, g);
+  }
+  timer_end();
+  cnt_.n_launch += 3;
+  cnt_.n_env += 1;
+  cnt_.env_flops += 8.0 * ((double)din * din * min_ * d * dout + (double)din * dout * min_ * mout * d * d +
+                           (double)din * dout * dout * mout * d);
+}
+
+// ---------------------------------------------------------------------------
+// local propagator: x <- exp(scale*Op) x
+// ---------------------------------------------------------------------------
+template <class MV>
+int Engine::krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev) {
+  const int ndim = (int)std::min<long>(n, cfg.max_krylov);
+  // _iter_info (_integrator.py:178-186)
+  const int n_warm = (int)std::min<long>(n, std::min(std::max(0, k_prev - 2), 15));
+  const bool lanczos = cfg.integrator == MITDVP_LANCZOS;
+  const bool cn = cfg.conserve_norm != 0;
+  zc* V = V_.p;
+  const long ldv = n;
+  zc* alpha_p = red_.p + RED_ALPHA;
+  double* nrm_p = reinterpret_cast<double*>(red_.p + RED_NRM);
+  zc* h_p = red_.p + RED_H;
+  double* misc_d = reinterpret_cast<double*>(red_.p + RED_MISC);
+
+  // _normalize (_integrator.py:189-203)
+  double beta0 = 1.0;
+  HIP_CHECK(hipMemcpyAsync(V, x, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  if (!cn) {
+    vec_sumsq(st_, x, n, misc_d);
+    read_partials(RED_MISC, NPART / 2);
+    const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+    double s = 0;
+    for (int i = 0; i < NPART; ++i) s += hp[i];
+    beta0 = std::sqrt(s);
+    if (beta0 == 0.0) throw ArgError("Initial psi has zero norm.");
+    vec_scale(st_, V, n, make_double2(1.0 / beta0, 0.0));
+  }
+
+  std::vector<hzc> alpha;            // Lanczos diagonal
+  std::vector<double> beta;          // norms of the new vectors
+  std::vector<hzc> hess((size_t)(ndim + 1) * ndim, hzc(0, 0));  // Arnoldi Hessenberg (row-major, ld = ndim)
+  std::vector<hzc> coef_prev;
+  int next_unread = 0;
+
+  auto sum_z = [&](size_t off) {
+    double re = 0, im = 0;
+    for (int i = 0; i < NPART; ++i) { re += h_red_[off + i].x; im += h_red_[off + i].y; }
+    return hzc(re, im);
+  };
+  auto sum_d = [&](size_t off_zc, int row) {
+    const double* p = reinterpret_cast<const double*>(h_red_ + off_zc) + (size_t)row * NPART;
+    double s = 0;
+    for (int i = 0; i < NPART; ++i) s += p[i];
+    return s;
+  };
+
+  auto finalize = [&](const std::vector<hzc>& coef, int k) {
+    Coefs c{};
+    for (int j = 0; j < k; ++j) {
+      const hzc v = cn ? coef[j] : coef[j] * beta0;  // _rescale, :206-213
+      c.c[j] = make_double2(v.real(), v.imag());
+    }
+    if (cn) {
+      vec_lincomb(st_, x, V, ldv, k, c, n, misc_d);
+      read_partials(RED_MISC, NPART / 2);
+      const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+      double s = 0;
+      for (int i = 0; i < NPART; ++i) s += hp[i];
+      vec_scale(st_, x, n, make_double2(1.0 / std::sqrt(s), 0.0));
+    } else {
+      vec_lincomb(st_, x, V, ldv, k, c, n, nullptr);
+    }
+    cnt_.n_launch += 2;
+  };
+
+  for (int l = 0; l < ndim; ++l) {
+    zc* vl = V + (size_t)l * ldv;
+    zc* vn = V + (size_t)(l + 1) * ldv;
+    matvec(vl, vn);
+    timer_begin(4);
+    if (lanczos) {
+      // alpha_l = <v0 | H v_l> (reference, :556) or <v_l | H v_l> (orthodox)
+      vec_dot(st_, cfg.lanczos_variant == 0 ? V : vl, vn, n, true, alpha_p + (size_t)l * NPART);
+      vec_lanczos_update(st_, vn, vl, l > 0 ? V + (size_t)(l - 1) * ldv : nullptr, n, alpha_p + (size_t)l * NPART,
+                         l > 0 ? nrm_p + (size_t)(l - 1) * NPART : nullptr, nrm_p + (size_t)l * NPART);
+    } else {
+      vec_multi_dot(st_, V, ldv, l + 1, vn, n, h_p + (size_t)l * MAXK * NPART);
+      vec_arnoldi_update(st_, vn, V, ldv, l + 1, n, h_p + (size_t)l * MAXK * NPART, nrm_p + (size_t)l * NPART);
+    }
+    vec_scale_inv_norm(st_, vn, n, nrm_p + (size_t)l * NPART, KRYLOV_EPS);
+    timer_end();
+    cnt_.n_launch += 3;
+
+    const bool last_possible = (l + 1 == n);
+    if (l < n_warm && !last_possible && l + 1 < ndim) continue;  // warm-up: no host sync (:578-579)
+
+    // ---- bring the scalars of iterations [next_unread, l] to the host -------
+    if (lanczos) {
+      read_partials(RED_ALPHA + (size_t)next_unread * NPART, (size_t)(l + 1 - next_unread) * NPART);
+    } else {
+      read_partials(RED_H + (size_t)next_unread * MAXK * NPART, (size_t)(l + 1 - next_unread) * MAXK * NPART);
+    }
+    read_partials(RED_NRM, (size_t)MAXK * NPART / 2 + 1);
+    int ld = l;
+    bool exhausted = false;
+    for (int q = next_unread; q <= l; ++q) {
+      const double b = std::sqrt(sum_d(RED_NRM, q));
+      if ((int)beta.size() <= q) beta.resize(q + 1);
+      beta[q] = b;
+      if (lanczos) {
+        if ((int)alpha.size() <= q) alpha.resize(q + 1);
+        alpha[q] = sum_z(RED_ALPHA + (size_t)q * NPART);
+      } else {
+        for (int j = 0; j <= q; ++j) hess[(size_t)j * ndim + q] = sum_z(RED_H + ((size_t)q * MAXK + j) * NPART);
+        if (b > KRYLOV_EPS && q + 1 < ndim + 1) hess[(size_t)(q + 1) * ndim + q] = b;
+      }
+      if (b < KRYLOV_EPS || q + 1 == n) {  // Krylov space exhausted (:569, :392)
+        ld = q;
+        exhausted = true;
+        break;
+      }
+    }
+    next_unread = l + 1;
+    if (ld < n_warm && !exhausted) continue;
+
+    // ---- Ritz propagation in the Krylov space (:581-637, :397-409) ---------
+    const int k = ld + 1;
+    std::vector<hzc> coef(k);
+    if (ld == 0) {
+      coef[0] = std::exp(scale * (lanczos ? alpha[0] : hess[0]));
+    } else if (lanczos) {
+      bool real_alpha = true;
+      for (int q = 0; q < k; ++q)
+        if (std::fabs(alpha[q].imag()) > 1e-10) real_alpha = false;
+      if (real_alpha) {
+        std::vector<double> a(k), b(k);
+        for (int q = 0; q < k; ++q) { a[q] = alpha[q].real(); b[q] = beta[q]; }
+        coef = expm_tridiag_e0(a, b, k, scale);
+      } else {
+        std::vector<hzc> T((size_t)k * k, hzc(0, 0));
+        for (int q = 0; q < k; ++q) {
+          T[(size_t)q * k + q] = scale * alpha[q];
+          if (q + 1 < k) T[(size_t)q * k + q + 1] = T[(size_t)(q + 1) * k + q] = scale * beta[q];
+        }
+        coef = expm_col0(T, k);
+      }
+    } else {
+      std::vector<hzc> Hk((size_t)k * k);
+      for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) Hk[(size_t)i * k + j] = scale * hess[(size_t)i * ndim + j];
+      coef = expm_col0(Hk, k);
+    }
+
+    if (exhausted) {
+      finalize(coef, k);
+      return k;
+    }
+    if (!coef_prev.empty()) {
+      // || psi_k - psi_{k-1} ||  (:644-652) without materialising either vector
+      Coefs dc{};
+      for (int j = 0; j < k; ++j) {
+        const hzc dlt = coef[j] - (j < (int)coef_prev.size() ? coef_prev[j] : hzc(0, 0));
+        dc.c[j] = make_double2(dlt.real(), dlt.imag());
+      }
+      vec_lincomb(st_, nullptr, V, ldv, k, dc, n, misc_d);
+      cnt_.n_launch += 1;
+      read_partials(RED_MISC, NPART / 2);
+      const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+      double s = 0;
+      for (int i = 0; i < NPART; ++i) s += hp[i];
+      if (std::sqrt(s) < cfg.thresh) {
+        finalize(coef, k);
+        return k;
+      }
+    }
+    coef_prev = coef;
+  }
+  throw NotConverged(std::string(lanczos ? "Short Iterative Lanczos" : "Short Iterative Arnoldi") +
+                     " is not converged in " + std::to_string(ndim) + " basis. Try shorter time interval.");
+}
+
+// ---------------------------------------------------------------------------
+// gauge moves
+// ---------------------------------------------------------------------------
+void Engine::gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* sigma_out) {
+  const long n = (long)dl * d * dr;
+  HIP_CHECK(hipMemcpyAsync(tmp1_.p, psi, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  timer_begin(3);
+  long nl = 0;
+  qr_householder(st_, tmp1_.p, dl * d, dr, A_out, sigma_out, qrwork_.p, &nl);
+  timer_end();
+  cnt_.n_launch += nl;
+  cnt_.n_qr += 1;
+  const double m = (double)dl * d, nn = dr;
+  cnt_.qr_flops += 4.0 * (4.0 * m * nn * nn - 4.0 * nn * nn * nn / 3.0);
+}
+
+void Engine::gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc* Bt_out, zc* sigma_out) {
+  timer_begin(3);
+  long nl = 0;
+  transpose_rev3(st_, psi, tmp1_.p, dl, d, dr);  // (dr, d, dl)
+  qr_householder(st_, tmp1_.p, dr * d, dl, Bt_out, sig2_.p, qrwork_.p, &nl);
+  transpose_batched(st_, sig2_.p, sigma_out, dl, dl, dl, dl, 1, 0, 0);  // sigma = R^T
+  if (B_out) transpose_rev3(st_, Bt_out, B_out, dr, d, dl);             // (dl, d, dr)
+  timer_end();
+  cnt_.n_launch += nl + 3;
+  cnt_.n_qr += 1;
+  const double m = (double)dr * d, nn = dl;
+  cnt_.qr_flops += 4.0 * (4.0 * m * nn * nn - 4.0 * nn * nn * nn / 3.0);
+}
+
+// ---------------------------------------------------------------------------
+// initial state
+// ---------------------------------------------------------------------------
+void Engine::init_random(const int* dims, int D, uint64_t seed) {
+  if (D < 1) throw ArgError("bond_dim must be >= 1");
+  // LatticeInfo.get_bond_dim (_mps_cls.py:2616-2631), products saturated at D
+  auto satprod = [&](int lo, int hi) {
+    double p = 1;
+    for (int i = lo; i < hi; ++i) { p *= dims[i]; if (p > D) return (long)D + 1; }
+    return (long)p;
+  };
+  for (int i = 0; i < L_; ++i) {
+    if (dims[i] < 1) throw ArgError("bad physical dimension");
+    const long left = i == 0 ? 1 : std::min<long>(D, satprod(0, i));
+    const long right = i == L_ - 1 ? 1 : std::min<long>(D, satprod(i + 1, L_));
+    const long dc = dims[i];
+    dl_[i] = (int)std::min({left, dc * right, (long)D});
+    dr_[i] = (int)std::min({left * dc, right, (long)D});
+    dd_[i] = dims[i];
+    const size_t e = (size_t)dl_[i] * dd_[i] * dr_[i];
+    site_[i].reserve(e);
+    vec_randn(st_, site_[i].p, (long)e, seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
+    gauge_[i] = -1;
+  }
+  invalidate_env();
+  canonicalize(1.0);
+}
+
+void Engine::canonicalize(double scale) {
+  require_ready();
+  DevBuf spare = pool_get(V_.n / MAXK);
+  for (int p = L_ - 1; p > 0; --p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    // C2sigmaB (_mps_cls.py:2684-2693)
+    gauge_qr_right(site_[p].p, dl, d, dr, spare.p, tmp2_.p, sig_.p);
+    std::swap(site_[p], spare);
+    gauge_[p] = MITDVP_GAUGE_B;
+    // site[p-1] <- site[p-1] . sigma
+    const int m = dl_[p - 1] * dd_[p - 1];
+    ZgemmDesc g = zgemm_desc(site_[p - 1].p, sig_.p, spare.p, m, dl, dl);
+    zgemm(st_, g);
+    std::swap(site_[p - 1], spare);
+    cnt_.n_launch += 1;
+  }
+  pool_put(std::move(spare));
+  const long n0 = (long)dl_[0] * dd_[0] * dr_[0];
+  vec_sumsq(st_, site_[0].p, n0, reinterpret_cast<double*>(red_.p + RED_MISC));
+  read_partials(RED_MISC, NPART / 2);
+  const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+  double s = 0;
+  for (int i = 0; i < NPART; ++i) s += hp[i];
+  if (s == 0.0) throw ArgError("canonicalize: zero state");
+  vec_scale(st_, site_[0].p, n0, make_double2(scale / std::sqrt(s), 0.0));
+  gauge_[0] = MITDVP_GAUGE_PSI;
+  center_ = 0;
+  invalidate_env();
+}
+
+// ---------------------------------------------------------------------------
+// sweep
+// ---------------------------------------------------------------------------
+hzc Engine::scale_site(double dt) const { return cfg.relax ? hzc(-dt / 2, 0.0) : hzc(0.0, -dt / 2); }
+hzc Engine::scale_bond(double dt) const { return cfg.relax ? hzc(+dt / 2, 0.0) : hzc(0.0, +dt / 2); }
+
+void Engine::build_right_envs() {
+  // construct_op_sites(begin=L-1, end=0) (_mps_cls.py:835-843, :1738-1796)
+  for (int p = L_ - 1; p >= 1; --p) {
+    if (envR_ok_[p]) continue;
+    if (!envR_ok_[p + 1]) throw ArgError("internal: right environment chain broken");
+    if (gauge_[p] != MITDVP_GAUGE_B) throw ArgError("sites right of the centre must be in gauge B");
+    const MpoSite& w = mpo(0, p);
+    transpose_rev3(st_, site_[p].p, tmp1_.p, dl_[p], dd_[p], dr_[p]);
+    envR_[p] = pool_get((size_t)dl_[p] * w.ml * dl_[p]);
+    env_update(envR_[p + 1].p, tmp1_.p, w.w2r.p, envR_[p].p, dr_[p], w.mr, dd_[p], dl_[p], w.ml);
+    envR_ok_[p] = 1;
+  }
+}
+
+void Engine::local_site_exp(int p, double dt) {
+  const MpoSite& w = mpo(0, p);
+  if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
+  const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+  const zc* Lb = envL_[p].p;
+  const zc* Rb = envR_[p + 1].p;
+  const hzc shift = op(0).shift;
+  auto mv = [&](const zc* in, zc* out) { heff_apply(Lb, w, Rb, in, out, dl, d, dr, shift); };
+  kprev_[p] = krylov_exp(scale_site(dt), mv, site_[p].p, (long)dl * d * dr, kprev_[p]);
+  cnt_.n_exp_site += 1;
+}
+
+void Engine::sweep(double dt, bool forward) {
+  require_ready();
+  if (L_ == 1) {
+    if (center_ != 0) throw ArgError("no centre site");
+    local_site_exp(0, dt);
+    return;
+  }
+  const int begin = forward ? 0 : L_ - 1, end = forward ? L_ - 1 : 0;
+  if (center_ != begin) throw ArgError("sweep must start at the centre (Psi) site");
+  if (forward) build_right_envs();
+  else
+    for (int b = 1; b < L_; ++b)
+      if (!envL_ok_[b]) throw ArgError("backward sweep needs the left environments of a forward sweep");
+  const hzc shift = op(0).shift;
+  DevBuf spare = pool_get(V_.n / MAXK);
+  for (int p = begin; forward ? p <= end : p >= end; p += forward ? 1 : -1) {
+    local_site_exp(p, dt);  // exp_superH_propagation_direct
+    if (p == end) break;
+    const MpoSite& w = mpo(0, p);
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    if (forward) {
+      // Psi2Asigma: site[p] (destroyed) -> A in spare, sigma in sig_
+      timer_begin(3);
+      long nl = 0;
+      qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl);
+      timer_end();
+      cnt_.n_launch += nl; cnt_.n_qr += 1;
+      cnt_.qr_flops += 4.0 * (4.0 * (double)dl * d * dr * dr - 4.0 * (double)dr * dr * dr / 3.0);
+      std::swap(site_[p], spare);
+      gauge_[p] = MITDVP_GAUGE_A;
+      // renormalize_op_psite: L_{p+1}
+      envL_[p + 1] = pool_get((size_t)dr * w.mr * dr);
+      env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr);
+      envL_ok_[p + 1] = 1;
+      // exp(+i K dt/2) on the bond matrix
+      const zc* Lb = envL_[p + 1].p;
+      const zc* Rb = envR_[p + 1].p;
+      const int m = w.mr;
+      auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dr, dr, m, shift); };
+      kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dr * dr, kprev_[p]);
+      cnt_.n_exp_bond += 1;
+      envR_ok_[p + 1] = 0;
+      pool_put(std::move(envR_[p + 1]));
+      // trans_next_psite_APsiB: Psi(p+1) = sigma . B(p+1)
+      ZgemmDesc g = zgemm_desc(sig_.p, site_[p + 1].p, spare.p, dr, dd_[p + 1] * dr_[p + 1], dr);
+      zgemm(st_, g);
+      cnt_.n_launch += 1;
+      std::swap(site_[p + 1], spare);
+      gauge_[p + 1] = MITDVP_GAUGE_PSI;
+      center_ = p + 1;
+    } else {
+      // Psi2sigmaB: B in spare, mirrored B~ (dr,d,dl) in tmp2_, sigma (dl x dl) in sig_
+      gauge_qr_right(site_[p].p, dl, d, dr, spare.p, tmp2_.p, sig_.p);
+      std::swap(site_[p], spare);
+      gauge_[p] = MITDVP_GAUGE_B;
+      envR_[p] = pool_get((size_t)dl * w.ml * dl);
+      env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml);
+      envR_ok_[p] = 1;
+      const zc* Lb = envL_[p].p;
+      const zc* Rb = envR_[p].p;
+      const int m = w.ml;
+      auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dl, dl, m, shift); };
+      kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dl * dl, kprev_[p]);
+      cnt_.n_exp_bond += 1;
+      envL_ok_[p] = 0;
+      pool_put(std::move(envL_[p]));
+      // Psi(p-1) = A(p-1) . sigma
+      ZgemmDesc g = zgemm_desc(site_[p - 1].p, sig_.p, spare.p, dl_[p - 1] * dd_[p - 1], dl, dl);
+      zgemm(st_, g);
+      cnt_.n_launch += 1;
+      std::swap(site_[p - 1], spare);
+      gauge_[p - 1] = MITDVP_GAUGE_PSI;
+      center_ = p - 1;
+    }
+  }
+  pool_put(std::move(spare));
+}
+
+void Engine::step(double dt) {
+  sweep(dt, true);
+  sweep(dt, false);
+}
+
+// ---------------------------------------------------------------------------
+// observables
+// ---------------------------------------------------------------------------
+double Engine::norm() {
+  if (center_ < 0) throw ArgError("no centre site");
+  const long n = (long)dl_[center_] * dd_[center_] * dr_[center_];
+  vec_sumsq(st_, site_[center_].p, n, reinterpret_cast<double*>(red_.p + RED_MISC));
+  read_partials(RED_MISC, NPART / 2);
+  const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+  double s = 0;
+  for (int i = 0; i < NPART; ++i) s += hp[i];
+  return std::sqrt(s);
+}
+
+hzc Engine::expect(int op_id) {
+  require_ready();
+  if (center_ != 0) throw ArgError("expectation needs the centre at site 0 (psite = 0)");
+  Operator& o = op(op_id);
+  const zc* R1 = nullptr;
+  DevBuf ra, rb;
+  bool cached = (op_id == 0);
+  for (int b = 1; b < L_ && cached; ++b) cached = envR_ok_[b];
+  if (L_ == 1) {
+    R1 = envR_[1].p;
+  } else if (cached) {
+    R1 = envR_[1].p;
+  } else {
+    // fresh right environments (_mps_cls.py:570-576)
+    size_t mx = 1;
+    for (int p = 1; p < L_; ++p) mx = std::max(mx, (size_t)dl_[p] * mpo(op_id, p).ml * dl_[p]);
+    ra = pool_get(mx);
+    rb = pool_get(mx);
+    const zc* cur = envR_[L_].p;
+    for (int p = L_ - 1; p >= 1; --p) {
+      const MpoSite& w = mpo(op_id, p);
+      if (gauge_[p] != MITDVP_GAUGE_B) throw ArgError("sites right of the centre must be in gauge B");
+      transpose_rev3(st_, site_[p].p, tmp1_.p, dl_[p], dd_[p], dr_[p]);
+      env_update(cur, tmp1_.p, w.w2r.p, ra.p, dr_[p], w.mr, dd_[p], dl_[p], w.ml);
+      cur = ra.p;
+      std::swap(ra, rb);  // result now lives in rb
+    }
+    R1 = cur;
+  }
+  const MpoSite& w0 = mpo(op_id, 0);
+  heff_apply(envL_[0].p, w0, R1, site_[0].p, tmp2_.p, dl_[0], dd_[0], dr_[0], o.shift);
+  const long n0 = (long)dl_[0] * dd_[0] * dr_[0];
+  vec_dot(st_, site_[0].p, tmp2_.p, n0, true, red_.p + RED_MISC);
+  read_partials(RED_MISC, NPART);
+  double re = 0, im = 0;
+  for (int i = 0; i < NPART; ++i) { re += h_red_[RED_MISC + i].x; im += h_red_[RED_MISC + i].y; }
+  pool_put(std::move(ra));
+  pool_put(std::move(rb));
+  return hzc(re, im);
+}
+
+hzc Engine::autocorr() {
+  require_ready();
+  // <Psi^*|Psi>: block = einsum("abc,abk->ck", bra, einsum("ibk,ai->abk", ket, block))
+  // with bra = ket unconjugated (wavefunction.py:226-257 with conj=False)
+  const zc one = make_double2(1.0, 0.0);
+  HIP_CHECK(hipMemcpyAsync(sig_.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  zc* T = sig_.p;
+  zc* Tn = sig2_.p;
+  for (int p = 0; p < L_; ++p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    ZgemmDesc u = zgemm_desc(T, site_[p].p, tmp1_.p, dl, d * dr, dl);  // U[m][(s,j)] = T[m][n] C[n][(s,j)]
+    zgemm(st_, u);
+    ZgemmDesc t = zgemm_desc(site_[p].p, tmp1_.p, Tn, dr, dr, dl * d);  // T'[i][j] = C[(m,s)][i] U[(m,s)][j]
+    t.transA = 1; t.lda = dr;
+    zgemm(st_, t);
+    std::swap(T, Tn);
+  }
+  hzc out;
+  HIP_CHECK(hipMemcpyAsync(&out, T, sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  return out;
+}
+
+void Engine::site_rdm(int isite, double* out) {
+  require_ready();
+  if (center_ != 0) throw ArgError("reduced density needs the centre at site 0");
+  if (isite < 0 || isite >= L_) throw ArgError("bad site index");
+  // T[a][a'] = sum over sites < isite of ket (x) conj(bra); sites > isite are right-canonical
+  const zc one = make_double2(1.0, 0.0);
+  HIP_CHECK(hipMemcpyAsync(sig_.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  zc* T = sig_.p;
+  zc* Tn = sig2_.p;
+  for (int p = 0; p <= isite; ++p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    // U[a'][(j,s)] = sum_a T[a][a'] C[a][(j,s)]
+    ZgemmDesc u = zgemm_desc(T, site_[p].p, tmp1_.p, dl, d * dr, dl);
+    u.transA = 1; u.lda = dl;
+    zgemm(st_, u);
+    if (p < isite) {
+      // T'[s][s'] = sum_(a',j) U[(a',j)][s] conj(C[(a',j)][s'])
+      ZgemmDesc t = zgemm_desc(tmp1_.p, site_[p].p, Tn, dr, dr, dl * d);
+      t.transA = 1; t.lda = dr; t.conjB = 1;
+      zgemm(st_, t);
+      std::swap(T, Tn);
+    } else {
+      // rho_a'[j][j'] = sum_s U[a'][j][s] conj(C[a'][j'][s]); summed over a' on the host
+      ZgemmDesc r = zgemm_desc(tmp1_.p, site_[p].p, tmp2_.p, d, d, dr);
+      r.transB = 1; r.conjB = 1; r.ldb = dr; r.ldc = d;
+      r.batch = dl; r.strideA = (long)d * dr; r.strideB = (long)d * dr; r.strideC = (long)d * d;
+      zgemm(st_, r);
+      std::vector<hzc> h((size_t)dl * d * d);
+      HIP_CHECK(hipMemcpyAsync(h.data(), tmp2_.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      hzc* o = reinterpret_cast<hzc*>(out);
+      for (int e = 0; e < d * d; ++e) o[e] = hzc(0, 0);
+      for (int a = 0; a < dl; ++a)
+        for (int e = 0; e < d * d; ++e) o[e] += h[(size_t)a * d * d + e];
+    }
+  }
+}
+
+void Engine::krylov_stats(int* per_site) const {
+  for (int i = 0; i < L_; ++i) per_site[i] = kprev_[i];
+}
+
+}  // namespace mitdvp
+
+#include "capi.inc"

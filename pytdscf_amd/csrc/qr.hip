@@ -1,0 +1,324 @@
+// qr.hip -- complex Householder QR on the GPU for the TDVP gauge move
+// (SiteCoef.gauge_trf, reference _site_cls.py:138-292, which calls LAPACK
+// zgeqrf + zungqr through scipy.linalg.qr(mode="economic")).
+//
+// The algorithm is LAPACK's (zgeqr2 panels + zlarft/zlarfb compact-WY block
+// reflectors + zungqr), so that for full-rank input Q and R agree with the
+// reference's to rounding, including the sign convention (real diagonal of R,
+// beta = -sign(Re alpha)*||x||) and the behaviour on rank-deficient panels
+// (orthonormal completion instead of a breakdown, which CholQR cannot give).
+//
+// Panel columns are reduced with two small multi-workgroup launches per column
+// (row-major panel: 32 columns = 512 contiguous bytes per row); everything of
+// O(m n^2) goes through the MFMA zgemm kernel.
+#include "qr.h"
+
+#include "vecops.h"
+
+namespace mitdvp {
+
+__device__ __forceinline__ double qr_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double qr_block_sum(double v, double* sh) {
+  v = qr_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sh[4] = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return sh[4];
+}
+
+struct House {
+  double beta;
+  zc tau;
+  zc scale;
+};
+
+// LAPACK zlarfg without the safmin rescaling loop
+__device__ __forceinline__ House zlarfg(zc alpha, double xnorm2) {
+  House h;
+  if (xnorm2 == 0.0 && alpha.y == 0.0) {
+    h.beta = alpha.x;
+    h.tau = make_double2(0.0, 0.0);
+    h.scale = make_double2(0.0, 0.0);
+    return h;
+  }
+  const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2);
+  const double beta = alpha.x >= 0.0 ? -nrm : nrm;
+  h.beta = beta;
+  h.tau = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
+  const double dr = alpha.x - beta, di = alpha.y;
+  const double den = dr * dr + di * di;
+  h.scale = make_double2(dr / den, -di / den);
+  return h;
+}
+
+// pn[b] = sum_{i>j} |A[i,j]|^2 over the block's rows ; scal[0] = A[j,j]
+__global__ __launch_bounds__(256) void k_qr_colnorm(const zc* __restrict__ A, long lda, int m, int j,
+                                                    double* __restrict__ pn, zc* __restrict__ scal) {
+  __shared__ double sh[5];
+  const int i = blockIdx.x * QR_ROWS + threadIdx.x;
+  double s = 0;
+  if (i < m && i > j) {
+    const zc a = A[(long)i * lda + j];
+    s = a.x * a.x + a.y * a.y;
+  }
+  if (i == j) scal[0] = A[(long)i * lda + j];
+  s = qr_block_sum(s, sh);
+  if (threadIdx.x == 0) pn[blockIdx.x] = s;
+}
+
+// Householder vector of column j and its products with the rest of the panel:
+//   pw[b][c] = sum_{i in block} conj(v_i) A[i,c]   for j < c < j1
+// then column j is overwritten with v (below the diagonal) and beta (diagonal).
+__global__ __launch_bounds__(256) void k_qr_house(zc* __restrict__ A, long lda, int m, int j, int j0, int j1,
+                                                  const double* __restrict__ pn, int nblk,
+                                                  const zc* __restrict__ scal, zc* __restrict__ tau,
+                                                  zc* __restrict__ pw) {
+  __shared__ double sh[5];
+  __shared__ zc red[8][32];
+  double x2 = 0;
+  for (int i = threadIdx.x; i < nblk; i += 256) x2 += pn[i];
+  x2 = qr_block_sum(x2, sh);
+  const zc alpha = scal[0];
+  const House h = zlarfg(alpha, x2);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = j0 + tx;
+  const int r0 = blockIdx.x * QR_ROWS;
+  const bool active = c > j && c < j1;
+  double are = 0, aim = 0;
+  for (int q = 0; q < QR_ROWS / 8; ++q) {
+    const int i = r0 + ty + 8 * q;
+    if (i < m && i >= j && active) {
+      zc v;
+      if (i == j) {
+        v = make_double2(1.0, 0.0);
+      } else {
+        const zc x = A[(long)i * lda + j];
+        v = zmul(x, h.scale);
+      }
+      const zc a = A[(long)i * lda + c];
+      are += v.x * a.x + v.y * a.y;  // conj(v) * a
+      aim += v.x * a.y - v.y * a.x;
+    }
+  }
+  red[ty][tx] = make_double2(are, aim);
+  __syncthreads();
+  if (ty == 0) {
+    double sr = 0, si = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sr += red[q][tx].x; si += red[q][tx].y; }
+    pw[(long)blockIdx.x * QR_NB + tx] = make_double2(sr, si);
+  }
+  __syncthreads();
+  // overwrite column j (all reads of the raw column in this block are done)
+  if (tx == j - j0) {
+    for (int q = 0; q < QR_ROWS / 8; ++q) {
+      const int i = r0 + ty + 8 * q;
+      if (i < m) {
+        if (i > j) {
+          const long o = (long)i * lda + j;
+          A[o] = zmul(A[o], h.scale);
+        } else if (i == j) {
+          A[(long)i * lda + j] = make_double2(h.beta, 0.0);
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) tau[j] = h.tau;
+}
+
+// A[i,c] -= conj(tau) v_i w_c for the remaining panel columns; fused column
+// norm of column j+1 for the next reflector.
+__global__ __launch_bounds__(256) void k_qr_apply(zc* __restrict__ A, long lda, int m, int j, int j0, int j1,
+                                                  const zc* __restrict__ tau, const zc* __restrict__ pw, int nblk,
+                                                  double* __restrict__ pn_out, zc* __restrict__ scal) {
+  __shared__ double sh[5];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = j0 + tx;
+  const int r0 = blockIdx.x * QR_ROWS;
+  const bool active = c > j && c < j1;
+  zc w = make_double2(0.0, 0.0);
+  if (active)
+    for (int b = 0; b < nblk; ++b) w = zadd(w, pw[(long)b * QR_NB + tx]);
+  const zc tc = zconj(tau[j]);
+  const zc f = zmul(tc, w);
+  double nrm = 0;
+  for (int q = 0; q < QR_ROWS / 8; ++q) {
+    const int i = r0 + ty + 8 * q;
+    if (i < m && i >= j && active) {
+      const zc v = (i == j) ? make_double2(1.0, 0.0) : A[(long)i * lda + j];
+      const long o = (long)i * lda + c;
+      const zc a = zsub(A[o], zmul(v, f));
+      A[o] = a;
+      if (c == j + 1) {
+        if (i > j + 1) nrm += a.x * a.x + a.y * a.y;
+        if (i == j + 1) scal[0] = a;
+      }
+    }
+  }
+  nrm = qr_block_sum(nrm, sh);
+  if (threadIdx.x == 0) pn_out[blockIdx.x] = nrm;
+}
+
+// Vp[i-j0][c-j0] = unit lower trapezoid of the panel
+__global__ __launch_bounds__(256) void k_qr_extract_v(const zc* __restrict__ A, long lda, int m, int j0, int nbp,
+                                                      zc* __restrict__ Vp) {
+  const long n = (long)(m - j0) * nbp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int r = e / nbp, cc = e % nbp;
+    const int i = j0 + r, c = j0 + cc;
+    zc v;
+    if (i == c) v = make_double2(1.0, 0.0);
+    else if (i > c) v = A[(long)i * lda + c];
+    else v = make_double2(0.0, 0.0);
+    Vp[e] = v;
+  }
+}
+
+// zlarft (forward, columnwise) from G = V^H V and tau; one workgroup
+__global__ __launch_bounds__(256) void k_qr_build_t(const zc* __restrict__ G, const zc* __restrict__ tau, int nbp,
+                                                    zc* __restrict__ T) {
+  __shared__ zc Ts[QR_NB][QR_NB + 1];
+  __shared__ zc zs[QR_NB];
+  const int t = threadIdx.x;
+  for (int e = t; e < QR_NB * QR_NB; e += 256) Ts[e / QR_NB][e % QR_NB] = make_double2(0.0, 0.0);
+  __syncthreads();
+  for (int i = 0; i < nbp; ++i) {
+    const zc ti = tau[i];
+    if (t < i) {
+      const zc g = G[(long)t * nbp + i];
+      zs[t] = make_double2(-(ti.x * g.x - ti.y * g.y), -(ti.x * g.y + ti.y * g.x));
+    }
+    __syncthreads();
+    if (t < i) {
+      zc acc = make_double2(0.0, 0.0);
+      for (int s = t; s < i; ++s) acc = zadd(acc, zmul(Ts[t][s], zs[s]));
+      Ts[t][i] = acc;
+    }
+    if (t == 0) Ts[i][i] = ti;
+    __syncthreads();
+  }
+  for (int e = t; e < nbp * nbp; e += 256) T[e] = Ts[e / nbp][e % nbp];
+}
+
+__global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, long lda, int n, zc* __restrict__ R) {
+  const long tot = (long)n * n;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const int i = e / n, c = e % n;
+    R[e] = c >= i ? A[(long)i * lda + c] : make_double2(0.0, 0.0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+size_t qr_work_elems(int m, int n) {
+  const int nblk = (m + QR_ROWS - 1) / QR_ROWS;
+  const int npan = (n + QR_NB - 1) / QR_NB;
+  size_t e = 0;
+  e += (size_t)m * QR_NB;          // Vp
+  e += 2 * (size_t)QR_NB * n;      // W, W2
+  e += (size_t)QR_NB * QR_NB;      // G
+  e += (size_t)npan * QR_NB * QR_NB;  // T
+  e += n;                          // tau
+  e += nblk;                       // pn (doubles, over-allocated as zc)
+  e += (size_t)nblk * QR_NB;       // pw
+  e += 8;                          // scal
+  return e;
+}
+
+void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch) {
+  if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
+  if (n <= 0) return;
+  const long lda = n;
+  const int nblk = (m + QR_ROWS - 1) / QR_ROWS;
+  const int npan = (n + QR_NB - 1) / QR_NB;
+  zc* Vp = work;
+  zc* W = Vp + (size_t)m * QR_NB;
+  zc* W2 = W + (size_t)QR_NB * n;
+  zc* G = W2 + (size_t)QR_NB * n;
+  zc* T = G + (size_t)QR_NB * QR_NB;
+  zc* tau = T + (size_t)npan * QR_NB * QR_NB;
+  double* pn = reinterpret_cast<double*>(tau + n);
+  zc* pw = tau + n + nblk;
+  zc* scal = pw + (size_t)nblk * QR_NB;
+  long nl = 0;
+  const zc one = make_double2(1.0, 0.0), mone = make_double2(-1.0, 0.0);
+
+  auto extract_v = [&](int j0, int nbp) {
+    const int mp = m - j0;
+    hipLaunchKernelGGL(k_qr_extract_v, dim3(vec_blocks((long)mp * nbp)), dim3(256), 0, st, A, lda, m, j0, nbp, Vp);
+    ++nl;
+  };
+
+  for (int ip = 0; ip < npan; ++ip) {
+    const int j0 = ip * QR_NB, j1 = min(n, j0 + QR_NB), nbp = j1 - j0, mp = m - j0;
+    hipLaunchKernelGGL(k_qr_colnorm, dim3(nblk), dim3(256), 0, st, A, lda, m, j0, pn, scal);
+    ++nl;
+    for (int j = j0; j < j1; ++j) {
+      hipLaunchKernelGGL(k_qr_house, dim3(nblk), dim3(256), 0, st, A, lda, m, j, j0, j1, pn, nblk, scal, tau, pw);
+      if (j + 1 < j1) {
+        hipLaunchKernelGGL(k_qr_apply, dim3(nblk), dim3(256), 0, st, A, lda, m, j, j0, j1, tau, pw, nblk, pn, scal);
+        ++nl;
+      }
+      ++nl;
+    }
+    HIP_CHECK(hipGetLastError());
+    // compact WY: T from G = V^H V
+    extract_v(j0, nbp);
+    {
+      ZgemmDesc g = zgemm_desc(Vp, Vp, G, nbp, nbp, mp);
+      g.transA = 1; g.conjA = 1; g.lda = nbp; g.ldb = nbp; g.ldc = nbp;
+      zgemm(st, g);
+      ++nl;
+    }
+    zc* Tp = T + (size_t)ip * QR_NB * QR_NB;
+    hipLaunchKernelGGL(k_qr_build_t, dim3(1), dim3(256), 0, st, G, tau + j0, nbp, Tp);
+    ++nl;
+    const int n2 = n - j1;
+    if (n2 > 0) {
+      zc* A2 = A + (long)j0 * lda + j1;
+      ZgemmDesc w = zgemm_desc(Vp, A2, W, nbp, n2, mp);  // W = V^H A2
+      w.transA = 1; w.conjA = 1; w.lda = nbp; w.ldb = lda; w.ldc = n2;
+      zgemm(st, w);
+      ZgemmDesc w2 = zgemm_desc(Tp, W, W2, nbp, n2, nbp);  // W2 = T^H W
+      w2.transA = 1; w2.conjA = 1; w2.lda = nbp; w2.ldb = n2; w2.ldc = n2;
+      zgemm(st, w2);
+      ZgemmDesc u = zgemm_desc(Vp, W2, A2, mp, n2, nbp);  // A2 -= V W2
+      u.lda = nbp; u.ldb = n2; u.ldc = lda; u.alpha = mone; u.beta = one;
+      zgemm(st, u);
+      nl += 3;
+    }
+  }
+  // R
+  hipLaunchKernelGGL(k_qr_extract_r, dim3(vec_blocks((long)n * n)), dim3(256), 0, st, A, lda, n, R);
+  ++nl;
+  // Q = H_1 ... H_k [I; 0]  (zungqr, block reflectors applied in reverse)
+  set_identity(st, Q, m, n, n);
+  ++nl;
+  for (int ip = npan - 1; ip >= 0; --ip) {
+    const int j0 = ip * QR_NB, j1 = min(n, j0 + QR_NB), nbp = j1 - j0, mp = m - j0;
+    const int nq = n - j0;
+    extract_v(j0, nbp);
+    zc* Tp = T + (size_t)ip * QR_NB * QR_NB;
+    zc* Q2 = Q + (long)j0 * n + j0;
+    ZgemmDesc w = zgemm_desc(Vp, Q2, W, nbp, nq, mp);  // W = V^H Q2
+    w.transA = 1; w.conjA = 1; w.lda = nbp; w.ldb = n; w.ldc = nq;
+    zgemm(st, w);
+    ZgemmDesc w2 = zgemm_desc(Tp, W, W2, nbp, nq, nbp);  // W2 = T W
+    w2.lda = nbp; w2.ldb = nq; w2.ldc = nq;
+    zgemm(st, w2);
+    ZgemmDesc u = zgemm_desc(Vp, W2, Q2, mp, nq, nbp);  // Q2 -= V W2
+    u.lda = nbp; u.ldb = nq; u.ldc = n; u.alpha = mone; u.beta = one;
+    zgemm(st, u);
+    nl += 3;
+  }
+  HIP_CHECK(hipGetLastError());
+  if (nlaunch) *nlaunch += nl;
+}
+
+}  // namespace mitdvp

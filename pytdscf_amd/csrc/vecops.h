@@ -1,0 +1,32 @@
+// vecops.h -- Krylov vector kernels, transposes, RNG (see vecops.hip)
+#pragma once
+#include "common.h"
+
+namespace mitdvp {
+
+constexpr int NPART = 256;  // partial sums written by every reduction kernel
+constexpr int MAXK = 21;    // Krylov vectors kept: ndim (<= 20) + 1
+
+struct Coefs {
+  zc c[MAXK];
+};
+
+int vec_blocks(long n);
+void vec_dot(hipStream_t st, const zc* x, const zc* y, long n, bool conj_x, zc* out_p /*[NPART]*/);
+void vec_sumsq(hipStream_t st, const zc* x, long n, double* out_p /*[NPART]*/);
+void vec_lanczos_update(hipStream_t st, zc* v, const zc* vm1, const zc* vm2 /*nullable*/, long n,
+                        const zc* alpha_p, const double* betaprev_p, double* out_p);
+void vec_scale_inv_norm(hipStream_t st, zc* v, long n, const double* nrm_p, double eps);
+void vec_multi_dot(hipStream_t st, const zc* V, long ldv, int k, const zc* v, long n, zc* out_p /*[k][NPART]*/);
+void vec_arnoldi_update(hipStream_t st, zc* v, const zc* V, long ldv, int k, long n, const zc* h_p, double* out_p);
+void vec_lincomb(hipStream_t st, zc* out /*nullable*/, const zc* V, long ldv, int k, const Coefs& c, long n,
+                 double* nrm_p /*nullable*/);
+void vec_axpby(hipStream_t st, zc* y, const zc* x, long n, zc a, zc b);
+void vec_scale(hipStream_t st, zc* y, long n, zc a);
+void vec_randn(hipStream_t st, zc* out, long n, uint64_t seed);
+void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld);
+void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols, long ldi, long ldo, int batch,
+                       long in_bs, long out_bs);
+void transpose_rev3(hipStream_t st, const zc* in, zc* out, int na, int nj, int ns);
+
+}  // namespace mitdvp

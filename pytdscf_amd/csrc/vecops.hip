@@ -1,0 +1,318 @@
+// vecops.hip -- HBM-bound helper kernels of the TDVP engine: Krylov vector
+// algebra with device-resident scalars, tensor-leg transposes, RNG.
+//
+// Reductions are two-stage and deterministic: a producer kernel writes one
+// partial per workgroup, the CONSUMER kernel (or the host, after an async copy)
+// sums the partials in a fixed order.  No atomics, no host round trip between
+// the kernels of one Krylov iteration (the reference syncs twice per iteration,
+// _integrator.py:553-554).
+#include "vecops.h"
+
+namespace mitdvp {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum over the 256-thread block; result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh /*[5]*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sh[4] = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return sh[4];
+}
+
+__device__ __forceinline__ zc sum_partials_z(const zc* p, int np, double* sh) {
+  double re = 0, im = 0;
+  for (int i = threadIdx.x; i < np; i += 256) { re += p[i].x; im += p[i].y; }
+  re = block_sum(re, sh);
+  im = block_sum(im, sh);
+  return make_double2(re, im);
+}
+__device__ __forceinline__ double sum_partials_d(const double* p, int np, double* sh) {
+  double re = 0;
+  for (int i = threadIdx.x; i < np; i += 256) re += p[i];
+  return block_sum(re, sh);
+}
+
+// out[b] = sum_i conj(x_i) * y_i   (conj_x = 0: no conjugation)
+__global__ __launch_bounds__(256) void k_dot(const zc* __restrict__ x, const zc* __restrict__ y, long n,
+                                             int conj_x, zc* __restrict__ out) {
+  __shared__ double sh[5];
+  double re = 0, im = 0;
+  const double s = conj_x ? 1.0 : -1.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const zc a = x[i], b = y[i];
+    re += a.x * b.x + s * a.y * b.y;
+    im += a.x * b.y - s * a.y * b.x;
+  }
+  re = block_sum(re, sh);
+  im = block_sum(im, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = make_double2(re, im);
+}
+
+// out[b] = sum |x_i|^2
+__global__ __launch_bounds__(256) void k_sumsq(const zc* __restrict__ x, long n, double* __restrict__ out) {
+  __shared__ double sh[5];
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const zc a = x[i];
+    s += a.x * a.x + a.y * a.y;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// Lanczos three-term update (reference form, _integrator.py:556-562):
+//   alpha = sum(alpha_p);  beta_prev = sqrt(sum(betaprev_p))
+//   v -= alpha * vm1 + beta_prev * vm2 ;  out[b] = sum |v|^2
+__global__ __launch_bounds__(256) void k_lanczos_update(zc* __restrict__ v, const zc* __restrict__ vm1,
+                                                        const zc* __restrict__ vm2, long n,
+                                                        const zc* __restrict__ alpha_p,
+                                                        const double* __restrict__ betaprev_p, int np,
+                                                        double* __restrict__ out) {
+  __shared__ double sh[5];
+  const zc alpha = sum_partials_z(alpha_p, np, sh);
+  double bp = 0.0;
+  if (vm2) bp = sqrt(sum_partials_d(betaprev_p, np, sh));
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    zc x = v[i];
+    const zc a = vm1[i];
+    x.x -= alpha.x * a.x - alpha.y * a.y;
+    x.y -= alpha.x * a.y + alpha.y * a.x;
+    if (vm2) {
+      const zc c = vm2[i];
+      x.x -= bp * c.x;
+      x.y -= bp * c.y;
+    }
+    v[i] = x;
+    s += x.x * x.x + x.y * x.y;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// v /= sqrt(sum(nrm_p)) unless that norm is below eps (Krylov space exhausted,
+// _integrator.py:563-567, :254-256)
+__global__ __launch_bounds__(256) void k_scale_inv_norm(zc* __restrict__ v, long n,
+                                                        const double* __restrict__ nrm_p, int np, double eps) {
+  __shared__ double sh[5];
+  const double beta = sqrt(sum_partials_d(nrm_p, np, sh));
+  if (!(beta >= eps)) return;
+  const double inv = 1.0 / beta;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    zc x = v[i];
+    x.x *= inv;
+    x.y *= inv;
+    v[i] = x;
+  }
+}
+
+// Arnoldi: h_j = <V_j | v>, j < k   -> out[j*np + b]   (_orth_step_np, _integrator.py:250)
+__global__ __launch_bounds__(256) void k_multi_dot(const zc* __restrict__ V, long ldv, int k,
+                                                   const zc* __restrict__ v, long n, zc* __restrict__ out) {
+  __shared__ double sh[5];
+  double re[MAXK], im[MAXK];
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) { re[j] = 0; im[j] = 0; }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const zc b = v[i];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+      if (j < k) {
+        const zc a = V[(long)j * ldv + i];
+        re[j] += a.x * b.x + a.y * b.y;
+        im[j] += a.x * b.y - a.y * b.x;
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j)
+    if (j < k) {
+      const double r = block_sum(re[j], sh);
+      const double m = block_sum(im[j], sh);
+      if (threadIdx.x == 0) out[(long)j * gridDim.x + blockIdx.x] = make_double2(r, m);
+    }
+}
+
+// Arnoldi: v -= sum_j h_j V_j ; out[b] = sum |v|^2   (_integrator.py:251-252)
+__global__ __launch_bounds__(256) void k_arnoldi_update(zc* __restrict__ v, const zc* __restrict__ V, long ldv,
+                                                        int k, long n, const zc* __restrict__ h_p, int np,
+                                                        double* __restrict__ out) {
+  __shared__ double sh[5];
+  __shared__ zc hs[MAXK];
+  for (int j = 0; j < k; ++j) {
+    const zc h = sum_partials_z(h_p + (long)j * np, np, sh);
+    if (threadIdx.x == 0) hs[j] = h;
+  }
+  __syncthreads();
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    zc x = v[i];
+    for (int j = 0; j < k; ++j) {
+      const zc a = V[(long)j * ldv + i];
+      const zc h = hs[j];
+      x.x -= h.x * a.x - h.y * a.y;
+      x.y -= h.x * a.y + h.y * a.x;
+    }
+    v[i] = x;
+    s += x.x * x.x + x.y * x.y;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// out = sum_j c_j V_j (out may be null: norm only); nrm[b] = sum |.|^2 (nrm may be null)
+__global__ __launch_bounds__(256) void k_lincomb(zc* __restrict__ out, const zc* __restrict__ V, long ldv, int k,
+                                                 Coefs c, long n, double* __restrict__ nrm) {
+  __shared__ double sh[5];
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double re = 0, im = 0;
+    for (int j = 0; j < k; ++j) {
+      const zc a = V[(long)j * ldv + i];
+      re += c.c[j].x * a.x - c.c[j].y * a.y;
+      im += c.c[j].x * a.y + c.c[j].y * a.x;
+    }
+    if (out) out[i] = make_double2(re, im);
+    s += re * re + im * im;
+  }
+  if (nrm) {
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) nrm[blockIdx.x] = s;
+  }
+}
+
+// y = a*x + b*y
+__global__ __launch_bounds__(256) void k_axpby(zc* __restrict__ y, const zc* __restrict__ x, long n, zc a, zc b) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const zc xv = x[i], yv = y[i];
+    y[i] = make_double2(a.x * xv.x - a.y * xv.y + b.x * yv.x - b.y * yv.y,
+                        a.x * xv.y + a.y * xv.x + b.x * yv.y + b.y * yv.x);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scale(zc* __restrict__ y, long n, zc a) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const zc yv = y[i];
+    y[i] = make_double2(a.x * yv.x - a.y * yv.y, a.x * yv.y + a.y * yv.x);
+  }
+}
+
+// out[c][r] = in[r][c], batched: in_b = in + b*in_bs (row stride ldi), out_b = out + b*out_bs (ldo)
+__global__ __launch_bounds__(256) void k_transpose(const zc* __restrict__ in, zc* __restrict__ out, int rows,
+                                                   int cols, long ldi, long ldo, long in_bs, long out_bs) {
+  __shared__ zc tile[32][33];
+  const zc* ib = in + (long)blockIdx.z * in_bs;
+  zc* ob = out + (long)blockIdx.z * out_bs;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + ty + 8 * q, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * q][tx] = ib[(long)r * ldi + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = c0 + ty + 8 * q, r = r0 + tx;
+    if (r < rows && c < cols) ob[(long)c * ldo + r] = tile[tx][ty + 8 * q];
+  }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// complex standard normal (counter based, reproducible for a given seed)
+__global__ __launch_bounds__(256) void k_randn(zc* __restrict__ out, long n, uint64_t seed) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const uint64_t a = splitmix64(seed ^ (uint64_t)(2 * i));
+    const uint64_t b = splitmix64(seed ^ (uint64_t)(2 * i + 1) ^ 0xD1B54A32D192ED03ull);
+    const double u1 = ((a >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+    const double u2 = (b >> 11) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586476925 * u2, &sn, &cs);
+    out[i] = make_double2(r * cs, r * sn);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_identity(zc* __restrict__ out, int rows, int cols, long ld) {
+  const long n = (long)rows * cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int r = i / cols, c = i % cols;
+    out[(long)r * ld + c] = make_double2(r == c ? 1.0 : 0.0, 0.0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host wrappers
+// ---------------------------------------------------------------------------
+int vec_blocks(long n) {
+  long nb = (n + 1023) / 1024;
+  if (nb < 1) nb = 1;
+  if (nb > NPART) nb = NPART;
+  return (int)nb;
+}
+
+#define LAUNCH(k, nb, st, ...)                               \
+  do {                                                       \
+    hipLaunchKernelGGL(k, dim3(nb), dim3(256), 0, st, __VA_ARGS__); \
+    HIP_CHECK(hipGetLastError());                            \
+  } while (0)
+
+void vec_dot(hipStream_t st, const zc* x, const zc* y, long n, bool conj_x, zc* out_p) {
+  LAUNCH(k_dot, NPART, st, x, y, n, conj_x ? 1 : 0, out_p);
+}
+void vec_sumsq(hipStream_t st, const zc* x, long n, double* out_p) { LAUNCH(k_sumsq, NPART, st, x, n, out_p); }
+void vec_lanczos_update(hipStream_t st, zc* v, const zc* vm1, const zc* vm2, long n, const zc* alpha_p,
+                        const double* betaprev_p, double* out_p) {
+  LAUNCH(k_lanczos_update, NPART, st, v, vm1, vm2, n, alpha_p, betaprev_p, NPART, out_p);
+}
+void vec_scale_inv_norm(hipStream_t st, zc* v, long n, const double* nrm_p, double eps) {
+  LAUNCH(k_scale_inv_norm, vec_blocks(n), st, v, n, nrm_p, NPART, eps);
+}
+void vec_multi_dot(hipStream_t st, const zc* V, long ldv, int k, const zc* v, long n, zc* out_p) {
+  if (k > MAXK) throw ArgError("vec_multi_dot: k > MAXK");
+  LAUNCH(k_multi_dot, NPART, st, V, ldv, k, v, n, out_p);
+}
+void vec_arnoldi_update(hipStream_t st, zc* v, const zc* V, long ldv, int k, long n, const zc* h_p, double* out_p) {
+  LAUNCH(k_arnoldi_update, NPART, st, v, V, ldv, k, n, h_p, NPART, out_p);
+}
+void vec_lincomb(hipStream_t st, zc* out, const zc* V, long ldv, int k, const Coefs& c, long n, double* nrm_p) {
+  if (k > MAXK) throw ArgError("vec_lincomb: k > MAXK");
+  LAUNCH(k_lincomb, NPART, st, out, V, ldv, k, c, n, nrm_p);
+}
+void vec_axpby(hipStream_t st, zc* y, const zc* x, long n, zc a, zc b) { LAUNCH(k_axpby, vec_blocks(n), st, y, x, n, a, b); }
+void vec_scale(hipStream_t st, zc* y, long n, zc a) { LAUNCH(k_scale, vec_blocks(n), st, y, n, a); }
+void vec_randn(hipStream_t st, zc* out, long n, uint64_t seed) { LAUNCH(k_randn, vec_blocks(n), st, out, n, seed); }
+void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld) {
+  LAUNCH(k_identity, vec_blocks((long)rows * cols), st, out, rows, cols, ld);
+}
+
+void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols, long ldi, long ldo, int batch,
+                       long in_bs, long out_bs) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return;
+  if (batch > 65535) throw ArgError("transpose: batch too large");
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, in, out, rows, cols, ldi, ldo, in_bs, out_bs);
+  HIP_CHECK(hipGetLastError());
+}
+
+// out[s][j][a] = in[a][j][s]   (in: (na, nj, ns) C order)
+void transpose_rev3(hipStream_t st, const zc* in, zc* out, int na, int nj, int ns) {
+  // for every j: matrix in_j[a][s] (row stride nj*ns) -> out_j[s][a] (row stride nj*na)
+  transpose_batched(st, in, out, na, ns, (long)nj * ns, (long)nj * na, nj, ns, na);
+}
+
+}  // namespace mitdvp

@@ -1,0 +1,340 @@
+// zgemm.hip -- complex128 GEMM on the CDNA4 FP64 matrix cores.
+//
+// Every contraction on the TDVP hot path (H_eff / K_eff applies, environment
+// updates, bond absorption, the block-reflector updates inside QR) is a
+// row-major complex GEMM, so this kernel is the dominant kernel of the engine.
+//
+// Design (gfx950):
+//   * v_mfma_f64_16x16x4_f64, one real MFMA per (re,im) x (re,im) product:
+//       Cre += Are*Bre - Aim*Bim ;  Cim += Are*Bim + Aim*Bre     ("4M" form)
+//     complex MAC = 4 real MFMA-MACs = 8 flop, which is exactly the flop count
+//     SURVEY 8(d) uses, so MFMA utilisation = algorithmic flops / peak.
+//   * operands stay interleaved (re,im) in HBM and LDS: one lane's A (or B)
+//     operand for the 4 MFMAs is ONE 16-byte element = one ds_read_b128, so
+//     transposed / conjugated operand forms cost nothing extra.
+//   * 256-thread workgroups, 2x2 waves, each wave owns WMxWN 16x16 blocks with
+//     (re,im) accumulators in registers (WM=WN=4: 256 accumulator VGPRs, one
+//     wave per SIMD -- the f64 MFMA is 16 passes long, LDS/global traffic per
+//     MFMA is tiny, so occupancy is not what hides latency here).
+//   * register-staged global->LDS prefetch of the next K tile while the MFMAs of
+//     the current tile issue.
+//   * XCD-aware block remap + grouped tile order so that the blocks sharing an
+//     L2 walk neighbouring tiles.
+#include "common.h"
+
+namespace mitdvp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// C/D lane map of v_mfma_f64_16x16x4_f64, detected once by mfma_layout_probe():
+//   mode 0: row = (lane>>4) + 4*reg     (cdna_hip_programming.md section 3)
+//   mode 1: row = 4*(lane>>4) + reg     (the f32 16x16x4 map)
+static int g_cd_mode = -1;
+
+__device__ __forceinline__ int cd_row(int mode, int lk, int r) {
+  return mode == 0 ? (lk + 4 * r) : (4 * lk + r);
+}
+
+template <int WM, int WN, int BK, bool TA, bool TB>
+__global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
+  constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
+  constexpr int LDAS = TA ? BM : (BK + 1);  // LDS row stride (complex elements)
+  constexpr int LDBS = TB ? (BK + 1) : BN;
+  constexpr int A_SZ = TA ? BK * BM : BM * (BK + 1);
+  constexpr int B_SZ = TB ? BN * (BK + 1) : BK * BN;
+  constexpr int A_PT = (BM * BK) / 256, B_PT = (BN * BK) / 256;
+  static_assert((BM * BK) % 256 == 0 && (BN * BK) % 256 == 0, "tile/threads");
+  __shared__ zc smem[A_SZ + B_SZ];
+  zc* As = smem;
+  zc* Bs = smem + A_SZ;
+
+  // ---- block -> tile (XCD remap, then grouped order) ----------------------
+  const int nwg = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  constexpr int G = 8;
+  const int per_group = G * ntn;
+  const int group = bid / per_group;
+  const int first_m = group * G;
+  const int gsz = min(ntm - first_m, G);
+  const int rem = bid - group * per_group;
+  const int tm = first_m + rem % gsz;
+  const int tn = rem / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int b = blockIdx.y;
+
+  const zc* __restrict__ A = d.A + (long)b * d.strideA;
+  const zc* __restrict__ B = d.B + (long)b * d.strideB;
+  zc* __restrict__ C = d.C + (long)b * d.strideC;
+  const int M = d.M, N = d.N, K = d.K;
+  const long lda = d.lda, ldb = d.ldb;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int li = lane & 15, lk = lane >> 4;
+
+  zc ra[A_PT], rb[B_PT];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < A_PT; ++p) {
+      const int e = t + p * 256;
+      int m, k;
+      if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
+      const int gm = m0 + m, gk = k0 + k;
+      const bool ok = gm < M && gk < K;
+      const long off = TA ? (long)gk * lda + gm : (long)gm * lda + gk;
+      const zc v = A[ok ? off : 0];  // always-valid address: no divergent branch
+      ra[p].x = ok ? v.x : 0.0;
+      ra[p].y = ok ? v.y : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < B_PT; ++p) {
+      const int e = t + p * 256;
+      int n, k;
+      if (TB) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
+      const int gn = n0 + n, gk = k0 + k;
+      const bool ok = gn < N && gk < K;
+      const long off = TB ? (long)gn * ldb + gk : (long)gk * ldb + gn;
+      const zc v = B[ok ? off : 0];
+      rb[p].x = ok ? v.x : 0.0;
+      rb[p].y = ok ? v.y : 0.0;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < A_PT; ++p) {
+      const int e = t + p * 256;
+      int m, k;
+      if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
+      As[TA ? k * LDAS + m : m * LDAS + k] = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < B_PT; ++p) {
+      const int e = t + p * 256;
+      int n, k;
+      if (TB) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
+      Bs[TB ? n * LDBS + k : k * LDBS + n] = rb[p];
+    }
+  };
+
+  // Accumulators are born as MFMA results (0*0 + 0) so that they live in the
+  // AGPR half of the register file for the whole K loop: with a plain constant
+  // initialiser hipcc (ROCm 7.2) routes the loop-carried values through VGPR
+  // phis and copies all of them AGPR<->VGPR on every K tile.
+  double zin = 0.0;
+  asm volatile("" : "+v"(zin));
+  d4 accRe[WM][WN], accIm[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+      accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+    }
+
+  const double sa = d.conjA ? -1.0 : 1.0;
+  const double sb = d.conjB ? -1.0 : 1.0;
+
+  const int nkt = (K + BK - 1) / BK;
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) gload((kt + 1) * BK);
+#pragma unroll
+    for (int k4 = 0; k4 < BK / 4; ++k4) {
+      const int kk = k4 * 4 + lk;
+      zc a[WM], bb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = (wm * WM + i) * 16 + li;
+        a[i] = As[TA ? kk * LDAS + row : row * LDAS + kk];
+        a[i].y *= sa;
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = (wn * WN + j) * 16 + li;
+        bb[j] = Bs[TB ? col * LDBS + kk : kk * LDBS + col];
+        bb[j].y *= sb;
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const double nai = -a[i].y;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].x, accRe[i][j], 0, 0, 0);
+          accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].y, accIm[i][j], 0, 0, 0);
+          accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bb[j].y, accRe[i][j], 0, 0, 0);
+          accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].x, accIm[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      sstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C = alpha*acc + beta*C -----------------------------------
+  const zc alpha = d.alpha, beta = d.beta;
+  const bool has_beta = (beta.x != 0.0 || beta.y != 0.0);
+  const long ldc = d.ldc;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (wm * WM + i) * 16 + cd_row(cd_mode, lk, r);
+        const int col = n0 + (wn * WN + j) * 16 + li;
+        if (row < M && col < N) {
+          zc v = make_double2(accRe[i][j][r], accIm[i][j][r]);
+          zc o = zmul(alpha, v);
+          zc* p = C + (long)row * ldc + col;
+          if (has_beta) o = zadd(o, zmul(beta, *p));
+          *p = o;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------
+// MFMA probes
+// ---------------------------------------------------------------------------
+__global__ void mfma_layout_kernel(const double* A /*16x4*/, const double* B /*4x16*/, double* out /*64*4*/) {
+  const int lane = threadIdx.x;
+  const int li = lane & 15, lk = lane >> 4;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[li * 4 + lk], B[lk * 16 + li], acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
+}
+
+void mfma_layout_probe(hipStream_t st, int* host_out) {
+  double hA[64], hB[64], hD[256], ref[256];
+  for (int i = 0; i < 16; ++i)
+    for (int k = 0; k < 4; ++k) hA[i * 4 + k] = 1.0 + i + 17.0 * k;
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 16; ++j) hB[k * 16 + j] = 1.0 + 3.0 * j + 101.0 * k * k;
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += hA[i * 4 + k] * hB[k * 16 + j];
+      ref[i * 16 + j] = s;
+    }
+  double *dA, *dB, *dD;
+  HIP_CHECK(hipMalloc(&dA, sizeof(hA)));
+  HIP_CHECK(hipMalloc(&dB, sizeof(hB)));
+  HIP_CHECK(hipMalloc(&dD, sizeof(hD)));
+  HIP_CHECK(hipMemcpyAsync(dA, hA, sizeof(hA), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(dB, hB, sizeof(hB), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, st, dA, dB, dD);
+  HIP_CHECK(hipMemcpyAsync(hD, dD, sizeof(hD), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipFree(dA));
+  HIP_CHECK(hipFree(dB));
+  HIP_CHECK(hipFree(dD));
+  // locate every (lane, reg) value in the reference product (all values distinct)
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 4; ++r) {
+      int fr = -1, fc = -1;
+      for (int i = 0; i < 16 && fr < 0; ++i)
+        for (int j = 0; j < 16; ++j)
+          if (ref[i * 16 + j] == hD[l * 4 + r]) { fr = i; fc = j; break; }
+      if (host_out) { host_out[(l * 4 + r) * 2] = fr; host_out[(l * 4 + r) * 2 + 1] = fc; }
+    }
+  int mode = -1;
+  for (int m = 0; m < 2 && mode < 0; ++m) {
+    bool ok = true;
+    for (int l = 0; l < 64 && ok; ++l)
+      for (int r = 0; r < 4; ++r) {
+        const int lk = l >> 4, li = l & 15;
+        const int row = m == 0 ? lk + 4 * r : 4 * lk + r;
+        if (hD[l * 4 + r] != ref[row * 16 + li]) { ok = false; break; }
+      }
+    if (ok) mode = m;
+  }
+  if (mode < 0) throw HipError("v_mfma_f64_16x16x4_f64: unknown operand/result lane map");
+  g_cd_mode = mode;
+}
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+  d4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) out[0] = s;  // keep the chain live
+}
+
+double mfma_peak_probe(hipStream_t st) {
+  double* dout;
+  HIP_CHECK(hipMalloc(&dout, 8));
+  const int blocks = 256 * 4, iters = 2000;
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dout, 10);
+  HIP_CHECK(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dout, iters);
+  HIP_CHECK(hipEventRecord(e1, st));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  HIP_CHECK(hipEventDestroy(e0));
+  HIP_CHECK(hipEventDestroy(e1));
+  HIP_CHECK(hipFree(dout));
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
+  return flops / (ms * 1e-3) / 1e12;
+}
+
+// ---------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------
+template <int WM, int WN, int BK>
+static void launch_cfg(hipStream_t st, const ZgemmDesc& d) {
+  constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
+  const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, d.batch), block(256);
+  const int mode = g_cd_mode;
+  if (!d.transA && !d.transB)
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, false>), grid, block, 0, st, d, ntm, ntn, mode);
+  else if (!d.transA && d.transB)
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, true>), grid, block, 0, st, d, ntm, ntn, mode);
+  else if (d.transA && !d.transB)
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, false>), grid, block, 0, st, d, ntm, ntn, mode);
+  else
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, true>), grid, block, 0, st, d, ntm, ntn, mode);
+  HIP_CHECK(hipGetLastError());
+}
+
+void zgemm(hipStream_t st, const ZgemmDesc& d) {
+  if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
+  if (d.K < 0) throw ArgError("zgemm: negative K");
+  if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
+  if (g_cd_mode < 0) mfma_layout_probe(st, nullptr);
+  int cfg = d.tile_cfg;
+  if (cfg < 0) {
+    auto tiles = [&](int bm) { return (long)((d.M + bm - 1) / bm) * ((d.N + bm - 1) / bm) * d.batch; };
+    // 256 CUs: prefer the big tile once it fills the chip at least ~1.5 times
+    if (tiles(128) >= 384) cfg = 0;
+    else if (tiles(64) >= 256) cfg = 1;
+    else cfg = 2;
+  }
+  switch (cfg) {
+    case 0: launch_cfg<4, 4, 8>(st, d); break;
+    case 1: launch_cfg<2, 2, 8>(st, d); break;
+    case 2: launch_cfg<1, 1, 8>(st, d); break;
+    default: throw ArgError("zgemm: bad tile_cfg");
+  }
+}
+
+}  // namespace mitdvp

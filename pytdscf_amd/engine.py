@@ -1,0 +1,259 @@
+"""Thin Python handle over the C ABI (``include/mitdvp.h``).
+
+Mirrors what ``WFunc``/``MPSCoefMPO`` expose for the hot path in the reference:
+``propagate`` (= ``MPSCoef.propagate``, _mps_cls.py:452-503), ``expectation``,
+``autocorr``, ``norm`` (_mps_cls.py:540-716).  Arrays are complex128, C order.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _c128(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.complex128))
+
+
+class TDVPEngine:
+    def __init__(
+        self,
+        nsite: int,
+        *,
+        device: int = 0,
+        integrator: str = "lanczos",
+        conserve_norm: bool = True,
+        relax: bool = False,
+        thresh: float = 1e-9,
+        max_krylov: int = 20,
+        lanczos_variant: str = "reference",
+    ):
+        lib = _lib.load()
+        cfg = _lib.Config()
+        cfg.nsite = nsite
+        cfg.device = device
+        cfg.integrator = {"lanczos": _lib.LANCZOS, "arnoldi": _lib.ARNOLDI}[integrator]
+        cfg.conserve_norm = int(bool(conserve_norm))
+        cfg.relax = int(bool(relax))
+        cfg.thresh = thresh
+        cfg.max_krylov = max_krylov
+        cfg.lanczos_variant = {"reference": 0, "orthodox": 1}[lanczos_variant]
+        self._lib = lib
+        self._h = C.c_void_p()
+        self.nsite = nsite
+        _lib.check(lib.mitdvp_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.mitdvp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(rc, self._h)
+
+    # ---- state ---------------------------------------------------------
+    def set_site(self, isite: int, data, gauge: str = "C"):
+        a = _c128(data)
+        if a.ndim != 3:
+            raise ValueError("site tensor must be (D_l, d, D_r)")
+        g = {"Psi": _lib.GAUGE_PSI, "A": _lib.GAUGE_A, "B": _lib.GAUGE_B, "C": _lib.GAUGE_C}[gauge]
+        self._ck(self._lib.mitdvp_set_site(self._h, isite, _dp(a), a.shape[0], a.shape[1], a.shape[2], g))
+
+    def set_mps(self, cores, canonicalize: bool = False, scale: float = 1.0):
+        """cores: site-0-centred canonical MPS (gauges Psi,B,...,B), or arbitrary
+        cores with ``canonicalize=True`` (alloc_superblock_random's QR sweep)."""
+        for i, c in enumerate(cores):
+            self.set_site(i, c, "C" if canonicalize else ("Psi" if i == 0 else "B"))
+        if canonicalize:
+            self._ck(self._lib.mitdvp_canonicalize(self._h, scale))
+
+    def get_site(self, isite: int) -> np.ndarray:
+        l, n, r, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._lib.mitdvp_get_site_shape(self._h, isite, C.byref(l), C.byref(n), C.byref(r), C.byref(g)))
+        out = np.empty((l.value, n.value, r.value), dtype=np.complex128)
+        self._ck(self._lib.mitdvp_get_site(self._h, isite, _dp(out)))
+        return out
+
+    def get_mps(self):
+        return [self.get_site(i) for i in range(self.nsite)]
+
+    def init_random(self, dims, bond_dim: int, seed: int = 1):
+        arr = (C.c_int * len(dims))(*dims)
+        self._ck(self._lib.mitdvp_init_random(self._h, arr, bond_dim, seed))
+
+    def set_mpo(self, cores, op_id: int = 0, shift: complex = 0.0):
+        for i, w in enumerate(cores):
+            a = _c128(w)
+            if a.ndim != 4:
+                raise ValueError("MPO core must be (M_l, d, d, M_r)")
+            self._ck(
+                self._lib.mitdvp_set_mpo_core(self._h, op_id, i, _dp(a), a.shape[0], a.shape[1], a.shape[2], a.shape[3])
+            )
+        self._ck(self._lib.mitdvp_set_shift(self._h, op_id, complex(shift).real, complex(shift).imag))
+
+    # ---- hot path ------------------------------------------------------
+    def propagate(self, dt_au: float):
+        self._ck(self._lib.mitdvp_step(self._h, dt_au))
+
+    def sweep(self, dt_au: float, forward: bool):
+        self._ck(self._lib.mitdvp_sweep(self._h, dt_au, int(forward)))
+
+    def invalidate_env(self):
+        self._ck(self._lib.mitdvp_invalidate_env(self._h))
+
+    # ---- observables ---------------------------------------------------
+    def expectation(self, op_id: int = 0) -> complex:
+        out = np.zeros(2)
+        self._ck(self._lib.mitdvp_expect(self._h, op_id, _dp(out)))
+        return complex(out[0], out[1])
+
+    def autocorr(self) -> complex:
+        out = np.zeros(2)
+        self._ck(self._lib.mitdvp_autocorr(self._h, _dp(out)))
+        return complex(out[0], out[1])
+
+    def norm(self) -> float:
+        out = C.c_double()
+        self._ck(self._lib.mitdvp_norm(self._h, C.byref(out)))
+        return out.value
+
+    def site_rdm(self, isite: int) -> np.ndarray:
+        d = self.get_site_shape(isite)[1]
+        out = np.empty((d, d), dtype=np.complex128)
+        self._ck(self._lib.mitdvp_site_rdm(self._h, isite, _dp(out)))
+        return out
+
+    def get_site_shape(self, isite: int):
+        l, n, r, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._lib.mitdvp_get_site_shape(self._h, isite, C.byref(l), C.byref(n), C.byref(r), C.byref(g)))
+        return l.value, n.value, r.value, g.value
+
+    def krylov_stats(self):
+        arr = (C.c_int * self.nsite)()
+        self._ck(self._lib.mitdvp_krylov_stats(self._h, arr))
+        return list(arr)
+
+    def counters(self) -> dict:
+        c = _lib.Counters()
+        self._ck(self._lib.mitdvp_counters_get(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def counters_reset(self):
+        self._ck(self._lib.mitdvp_counters_reset(self._h))
+
+    def set_profiling(self, on: bool):
+        self._ck(self._lib.mitdvp_set_profiling(self._h, int(on)))
+
+
+# ---- unit-level seam (SURVEY 8b "internal seam 1") ---------------------------
+def heff_apply(L, W, R, psi, device=0, reps=0):
+    L, W, R, psi = map(_c128, (L, W, R, psi))
+    dl, d, dr = psi.shape
+    out = np.empty_like(psi)
+    ms = C.c_double()
+    _lib.check(
+        _lib.load().mitdvp_heff_apply(
+            device, _dp(L), _dp(W), _dp(R), _dp(psi), dl, d, dr, W.shape[0], W.shape[3], _dp(out), reps, C.byref(ms)
+        )
+    )
+    return (out, ms.value) if reps else out
+
+
+def keff_apply(L, R, sval, device=0):
+    L, R, sval = map(_c128, (L, R, sval))
+    out = np.empty_like(sval)
+    _lib.check(_lib.load().mitdvp_keff_apply(device, _dp(L), _dp(R), _dp(sval), sval.shape[0], sval.shape[1], L.shape[1], _dp(out)))
+    return out
+
+
+def env_update(env, site, W, left: bool, device=0):
+    env, site, W = map(_c128, (env, site, W))
+    dl, d, dr = site.shape
+    ml, mr = W.shape[0], W.shape[3]
+    out = np.empty((dr, mr, dr) if left else (dl, ml, dl), dtype=np.complex128)
+    _lib.check(_lib.load().mitdvp_env_update(device, int(left), _dp(env), _dp(site), _dp(W), dl, d, dr, ml, mr, _dp(out)))
+    return out
+
+
+def gauge_trf(psi, key: str, device=0):
+    """key: "Psi2Asigma" -> (A, sigma);  "Psi2sigmaB" -> (B, sigma)."""
+    psi = _c128(psi)
+    dl, d, dr = psi.shape
+    k = {"Psi2Asigma": 0, "Psi2sigmaB": 1}[key]
+    site = np.empty_like(psi)
+    sig = np.empty((dr, dr) if k == 0 else (dl, dl), dtype=np.complex128)
+    _lib.check(_lib.load().mitdvp_gauge_trf(device, k, _dp(psi), dl, d, dr, _dp(site), _dp(sig)))
+    return site, sig
+
+
+def expm_dense(mat, x, scale, integrator="lanczos", conserve_norm=True, thresh=1e-9, k_prev=0, variant="reference", device=0):
+    mat, xx = _c128(mat), _c128(x)
+    y = np.empty_like(xx)
+    k = C.c_int()
+    s = complex(scale)
+    _lib.check(
+        _lib.load().mitdvp_expm_dense(
+            device,
+            {"lanczos": 0, "arnoldi": 1}[integrator],
+            int(conserve_norm),
+            {"reference": 0, "orthodox": 1}[variant],
+            _dp(mat),
+            mat.shape[0],
+            _dp(xx),
+            s.real,
+            s.imag,
+            thresh,
+            k_prev,
+            _dp(y),
+            C.byref(k),
+        )
+    )
+    return y, k.value
+
+
+def zgemm(A, B, C0=None, transA=False, conjA=False, transB=False, conjB=False, alpha=1.0, beta=0.0, tile_cfg=-1, reps=0, device=0):
+    """C = alpha*op(A)*op(B) + beta*C0 on the MFMA kernel (row-major)."""
+    A, B = _c128(A), _c128(B)
+    m, k = (A.shape[1], A.shape[0]) if transA else A.shape
+    n = B.shape[0] if transB else B.shape[1]
+    Cm = np.zeros((m, n), dtype=np.complex128) if C0 is None else _c128(C0).copy()
+    al = np.array([complex(alpha).real, complex(alpha).imag])
+    be = np.array([complex(beta).real, complex(beta).imag])
+    ms = C.c_double()
+    _lib.check(
+        _lib.load().mitdvp_zgemm(
+            device, int(transA), int(conjA), int(transB), int(conjB), m, n, k, _dp(A), _dp(B), _dp(Cm), _dp(al), _dp(be), tile_cfg, reps, C.byref(ms)
+        )
+    )
+    return (Cm, ms.value) if reps else Cm
+
+
+def bench_heff(dl, d, dr, ml, mr, reps=3, warmup=1, device=0) -> float:
+    ms = C.c_double()
+    _lib.check(_lib.load().mitdvp_bench_heff(device, dl, d, dr, ml, mr, reps, warmup, C.byref(ms)))
+    return ms.value
+
+
+def mfma_peak_probe(device=0) -> float:
+    out = C.c_double()
+    _lib.check(_lib.load().mitdvp_mfma_peak_probe(device, C.byref(out)))
+    return out.value
+
+
+def mfma_layout_probe(device=0) -> np.ndarray:
+    out = (C.c_int * 512)()
+    _lib.check(_lib.load().mitdvp_mfma_layout_probe(device, out))
+    return np.array(out).reshape(64, 4, 2)

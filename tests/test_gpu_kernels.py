@@ -1,0 +1,139 @@
+"""GPU: kernel-level checks of the HIP building blocks through the C ABI,
+against NumPy (complex128).  Tolerances: rounding-level (1e-12 relative to the
+operand norms) -- these are the same arithmetic in a different summation order."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def crandn(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+def test_mfma_layout_and_peak():
+    from pytdscf_amd import engine as E
+
+    lay = E.mfma_layout_probe()
+    assert (lay >= 0).all()  # every lane/register value found in the reference product
+    lanes = np.arange(64)
+    assert (lay[:, :, 1] == (lanes & 15)[:, None]).all()  # col = lane & 15
+    tf = E.mfma_peak_probe()
+    print(f"v_mfma_f64_16x16x4_f64 issue-rate probe: {tf:.1f} TFLOP/s")
+    assert tf > 20.0
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize(
+    "tA,cA,tB,cB", [(0, 0, 0, 0), (0, 0, 1, 0), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 1, 1), (1, 1, 1, 1), (0, 1, 0, 1)]
+)
+def test_zgemm_forms(tile, tA, cA, tB, cB):
+    from pytdscf_amd import engine as E
+
+    rng = np.random.default_rng(tile * 100 + tA * 8 + cA * 4 + tB * 2 + cB)
+    m, n, k = 150, 77, 45  # ragged on purpose
+    A = crandn(rng, *((k, m) if tA else (m, k)))
+    B = crandn(rng, *((n, k) if tB else (k, n)))
+    C0 = crandn(rng, m, n)
+    opA = A.T if tA else A
+    opB = B.T if tB else B
+    if cA:
+        opA = opA.conj()
+    if cB:
+        opB = opB.conj()
+    alpha, beta = 0.7 - 0.2j, -0.3 + 1.1j
+    ref = alpha * (opA @ opB) + beta * C0
+    out = E.zgemm(A, B, C0, bool(tA), bool(cA), bool(tB), bool(cB), alpha, beta, tile_cfg=tile)
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err < 1e-13
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 5, 300), (300, 1, 7), (16, 16, 4), (257, 129, 1), (33, 65, 130)])
+def test_zgemm_edges(shape):
+    from pytdscf_amd import engine as E
+
+    m, n, k = shape
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    A, B = crandn(rng, m, k), crandn(rng, k, n)
+    for tile in (-1, 0, 1, 2):
+        out = E.zgemm(A, B, tile_cfg=tile)
+        assert np.abs(out - A @ B).max() <= 1e-13 * max(1.0, np.abs(A @ B).max())
+
+
+def test_zgemm_large_and_rate():
+    from pytdscf_amd import engine as E
+
+    rng = np.random.default_rng(5)
+    m, n, k = 1024, 1024, 512
+    A, B = crandn(rng, m, k), crandn(rng, k, n)
+    out, ms = E.zgemm(A, B, reps=3)
+    ref = A @ B
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-13
+    print(f"zgemm {m}x{n}x{k}: {ms:.3f} ms = {8.0 * m * n * k / ms / 1e9:.2f} TFLOP/s")
+
+
+def test_heff_keff_env_vs_numpy():
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import engine as E
+
+    rng = np.random.default_rng(11)
+    for dl, d, dr, ml, mr in [(5, 3, 4, 3, 2), (1, 4, 6, 1, 5), (7, 2, 1, 4, 1), (40, 6, 33, 7, 5)]:
+        L, R = crandn(rng, dl, ml, dl), crandn(rng, dr, mr, dr)
+        W, psi = crandn(rng, ml, d, d, mr), crandn(rng, dl, d, dr)
+        ref = orc.heff_apply(L, W, R, psi)
+        out = E.heff_apply(L, W, R, psi)
+        assert np.abs(out - ref).max() < 1e-12 * np.abs(ref).max()
+        A = crandn(rng, dl, d, dr)
+        refl = orc.env_update_left(L, A, W)
+        outl = E.env_update(L, A, W, left=True)
+        assert np.abs(outl - refl).max() < 1e-12 * np.abs(refl).max()
+        refr = orc.env_update_right(R, A, W)
+        outr = E.env_update(R, A, W, left=False)
+        assert np.abs(outr - refr).max() < 1e-12 * np.abs(refr).max()
+        Rk, sv = crandn(rng, dr, ml, dr), crandn(rng, dl, dr)
+        refk = orc.keff_apply(L, Rk, sv)
+        outk = E.keff_apply(L, Rk, sv)
+        assert np.abs(outk - refk).max() < 1e-12 * np.abs(refk).max()
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 5), (1, 6, 4), (8, 5, 8), (40, 4, 70), (33, 9, 33), (64, 3, 100)])
+def test_gauge_trf_vs_lapack(shape):
+    """Householder QR with LAPACK's conventions: for full-rank input Q and R
+    agree with scipy's (the reference's, _site_cls.py:264-282) to rounding."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import engine as E
+
+    dl, d, dr = shape
+    rng = np.random.default_rng(dl * 100 + d * 10 + dr)
+    psi = crandn(rng, dl, d, dr)
+    if dl * d >= dr:
+        A, s = E.gauge_trf(psi, "Psi2Asigma")
+        Ar, sr = orc.qr_psi2Asigma(psi)
+        Am = A.reshape(dl * d, dr)
+        assert np.abs(Am.conj().T @ Am - np.eye(dr)).max() < 1e-14 * dr
+        assert np.abs(np.tensordot(A, s, axes=(2, 0)) - psi).max() < 1e-13 * np.abs(psi).max() * dr
+        assert np.abs(np.tril(s, -1)).max() == 0.0
+        np.testing.assert_allclose(A, Ar, atol=1e-11)
+        np.testing.assert_allclose(s, sr, atol=1e-11)
+    if dr * d >= dl:
+        B, s = E.gauge_trf(psi, "Psi2sigmaB")
+        sr, Br = orc.qr_psi2sigmaB(psi)
+        Bm = B.reshape(dl, d * dr)
+        assert np.abs(Bm @ Bm.conj().T - np.eye(dl)).max() < 1e-14 * dl
+        assert np.abs(np.tensordot(s, B, axes=(1, 0)) - psi).max() < 1e-13 * np.abs(psi).max() * dl
+        np.testing.assert_allclose(B, Br, atol=1e-11)
+        np.testing.assert_allclose(s, sr, atol=1e-11)
+
+
+def test_gauge_trf_rank_deficient():
+    """Zero-padded product state (reference initial states, _site_cls.py:444-448):
+    Q must still be a complete orthonormal set."""
+    from pytdscf_amd import engine as E
+
+    psi = np.zeros((6, 4, 6), dtype=np.complex128)
+    psi[0, :, 0] = [0.5, 0.5, 0.5, 0.5]
+    A, s = E.gauge_trf(psi, "Psi2Asigma")
+    Am = A.reshape(24, 6)
+    assert np.abs(Am.conj().T @ Am - np.eye(6)).max() < 1e-14
+    assert np.abs(np.tensordot(A, s, axes=(2, 0)) - psi).max() < 1e-14

@@ -1,0 +1,107 @@
+"""CPU: host-side logic of the shell (operator reduction, initial states) and
+the C-ABI library's load/export contract.  No compute calls (no GPU here)."""
+
+import numpy as np
+import pytest
+
+from oracle import tdvp_oracle as orc
+from pytdscf_amd import mps as M
+from pytdscf_amd import operators as O
+
+
+def test_library_exports_every_declared_symbol():
+    from pytdscf_amd import _lib
+
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.mitdvp_version().startswith(b"mitdvp")
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pytdscf_amd import TDVPEngine
+    from pytdscf_amd._lib import MitdvpError
+
+    with pytest.raises(MitdvpError):
+        TDVPEngine(4)
+
+
+def test_merge_terms_is_exact_sum():
+    rng = np.random.default_rng(0)
+    dims = [3, 2, 4, 2]
+
+    def term(sites, bonds, diag=False):
+        cores = []
+        for k, s in enumerate(sites):
+            shp = (bonds[k], dims[s], bonds[k + 1]) if diag else (bonds[k], dims[s], dims[s], bonds[k + 1])
+            cores.append(rng.standard_normal(shp) + 1j * rng.standard_normal(shp))
+        return cores, sites
+
+    t1 = term([0, 1, 2, 3], [1, 3, 2, 3, 1], diag=True)
+    t2 = term([0, 1, 2], [1, 2, 2, 1])
+    t3 = term([1, 3], [1, 2, 1])  # gap at site 2 carries the bond
+    merged = O.merge_operator_terms([t1, t2, t3], dims)
+    assert merged[0].shape[0] == 1 and merged[-1].shape[3] == 1
+    dense = O.mpo_to_dense(merged)
+    ref = sum(O.mpo_to_dense(O.full_chain(c, s, dims)) for c, s in (t1, t2, t3))
+    np.testing.assert_allclose(dense, ref, atol=1e-13)
+
+
+def test_product_state_and_bond_dims():
+    assert M.bond_dims([3] * 5, 6) == orc.bond_dims([3] * 5, 6)
+    cores = M.product_state_cores([[1, 1, 0], [0, 2, 0], [1, 0, 0]], bond_dim=4)
+    assert [c.shape for c in cores] == [(1, 3, 3), (3, 3, 3), (3, 3, 1)]
+    assert abs(np.linalg.norm(cores[0]) - 1) < 1e-15
+    assert np.count_nonzero(cores[1]) == 1
+
+
+def test_exciton_pin_through_merged_mpo(golden):
+    """Reference regression pin (tests/test_exiciton_propagate.py:174-184) reproduced
+    by the oracle on the direct-sum MPO: validates the reduction of the operator
+    dictionary (diag cores + partial-span kinetic term) on the CPU."""
+    g = golden("exciton.npz")
+    pot = [g[f"pot{i}"] for i in range(4)]
+    kin = [g[f"kin{i}"] for i in range(3)]
+    mpo = O.merge_operator_terms([(pot, [0, 1, 2, 3]), (kin, [0, 1, 2])], dims=[8, 8, 8, 2])
+    w = [g[f"w{i}"] for i in range(3)] + [np.array([0.0, 1.0])]
+    init = M.product_state_cores(w, bond_dim=2)
+    st = orc.OracleMPS(orc.canonicalize_site0(init), mpo)
+    dt = float(g["dt_au"])
+    e = None
+    for step in range(20):
+        if step == 19:
+            rdm = orc.site_rdm(st.cores, 3)
+        e = st.expectation()
+        st.propagate(dt)
+    assert e.real == pytest.approx(float(g["ref_pin_energy"]))
+    np.testing.assert_allclose(rdm, g["ref_pin_rdm33"], atol=1e-9)
+    np.testing.assert_allclose(rdm, g["n19_rdm33"], atol=1e-10)
+
+
+def test_henon_heiles_pin_through_merged_mpo(golden):
+    """tests/test_henon_heiles.py NumPy case (energy 0.018225341011652626)."""
+    g = golden("henon_heiles.npz")
+    pot = [g["pot0"], g["pot1"]]
+    kin = [g["kin0"], g["kin1"]]
+    mpo = O.merge_operator_terms([(pot, [0, 1]), (kin, [0, 1])], dims=[5, 5])
+    # init_weight_VIBSTATE: HO-eigenbasis weights rotated to the DVR grid with
+    # basis.get_unitary() (_mps_mpo.py:96-110): einsum("abc,bd->adc", core, U)
+    wts = [np.array([0.0, 1.0, 0, 0, 0]), np.array([1.0, 0, 0, 0, 0])]
+    init = M.product_state_cores(wts, bond_dim=4)
+    init = [np.einsum("abc,bd->adc", c, g[f"unitary{i}"]) for i, c in enumerate(init)]
+    st = orc.OracleMPS(orc.canonicalize_site0(init), mpo)
+    dt = float(g["dt_au"])
+    e = None
+    for _ in range(3):
+        e = st.expectation()
+        st.propagate(dt)
+    assert e.real == pytest.approx(float(g["ref_pin_energy"]))
+    ref = [g["n3_final0"], g["n3_final1"]]
+    fid = abs(orc.overlap(ref, st.cores))
+    assert abs(fid - 1) < 1e-9
