@@ -30,11 +30,23 @@ struct DevBuf {
     p = nullptr;
     n = 0;
   }
-  void reserve(size_t elems) {
+  void reserve(size_t elems) {  // contents are NOT preserved
     if (elems <= n) return;
     release();
     if (elems == 0) return;
     HIP_CHECK(hipMalloc(&p, elems * sizeof(zc)));
+    n = elems;
+  }
+  void grow_preserve(size_t elems, size_t used, hipStream_t st) {
+    if (elems <= n) return;
+    zc* q = nullptr;
+    HIP_CHECK(hipMalloc(&q, elems * sizeof(zc)));
+    if (p && used) {
+      HIP_CHECK(hipMemcpyAsync(q, p, used * sizeof(zc), hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+    release();
+    p = q;
     n = elems;
   }
 };

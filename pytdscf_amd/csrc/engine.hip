@@ -231,6 +231,11 @@ void Engine::size_workspaces() {
     }
   }
   ensure_work(ms, mx, my, qm, qn);
+  // site buffers are exchanged with a spare of capacity max_site during the
+  // sweep (QR / absorb write into the spare, then swap): give all of them that
+  // capacity so that any of them can play the spare's role afterwards.
+  for (int p = 0; p < L_; ++p)
+    if (site_[p].p) site_[p].grow_preserve((size_t)ms, (size_t)dl_[p] * dd_[p] * dr_[p], st_);
 }
 
 void Engine::require_ready() {
@@ -792,13 +797,15 @@ void Engine::site_rdm(int isite, double* out) {
       std::swap(T, Tn);
     } else {
       // rho_a'[j][j'] = sum_s U[a'][j][s] conj(C[a'][j'][s]); summed over a' on the host
-      ZgemmDesc r = zgemm_desc(tmp1_.p, site_[p].p, tmp2_.p, d, d, dr);
+      DevBuf rho = pool_get((size_t)dl * d * d);
+      ZgemmDesc r = zgemm_desc(tmp1_.p, site_[p].p, rho.p, d, d, dr);
       r.transB = 1; r.conjB = 1; r.ldb = dr; r.ldc = d;
       r.batch = dl; r.strideA = (long)d * dr; r.strideB = (long)d * dr; r.strideC = (long)d * d;
       zgemm(st_, r);
       std::vector<hzc> h((size_t)dl * d * d);
-      HIP_CHECK(hipMemcpyAsync(h.data(), tmp2_.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipMemcpyAsync(h.data(), rho.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
       HIP_CHECK(hipStreamSynchronize(st_));
+      pool_put(std::move(rho));
       hzc* o = reinterpret_cast<hzc*>(out);
       for (int e = 0; e < d * d; ++e) o[e] = hzc(0, 0);
       for (int a = 0; a < dl; ++a)

@@ -20,6 +20,9 @@
 //     the current tile issue.
 //   * XCD-aware block remap + grouped tile order so that the blocks sharing an
 //     L2 walk neighbouring tiles.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mitdvp {
@@ -216,10 +219,14 @@ __global__ void mfma_layout_kernel(const double* A /*16x4*/, const double* B /*4
 
 void mfma_layout_probe(hipStream_t st, int* host_out) {
   double hA[64], hB[64], hD[256], ref[256];
-  for (int i = 0; i < 16; ++i)
-    for (int k = 0; k < 4; ++k) hA[i * 4 + k] = 1.0 + i + 17.0 * k;
-  for (int k = 0; k < 4; ++k)
-    for (int j = 0; j < 16; ++j) hB[k * 16 + j] = 1.0 + 3.0 * j + 101.0 * k * k;
+  // D[i][j] = (i+1) + 1000 (j+1) + 2: every entry distinct, and a k-slot mismatch
+  // between the A and B lane maps would pair the wrong factors
+  for (int i = 0; i < 16; ++i) {
+    hA[i * 4 + 0] = i + 1.0; hA[i * 4 + 1] = 1.0; hA[i * 4 + 2] = 0.5; hA[i * 4 + 3] = 0.25;
+  }
+  for (int j = 0; j < 16; ++j) {
+    hB[0 * 16 + j] = 1.0; hB[1 * 16 + j] = 1000.0 * (j + 1); hB[2 * 16 + j] = 2.0; hB[3 * 16 + j] = 4.0;
+  }
   for (int i = 0; i < 16; ++i)
     for (int j = 0; j < 16; ++j) {
       double s = 0;
@@ -262,38 +269,60 @@ void mfma_layout_probe(hipStream_t st, int* host_out) {
   g_cd_mode = mode;
 }
 
-__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, unsigned long long* stamps) {
   d4 acc[8];
   for (int i = 0; i < 8; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
   double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
   }
   double s = 0;
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   if (s == 123.456) out[0] = s;  // keep the chain live
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
 }
 
+// Raw v_mfma_f64_16x16x4_f64 issue rate with `waves_per_simd` resident waves on
+// every SIMD.  Prints cycles per MFMA and the in-kernel clock when
+// MITDVP_VERBOSE is set (MI355X_MICROARCH.md, DVFS give-back item 6).
 double mfma_peak_probe(hipStream_t st) {
   double* dout;
+  unsigned long long* dst;
   HIP_CHECK(hipMalloc(&dout, 8));
-  const int blocks = 256 * 4, iters = 2000;
-  hipEvent_t e0, e1;
-  HIP_CHECK(hipEventCreate(&e0));
-  HIP_CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dout, 10);
-  HIP_CHECK(hipEventRecord(e0, st));
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dout, iters);
-  HIP_CHECK(hipEventRecord(e1, st));
-  HIP_CHECK(hipEventSynchronize(e1));
-  float ms = 0;
-  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  HIP_CHECK(hipEventDestroy(e0));
-  HIP_CHECK(hipEventDestroy(e1));
+  HIP_CHECK(hipMalloc(&dst, 16));
+  double best = 0.0;
+  const bool verbose = getenv("MITDVP_VERBOSE") != nullptr;
+  for (int wps = 1; wps <= 2; ++wps) {
+    const int blocks = 256 * wps, iters = 4000;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dout, 10, nullptr);
+    HIP_CHECK(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dout, iters, dst);
+    HIP_CHECK(hipEventRecord(e1, st));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    HIP_CHECK(hipEventDestroy(e0));
+    HIP_CHECK(hipEventDestroy(e1));
+    unsigned long long hs[2];
+    HIP_CHECK(hipMemcpy(hs, dst, 16, hipMemcpyDeviceToHost));
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
+    const double tf = flops / (ms * 1e-3) / 1e12;
+    if (verbose)
+      fprintf(stderr, "[mitdvp] f64 mfma probe: %d wave/SIMD: %.1f TFLOP/s, %.1f cycles per MFMA per wave, clock %.2f GHz\n",
+              wps, tf, (double)hs[0] / (iters * 8.0), (double)hs[0] / (double)hs[1] * 0.1);
+    best = std::max(best, tf);
+  }
   HIP_CHECK(hipFree(dout));
-  const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 4);
-  return flops / (ms * 1e-3) / 1e12;
+  HIP_CHECK(hipFree(dst));
+  return best;
 }
 
 // ---------------------------------------------------------------------------
