@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- TDVP sweeps/s of the MI355X engine on BASELINE.json's configs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4]
+
+One "step" = one half-sweep of one-site TDVP over all L sites of a synthetic
+full-rank MPS under a synthetic Hermitian MPO (SURVEY.md 8d inputs), i.e. L
+local exp(-i H_eff dt/2), L-1 QR gauge moves, L-1 environment updates, L-1 local
+exp(+i K_eff dt/2).  Sweeps alternate direction (forward, backward, ...), two of
+them are one PyTDSCF time step.  All tensors are generated on / resident in HBM
+before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the serial sweep
+is a strict dependency chain, so for round 1 the ranks run independent replicas
+(an ensemble of trajectories, SURVEY 8e "fallback"); value = N * sweeps / max
+time, "scaling": "weak".  No data-path collective.
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (spec), 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+
+WORKLOADS = {
+    # name: (L, d, D, M, dt_au, integrator, description)
+    "C2": (10, 10, 32, 6, 2.0, "lanczos", "Henon-Heiles-like L=10 d=10 D=32 M=6"),
+    "C3": (6, 32, 128, 16, 1.0, "lanczos", "H2CO-like grid MPO L=6 d=32 D=128 M=16"),
+    "C4": (64, 16, 1024, 32, 0.5, "lanczos", "synthetic exciton chain L=64 d=16 D=1024 M=32"),
+    "C5": (128, 4, 512, 16, 2.0, "lanczos", "spin-bath chain L=128 d=4 D=512 M=16 (Hilbert-space stand-in)"),
+}
+
+
+def flops_heff(dl, d, dr, ml, mr):
+    return 8.0 * (dl * dl * ml * d * dr + dl * dr * ml * mr * d * d + dl * dr * dr * mr * d)
+
+
+def cpu_baseline(L, d, D, M, kh, kk, n_threads, budget_s=30.0):
+    """Oracle (NumPy/OpenBLAS zgemm + LAPACK QR) timed on the host cores on a bounded
+    sample: one H_eff apply, one K_eff apply and one QR gauge move at the interior
+    site shape; extrapolated over the chain with per-site flop ratios and the
+    Krylov counts measured on the GPU run."""
+    from oracle import tdvp_oracle as orc
+
+    bd = orc.bond_dims([d] * L, D)
+    dl, dr = max(b[0] for b in bd), max(b[1] for b in bd)
+    ml = mr = M
+    rng = np.random.default_rng(0)
+
+    def crandn(*s):
+        return rng.standard_normal(s) + 1j * rng.standard_normal(s)
+
+    f_int = flops_heff(dl, d, dr, ml, mr)
+    if f_int > 2e11:
+        # chunk the apply over the left bond so the intermediates stay ~1 GB
+        Lb, Rb, psi = crandn(dl, ml, dl), crandn(dr, mr, dr), crandn(dl, d, dr)
+        W = crandn(ml, d, d, mr)
+        ch = max(1, min(dl, int(6.4e7 // (ml * d * dr))))
+        t0 = time.perf_counter()
+        orc.heff_apply_chunked(Lb, W, Rb, psi, ch)
+        t_h = time.perf_counter() - t0
+        sv = crandn(dl, dr)
+        t0 = time.perf_counter()
+        orc.keff_apply(Lb, Rb, sv)
+        t_k = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.qr_psi2Asigma(psi)
+        t_q = time.perf_counter() - t0
+        sample = f"1 H_eff apply ({t_h:.1f}s) + 1 K_eff apply ({t_k:.1f}s) + 1 QR ({t_q:.1f}s) at ({dl},{d},{dr}), M={M}; extrapolated over L={L}"
+        tot = 0.0
+        for p, (a, b) in enumerate(bd):
+            mlp = 1 if p == 0 else M
+            mrp = 1 if p == L - 1 else M
+            r = flops_heff(a, d, b, mlp, mrp) / f_int
+            tot += (kh + 1.0) * t_h * r  # k_H applies + one environment update
+            if p < L - 1:
+                tot += kk * t_k * (b / dr) ** 3 + t_q * (a * d * b * b) / (dl * d * dr * dr)
+        return dict(value=1.0 / tot, unit="sweeps/s", cores=n_threads, kind="port", sample=sample)
+    # small workloads: run the oracle end to end
+    mpo = orc.synthetic_mpo(L, d, M, seed=0)
+    mps = orc.synthetic_mps([d] * L, D, seed=1)
+    st = orc.OracleMPS(mps, mpo)
+    st.build_right_envs()
+    st.sweep(WORK_DT[0], True)
+    st.sweep(WORK_DT[0], False)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        st.sweep(WORK_DT[0], True)
+        st.sweep(WORK_DT[0], False)
+        n += 2
+        if time.perf_counter() - t0 > min(budget_s, 15.0) or n >= 20:
+            break
+    el = time.perf_counter() - t0
+    return dict(value=n / el, unit="sweeps/s", cores=n_threads, kind="port", sample=f"{n} full sweeps of the oracle, {el:.1f}s")
+
+
+WORK_DT = [0.0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("MITDVP_WORKLOAD", "C4"), choices=sorted(WORKLOADS))
+    ap.add_argument("--dt", type=float, default=None, help="time step in a.u. (default per workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oracle import tdvp_oracle as orc  # synthetic inputs + cpu_baseline leg only
+    from pytdscf_amd import TDVPEngine
+
+    L, d, D, M, dt, integ, desc = WORKLOADS[args.workload]
+    if args.dt is not None:
+        dt = args.dt
+    WORK_DT[0] = dt
+
+    eng = TDVPEngine(L, device=local_rank, integrator=integ)
+    eng.set_mpo(orc.synthetic_mpo(L, d, M, seed=0))
+    eng.init_random([d] * L, D, seed=1 + rank)  # device-side full-rank MPS, canonicalised on the GPU
+    e0 = eng.expectation().real  # also builds nothing persistent; forces setup to finish
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    note(f"{args.workload} set up on device (L={L} d={d} D={D} M={M}), <H>={e0:.9f}")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    forward = True
+    for i in range(args.warmup):
+        eng.sweep(dt, forward)
+        eng.norm()
+        note(f"warm-up sweep {i + 1}/{args.warmup} done")
+        forward = not forward
+    if args.warmup == 0:
+        # the right environments are state, not sweep work: build them before timing
+        eng.sweep(0.0, True)
+        eng.sweep(0.0, False)
+    eng.norm()
+    eng.counters_reset()
+    eng.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.sweep(dt, forward)
+        forward = not forward
+        if args.steps > 1 and L * D >= 32768:
+            eng.norm()
+            note(f"timed sweep {i + 1}/{args.steps} done")
+    nrm = eng.norm()  # synchronises the engine's stream
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    cnt = eng.counters()
+    eng.set_profiling(False)
+
+    if rank == 0:
+        kh = cnt["n_heff"] / max(cnt["n_exp_site"], 1)
+        kk = cnt["n_keff"] / max(cnt["n_exp_bond"], 1)
+        ach = cnt["heff_flops"] / max(cnt["heff_ms"], 1e-9) / 1e9  # TFLOP/s
+        out = {
+            "metric": "tdvp_sweeps_per_sec",
+            "value": args.gpus * args.steps / el,
+            "unit": "sweeps/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "c128",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {desc}",
+                "L": L, "d": d, "D": D, "M": M, "dt_au": dt, "thresh_sil": 1e-9,
+                "integrator": integ,
+                "step": "one half-sweep (L site exponentials, L-1 QR, L-1 env updates, L-1 bond exponentials)",
+                "mean_krylov_site": round(kh, 2),
+                "mean_krylov_bond": round(kk, 2),
+                "norm_after": nrm,
+                "energy_before": e0,
+                "parallelism": "single GPU" if args.gpus == 1 else f"{args.gpus} independent replicas",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)",
+                "achieved": ach,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "flops_per_apply": cnt["heff_flops"] / max(cnt["n_heff"], 1),
+                "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
+                "stage_ms_per_apply": [x / max(cnt["n_heff"], 1) for x in cnt["heff_stage_ms"]],
+                "n_apply": cnt["n_heff"],
+            },
+            "breakdown_ms": {
+                "heff": cnt["heff_ms"], "env": cnt["env_ms"], "keff": cnt["keff_ms"], "qr": cnt["qr_ms"],
+                "krylov_vec": cnt["krylov_vec_ms"], "wall": 1e3 * el,
+                "env_tflops": cnt["env_flops"] / max(cnt["env_ms"], 1e-9) / 1e9,
+                "keff_tflops": cnt["keff_flops"] / max(cnt["keff_ms"], 1e-9) / 1e9,
+                "qr_tflops": cnt["qr_flops"] / max(cnt["qr_ms"], 1e-9) / 1e9,
+                "launches": cnt["n_launch"],
+            },
+        }
+        if not args.no_cpu_baseline and args.gpus == 1:
+            nthr = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, nthr)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

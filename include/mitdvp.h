@@ -112,7 +112,8 @@ typedef struct {
   long long n_heff, n_keff, n_env, n_qr;
   long long n_exp_site, n_exp_bond;
   long long n_launch;    /* kernel launches issued                              */
-  double reserved[8];
+  double heff_stage_ms[3]; /* L.psi, W., .R stages of the H_eff applies (profiling on) */
+  double reserved[5];
 } mitdvp_counters;
 int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out);
 int mitdvp_counters_reset(mitdvp_engine* h);

@@ -147,6 +147,22 @@ def heff_apply(L: np.ndarray, W: np.ndarray, R: np.ndarray, psi: np.ndarray) -> 
     return out.reshape(Dl, d, Dr)
 
 
+def heff_apply_chunked(L, W, R, psi, chunk: int) -> np.ndarray:
+    """:func:`heff_apply` evaluated in blocks of ``chunk`` left-bond rows so the
+    stage intermediates stay bounded (used for the C4-size CPU baseline)."""
+    out = np.empty_like(psi)
+    for a0 in range(0, L.shape[0], chunk):
+        Lr = L[a0 : a0 + chunk]
+        na, Ml, Dl = Lr.shape
+        Dr, Mr, _ = R.shape
+        d = psi.shape[1]
+        X = (Lr.reshape(na * Ml, Dl) @ psi.reshape(Dl, d * Dr)).reshape(na, Ml * d, Dr)
+        W2 = W.transpose(1, 3, 0, 2).reshape(d * Mr, Ml * d)
+        Y = np.matmul(W2, X)
+        out[a0 : a0 + na] = (Y.reshape(na * d, Mr * Dr) @ R.reshape(Dr, Mr * Dr).T).reshape(na, d, Dr)
+    return out
+
+
 def keff_apply(L: np.ndarray, R: np.ndarray, sigma: np.ndarray) -> np.ndarray:
     """sigma'[a,r] = sum L[a,c,b] sigma[b,s] R[r,c,s].
 

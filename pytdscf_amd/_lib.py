@@ -56,11 +56,14 @@ class Counters(C.Structure):
         ("n_exp_site", C.c_longlong),
         ("n_exp_bond", C.c_longlong),
         ("n_launch", C.c_longlong),
-        ("reserved", C.c_double * 8),
+        ("heff_stage_ms", C.c_double * 3),
+        ("reserved", C.c_double * 5),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "heff_stage_ms")}
+        d["heff_stage_ms"] = list(self.heff_stage_ms)
+        return d
 
 
 _lib = None

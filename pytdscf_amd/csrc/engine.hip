@@ -108,6 +108,10 @@ void Engine::resolve_timers() {
       case 1: cnt_.env_ms += ms; break;
       case 2: cnt_.keff_ms += ms; break;
       case 3: cnt_.qr_ms += ms; break;
+      case 10: case 11: case 12:
+        cnt_.heff_stage_ms[t.kind - 10] += ms;
+        cnt_.heff_ms += ms;
+        break;
       default: cnt_.krylov_vec_ms += ms; break;
     }
     evpool_.emplace_back(t.a, t.b);
@@ -253,16 +257,20 @@ void Engine::require_ready() {
 void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
                         hzc shift) {
   const int ml = w.ml, mr = w.mr;
-  timer_begin(0);
+  timer_begin(10);
   {  // X[(a,c)][(j,s)] = L[(a,c)][b] psi[b][(j,s)]
     ZgemmDesc g = zgemm_desc(L, psi, X_.p, dl * ml, d * dr, dl);
     zgemm(st_, g);
   }
+  timer_end();
+  timer_begin(11);
   {  // Y_a[(i,t)][s] = W2L[(i,t)][(c,j)] X_a[(c,j)][s]
     ZgemmDesc g = zgemm_desc(w.w2l.p, X_.p, Y_.p, d * mr, dr, ml * d);
     g.batch = dl; g.strideA = 0; g.strideB = (long)ml * d * dr; g.strideC = (long)d * mr * dr;
     zgemm(st_, g);
   }
+  timer_end();
+  timer_begin(12);
   {  // out[(a,i)][r] = Y[(a,i)][(t,s)] R[r][(t,s)]
     ZgemmDesc g = zgemm_desc(Y_.p, R, out, dl * d, dr, mr * dr);
     g.transB = 1; g.ldb = (long)mr * dr;
