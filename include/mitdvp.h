@@ -143,6 +143,11 @@ int mitdvp_expm_dense(int device, int integrator, int conserve_norm, int lanczos
 int mitdvp_zgemm(int device, int transA, int conjA, int transB, int conjB, int m, int n, int k,
                  const double* A, const double* B, double* C, const double alpha[2], const double beta[2],
                  int tile_cfg, int reps, double* ms_out);
+/* Complex-product form of the MFMA zgemm kernel for everything that follows:
+ * 0 = "4M" (textbook, 4 real MFMA products), 1 = "3M" (Karatsuba, 3 products,
+ * normwise stable); the library default is 1 unless MITDVP_ZGEMM=4m is set. */
+int mitdvp_set_gemm_mode(int mode3m);
+int mitdvp_get_gemm_mode(void);
 /* Device-resident timing of the three-stage H_eff apply at a given shape
  * with random operands (bench roofline leg).  Returns avg ms per apply. */
 int mitdvp_bench_heff(int device, int dl, int d, int dr, int ml, int mr, int reps, int warmup, double* ms_out);

@@ -56,7 +56,8 @@ struct ZgemmDesc {
   int transB;  // 0: B stored [K][N]; 1: B stored [N][K]
   int conjB;
   zc alpha, beta;
-  int tile_cfg;  // -1 auto; 0: 128x128, 1: 64x64, 2: 32x32
+  int tile_cfg;  // -1 auto; 0: 128x128 (4M) / 128x64 (3M), 1: 64x64, 2: 32x32
+  int mode3m;    // -1 library default; 0: 4M product; 1: 3M (Karatsuba) product
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
 void zgemm(hipStream_t st, const ZgemmDesc& d);
@@ -66,8 +67,11 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.lda = K; d.ldb = N; d.ldc = N; d.batch = 1;
   d.alpha = make_double2(1.0, 0.0); d.beta = make_double2(0.0, 0.0);
   d.tile_cfg = -1;
+  d.mode3m = -1;
   return d;
 }
+int zgemm_default_mode();
+void zgemm_set_default_mode(int m);
 double mfma_peak_probe(hipStream_t st);
 void mfma_layout_probe(hipStream_t st, int* host_out);
 

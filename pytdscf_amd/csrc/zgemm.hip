@@ -38,7 +38,7 @@ __device__ __forceinline__ int cd_row(int mode, int lk, int r) {
   return mode == 0 ? (lk + 4 * r) : (4 * lk + r);
 }
 
-template <int WM, int WN, int BK, bool TA, bool TB>
+template <int WM, int WN, int BK, bool TA, bool TB, bool M3>
 __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
   constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
   constexpr int LDAS = TA ? BM : (BK + 1);  // LDS row stride (complex elements)
@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
 
   zc ra[A_PT], rb[B_PT];
 
+  // global -> registers: loads only (clamped to a valid address), so that nothing
+  // waits on them until the MFMAs of the current tile have been issued; the
+  // out-of-range mask is applied when the registers are written to LDS.
   auto gload = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < A_PT; ++p) {
@@ -91,9 +94,7 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
       const int gm = m0 + m, gk = k0 + k;
       const bool ok = gm < M && gk < K;
       const long off = TA ? (long)gk * lda + gm : (long)gm * lda + gk;
-      const zc v = A[ok ? off : 0];  // always-valid address: no divergent branch
-      ra[p].x = ok ? v.x : 0.0;
-      ra[p].y = ok ? v.y : 0.0;
+      ra[p] = A[ok ? off : 0];
     }
 #pragma unroll
     for (int p = 0; p < B_PT; ++p) {
@@ -103,25 +104,31 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
       const int gn = n0 + n, gk = k0 + k;
       const bool ok = gn < N && gk < K;
       const long off = TB ? (long)gn * ldb + gk : (long)gk * ldb + gn;
-      const zc v = B[ok ? off : 0];
-      rb[p].x = ok ? v.x : 0.0;
-      rb[p].y = ok ? v.y : 0.0;
+      rb[p] = B[ok ? off : 0];
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < A_PT; ++p) {
       const int e = t + p * 256;
       int m, k;
       if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
-      As[TA ? k * LDAS + m : m * LDAS + k] = ra[p];
+      const bool ok = (m0 + m) < M && (k0 + k) < K;
+      zc v = ra[p];
+      v.x = ok ? v.x : 0.0;
+      v.y = ok ? v.y : 0.0;
+      As[TA ? k * LDAS + m : m * LDAS + k] = v;
     }
 #pragma unroll
     for (int p = 0; p < B_PT; ++p) {
       const int e = t + p * 256;
       int n, k;
       if (TB) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
-      Bs[TB ? n * LDBS + k : k * LDBS + n] = rb[p];
+      const bool ok = (n0 + n) < N && (k0 + k) < K;
+      zc v = rb[p];
+      v.x = ok ? v.x : 0.0;
+      v.y = ok ? v.y : 0.0;
+      Bs[TB ? n * LDBS + k : k * LDBS + n] = v;
     }
   };
 
@@ -131,55 +138,93 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
   // phis and copies all of them AGPR<->VGPR on every K tile.
   double zin = 0.0;
   asm volatile("" : "+v"(zin));
-  d4 accRe[WM][WN], accIm[WM][WN];
+  // 4M: acc0 = Re, acc1 = Im.   3M (Karatsuba): acc0 = sum Ar*Br, acc1 = sum Ai*Bi,
+  // acc2 = sum (Ar+Ai)*(Br+Bi);  Re = acc0 - acc1, Im = acc2 - acc0 - acc1.
+  constexpr int NACC = M3 ? 3 : 2;
+  d4 acc[NACC][WM][WN];
 #pragma unroll
-  for (int i = 0; i < WM; ++i)
+  for (int q = 0; q < NACC; ++q)
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-      accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-    }
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        acc[q][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 
   const double sa = d.conjA ? -1.0 : 1.0;
   const double sb = d.conjB ? -1.0 : 1.0;
 
   const int nkt = (K + BK - 1) / BK;
   gload(0);
-  sstore();
+  sstore(0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) gload((kt + 1) * BK);
-#pragma unroll
-    for (int k4 = 0; k4 < BK / 4; ++k4) {
+    // fragments are double-buffered in registers: the ds_reads of k-step k4+1 are
+    // in flight while the MFMAs of k-step k4 issue
+    constexpr int NK4 = BK / 4;
+    zc fa[2][WM], fb[2][WN];
+    auto ldfrag = [&](int k4, zc (&a)[WM], zc (&bb)[WN]) {
       const int kk = k4 * 4 + lk;
-      zc a[WM], bb[WN];
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int row = (wm * WM + i) * 16 + li;
         a[i] = As[TA ? kk * LDAS + row : row * LDAS + kk];
-        a[i].y *= sa;
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int col = (wn * WN + j) * 16 + li;
         bb[j] = Bs[TB ? col * LDBS + kk : kk * LDBS + col];
-        bb[j].y *= sb;
       }
+    };
+    ldfrag(0, fa[0], fb[0]);
 #pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const double nai = -a[i].y;
+    for (int k4 = 0; k4 < NK4; ++k4) {
+      if (k4 + 1 < NK4) ldfrag(k4 + 1, fa[(k4 + 1) & 1], fb[(k4 + 1) & 1]);
+      zc a[WM], bb[WN];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].x, accRe[i][j], 0, 0, 0);
-          accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].y, accIm[i][j], 0, 0, 0);
-          accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bb[j].y, accRe[i][j], 0, 0, 0);
-          accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].x, accIm[i][j], 0, 0, 0);
+      for (int i = 0; i < WM; ++i) { a[i] = fa[k4 & 1][i]; a[i].y *= sa; }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) { bb[j] = fb[k4 & 1][j]; bb[j].y *= sb; }
+      if (M3) {
+        double as[WM], bs[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) as[i] = a[i].x + a[i].y;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bs[j] = bb[j].x + bb[j].y;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].x, acc[0][i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].y, acc[1][i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], acc[NACC - 1][i][j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const double nai = -a[i].y;
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].x, acc[0][i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].y, acc[1][i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bb[j].y, acc[0][i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].x, acc[1][i][j], 0, 0, 0);
         }
       }
     }
     __syncthreads();
     if (kt + 1 < nkt) {
-      sstore();
+      sstore((kt + 1) * BK);
       __syncthreads();
     }
   }
@@ -197,7 +242,13 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
         const int row = m0 + (wm * WM + i) * 16 + cd_row(cd_mode, lk, r);
         const int col = n0 + (wn * WN + j) * 16 + li;
         if (row < M && col < N) {
-          zc v = make_double2(accRe[i][j][r], accIm[i][j][r]);
+          zc v;
+          if (M3) {
+            const double p1 = acc[0][i][j][r], p2 = acc[1][i][j][r], p3 = acc[NACC - 1][i][j][r];
+            v = make_double2(p1 - p2, p3 - p1 - p2);
+          } else {
+            v = make_double2(acc[0][i][j][r], acc[1][i][j][r]);
+          }
           zc o = zmul(alpha, v);
           zc* p = C + (long)row * ldc + col;
           if (has_beta) o = zadd(o, zmul(beta, *p));
@@ -271,7 +322,10 @@ void mfma_layout_probe(hipStream_t st, int* host_out) {
 
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, unsigned long long* stamps) {
   d4 acc[8];
-  for (int i = 0; i < 8; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  double zin = 0.0;
+  asm volatile("" : "+v"(zin));
+  for (int i = 0; i < 8; ++i)  // born in AGPRs (see zgemm_kernel)
+    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
   double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -328,22 +382,35 @@ double mfma_peak_probe(hipStream_t st) {
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, bool M3>
 static void launch_cfg(hipStream_t st, const ZgemmDesc& d) {
   constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, d.batch), block(256);
   const int mode = g_cd_mode;
   if (!d.transA && !d.transB)
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, false>), grid, block, 0, st, d, ntm, ntn, mode);
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, false, M3>), grid, block, 0, st, d, ntm, ntn, mode);
   else if (!d.transA && d.transB)
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, true>), grid, block, 0, st, d, ntm, ntn, mode);
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, true, M3>), grid, block, 0, st, d, ntm, ntn, mode);
   else if (d.transA && !d.transB)
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, false>), grid, block, 0, st, d, ntm, ntn, mode);
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, false, M3>), grid, block, 0, st, d, ntm, ntn, mode);
   else
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, true>), grid, block, 0, st, d, ntm, ntn, mode);
+    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, true, M3>), grid, block, 0, st, d, ntm, ntn, mode);
   HIP_CHECK(hipGetLastError());
 }
+
+// Complex-product form: 0 = "4M" (4 real MFMAs per complex tile step, the
+// textbook product), 1 = "3M" (Karatsuba, 3 real MFMAs: 25 % less matrix-core
+// work, normwise -- not componentwise -- stable).  MITDVP_ZGEMM=4m|3m overrides.
+static int g_gemm_mode = -1;
+int zgemm_default_mode() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("MITDVP_ZGEMM");
+    g_gemm_mode = (e && (e[0] == '4')) ? 0 : 1;
+  }
+  return g_gemm_mode;
+}
+void zgemm_set_default_mode(int m) { g_gemm_mode = m ? 1 : 0; }
 
 void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
@@ -351,18 +418,28 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
   if (g_cd_mode < 0) mfma_layout_probe(st, nullptr);
   int cfg = d.tile_cfg;
+  const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
   if (cfg < 0) {
-    auto tiles = [&](int bm) { return (long)((d.M + bm - 1) / bm) * ((d.N + bm - 1) / bm) * d.batch; };
+    auto tiles = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
     // 256 CUs: prefer the big tile once it fills the chip at least ~1.5 times
-    if (tiles(128) >= 384) cfg = 0;
-    else if (tiles(64) >= 256) cfg = 1;
+    if (tiles(128, m3 ? 64 : 128) >= 384) cfg = 0;
+    else if (tiles(64, 64) >= 256) cfg = 1;
     else cfg = 2;
   }
-  switch (cfg) {
-    case 0: launch_cfg<4, 4, 8>(st, d); break;
-    case 1: launch_cfg<2, 2, 8>(st, d); break;
-    case 2: launch_cfg<1, 1, 8>(st, d); break;
-    default: throw ArgError("zgemm: bad tile_cfg");
+  if (m3) {
+    switch (cfg) {
+      case 0: launch_cfg<4, 2, 16, true>(st, d); break;
+      case 1: launch_cfg<2, 2, 16, true>(st, d); break;
+      case 2: launch_cfg<1, 1, 8, true>(st, d); break;
+      default: throw ArgError("zgemm: bad tile_cfg");
+    }
+  } else {
+    switch (cfg) {
+      case 0: launch_cfg<4, 4, 8, false>(st, d); break;
+      case 1: launch_cfg<2, 2, 8, false>(st, d); break;
+      case 2: launch_cfg<1, 1, 8, false>(st, d); break;
+      default: throw ArgError("zgemm: bad tile_cfg");
+    }
   }
 }
 

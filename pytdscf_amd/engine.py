@@ -241,6 +241,15 @@ def zgemm(A, B, C0=None, transA=False, conjA=False, transB=False, conjB=False, a
     return (Cm, ms.value) if reps else Cm
 
 
+def set_gemm_mode(mode: str):
+    """"4m" (textbook complex product) or "3m" (Karatsuba, library default)."""
+    _lib.load().mitdvp_set_gemm_mode({"4m": 0, "3m": 1}[mode.lower()])
+
+
+def get_gemm_mode() -> str:
+    return "3m" if _lib.load().mitdvp_get_gemm_mode() else "4m"
+
+
 def bench_heff(dl, d, dr, ml, mr, reps=3, warmup=1, device=0) -> float:
     ms = C.c_double()
     _lib.check(_lib.load().mitdvp_bench_heff(device, dl, d, dr, ml, mr, reps, warmup, C.byref(ms)))
