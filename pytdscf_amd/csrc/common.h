@@ -58,6 +58,7 @@ struct ZgemmDesc {
   zc alpha, beta;
   int tile_cfg;  // -1 auto; 0: 128x128 (4M) / 128x64 (3M), 1: 64x64, 2: 32x32
   int mode3m;    // -1 library default; 0: 4M product; 1: 3M (Karatsuba) product
+  int ksplit;    // internal: K range per workgroup row in split-K launches (0 = off)
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
 void zgemm(hipStream_t st, const ZgemmDesc& d);
@@ -68,6 +69,7 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.alpha = make_double2(1.0, 0.0); d.beta = make_double2(0.0, 0.0);
   d.tile_cfg = -1;
   d.mode3m = -1;
+  d.ksplit = 0;
   return d;
 }
 int zgemm_default_mode();

@@ -64,11 +64,12 @@ __global__ __launch_bounds__(256) void k_qr_colnorm(const zc* __restrict__ A, lo
   __shared__ double sh[5];
   const int i = blockIdx.x * QR_ROWS + threadIdx.x;
   double s = 0;
-  if (i < m && i > j) {
+  const bool mine = threadIdx.x < QR_ROWS;  // 256 threads, QR_ROWS rows per block
+  if (mine && i < m && i > j) {
     const zc a = A[(long)i * lda + j];
     s = a.x * a.x + a.y * a.y;
   }
-  if (i == j) scal[0] = A[(long)i * lda + j];
+  if (mine && i == j) scal[0] = A[(long)i * lda + j];
   s = qr_block_sum(s, sh);
   if (threadIdx.x == 0) pn[blockIdx.x] = s;
 }
@@ -92,17 +93,22 @@ __global__ __launch_bounds__(256) void k_qr_house(zc* __restrict__ A, long lda, 
   const int r0 = blockIdx.x * QR_ROWS;
   const bool active = c > j && c < j1;
   double are = 0, aim = 0;
+  // all loads of the block's rows are independent: issue them together
+  zc xs[QR_ROWS / 8], as_[QR_ROWS / 8];
+#pragma unroll
+  for (int q = 0; q < QR_ROWS / 8; ++q) {
+    const int i = r0 + ty + 8 * q;
+    const bool ok = i < m && i >= j && active;
+    const long ii = ok ? i : j;
+    xs[q] = A[ii * lda + j];
+    as_[q] = A[ii * lda + (ok ? c : j)];
+  }
+#pragma unroll
   for (int q = 0; q < QR_ROWS / 8; ++q) {
     const int i = r0 + ty + 8 * q;
     if (i < m && i >= j && active) {
-      zc v;
-      if (i == j) {
-        v = make_double2(1.0, 0.0);
-      } else {
-        const zc x = A[(long)i * lda + j];
-        v = zmul(x, h.scale);
-      }
-      const zc a = A[(long)i * lda + c];
+      const zc v = (i == j) ? make_double2(1.0, 0.0) : zmul(xs[q], h.scale);
+      const zc a = as_[q];
       are += v.x * a.x + v.y * a.y;  // conj(v) * a
       aim += v.x * a.y - v.y * a.x;
     }
@@ -143,19 +149,40 @@ __global__ __launch_bounds__(256) void k_qr_apply(zc* __restrict__ A, long lda, 
   const int c = j0 + tx;
   const int r0 = blockIdx.x * QR_ROWS;
   const bool active = c > j && c < j1;
+  // w_c = sum over blocks of pw[b][c]: the 8 row-lanes split the blocks
+  __shared__ zc wred[8][32];
+  {
+    double sr = 0, si = 0;
+    for (int b = ty; b < nblk; b += 8) {
+      const zc v = pw[(long)b * QR_NB + tx];
+      sr += v.x;
+      si += v.y;
+    }
+    wred[ty][tx] = make_double2(sr, si);
+  }
+  __syncthreads();
   zc w = make_double2(0.0, 0.0);
-  if (active)
-    for (int b = 0; b < nblk; ++b) w = zadd(w, pw[(long)b * QR_NB + tx]);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) w = zadd(w, wred[q][tx]);
   const zc tc = zconj(tau[j]);
   const zc f = zmul(tc, w);
   double nrm = 0;
+  zc vs[QR_ROWS / 8], as_[QR_ROWS / 8];
+#pragma unroll
+  for (int q = 0; q < QR_ROWS / 8; ++q) {
+    const int i = r0 + ty + 8 * q;
+    const bool ok = i < m && i >= j && active;
+    const long ii = ok ? i : j;
+    vs[q] = A[ii * lda + j];
+    as_[q] = A[ii * lda + (ok ? c : j)];
+  }
+#pragma unroll
   for (int q = 0; q < QR_ROWS / 8; ++q) {
     const int i = r0 + ty + 8 * q;
     if (i < m && i >= j && active) {
-      const zc v = (i == j) ? make_double2(1.0, 0.0) : A[(long)i * lda + j];
-      const long o = (long)i * lda + c;
-      const zc a = zsub(A[o], zmul(v, f));
-      A[o] = a;
+      const zc v = (i == j) ? make_double2(1.0, 0.0) : vs[q];
+      const zc a = zsub(as_[q], zmul(v, f));
+      A[(long)i * lda + c] = a;
       if (c == j + 1) {
         if (i > j + 1) nrm += a.x * a.x + a.y * a.y;
         if (i == j + 1) scal[0] = a;

@@ -23,9 +23,13 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mitdvp {
+
+extern __shared__ zc smem_dyn[];
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -47,9 +51,9 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
   constexpr int B_SZ = TB ? BN * (BK + 1) : BK * BN;
   constexpr int A_PT = (BM * BK) / 256, B_PT = (BN * BK) / 256;
   static_assert((BM * BK) % 256 == 0 && (BN * BK) % 256 == 0, "tile/threads");
-  __shared__ zc smem[A_SZ + B_SZ];
-  zc* As = smem;
-  zc* Bs = smem + A_SZ;
+  // two LDS stages (dynamic LDS: cfg 0 needs > 64 KiB), one barrier per K tile
+  constexpr int STAGE = A_SZ + B_SZ;
+  zc* smem = smem_dyn;
 
   // ---- block -> tile (XCD remap, then grouped order) ----------------------
   const int nwg = ntm * ntn;
@@ -69,11 +73,18 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
   const int m0 = tm * BM, n0 = tn * BN;
   const int b = blockIdx.y;
 
+  const long lda = d.lda, ldb = d.ldb;
   const zc* __restrict__ A = d.A + (long)b * d.strideA;
   const zc* __restrict__ B = d.B + (long)b * d.strideB;
   zc* __restrict__ C = d.C + (long)b * d.strideC;
-  const int M = d.M, N = d.N, K = d.K;
-  const long lda = d.lda, ldb = d.ldb;
+  const int M = d.M, N = d.N;
+  int K = d.K;
+  if (d.ksplit > 0) {  // split-K: "batch" b owns k in [b*ksplit, (b+1)*ksplit)
+    const long kb = (long)b * d.ksplit;
+    A = d.A + (TA ? kb * lda : kb);
+    B = d.B + (TB ? kb : kb * ldb);
+    K = min(d.ksplit, d.K - (int)kb);
+  }
 
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
@@ -82,53 +93,70 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
 
   zc ra[A_PT], rb[B_PT];
 
-  // global -> registers: loads only (clamped to a valid address), so that nothing
-  // waits on them until the MFMAs of the current tile have been issued; the
-  // out-of-range mask is applied when the registers are written to LDS.
-  auto gload = [&](int k0) {
+  // Per-thread load pointers, advanced by one K tile per load.  Rows / columns
+  // beyond M / N are clamped to the last valid one (their products land in
+  // output elements that are never stored); elements beyond K are read from
+  // element 0 of the operand (valid memory) and zeroed when written to LDS.
+  const zc* pa[A_PT];
+  const zc* pb[B_PT];
+  int la[A_PT], lb[B_PT];  // LDS element offsets inside a stage
+  // k index inside the tile: base (per thread) + compile-time offset per element
+  const int kbA = TA ? t / BM : t % BK;
+  const int kbB = TB ? t % BK : t / BN;
+  constexpr int KSA = TA ? 256 / BM : 0;
+  constexpr int KSB = TB ? 0 : 256 / BN;
+  static_assert(256 % BK == 0 && 256 % BM == 0 && 256 % BN == 0, "thread/tile mapping");
 #pragma unroll
-    for (int p = 0; p < A_PT; ++p) {
-      const int e = t + p * 256;
-      int m, k;
-      if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
-      const int gm = m0 + m, gk = k0 + k;
-      const bool ok = gm < M && gk < K;
-      const long off = TA ? (long)gk * lda + gm : (long)gm * lda + gk;
-      ra[p] = A[ok ? off : 0];
-    }
+  for (int p = 0; p < A_PT; ++p) {
+    const int e = t + p * 256;
+    int m, k;
+    if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
+    const int gm = min(m0 + m, M - 1);
+    pa[p] = A + (TA ? (long)k * lda + gm : (long)gm * lda + k);
+    la[p] = TA ? k * LDAS + m : m * LDAS + k;
+  }
 #pragma unroll
-    for (int p = 0; p < B_PT; ++p) {
-      const int e = t + p * 256;
-      int n, k;
-      if (TB) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
-      const int gn = n0 + n, gk = k0 + k;
-      const bool ok = gn < N && gk < K;
-      const long off = TB ? (long)gn * ldb + gk : (long)gk * ldb + gn;
-      rb[p] = B[ok ? off : 0];
-    }
-  };
-  auto sstore = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < A_PT; ++p) {
-      const int e = t + p * 256;
-      int m, k;
-      if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
-      const bool ok = (m0 + m) < M && (k0 + k) < K;
+  for (int p = 0; p < B_PT; ++p) {
+    const int e = t + p * 256;
+    int n, k;
+    if (TB) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
+    const int gn = min(n0 + n, N - 1);
+    pb[p] = B + (TB ? (long)gn * ldb + k : (long)k * ldb + gn);
+    lb[p] = A_SZ + (TB ? n * LDBS + k : k * LDBS + n);
+  }
+  const long stepA = TA ? (long)BK * lda : BK;
+  const long stepB = TB ? BK : (long)BK * ldb;
+
+  // side work of the pipeline, one element at a time so that it can be spread
+  // between the MFMAs of a tile: item < NP stores element `item` of the tile held
+  // in registers into LDS stage `stage` (kv = number of valid k in that tile);
+  // item >= NP loads element item-NP of the following tile (kv2 valid k).
+  constexpr int NP = A_PT + B_PT;
+  auto side = [&](int item, zc* stage, int kv, int kv2) {
+    if (item < A_PT) {
+      const int p = item;
+      const bool ok = kbA + p * KSA < kv;
       zc v = ra[p];
       v.x = ok ? v.x : 0.0;
       v.y = ok ? v.y : 0.0;
-      As[TA ? k * LDAS + m : m * LDAS + k] = v;
-    }
-#pragma unroll
-    for (int p = 0; p < B_PT; ++p) {
-      const int e = t + p * 256;
-      int n, k;
-      if (TB) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
-      const bool ok = (n0 + n) < N && (k0 + k) < K;
+      stage[la[p]] = v;
+    } else if (item < NP) {
+      const int p = item - A_PT;
+      const bool ok = kbB + p * KSB < kv;
       zc v = rb[p];
       v.x = ok ? v.x : 0.0;
       v.y = ok ? v.y : 0.0;
-      Bs[TB ? n * LDBS + k : k * LDBS + n] = v;
+      stage[lb[p]] = v;
+    } else if (item < NP + A_PT) {
+      const int p = item - NP;
+      const bool ok = kbA + p * KSA < kv2;
+      ra[p] = *(ok ? pa[p] : A);
+      pa[p] += stepA;
+    } else if (item < 2 * NP) {
+      const int p = item - NP - A_PT;
+      const bool ok = kbB + p * KSB < kv2;
+      rb[p] = *(ok ? pb[p] : B);
+      pb[p] += stepB;
     }
   };
 
@@ -152,47 +180,60 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
 
   const double sa = d.conjA ? -1.0 : 1.0;
   const double sb = d.conjB ? -1.0 : 1.0;
+  constexpr int NK4 = BK / 4;
+  constexpr int SLOTS = NK4 * WM;                       // MFMA groups per tile
+  constexpr int PER_SLOT = (2 * NP + SLOTS - 1) / SLOTS;  // side items after each group
+
+  // LDS -> register fragments of k-step k4 of a stage
+  auto ldfrag = [&](const zc* st, int k4, zc (&a)[WM], zc (&bb)[WN]) {
+    const int kk = k4 * 4 + lk;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int row = (wm * WM + i) * 16 + li;
+      a[i] = st[TA ? kk * LDAS + row : row * LDAS + kk];
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = (wn * WN + j) * 16 + li;
+      bb[j] = st[A_SZ + (TB ? col * LDBS + kk : kk * LDBS + col)];
+    }
+  };
 
   const int nkt = (K + BK - 1) / BK;
-  gload(0);
-  sstore(0);
+  // prologue: tile 0 -> LDS stage 0, tile 1 -> registers
+#pragma unroll
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K);
+#pragma unroll
+  for (int it = 0; it < NP; ++it) side(it, smem, K, 0);
+#pragma unroll
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K - BK);
   __syncthreads();
+
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) gload((kt + 1) * BK);
-    // fragments are double-buffered in registers: the ds_reads of k-step k4+1 are
-    // in flight while the MFMAs of k-step k4 issue
-    constexpr int NK4 = BK / 4;
+    const zc* st = smem + (kt & 1) * STAGE;
+    zc* nst = smem + ((kt + 1) & 1) * STAGE;
+    const int kv1 = K - (kt + 1) * BK;  // valid k of the tile in registers (<= 0: no such tile)
+    const int kv2 = kv1 - BK;           // ... of the tile to load now
     zc fa[2][WM], fb[2][WN];
-    auto ldfrag = [&](int k4, zc (&a)[WM], zc (&bb)[WN]) {
-      const int kk = k4 * 4 + lk;
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int row = (wm * WM + i) * 16 + li;
-        a[i] = As[TA ? kk * LDAS + row : row * LDAS + kk];
-      }
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int col = (wn * WN + j) * 16 + li;
-        bb[j] = Bs[TB ? col * LDBS + kk : kk * LDBS + col];
-      }
-    };
-    ldfrag(0, fa[0], fb[0]);
+    ldfrag(st, 0, fa[0], fb[0]);
 #pragma unroll
     for (int k4 = 0; k4 < NK4; ++k4) {
-      if (k4 + 1 < NK4) ldfrag(k4 + 1, fa[(k4 + 1) & 1], fb[(k4 + 1) & 1]);
+      if (k4 + 1 < NK4) ldfrag(st, k4 + 1, fa[(k4 + 1) & 1], fb[(k4 + 1) & 1]);
       zc a[WM], bb[WN];
 #pragma unroll
       for (int i = 0; i < WM; ++i) { a[i] = fa[k4 & 1][i]; a[i].y *= sa; }
 #pragma unroll
       for (int j = 0; j < WN; ++j) { bb[j] = fb[k4 & 1][j]; bb[j].y *= sb; }
+      double as[WM], bs[WN];
       if (M3) {
-        double as[WM], bs[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) as[i] = a[i].x + a[i].y;
 #pragma unroll
         for (int j = 0; j < WN; ++j) bs[j] = bb[j].x + bb[j].y;
+      }
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
+      for (int i = 0; i < WM; ++i) {
+        if (M3) {
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, bb[j].x, acc[0][i][j], 0, 0, 0);
@@ -202,10 +243,7 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             acc[NACC - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], acc[NACC - 1][i][j], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
+        } else {
           const double nai = -a[i].y;
 #pragma unroll
           for (int j = 0; j < WN; ++j)
@@ -220,13 +258,18 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
           for (int j = 0; j < WN; ++j)
             acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].x, acc[1][i][j], 0, 0, 0);
         }
+        // side work spread over the MFMA groups: first all LDS stores of tile
+        // kt+1 (the other stage), then the global loads of tile kt+2
+        // (sched_barrier pins this order: left alone, hipcc clusters all memory
+        // operations at the top of the tile, where nothing overlaps them)
+        const int slot = k4 * WM + i;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < PER_SLOT; ++q) side(slot * PER_SLOT + q, nst, kv1, kv2);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
-    if (kt + 1 < nkt) {
-      sstore((kt + 1) * BK);
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: C = alpha*acc + beta*C -----------------------------------
@@ -382,20 +425,31 @@ double mfma_peak_probe(hipStream_t st) {
 // ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
+template <int WM, int WN, int BK, bool TA, bool TB, bool M3>
+static void launch_one(hipStream_t st, const ZgemmDesc& d, dim3 grid, int ntm, int ntn) {
+  constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
+  constexpr int A_SZ = TA ? BK * BM : BM * (BK + 1);
+  constexpr int B_SZ = TB ? BN * (BK + 1) : BK * BN;
+  constexpr size_t lds = 2 * (size_t)(A_SZ + B_SZ) * sizeof(zc);
+  auto kern = zgemm_kernel<WM, WN, BK, TA, TB, M3>;
+  static bool attr_set = false;  // one flag per instantiation
+  if (!attr_set) {
+    if (lds > 65536)
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, ntm, ntn, g_cd_mode);
+}
+
 template <int WM, int WN, int BK, bool M3>
 static void launch_cfg(hipStream_t st, const ZgemmDesc& d) {
   constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, d.batch), block(256);
-  const int mode = g_cd_mode;
-  if (!d.transA && !d.transB)
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, false, M3>), grid, block, 0, st, d, ntm, ntn, mode);
-  else if (!d.transA && d.transB)
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, false, true, M3>), grid, block, 0, st, d, ntm, ntn, mode);
-  else if (d.transA && !d.transB)
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, false, M3>), grid, block, 0, st, d, ntm, ntn, mode);
-  else
-    hipLaunchKernelGGL((zgemm_kernel<WM, WN, BK, true, true, M3>), grid, block, 0, st, d, ntm, ntn, mode);
+  dim3 grid(ntm * ntn, d.batch);
+  if (!d.transA && !d.transB) launch_one<WM, WN, BK, false, false, M3>(st, d, grid, ntm, ntn);
+  else if (!d.transA && d.transB) launch_one<WM, WN, BK, false, true, M3>(st, d, grid, ntm, ntn);
+  else if (d.transA && !d.transB) launch_one<WM, WN, BK, true, false, M3>(st, d, grid, ntm, ntn);
+  else launch_one<WM, WN, BK, true, true, M3>(st, d, grid, ntm, ntn);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -412,6 +466,46 @@ int zgemm_default_mode() {
 }
 void zgemm_set_default_mode(int m) { g_gemm_mode = m ? 1 : 0; }
 
+// C = alpha * sum_z ws[z] + beta * C   (deterministic split-K combine)
+__global__ __launch_bounds__(256) void zgemm_splitk_reduce(const zc* __restrict__ ws, int splits, int M, int N,
+                                                           zc* __restrict__ C, long ldc, zc alpha, zc beta) {
+  const long tot = (long)M * N;
+  const bool has_beta = (beta.x != 0.0 || beta.y != 0.0);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    double re = 0.0, im = 0.0;
+    for (int z = 0; z < splits; ++z) {
+      const zc v = ws[(long)z * tot + e];
+      re += v.x;
+      im += v.y;
+    }
+    zc o = zmul(alpha, make_double2(re, im));
+    zc* p = C + (e / N) * ldc + (e % N);
+    if (has_beta) o = zadd(o, zmul(beta, *p));
+    *p = o;
+  }
+}
+
+static zc* g_splitk_ws = nullptr;  // grows on demand; one stream per device assumed
+static size_t g_splitk_elems = 0;
+
+static void launch_tiles(hipStream_t st, const ZgemmDesc& d, int cfg, int m3) {
+  if (m3) {
+    switch (cfg) {
+      case 0: launch_cfg<4, 2, 16, true>(st, d); break;
+      case 1: launch_cfg<2, 2, 16, true>(st, d); break;
+      case 2: launch_cfg<1, 1, 16, true>(st, d); break;
+      default: throw ArgError("zgemm: bad tile_cfg");
+    }
+  } else {
+    switch (cfg) {
+      case 0: launch_cfg<4, 4, 8, false>(st, d); break;
+      case 1: launch_cfg<2, 2, 16, false>(st, d); break;
+      case 2: launch_cfg<1, 1, 16, false>(st, d); break;
+      default: throw ArgError("zgemm: bad tile_cfg");
+    }
+  }
+}
+
 void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
   if (d.K < 0) throw ArgError("zgemm: negative K");
@@ -419,28 +513,48 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (g_cd_mode < 0) mfma_layout_probe(st, nullptr);
   int cfg = d.tile_cfg;
   const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
+  auto tiles = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
   if (cfg < 0) {
-    auto tiles = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
-    // 256 CUs: prefer the big tile once it fills the chip at least ~1.5 times
-    if (tiles(128, m3 ? 64 : 128) >= 384) cfg = 0;
-    else if (tiles(64, 64) >= 256) cfg = 1;
-    else cfg = 2;
+    // 64x64 tiles (two resident workgroups per CU fill each other's barrier
+    // bubbles) beat the 128-wide tile at every size measured on MI355X; the
+    // 32x32 tile is for outputs too small to give every CU a 64x64 tile.
+    cfg = tiles(64, 64) >= 256 ? 1 : 2;
   }
-  if (m3) {
-    switch (cfg) {
-      case 0: launch_cfg<4, 2, 16, true>(st, d); break;
-      case 1: launch_cfg<2, 2, 16, true>(st, d); break;
-      case 2: launch_cfg<1, 1, 8, true>(st, d); break;
-      default: throw ArgError("zgemm: bad tile_cfg");
-    }
-  } else {
-    switch (cfg) {
-      case 0: launch_cfg<4, 4, 8, false>(st, d); break;
-      case 1: launch_cfg<2, 2, 8, false>(st, d); break;
-      case 2: launch_cfg<1, 1, 8, false>(st, d); break;
-      default: throw ArgError("zgemm: bad tile_cfg");
+  // split-K for skinny outputs with a long contraction (QR block reflectors,
+  // K_eff second stage): too few tiles to fill 256 CUs otherwise
+  const int tb = cfg == 2 ? 32 : 64;
+  const long nt = cfg == 0 ? tiles(128, m3 ? 64 : 128) : tiles(tb, tb);
+  if (d.batch == 1 && nt < 192 && d.K >= 1024) {
+    int splits = (int)std::min<long>((384 + nt - 1) / nt, d.K / 256);
+    if (splits >= 2) {
+      int kc = (d.K + splits - 1) / splits;
+      kc = (kc + 15) / 16 * 16;
+      splits = (d.K + kc - 1) / kc;
+      const size_t need = (size_t)splits * d.M * d.N;
+      if (need > g_splitk_elems) {
+        if (g_splitk_ws) { HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipFree(g_splitk_ws)); }
+        HIP_CHECK(hipMalloc(&g_splitk_ws, need * sizeof(zc)));
+        g_splitk_elems = need;
+      }
+      ZgemmDesc p = d;
+      p.C = g_splitk_ws;
+      p.ldc = d.N;
+      p.strideA = p.strideB = 0;
+      p.strideC = (long)d.M * d.N;
+      p.batch = splits;
+      p.ksplit = kc;
+      p.alpha = make_double2(1.0, 0.0);
+      p.beta = make_double2(0.0, 0.0);
+      launch_tiles(st, p, cfg, m3);
+      const long tot = (long)d.M * d.N;
+      const int nb = (int)std::min<long>(1024, (tot + 255) / 256);
+      hipLaunchKernelGGL(zgemm_splitk_reduce, dim3(nb), dim3(256), 0, st, g_splitk_ws, splits, d.M, d.N, d.C, d.ldc,
+                         d.alpha, d.beta);
+      HIP_CHECK(hipGetLastError());
+      return;
     }
   }
+  launch_tiles(st, d, cfg, m3);
 }
 
 }  // namespace mitdvp

@@ -61,6 +61,26 @@ def test_zgemm_edges(shape):
         assert np.abs(out - A @ B).max() <= 1e-13 * max(1.0, np.abs(A @ B).max())
 
 
+@pytest.mark.parametrize("shape", [(32, 992, 16384), (32, 32, 8192), (70, 130, 4100), (1, 1, 5000)])
+@pytest.mark.parametrize("mode", ["3m", "4m"])
+def test_zgemm_split_k(shape, mode):
+    """Skinny outputs with a long contraction take the deterministic split-K path."""
+    from pytdscf_amd import engine as E
+
+    m, n, k = shape
+    rng = np.random.default_rng(m + n + k)
+    A, B, C0 = crandn(rng, k, m), crandn(rng, k, n), crandn(rng, m, n)
+    E.set_gemm_mode(mode)
+    try:
+        out = E.zgemm(A, B, C0, transA=True, conjA=True, alpha=-1.0, beta=0.5 + 0.25j)
+        out2 = E.zgemm(A, B, C0, transA=True, conjA=True, alpha=-1.0, beta=0.5 + 0.25j)
+    finally:
+        E.set_gemm_mode("3m")
+    ref = -(A.conj().T @ B) + (0.5 + 0.25j) * C0
+    assert np.abs(out - ref).max() < 1e-13 * np.abs(ref).max() * np.sqrt(k)
+    assert np.array_equal(out, out2)  # deterministic combine
+
+
 def test_zgemm_large_and_rate():
     from pytdscf_amd import engine as E
 
