@@ -109,6 +109,20 @@ def cpu_baseline(L, d, D, M, kh, kk, n_threads, budget_s=30.0):
 WORK_DT = [0.0]
 
 
+def heff_traffic(d, D, M):
+    """HBM-side bytes per H_eff apply from the committed PMC passes (separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/heff_probe.py, FETCH
+    doubled per MI355X_MICROARCH.md); None for shapes that were not measured."""
+    f = os.path.join(ROOT, "profiles", "r01_heff_traffic.json")
+    try:
+        t = json.load(open(f))
+    except OSError:
+        return None
+    if t["shape"] == {"D": D, "d": d, "M": M}:
+        return t["total_bytes"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,7 +241,7 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": heff_traffic(d, D, M),
                 "flops_per_apply": cnt["heff_flops"] / max(cnt["n_heff"], 1),
                 "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
                 "stage_ms_per_apply": [x / max(cnt["n_heff"], 1) for x in cnt["heff_stage_ms"]],

@@ -1,5 +1,11 @@
 """pytdscf_amd -- MI355X-native one-site TDVP sweep engine behind PyTDSCF's surface."""
 
+from . import units  # noqa: F401
+from .api import BasInfo, Model, Simulator, TensorHamiltonian, TensorOperator, WFunc  # noqa: F401
+from .basis import Boson, Exciton, HarmonicOscillator  # noqa: F401
 from .engine import TDVPEngine  # noqa: F401
 
-__all__ = ["TDVPEngine"]
+__all__ = [
+    "TDVPEngine", "Simulator", "Model", "BasInfo", "TensorHamiltonian", "TensorOperator", "WFunc",
+    "Exciton", "Boson", "HarmonicOscillator", "units",
+]

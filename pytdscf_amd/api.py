@@ -1,0 +1,316 @@
+"""Thin Python shell with PyTDSCF's user surface for the MPO / MPS-SM path
+(SURVEY 8b): ``TensorOperator``, ``TensorHamiltonian``, ``BasInfo``, ``Model``,
+``Simulator`` and a ``WFunc`` handle.  Same names, argument meaning and error
+behaviour as the reference classes cited in each docstring; all numerics go
+through ``libmitdvp.so`` (no CPU fallback).  Not supported (raise
+``NotImplementedError`` like the reference does for unsupported combos):
+multi-state direct-product MPS, SoP/PolynomialHamiltonian, MCTDH SPFs,
+adaptive bond dimension, MPI sharding, Liouville space.
+"""
+
+from __future__ import annotations
+
+import os
+import warnings
+
+import numpy as np
+
+from . import units
+from .engine import TDVPEngine
+from .mps import product_state_cores
+from .operators import merge_operator_terms
+
+
+class TensorOperator:
+    """``TensorOperator(mpo=[cores], legs=(...))`` -- dvr_operator_cls.py:92-180.
+
+    Only the already-decomposed form (``mpo=``) is part of the hot-path
+    boundary; dense-tensor decomposition is setup-time work of the reference.
+    ``legs``: one entry per diagonal 3-leg core, two equal entries per 4-leg core.
+    """
+
+    def __init__(self, *, shape=None, tensor=None, only_diag=False, legs=None, name=None, mpo=None):
+        if mpo is None:
+            raise NotImplementedError("pytdscf_amd ingests finished MPO cores (mpo=...); TT decomposition is setup-time work")
+        self.tensor_decomposed = [np.asarray(c) for c in mpo]
+        self.only_diag = all(c.ndim == 3 for c in self.tensor_decomposed)
+        if legs is None:
+            legs = []
+            for i, c in enumerate(self.tensor_decomposed):
+                legs += [i] if c.ndim == 3 else [i, i]
+        self.legs = tuple(legs)
+        self.name = name
+        self.bond_dimension = [1] + [c.shape[-1] for c in self.tensor_decomposed]
+        sites, it = [], iter(self.legs)
+        for c in self.tensor_decomposed:
+            s = next(it)
+            if c.ndim == 4 and next(it) != s:
+                raise ValueError("4-leg core needs two equal consecutive legs")
+            sites.append(int(s))
+        self.sites = sites
+
+
+def _as_term_dict(x):
+    if x is None:
+        return {}
+    if isinstance(x, dict):
+        return x
+    if isinstance(x, list):  # [[{...}]] : [istate][jstate]
+        if len(x) != 1 or len(x[0]) != 1:
+            raise NotImplementedError("direct-product multi-state MPS: encode electronic states as an Exciton site")
+        return x[0][0] or {}
+    raise TypeError("potential/kinetic must be a dict or [[dict]]")
+
+
+class TensorHamiltonian:
+    """``TensorHamiltonian(ndof, potential, name, kinetic, ..., backend)`` --
+    hamiltonian_cls.py:628-752.  Holds the operator dictionary; ``as_mpo(dims)``
+    reduces it to the single direct-sum MPO the engine contracts."""
+
+    def __init__(self, ndof, potential, name="hamiltonian", kinetic=None, decompose_type="QRD", rate=None,
+                 bond_dimension=None, backend="hip"):
+        self.ndof = int(ndof)
+        self.name = name
+        self.nstate = 1
+        self.backend = backend
+        self.terms = {}
+        self.terms.update(_as_term_dict(potential))
+        for k, v in _as_term_dict(kinetic).items():
+            if k in self.terms:
+                raise ValueError(f"operator key {k} given twice")
+            self.terms[k] = v
+        self.coupleJ = [[0.0]]  # hamiltonian_cls.py:337-358 scalar couplings
+
+    def as_mpo(self, dims):
+        return merge_operator_terms([(op.tensor_decomposed, op.sites) for op in self.terms.values()], dims)
+
+    def apply_backend(self, backend):
+        self.backend = backend
+
+
+class BasInfo:
+    """``BasInfo(prim_info)`` -- model_cls.py:323-.  prim_info[istate][idof]."""
+
+    def __init__(self, prim_info, spf_info=None, ndof_per_sites=None):
+        if not isinstance(prim_info[0], (list, tuple)):
+            prim_info = [prim_info]
+        if len(prim_info) != 1:
+            raise NotImplementedError("direct-product multi-state MPS: encode electronic states as an Exciton site")
+        self.prim_info = [list(p) for p in prim_info]
+        self.is_DVR = True
+        self.is_standard_method = True
+
+    def get_nstate(self):
+        return len(self.prim_info)
+
+    def get_ndof(self):
+        return len(self.prim_info[0])
+
+    def get_nprim(self, istate, idof):
+        b = self.prim_info[istate][idof]
+        return b.nprim if hasattr(b, "nprim") else len(b)
+
+
+class Model:
+    """``Model(basinfo, operators, *, bond_dim, ...)`` -- model_cls.py:64-120.
+
+    operators: TensorHamiltonian | list of MPO cores | dict with keys
+    "hamiltonian" or "potential"(+"kinetic") and observables (model_cls.py:215-284).
+    Attributes ``m_aux_max``, ``init_HartreeProduct`` (weights or explicit 3-D
+    cores, _site_cls.py:446-471), ``init_weight_VIBSTATE`` (HO-eigenbasis weights
+    rotated to the DVR grid, _mps_mpo.py:96-110)."""
+
+    def __init__(self, basinfo, operators, *, bond_dim=None, build_td_hamiltonian=None, space="hilbert",
+                 subspace_inds=None, one_gate_to_apply=None, kraus_op=None):
+        self.basinfo = basinfo if isinstance(basinfo, BasInfo) else BasInfo(basinfo)
+        if space.lower() != "hilbert":
+            raise NotImplementedError("Liouville space is a 'next' row (SURVEY 8f)")
+        if one_gate_to_apply is not None or kraus_op is not None or build_td_hamiltonian is not None:
+            raise NotImplementedError("gates / Kraus operators / time-dependent Hamiltonians are 'next' rows")
+        self.space = "hilbert"
+        ops = {"hamiltonian": operators} if isinstance(operators, (TensorHamiltonian, list)) else dict(operators)
+        self.dims = [self.basinfo.get_nprim(0, i) for i in range(self.basinfo.get_ndof())]
+        out = {}
+        if "potential" in ops:
+            if "hamiltonian" in ops:
+                raise ValueError("Cannot specify 'hamiltonian' when 'potential' is given.")
+            pot, kin = ops.pop("potential"), ops.pop("kinetic", None)
+            out["hamiltonian"] = TensorHamiltonian(
+                len(self.dims), {"potential": TensorOperator(mpo=pot)},
+                kinetic=None if kin is None else {"kinetic": TensorOperator(mpo=kin)})
+        for name, op in ops.items():
+            if isinstance(op, TensorHamiltonian):
+                out[name] = op
+            elif isinstance(op, list):
+                if len(op) != len(self.dims):
+                    raise ValueError(f"Operator {name} length must be equal to ndof of basis. But, got {len(op)} and {len(self.dims)}.")
+                out[name] = TensorHamiltonian(len(self.dims), {name: TensorOperator(mpo=op)})
+            else:
+                raise TypeError(f"Operator {name} must be HamiltonianMixin or list of arrays.")
+        self.hamiltonian = out.pop("hamiltonian")
+        self.observables = out
+        self.nstate = 1
+        self.m_aux_max = bond_dim
+        self.use_mpo = True
+        self.init_HartreeProduct = None
+        self.init_weight_VIBSTATE = None
+
+    def get_nstate(self):
+        return 1
+
+    def get_ndof(self):
+        return len(self.dims)
+
+    def initial_cores(self):
+        D = self.m_aux_max if self.m_aux_max is not None else 1
+        if self.init_HartreeProduct is not None:
+            return product_state_cores(self.init_HartreeProduct[0], D)
+        if self.init_weight_VIBSTATE is not None:
+            w = self.init_weight_VIBSTATE[0]
+        else:
+            w = [[1.0] + [0.0] * (d - 1) for d in self.dims]
+        cores = product_state_cores(w, D)
+        rot = []
+        for c, b in zip(cores, self.basinfo.prim_info[0]):
+            rot.append(np.einsum("abc,bd->adc", c, b.get_unitary()) if hasattr(b, "get_unitary") else c)
+        return rot
+
+
+class WFunc:
+    """Handle returned by ``Simulator.propagate`` (wavefunction.py:34-): the
+    state lives on the GPU inside ``self.engine``."""
+
+    def __init__(self, engine: TDVPEngine, op_ids: dict):
+        self.engine = engine
+        self._op_ids = op_ids
+
+    def norm(self):
+        return self.engine.norm()
+
+    def pop_states(self):
+        return [self.engine.norm() ** 2]
+
+    def autocorr(self):
+        return self.engine.autocorr()
+
+    def expectation(self, matOp):
+        name = matOp if isinstance(matOp, str) else getattr(matOp, "name", "hamiltonian")
+        v = self.engine.expectation(self._op_ids[name])
+        if abs(np.angle(v)) > 1e-2 and abs(abs(np.angle(v)) - np.pi) > 1e-2:
+            warnings.warn(f"Expectation value {v} is not real, probably due to non-Hermitian operator or numerical error.")
+        return v.real
+
+    def get_reduced_densities(self, remain_nleg):
+        """Only one-site keys, e.g. (0, 0, 0, 2) = both legs of site 3 kept
+        (properties.py:69-82)."""
+        legs = remain_nleg[0] if isinstance(remain_nleg, list) else remain_nleg
+        nz = [i for i, n in enumerate(legs) if n]
+        if len(nz) != 1 or legs[nz[0]] != 2:
+            raise NotImplementedError("only one-site reduced densities (both legs of one site) are built so far")
+        return [self.engine.site_rdm(nz[0])]
+
+    def get_mps(self):
+        return self.engine.get_mps()
+
+
+class Simulator:
+    """``Simulator(jobname, model, ci_type="MPS", backend="hip", ...)`` --
+    simulator_cls.py:58-94; ``propagate`` follows :160-285 and the loop of
+    ``_execute`` (:400-454): observables are evaluated BEFORE each step and the
+    returned energy is the one of the last loop iteration (Appendix B.1)."""
+
+    def __init__(self, jobname, model, ci_type="MPS", backend="hip", proj_gs=False, t2_trick=True, verbose=2):
+        if ci_type.lower() not in ("mps", "mps-sm"):
+            raise NotImplementedError("only the MPS standard method (MPO Hamiltonian) is on the accelerated path")
+        if backend.lower() not in ("hip", "numpy", "jax"):
+            raise ValueError(f"unknown backend {backend}")
+        if backend.lower() != "hip":
+            warnings.warn("pytdscf_amd always runs on the MI355X HIP engine; backend string accepted for script compatibility")
+        if proj_gs:
+            raise NotImplementedError("proj_gs")
+        self.jobname, self.model, self.t2_trick, self.verbose = jobname, model, t2_trick, verbose
+
+    def _engine(self, integrator, conserve_norm, thresh, relax=False):
+        m = self.model
+        eng = TDVPEngine(len(m.dims), integrator=integrator, conserve_norm=conserve_norm, thresh=thresh, relax=relax)
+        ids = {"hamiltonian": 0}
+        eng.set_mpo(m.hamiltonian.as_mpo(m.dims), 0, shift=m.hamiltonian.coupleJ[0][0])
+        for k, (name, op) in enumerate(m.observables.items(), start=1):
+            eng.set_mpo(op.as_mpo(m.dims), k)
+            ids[name] = k
+        eng.set_mps(m.initial_cores(), canonicalize=True, scale=1.0)
+        return eng, ids
+
+    def propagate(self, stepsize=0.1, maxstep=5000, restart=False, savefile_ext="", loadfile_ext="_operate",
+                  backup_interval=1000, autocorr=True, energy=True, norm=True, populations=True, observables=False,
+                  reduced_density=None, Δt=None, thresh_sil=1.0e-09, autocorr_per_step=1, observables_per_step=1,
+                  energy_per_step=1, norm_per_step=1, populations_per_step=1, parallel_split_indices=None,
+                  adaptive=False, adaptive_Dmax=20, adaptive_dD=5, adaptive_p_proj=1.0e-04, adaptive_p_svd=1.0e-07,
+                  integrator="lanczos", display_time_unit="fs", conserve_norm=True):
+        if restart or adaptive or parallel_split_indices is not None:
+            raise NotImplementedError("restart / adaptive / MPI sharding are 'next' rows (SURVEY 8f)")
+        if integrator not in ("lanczos", "arnoldi"):
+            raise ValueError(f"Invalid integrator: {integrator}")
+        dt_fs = Δt if Δt is not None else stepsize
+        dt_au = dt_fs / units.au_in_fs
+        eng, ids = self._engine(integrator, conserve_norm, thresh_sil)
+        wf = WFunc(eng, ids)
+        outdir = f"{self.jobname}_prop"
+        os.makedirs(outdir, exist_ok=True)
+        tconv = {"fs": units.au_in_fs, "ps": units.au_in_fs * 1e-3, "au": 1.0}[display_time_unit]
+        files = {k: open(os.path.join(outdir, f"{k}.dat"), "w") for k in ("autocorr", "populations", "expectations")}
+        self.rdm_trace = []
+        ener = None
+        try:
+            for istep in range(maxstep):
+                t = istep * dt_au * tconv
+                if autocorr and istep % autocorr_per_step == 0:
+                    a = eng.autocorr()
+                    if istep == 0:
+                        files["autocorr"].write(f"# time [{display_time_unit}]\t auto-correlation\n")
+                    files["autocorr"].write(f"{(2 * t if self.t2_trick else t):6.9f}\t{a.real: 6.9f}{a.imag:+6.9f}j\n")
+                if populations and istep % populations_per_step == 0:
+                    if istep == 0:
+                        files["populations"].write(f"# time [{display_time_unit}]\tpop_0      \n")
+                    files["populations"].write(f"{t:6.9f}\t{eng.norm() ** 2:6.9f}\t\n")
+                row = {}
+                if energy and istep % energy_per_step == 0:
+                    ener = eng.expectation(0).real
+                    row["energy"] = ener
+                if observables and istep % observables_per_step == 0:
+                    for name, k in ids.items():
+                        if k:
+                            row[name] = eng.expectation(k).real
+                if row:
+                    if istep == 0:
+                        files["expectations"].write(f"# time [{display_time_unit}]\t" + "\t".join(f"{k:<11}" for k in row) + "\n")
+                    files["expectations"].write(f"{t:6.9f}\t" + "".join(f"{v:6.9f}\t" for v in row.values()) + "\n")
+                if reduced_density is not None and istep % reduced_density[1] == 0:
+                    rec = {}
+                    for key in reduced_density[0]:
+                        if len(key) == 2 and key[0] == key[1]:
+                            rec[tuple(key)] = eng.site_rdm(key[0])
+                    self.rdm_trace.append((t, rec))
+                eng.propagate(dt_au)
+        finally:
+            for f in files.values():
+                f.close()
+        return ener, wf
+
+    def relax(self, stepsize=0.1, maxstep=20, improved_relax=False, restart=False, savefile_ext="_gs", loadfile_ext="",
+              backup_interval=10, norm=True, populations=True, observables=False, integrator="lanczos",
+              display_time_unit="fs", thresh_sil=1.0e-09, **kw):
+        """Imaginary-time relaxation (simulator_cls.py:95-159; exp(-H dt/2) with
+        renormalisation, _mps_cls.py:1086-1094).  Improved relaxation is a 'next' row."""
+        if improved_relax:
+            raise NotImplementedError("improved relaxation (Lanczos diagonalisation) is a 'next' row")
+        eng, ids = self._engine(integrator, True, thresh_sil, relax=True)
+        dt_au = stepsize / units.au_in_fs
+        ener = None
+        for _ in range(maxstep):
+            ener = eng.expectation(0).real
+            eng.propagate(dt_au)
+        return ener, WFunc(eng, ids)
+
+    def operate(self, *a, **k):
+        raise NotImplementedError("operate (dipole application) is outside the accelerated path")

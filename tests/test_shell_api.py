@@ -1,0 +1,91 @@
+"""The PyTDSCF-shaped user surface: scripts of the reference's own
+tests, re-typed against ``pytdscf_amd`` (same class names / kwargs)."""
+
+import numpy as np
+import pytest
+
+from oracle import tdvp_oracle as orc
+
+
+def _exciton_model(g):
+    from pytdscf_amd import Exciton, HarmonicOscillator as HO, Model, TensorHamiltonian, TensorOperator
+
+    prim_info = [HO(8, f, units="cm-1") for f in (1000, 2000, 3000)] + [Exciton(nstate=2, names=["S0", "S1"])]
+    pot = [g[f"pot{i}"] for i in range(4)]
+    kin = [g[f"kin{i}"] for i in range(3)]
+    potential = [[{(0, 1, 2, (3, 3)): TensorOperator(mpo=pot, legs=(0, 1, 2, 3, 3))}]]
+    kinetic = [[{((0, 0), (1, 1), (2, 2)): TensorOperator(mpo=kin, legs=(0, 0, 1, 1, 2, 2))}]]
+    hamiltonian = TensorHamiltonian(ndof=4, potential=potential, kinetic=kinetic, backend="hip")
+    model = Model(prim_info, {"hamiltonian": hamiltonian}, bond_dim=2)
+    model.init_HartreeProduct = [[ho.get_unitary()[0].tolist() for ho in prim_info[:3]] + [np.array([0.0, 1.0]).tolist()]]
+    return model
+
+
+def test_model_reduction_cpu(golden):
+    """Model -> (one MPO, initial cores) reproduces the reference pins through the oracle."""
+    g = golden("exciton.npz")
+    model = _exciton_model(g)
+    mpo = model.hamiltonian.as_mpo(model.dims)
+    assert [w.shape for w in mpo] == [(1, 8, 8, 5), (5, 8, 8, 6), (6, 8, 8, 4), (4, 2, 2, 1)]
+    st = orc.OracleMPS(orc.canonicalize_site0(model.initial_cores()), mpo)
+    e = None
+    for _ in range(20):
+        e = st.expectation()
+        st.propagate(float(g["dt_au"]))
+    assert e.real == pytest.approx(float(g["ref_pin_energy"]))
+
+
+def test_units_match_reference(golden):
+    from pytdscf_amd import units
+
+    g = golden("henon_heiles.npz")
+    assert units.au_in_fs == float(g["au_in_fs"])
+    assert units.au_in_cm1 == float(g["au_in_cm1"])
+
+
+def test_unsupported_combinations_raise():
+    from pytdscf_amd import Exciton, Model, Simulator
+
+    core = np.zeros((1, 2, 2, 1))
+    with pytest.raises(NotImplementedError):
+        Model([Exciton(2)], [core], bond_dim=2, space="liouville")
+    with pytest.raises(ValueError):
+        Model([Exciton(2), Exciton(2)], {"hamiltonian": [core]}, bond_dim=2)
+    m = Model([Exciton(2)], [core], bond_dim=2)
+    with pytest.raises(NotImplementedError):
+        Simulator("j", m, ci_type="MCTDH")
+
+
+@pytest.mark.gpu
+def test_exciton_script_on_gpu(golden, tmp_path, monkeypatch):
+    """tests/test_exiciton_propagate.py of the reference, through the shell."""
+    from pytdscf_amd import Simulator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("exciton.npz")
+    simulator = Simulator("LVC_Exciton_test", _exciton_model(g), backend="hip")
+    ener_calc, wf = simulator.propagate(stepsize=0.1, maxstep=20, reduced_density=([(3, 3)], 1))
+    assert pytest.approx(ener_calc) == 0.010000180312707298
+    t, rdm = simulator.rdm_trace[-1]
+    np.testing.assert_allclose(rdm[(3, 3)], g["ref_pin_rdm33"], atol=1e-9)
+    assert abs(wf.norm() - 1) < 1e-12
+    lines = open(tmp_path / "LVC_Exciton_test_prop" / "autocorr.dat").read().splitlines()
+    assert lines[0].startswith("# time [fs]") and len(lines) == 21
+
+
+@pytest.mark.gpu
+def test_henon_heiles_script_on_gpu(golden, tmp_path, monkeypatch):
+    """tests/test_henon_heiles.py NumPy case through the shell (MPO cores from the fixture)."""
+    from pytdscf_amd import HarmonicOscillator as HO, Model, Simulator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("henon_heiles.npz")
+    dvr_prims = [HO(5, 2000) for _ in range(2)]
+    operators = {"potential": [g["pot0"], g["pot1"]], "kinetic": [g["kin0"], g["kin1"]]}
+    model = Model(dvr_prims, operators=operators, bond_dim=4)
+    model.init_weight_VIBSTATE = [[[0.0, 1.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0, 0.0]]]
+    simulator = Simulator(jobname="henon_heiles", model=model, backend="hip")
+    ener_calc, wf = simulator.propagate(maxstep=3, stepsize=0.001)
+    assert pytest.approx(ener_calc) == 0.018225341011652626
+    ref = [g["n3_final0"], g["n3_final1"]]
+    assert abs(abs(orc.overlap(ref, wf.get_mps())) - 1) < 1e-9
