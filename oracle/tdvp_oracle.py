@@ -524,7 +524,8 @@ def synthetic_mps(dims: list[int], D: int, seed: int = 1):
     bd = bond_dims(dims, D)
     cores = []
     for (dl, dr), d in zip(bd, dims):
-        cores.append(rng.standard_normal((dl, d, dr)) + 1j * rng.standard_normal((dl, d, dr)))
+        c = rng.standard_normal((dl, d, dr)) + 1j * rng.standard_normal((dl, d, dr))
+        cores.append(c / math.sqrt(2.0 * dl * d))  # O(1) singular values: no overflow on long chains
     return canonicalize_site0(cores)
 
 

@@ -568,6 +568,14 @@ void Engine::canonicalize(double scale) {
     gauge_qr_right(site_[p].p, dl, d, dr, spare.p, tmp2_.p, sig_.p);
     std::swap(site_[p], spare);
     gauge_[p] = MITDVP_GAUGE_B;
+    // The overall norm is reset at the end of the sweep, so sigma is rescaled to
+    // unit Frobenius norm on the device: unnormalised (e.g. random) cores would
+    // otherwise grow geometrically along a long chain and overflow.
+    {
+      double* nrm = reinterpret_cast<double*>(red_.p + RED_MISC);
+      vec_sumsq(st_, sig_.p, (long)dl * dl, nrm);
+      vec_scale_inv_norm(st_, sig_.p, (long)dl * dl, nrm, 1e-300);
+    }
     // site[p-1] <- site[p-1] . sigma
     const int m = dl_[p - 1] * dd_[p - 1];
     ZgemmDesc g = zgemm_desc(site_[p - 1].p, sig_.p, spare.p, m, dl, dl);

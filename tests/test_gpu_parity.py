@@ -171,3 +171,32 @@ def test_device_random_state_properties():
     eng.propagate(-0.4)
     eng.propagate(-0.4)
     assert abs(_fidelity(orc, before, eng.get_mps()) - 1) < 1e-7  # reversible up to thresh_sil accumulation
+
+
+def test_nonconvergence_raises_value_error():
+    """Like the reference (_integrator.py:653): more than 20 Krylov vectors -> ValueError,
+    re-raised through the C ABI status code MITDVP_ENOTCONV."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L, d, M, D = 6, 4, 4, 8
+    eng = TDVPEngine(L)
+    eng.set_mpo([50.0 * w for w in orc.synthetic_mpo(L, d, M, seed=0)])
+    eng.set_mps(orc.synthetic_mps([d] * L, D, seed=1))
+    with pytest.raises(ValueError, match="not converged"):
+        eng.propagate(50.0)
+
+
+def test_bad_arguments_raise():
+    from pytdscf_amd import TDVPEngine
+
+    eng = TDVPEngine(3)
+    with pytest.raises(ValueError):
+        eng.set_site(5, np.zeros((1, 2, 1)))
+    with pytest.raises(ValueError):
+        eng.propagate(0.1)  # nothing set
+    eng.set_site(0, np.ones((1, 2, 2)), "Psi")
+    eng.set_site(1, np.ones((3, 2, 2)), "B")  # bond mismatch 2 != 3
+    eng.set_site(2, np.ones((2, 2, 1)), "B")
+    with pytest.raises(ValueError, match="mismatch"):
+        eng.expectation()
