@@ -58,47 +58,96 @@ __device__ __forceinline__ House zlarfg(zc alpha, double xnorm2) {
   return h;
 }
 
-// pn[b] = sum_{i>j} |A[i,j]|^2 over the block's rows ; scal[0] = A[j,j]
-__global__ __launch_bounds__(256) void k_qr_colnorm(const zc* __restrict__ A, long lda, int m, int j,
-                                                    double* __restrict__ pn, zc* __restrict__ scal) {
-  __shared__ double sh[5];
-  const int i = blockIdx.x * QR_ROWS + threadIdx.x;
-  double s = 0;
-  const bool mine = threadIdx.x < QR_ROWS;  // 256 threads, QR_ROWS rows per block
-  if (mine && i < m && i > j) {
-    const zc a = A[(long)i * lda + j];
-    s = a.x * a.x + a.y * a.y;
-  }
-  if (mine && i == j) scal[0] = A[(long)i * lda + j];
-  s = qr_block_sum(s, sh);
-  if (threadIdx.x == 0) pn[blockIdx.x] = s;
-}
-
-// Householder vector of column j and its products with the rest of the panel:
-//   pw[b][c] = sum_{i in block} conj(v_i) A[i,c]   for j < c < j1
-// then column j is overwritten with v (below the diagonal) and beta (diagonal).
-__global__ __launch_bounds__(256) void k_qr_house(zc* __restrict__ A, long lda, int m, int j, int j0, int j1,
-                                                  const double* __restrict__ pn, int nblk,
-                                                  const zc* __restrict__ scal, zc* __restrict__ tau,
-                                                  zc* __restrict__ pw) {
-  __shared__ double sh[5];
+// ---------------------------------------------------------------------------
+// Panel factorisation (zgeqr2), ONE launch per column.
+//
+// For column j the reflector needs ||x||^2 and w_c = v^H A[:,c]; both follow
+// from the raw products y_c = sum_{i>j} conj(A[i,j]) A[i,c], c = j..j1-1
+// (y_j = ||x||^2), because v = x * scale below the diagonal and v_j = 1:
+//     w_c = conj(scale) * y_c + A[j,c].
+// Kernel j therefore (1) sums the per-block partial y of column j written by
+// kernel j-1, (2) forms beta/tau/scale, (3) updates its rows of the panel and
+// stores v, (4) accumulates the partial y of column j+1 from the rows it has
+// just updated, (5) the block owning row j+1 exports that row (A[j+1,c]) for
+// the next kernel (double buffered: it is rewritten by its owner while other
+// blocks still need the old values).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_qr_panel_init(const zc* __restrict__ A, long lda, int m, int j0, int j1,
+                                                       zc* __restrict__ py, zc* __restrict__ rowbuf) {
   __shared__ zc red[8][32];
-  double x2 = 0;
-  for (int i = threadIdx.x; i < nblk; i += 256) x2 += pn[i];
-  x2 = qr_block_sum(x2, sh);
-  const zc alpha = scal[0];
-  const House h = zlarfg(alpha, x2);
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = j0 + tx;
   const int r0 = blockIdx.x * QR_ROWS;
+  const bool active = c < j1;
+  double sr = 0, si = 0;
+#pragma unroll
+  for (int q = 0; q < QR_ROWS / 8; ++q) {
+    const int i = r0 + ty + 8 * q;
+    const bool ok = i < m && i > j0 && active;
+    const long ii = ok ? i : j0;
+    const zc x = A[ii * lda + j0];
+    const zc a = A[ii * lda + (ok ? c : j0)];
+    if (ok) {
+      sr += x.x * a.x + x.y * a.y;  // conj(x) * a
+      si += x.x * a.y - x.y * a.x;
+    }
+    if (i == j0 && active) rowbuf[tx] = A[(long)i * lda + c];
+  }
+  red[ty][tx] = make_double2(sr, si);
+  __syncthreads();
+  if (ty == 0) {
+    double ar = 0, ai = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ar += red[q][tx].x; ai += red[q][tx].y; }
+    py[(long)blockIdx.x * QR_NB + tx] = make_double2(ar, ai);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_qr_col(zc* __restrict__ A, long lda, int m, int j, int j0, int j1,
+                                                const zc* __restrict__ py_in, int nblk, zc* __restrict__ py_out,
+                                                const zc* __restrict__ row_in, zc* __restrict__ row_out,
+                                                zc* __restrict__ tau) {
+  __shared__ zc red[8][32];
+  __shared__ zc ysum[32];
+  __shared__ zc xnext[8][QR_ROWS / 8];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = j0 + tx;
+  const int r0 = blockIdx.x * QR_ROWS;
+  const int jj = j - j0;
+  // (1) y_c = sum over blocks of the partials of column j
+  {
+    double sr = 0, si = 0;
+    for (int b = ty; b < nblk; b += 8) {
+      const zc v = py_in[(long)b * QR_NB + tx];
+      sr += v.x;
+      si += v.y;
+    }
+    red[ty][tx] = make_double2(sr, si);
+  }
+  __syncthreads();
+  if (ty == 0) {
+    zc y = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y = zadd(y, red[q][tx]);
+    ysum[tx] = y;
+  }
+  __syncthreads();
+  // (2) reflector scalars
+  const House h = zlarfg(row_in[jj], ysum[jj].x);
   const bool active = c > j && c < j1;
-  double are = 0, aim = 0;
-  // all loads of the block's rows are independent: issue them together
+  // w_c = conj(scale) y_c + A[j,c]
+  zc f = make_double2(0.0, 0.0);
+  if (active) {
+    const zc w = zadd(zmul(zconj(h.scale), ysum[tx]), row_in[tx]);
+    f = zmul(zconj(h.tau), w);
+  }
+  // (3) update the block's rows; (4) partial y of column j+1
+  const bool have_next = j + 1 < j1;
   zc xs[QR_ROWS / 8], as_[QR_ROWS / 8];
 #pragma unroll
   for (int q = 0; q < QR_ROWS / 8; ++q) {
     const int i = r0 + ty + 8 * q;
-    const bool ok = i < m && i >= j && active;
+    const bool ok = i < m && i >= j && c < j1 && c >= j;
     const long ii = ok ? i : j;
     xs[q] = A[ii * lda + j];
     as_[q] = A[ii * lda + (ok ? c : j)];
@@ -106,91 +155,43 @@ __global__ __launch_bounds__(256) void k_qr_house(zc* __restrict__ A, long lda, 
 #pragma unroll
   for (int q = 0; q < QR_ROWS / 8; ++q) {
     const int i = r0 + ty + 8 * q;
-    if (i < m && i >= j && active) {
+    const bool row_ok = i < m && i >= j;
+    zc anew = as_[q];
+    if (row_ok) {
       const zc v = (i == j) ? make_double2(1.0, 0.0) : zmul(xs[q], h.scale);
-      const zc a = as_[q];
-      are += v.x * a.x + v.y * a.y;  // conj(v) * a
-      aim += v.x * a.y - v.y * a.x;
-    }
-  }
-  red[ty][tx] = make_double2(are, aim);
-  __syncthreads();
-  if (ty == 0) {
-    double sr = 0, si = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { sr += red[q][tx].x; si += red[q][tx].y; }
-    pw[(long)blockIdx.x * QR_NB + tx] = make_double2(sr, si);
-  }
-  __syncthreads();
-  // overwrite column j (all reads of the raw column in this block are done)
-  if (tx == j - j0) {
-    for (int q = 0; q < QR_ROWS / 8; ++q) {
-      const int i = r0 + ty + 8 * q;
-      if (i < m) {
-        if (i > j) {
-          const long o = (long)i * lda + j;
-          A[o] = zmul(A[o], h.scale);
-        } else if (i == j) {
-          A[(long)i * lda + j] = make_double2(h.beta, 0.0);
-        }
+      if (active) {
+        anew = zsub(as_[q], zmul(v, f));
+        A[(long)i * lda + c] = anew;
+      } else if (c == j) {
+        A[(long)i * lda + j] = (i == j) ? make_double2(h.beta, 0.0) : v;
       }
     }
+    as_[q] = anew;
+    if (tx == jj + 1) xnext[ty][q] = anew;  // column j+1 of this row, after the update
+    if (have_next && i == j + 1 && c > j && c < j1) row_out[tx] = anew;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) tau[j] = h.tau;
-}
-
-// A[i,c] -= conj(tau) v_i w_c for the remaining panel columns; fused column
-// norm of column j+1 for the next reflector.
-__global__ __launch_bounds__(256) void k_qr_apply(zc* __restrict__ A, long lda, int m, int j, int j0, int j1,
-                                                  const zc* __restrict__ tau, const zc* __restrict__ pw, int nblk,
-                                                  double* __restrict__ pn_out, zc* __restrict__ scal) {
-  __shared__ double sh[5];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = j0 + tx;
-  const int r0 = blockIdx.x * QR_ROWS;
-  const bool active = c > j && c < j1;
-  // w_c = sum over blocks of pw[b][c]: the 8 row-lanes split the blocks
-  __shared__ zc wred[8][32];
-  {
-    double sr = 0, si = 0;
-    for (int b = ty; b < nblk; b += 8) {
-      const zc v = pw[(long)b * QR_NB + tx];
-      sr += v.x;
-      si += v.y;
-    }
-    wred[ty][tx] = make_double2(sr, si);
-  }
+  if (!have_next) return;
   __syncthreads();
-  zc w = make_double2(0.0, 0.0);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) w = zadd(w, wred[q][tx]);
-  const zc tc = zconj(tau[j]);
-  const zc f = zmul(tc, w);
-  double nrm = 0;
-  zc vs[QR_ROWS / 8], as_[QR_ROWS / 8];
+  double sr = 0, si = 0;
 #pragma unroll
   for (int q = 0; q < QR_ROWS / 8; ++q) {
     const int i = r0 + ty + 8 * q;
-    const bool ok = i < m && i >= j && active;
-    const long ii = ok ? i : j;
-    vs[q] = A[ii * lda + j];
-    as_[q] = A[ii * lda + (ok ? c : j)];
-  }
-#pragma unroll
-  for (int q = 0; q < QR_ROWS / 8; ++q) {
-    const int i = r0 + ty + 8 * q;
-    if (i < m && i >= j && active) {
-      const zc v = (i == j) ? make_double2(1.0, 0.0) : vs[q];
-      const zc a = zsub(as_[q], zmul(v, f));
-      A[(long)i * lda + c] = a;
-      if (c == j + 1) {
-        if (i > j + 1) nrm += a.x * a.x + a.y * a.y;
-        if (i == j + 1) scal[0] = a;
-      }
+    if (i < m && i > j + 1 && c > j && c < j1) {
+      const zc x = xnext[ty][q];
+      const zc a = as_[q];
+      sr += x.x * a.x + x.y * a.y;
+      si += x.x * a.y - x.y * a.x;
     }
   }
-  nrm = qr_block_sum(nrm, sh);
-  if (threadIdx.x == 0) pn_out[blockIdx.x] = nrm;
+  red[ty][tx] = make_double2(sr, si);
+  __syncthreads();
+  if (ty == 0) {
+    double ar = 0, ai = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ar += red[q][tx].x; ai += red[q][tx].y; }
+    py_out[(long)blockIdx.x * QR_NB + tx] = make_double2(ar, ai);
+  }
 }
 
 // Vp[i-j0][c-j0] = unit lower trapezoid of the panel
@@ -252,9 +253,8 @@ size_t qr_work_elems(int m, int n) {
   e += (size_t)QR_NB * QR_NB;      // G
   e += (size_t)npan * QR_NB * QR_NB;  // T
   e += n;                          // tau
-  e += nblk;                       // pn (doubles, over-allocated as zc)
-  e += (size_t)nblk * QR_NB;       // pw
-  e += 8;                          // scal
+  e += 2 * (size_t)nblk * QR_NB;   // partial y, double buffered
+  e += 2 * QR_NB;                  // exported row, double buffered
   return e;
 }
 
@@ -270,9 +270,8 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   zc* G = W2 + (size_t)QR_NB * n;
   zc* T = G + (size_t)QR_NB * QR_NB;
   zc* tau = T + (size_t)npan * QR_NB * QR_NB;
-  double* pn = reinterpret_cast<double*>(tau + n);
-  zc* pw = tau + n + nblk;
-  zc* scal = pw + (size_t)nblk * QR_NB;
+  zc* py[2] = {tau + n, tau + n + (size_t)nblk * QR_NB};
+  zc* rowb[2] = {py[1] + (size_t)nblk * QR_NB, py[1] + (size_t)nblk * QR_NB + QR_NB};
   long nl = 0;
   const zc one = make_double2(1.0, 0.0), mone = make_double2(-1.0, 0.0);
 
@@ -284,14 +283,12 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
 
   for (int ip = 0; ip < npan; ++ip) {
     const int j0 = ip * QR_NB, j1 = min(n, j0 + QR_NB), nbp = j1 - j0, mp = m - j0;
-    hipLaunchKernelGGL(k_qr_colnorm, dim3(nblk), dim3(256), 0, st, A, lda, m, j0, pn, scal);
+    hipLaunchKernelGGL(k_qr_panel_init, dim3(nblk), dim3(256), 0, st, A, lda, m, j0, j1, py[0], rowb[0]);
     ++nl;
     for (int j = j0; j < j1; ++j) {
-      hipLaunchKernelGGL(k_qr_house, dim3(nblk), dim3(256), 0, st, A, lda, m, j, j0, j1, pn, nblk, scal, tau, pw);
-      if (j + 1 < j1) {
-        hipLaunchKernelGGL(k_qr_apply, dim3(nblk), dim3(256), 0, st, A, lda, m, j, j0, j1, tau, pw, nblk, pn, scal);
-        ++nl;
-      }
+      const int cur = (j - j0) & 1;
+      hipLaunchKernelGGL(k_qr_col, dim3(nblk), dim3(256), 0, st, A, lda, m, j, j0, j1, py[cur], nblk, py[cur ^ 1],
+                         rowb[cur], rowb[cur ^ 1], tau);
       ++nl;
     }
     HIP_CHECK(hipGetLastError());
