@@ -10,10 +10,15 @@ exp(+i K_eff dt/2).  Sweeps alternate direction (forward, backward, ...), two of
 them are one PyTDSCF time step.  All tensors are generated on / resident in HBM
 before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the serial sweep
-is a strict dependency chain, so for round 1 the ranks run independent replicas
-(an ensemble of trajectories, SURVEY 8e "fallback"); value = N * sweeps / max
-time, "scaling": "weak".  No data-path collective.
+N > 1 (launched by torch.distributed.run, one rank per GPU), --parallel:
+  tp        (default when D % N == 0) ONE sweep shared by all GPUs, "scaling":
+            "strong": every H_eff / K_eff apply and environment update is sharded
+            over the bra-side bond index (each rank contracts D/N rows of the
+            environment block), combined by one RCCL all-gather / all-reduce per
+            contraction chain over xGMI; Krylov algebra and QR are replicated.
+            Exact: same results as one GPU up to summation order.
+  replicas  N independent trajectories (SURVEY 8e "fallback"), "scaling": "weak",
+            no data-path collective.
 
 Prints ONE JSON line on rank 0.
 """
@@ -132,6 +137,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("MITDVP_WORKLOAD", "C4"), choices=sorted(WORKLOADS))
     ap.add_argument("--dt", type=float, default=None, help="time step in a.u. (default per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallel", default=os.environ.get("MITDVP_PARALLEL", "auto"), choices=["auto", "tp", "replicas"])
     args = ap.parse_args()
 
     from pytdscf_amd.dist import Comm, replica_throughput
@@ -157,7 +163,17 @@ def main():
     liouville = integ == "arnoldi"
     eng = TDVPEngine(L, device=local_rank, integrator=integ, conserve_norm=not liouville)
     eng.set_mpo(orc.synthetic_liouvillian_mpo(L, M, seed=0, gamma=0.002) if liouville else orc.synthetic_mpo(L, d, M, seed=0))
-    eng.init_random([d] * L, D, seed=1 + rank)  # device-side full-rank MPS, canonicalised on the GPU
+    mode = args.parallel
+    if mode == "auto":
+        mode = "tp" if (world > 1 and D % world == 0 and D >= 8 * world) else "replicas"
+    if world == 1:
+        mode = "single"
+    # tp: every rank holds the same replicated state (same seed); replicas: one trajectory per rank
+    eng.init_random([d] * L, D, seed=1 + (rank if mode == "replicas" else 0))
+    if mode == "tp":
+        from pytdscf_amd.dist import attach_parallel
+
+        attach_parallel(eng, comm)
     e0 = eng.expectation().real  # also builds nothing persistent; forces setup to finish
 
     def note(msg):
@@ -192,7 +208,11 @@ def main():
     nrm = eng.norm()  # synchronises the engine's stream
     barrier()
     el_rank = time.perf_counter() - t0
-    value, el = replica_throughput(comm, float(args.steps), el_rank)
+    if mode == "tp":  # one shared job: units are counted once
+        el = comm.max_over_ranks(el_rank)
+        value = args.steps / el
+    else:
+        value, el = replica_throughput(comm, float(args.steps), el_rank)
     cnt = eng.counters()
     eng.set_profiling(False)
 
@@ -209,7 +229,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if mode == "tp" else "weak",
             "vs_baseline": None,
             "dtype": "c128",
             "data": "synthetic",
@@ -222,11 +242,14 @@ def main():
                 "mean_krylov_bond": round(kk, 2),
                 "norm_after": nrm,
                 "energy_before": e0,
-                "parallelism": "single GPU" if args.gpus == 1 else f"{args.gpus} independent replicas",
+                "parallelism": {"single": "single GPU", "replicas": f"{args.gpus} independent replicas",
+                                "tp": f"bond-sharded over {args.gpus} GPUs (RCCL all-gather / all-reduce)"}[mode],
+                "collectives": int(cnt["n_collectives"]),
+                "collective_GB": cnt["collective_bytes"] / 1e9,
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)",
+                "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)" + (" -- per GPU, this rank's bond shard" if mode == "tp" else ""),
                 "achieved": ach,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

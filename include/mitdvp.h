@@ -94,6 +94,21 @@ int mitdvp_sweep(mitdvp_engine* h, double dt_au, int forward);
 /* op_sys_sites = None (_mps_cls.py:2311,2371,2417, wavefunction.py:64-65). */
 int mitdvp_invalidate_env(mitdvp_engine* h);
 
+/* -- multi-GPU: bond-sharded (tensor-parallel) applies ------------------- */
+/* One process per GPU, every rank holds the replicated state and calls the
+ * same sequence of entry points.  H_eff / K_eff applies and environment
+ * updates are computed for this rank's slice of the bra-side bond index and
+ * combined by ONE collective each, issued through `fn` (RCCL via
+ * torch.distributed in pytdscf_amd/dist.py; gloo in the tests):
+ *   op 0: in-place all-gather  (rank r owns bytes [r*nbytes/N, (r+1)*nbytes/N))
+ *   op 1: in-place all-reduce  (sum, float64)
+ * `fn` is called with the engine's stream drained and must return after the
+ * collective has completed on the device.  The reference's only parallel path
+ * is the approximate mpi4py real-space scheme (_mps_parallel.py:106-268); this
+ * one is exact (same results as 1 GPU up to summation order). */
+typedef int (*mitdvp_collective_fn)(void* user, int op, void* dev_ptr, size_t nbytes);
+int mitdvp_set_parallel(mitdvp_engine* h, int nranks, int rank, mitdvp_collective_fn fn, void* user);
+
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */
@@ -113,7 +128,9 @@ typedef struct {
   long long n_exp_site, n_exp_bond;
   long long n_launch;    /* kernel launches issued                              */
   double heff_stage_ms[3]; /* L.psi, W., .R stages of the H_eff applies (profiling on) */
-  double reserved[5];
+  double n_collectives;    /* collectives issued (bond-sharded mode)                   */
+  double collective_bytes; /* sum of the collective buffer sizes                       */
+  double reserved[3];
 } mitdvp_counters;
 int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out);
 int mitdvp_counters_reset(mitdvp_engine* h);

@@ -57,7 +57,9 @@ class Counters(C.Structure):
         ("n_exp_bond", C.c_longlong),
         ("n_launch", C.c_longlong),
         ("heff_stage_ms", C.c_double * 3),
-        ("reserved", C.c_double * 5),
+        ("n_collectives", C.c_double),
+        ("collective_bytes", C.c_double),
+        ("reserved", C.c_double * 3),
     ]
 
     def as_dict(self):
@@ -65,6 +67,8 @@ class Counters(C.Structure):
         d["heff_stage_ms"] = list(self.heff_stage_ms)
         return d
 
+
+COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 
 _lib = None
 
@@ -112,6 +116,7 @@ def load() -> C.CDLL:
         "mitdvp_counters_get": (i, [vp, C.POINTER(Counters)]),
         "mitdvp_counters_reset": (i, [vp]),
         "mitdvp_set_profiling": (i, [vp, i]),
+        "mitdvp_set_parallel": (i, [vp, i, i, COLLECTIVE_FN, vp]),
         "mitdvp_heff_apply": (i, [i, dp, dp, dp, dp, i, i, i, i, i, dp, i, dp]),
         "mitdvp_keff_apply": (i, [i, dp, dp, dp, i, i, i, dp]),
         "mitdvp_env_update": (i, [i, i, dp, dp, dp, i, i, i, i, i, dp]),

@@ -62,6 +62,12 @@ struct Operator {
   hzc shift{0.0, 0.0};
 };
 
+// collective callback: op on a device buffer of nbytes (complex128 elements)
+//   COLL_ALLGATHER: rank r's shard is bytes [r*nbytes/N, (r+1)*nbytes/N); fill the rest
+//   COLL_ALLREDUCE: element-wise sum over ranks (as float64)
+typedef int (*CollFn)(void* user, int op, void* dev_ptr, size_t nbytes);
+enum { COLL_ALLGATHER = 0, COLL_ALLREDUCE = 1 };
+
 struct PhaseTimer {
   hipEvent_t a, b;
   int kind;
@@ -96,6 +102,7 @@ class Engine {
   void counters_get(mitdvp_counters* out);
   void counters_reset();
   void set_profiling(bool on) { profiling_ = on; }
+  void set_parallel(int nranks, int rank, CollFn fn, void* user);
 
   std::string last_error;
 
@@ -137,6 +144,13 @@ class Engine {
   zc* h_red_ = nullptr;  // pinned host mirror of red_
   size_t red_elems_ = 0;
   std::vector<int> kprev_;
+
+  // bond-sharded multi-GPU execution
+  int nranks_ = 1, rank_ = 0;
+  CollFn coll_ = nullptr;
+  void* coll_user_ = nullptr;
+  bool shard_range(int n, int& a0, int& a1) const;
+  void collective(int op, zc* p, size_t elems);
 
   // counters
   mitdvp_counters cnt_{};

@@ -254,77 +254,125 @@ void Engine::require_ready() {
 // ---------------------------------------------------------------------------
 // contractions
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// bond-sharded execution over several GPUs (one process per GPU)
+//
+// The three contractions of an apply / environment update are independent for
+// every value of the leading (bra-side) bond index of the environment block, so
+// rank r computes the rows a in [r*n/N, (r+1)*n/N) from replicated operands and
+// the ranks exchange results with ONE collective per contraction chain:
+//   H_eff / K_eff apply : in-place all-gather of the result vector
+//   environment update  : in-place all-reduce (sum over the sharded bra index)
+// Everything else (Krylov vector algebra, QR, absorption) is computed
+// redundantly on identical data, so all ranks take identical control-flow
+// decisions without exchanging scalars.  The collective itself is a callback
+// (RCCL through torch.distributed in production, gloo in the 1-GPU tests).
+// ---------------------------------------------------------------------------
+void Engine::set_parallel(int nranks, int rank, CollFn fn, void* user) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) throw ArgError("set_parallel: bad rank / nranks");
+  if (nranks > 1 && !fn) throw ArgError("set_parallel: a collective callback is required for nranks > 1");
+  nranks_ = nranks; rank_ = rank; coll_ = fn; coll_user_ = user;
+}
+
+bool Engine::shard_range(int n, int& a0, int& a1) const {
+  a0 = 0; a1 = n;
+  if (nranks_ <= 1 || n % nranks_ != 0 || n < 8 * nranks_) return false;  // small / ragged bonds stay replicated
+  const int c = n / nranks_;
+  a0 = rank_ * c; a1 = a0 + c;
+  return true;
+}
+
+void Engine::collective(int op, zc* p, size_t elems) {
+  HIP_CHECK(hipStreamSynchronize(st_));
+  const int rc = coll_(coll_user_, op, p, elems * sizeof(zc));
+  if (rc != 0) throw HipError("collective callback failed (rc=" + std::to_string(rc) + ")");
+  cnt_.n_collectives += 1;
+  cnt_.collective_bytes += (double)(elems * sizeof(zc));
+}
+
 void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
                         hzc shift) {
   const int ml = w.ml, mr = w.mr;
+  int a0, a1;
+  const bool sharded = shard_range(dl, a0, a1);
+  const int na = a1 - a0;
   timer_begin(10);
   {  // X[(a,c)][(j,s)] = L[(a,c)][b] psi[b][(j,s)]
-    ZgemmDesc g = zgemm_desc(L, psi, X_.p, dl * ml, d * dr, dl);
+    ZgemmDesc g = zgemm_desc(L + (size_t)a0 * ml * dl, psi, X_.p, na * ml, d * dr, dl);
     zgemm(st_, g);
   }
   timer_end();
   timer_begin(11);
   {  // Y_a[(i,t)][s] = W2L[(i,t)][(c,j)] X_a[(c,j)][s]
     ZgemmDesc g = zgemm_desc(w.w2l.p, X_.p, Y_.p, d * mr, dr, ml * d);
-    g.batch = dl; g.strideA = 0; g.strideB = (long)ml * d * dr; g.strideC = (long)d * mr * dr;
+    g.batch = na; g.strideA = 0; g.strideB = (long)ml * d * dr; g.strideC = (long)d * mr * dr;
     zgemm(st_, g);
   }
   timer_end();
   timer_begin(12);
   {  // out[(a,i)][r] = Y[(a,i)][(t,s)] R[r][(t,s)]
-    ZgemmDesc g = zgemm_desc(Y_.p, R, out, dl * d, dr, mr * dr);
+    ZgemmDesc g = zgemm_desc(Y_.p, R, out + (size_t)a0 * d * dr, na * d, dr, mr * dr);
     g.transB = 1; g.ldb = (long)mr * dr;
     zgemm(st_, g);
   }
+  timer_end();
+  if (sharded) collective(COLL_ALLGATHER, out, (size_t)dl * d * dr);
   if (shift != hzc(0.0, 0.0))
     vec_axpby(st_, out, psi, (long)dl * d * dr, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
-  timer_end();
   cnt_.n_launch += 3;
   cnt_.n_heff += 1;
-  cnt_.heff_flops += 8.0 * ((double)dl * dl * ml * d * dr + (double)dl * dr * ml * mr * d * d + (double)dl * dr * dr * mr * d);
+  cnt_.heff_flops += 8.0 * ((double)na * dl * ml * d * dr + (double)na * dr * ml * mr * d * d + (double)na * dr * dr * mr * d);
 }
 
 void Engine::keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift) {
+  int a0, a1;
+  const bool sharded = shard_range(d1, a0, a1);
+  const int na = a1 - a0;
   timer_begin(2);
   {  // X[(a,c)][s] = L[(a,c)][b] sig[b][s]
-    ZgemmDesc g = zgemm_desc(L, sig, X_.p, d1 * m, d2, d1);
+    ZgemmDesc g = zgemm_desc(L + (size_t)a0 * m * d1, sig, X_.p, na * m, d2, d1);
     zgemm(st_, g);
   }
   {  // out[a][r] = X[a][(c,s)] R[r][(c,s)]
-    ZgemmDesc g = zgemm_desc(X_.p, R, out, d1, d2, m * d2);
+    ZgemmDesc g = zgemm_desc(X_.p, R, out + (size_t)a0 * d2, na, d2, m * d2);
     g.transB = 1; g.ldb = (long)m * d2;
     zgemm(st_, g);
   }
+  timer_end();
+  if (sharded) collective(COLL_ALLGATHER, out, (size_t)d1 * d2);
   if (shift != hzc(0.0, 0.0))
     vec_axpby(st_, out, sig, (long)d1 * d2, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
-  timer_end();
   cnt_.n_launch += 2;
   cnt_.n_keff += 1;
-  cnt_.keff_flops += 8.0 * ((double)d1 * d1 * m * d2 + (double)d1 * d2 * d2 * m);
+  cnt_.keff_flops += 8.0 * ((double)na * d1 * m * d2 + (double)na * d2 * d2 * m);
 }
 
 void Engine::env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
                         int mout) {
+  int m0, m1;
+  const bool sharded = shard_range(din, m0, m1);
+  const int nm = m1 - m0;
   timer_begin(1);
   {  // X[(m,p)][(s,j)] = env[(m,p)][n] T[n][(s,j)]
-    ZgemmDesc g = zgemm_desc(env_in, T, X_.p, din * min_, d * dout, din);
+    ZgemmDesc g = zgemm_desc(env_in + (size_t)m0 * min_ * din, T, X_.p, nm * min_, d * dout, din);
     zgemm(st_, g);
   }
   {  // Y_m[(r,q)][j] = W2[(r,q)][(p,s)] X_m[(p,s)][j]
     ZgemmDesc g = zgemm_desc(w2, X_.p, Y_.p, d * mout, dout, min_ * d);
-    g.batch = din; g.strideA = 0; g.strideB = (long)min_ * d * dout; g.strideC = (long)d * mout * dout;
+    g.batch = nm; g.strideA = 0; g.strideB = (long)min_ * d * dout; g.strideC = (long)d * mout * dout;
     zgemm(st_, g);
   }
-  {  // env'[i][(q,j)] = conj(T)[(m,r)][i] Y[(m,r)][(q,j)]
-    ZgemmDesc g = zgemm_desc(T, Y_.p, env_out, dout, mout * dout, din * d);
+  {  // env'[i][(q,j)] = conj(T)[(m,r)][i] Y[(m,r)][(q,j)]   (sum over this rank's m)
+    ZgemmDesc g = zgemm_desc(T + (size_t)m0 * d * dout, Y_.p, env_out, dout, mout * dout, nm * d);
     g.transA = 1; g.conjA = 1; g.lda = dout;
     zgemm(st_, g);
   }
   timer_end();
+  if (sharded) collective(COLL_ALLREDUCE, env_out, (size_t)dout * mout * dout);
   cnt_.n_launch += 3;
   cnt_.n_env += 1;
-  cnt_.env_flops += 8.0 * ((double)din * din * min_ * d * dout + (double)din * dout * min_ * mout * d * d +
-                           (double)din * dout * dout * mout * d);
+  cnt_.env_flops += 8.0 * ((double)nm * din * min_ * d * dout + (double)nm * dout * min_ * mout * d * d +
+                           (double)nm * dout * dout * mout * d);
 }
 
 // ---------------------------------------------------------------------------

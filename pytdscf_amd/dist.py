@@ -23,11 +23,13 @@ class Comm:
             import torch
             import torch.distributed as dist
 
+            backend = os.environ.get("MITDVP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if torch.cuda.is_available():
                 torch.cuda.set_device(self.local_rank)
+            if backend == "nccl":
                 self.device = torch.device("cuda", self.local_rank)
                 dist.init_process_group("nccl", device_id=self.device)
-            else:
+            else:  # gloo: CPU-only hosts, or several test ranks sharing one GPU
                 self.device = torch.device("cpu")
                 dist.init_process_group("gloo")
             self.dist = dist
@@ -73,3 +75,78 @@ def replica_throughput(comm: Comm, units_this_rank: float, elapsed_this_rank: fl
     tmax = comm.max_over_ranks(elapsed_this_rank)
     units = comm.sum_over_ranks(units_this_rank)
     return units / tmax, tmax
+
+
+# ---------------------------------------------------------------------------
+# bond-sharded (tensor-parallel) execution: the collectives the engine asks for
+# ---------------------------------------------------------------------------
+class _DevPtr:
+    """Zero-copy view of engine-owned device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr: int, n_f64: int):
+        self.__cuda_array_interface__ = {
+            "shape": (n_f64,),
+            "typestr": "<f8",
+            "data": (int(ptr), False),
+            "version": 2,
+        }
+
+
+def attach_parallel(engine, comm: Comm, host_staged: bool | None = None):
+    """Put ``engine`` (a TDVPEngine living on this rank's GPU) into bond-sharded
+    mode over ``comm``.  All ranks must hold the same replicated state and issue
+    the same calls.  Collectives run on the engine's device buffers:
+
+    * backend nccl (= RCCL over xGMI): ``all_gather_into_tensor`` / ``all_reduce``
+      directly on the device memory;
+    * backend gloo (tests, several ranks sharing one GPU): staged through the host.
+    """
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    if comm.world == 1:
+        return None
+    dist = comm.dist
+    if host_staged is None:
+        host_staged = dist.get_backend() != "nccl"
+    rank, world = comm.rank, comm.world
+    dev = torch.device("cuda", engine.device)
+
+    def cb(user, op, ptr, nbytes):
+        try:
+            n = nbytes // 8
+            t = torch.as_tensor(_DevPtr(ptr, n), device=dev)
+            if op == 0:  # in-place all-gather of equal shards
+                chunk = n // world
+                mine = t[rank * chunk : (rank + 1) * chunk]
+                if host_staged:
+                    parts = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts, mine.cpu())
+                    t.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(t, mine.clone())
+            elif op == 1:  # in-place all-reduce (sum)
+                if host_staged:
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t)
+            else:
+                return 2
+            torch.cuda.synchronize(dev)
+            return 0
+        except Exception as e:  # never let an exception unwind through the C frame
+            import sys
+            import traceback
+
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    fn = _lib.COLLECTIVE_FN(cb)
+    engine._collective_cb = fn  # keep the trampoline alive as long as the engine
+    _lib.check(_lib.load().mitdvp_set_parallel(engine._h, world, rank, fn, None), engine._h)
+    return fn

@@ -48,6 +48,7 @@ class TDVPEngine:
         self._lib = lib
         self._h = C.c_void_p()
         self.nsite = nsite
+        self.device = device
         _lib.check(lib.mitdvp_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):

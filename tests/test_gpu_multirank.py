@@ -1,0 +1,124 @@
+"""GPU: bond-sharded (tensor-parallel) execution, 2 and 3 ranks sharing the one
+GPU of the test box over gloo (host-staged collectives), against the 1-rank
+engine; plus the nccl device-memory path at world_size 1."""
+
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+WORKER = """
+import sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from pytdscf_amd import TDVPEngine
+from pytdscf_amd.dist import Comm, attach_parallel
+comm = Comm()
+L, d, M, D = 8, 4, 5, 48            # 48 = 2 * 24 = 3 * 16: shards for 2 and 3 ranks
+mpo = orc.synthetic_mpo(L, d, M, seed=3)
+mps = orc.synthetic_mps([d] * L, D, seed=4)
+eng = TDVPEngine(L, device=0, integrator={integ!r}, conserve_norm={cn})
+eng.set_mpo(mpo)
+eng.set_mps(mps)
+attach_parallel(eng, comm)
+e0 = eng.expectation()
+for _ in range(2):
+    eng.propagate(0.4)
+out = dict(rank=comm.rank, e0=[e0.real, e0.imag], e=[eng.expectation().real, eng.expectation().imag],
+           norm=eng.norm(), ac=[eng.autocorr().real, eng.autocorr().imag], k=eng.krylov_stats(),
+           ncoll=eng.counters()["n_collectives"])
+np.save({out!r} + f".rank{{comm.rank}}.npy", np.concatenate([c.reshape(-1) for c in eng.get_mps()]))
+print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+comm.close()
+"""
+
+
+def _run(world, tmp_path, integ="lanczos", cn=True, backend_env=None):
+    import json
+
+    script = tmp_path / f"w{world}.py"
+    out = str(tmp_path / f"mps_w{world}")
+    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, integ=integ, cn=cn, out=out)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               MITDVP_DIST_BACKEND="gloo")
+    if backend_env:
+        env.update(backend_env)
+    procs = [
+        subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        for r in range(world)
+    ]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
+    vecs = [np.load(out + f".rank{r}.npy") for r in range(world)]
+    return res, vecs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bond_sharded_matches_single_rank(world, tmp_path):
+    ref, vref = _run(1, tmp_path)
+    res, vecs = _run(world, tmp_path)
+    assert ref[0]["ncoll"] == 0 and all(r["ncoll"] > 0 for r in res)
+    for r, v in zip(res, vecs):
+        assert r["k"] == ref[0]["k"]                       # identical control flow on every rank
+        assert abs(r["norm"] - 1) < 1e-12
+        assert abs(complex(*r["e"]) - complex(*ref[0]["e"])) < 1e-10 * abs(complex(*ref[0]["e"]))
+        assert abs(complex(*r["ac"]) - complex(*ref[0]["ac"])) < 1e-10
+        assert np.abs(v - vref[0]).max() < 1e-10           # same tensors up to summation order
+    for v in vecs[1:]:
+        assert np.array_equal(v, vecs[0])                  # replicated state stays bit-identical across ranks
+
+
+def test_bond_sharded_arnoldi(tmp_path):
+    ref, vref = _run(1, tmp_path, integ="arnoldi", cn=False)
+    res, vecs = _run(2, tmp_path, integ="arnoldi", cn=False)
+    assert res[0]["k"] == ref[0]["k"]
+    assert np.abs(vecs[0] - vref[0]).max() < 1e-10 and np.array_equal(vecs[0], vecs[1])
+
+
+def test_nccl_device_collectives_world1(tmp_path):
+    """The production path (RCCL on the engine's device buffers through the CUDA
+    array interface) at world_size 1: all-gather / all-reduce are identities."""
+    script = tmp_path / "n.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np, torch, torch.distributed as dist
+        from pytdscf_amd.dist import _DevPtr
+        from pytdscf_amd import engine as E
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        # engine-owned device memory, viewed zero-copy by torch
+        x = torch.arange(64, dtype=torch.float64, device="cuda")
+        t = torch.as_tensor(_DevPtr(x.data_ptr(), 64), device="cuda:0")
+        dist.all_reduce(t)
+        dist.all_gather_into_tensor(t, t.clone())
+        torch.cuda.synchronize()
+        assert torch.equal(x.cpu(), torch.arange(64, dtype=torch.float64))
+        t += 1.0
+        assert float(x[3]) == 4.0  # zero copy
+        dist.destroy_process_group()
+        print("OK")
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout + p.stderr
