@@ -350,6 +350,7 @@ class OracleMPS:
     thresh: float = 1e-9
     conserve_norm: bool = True
     shift: complex = 0.0  # coupleJ[0][0] * ovlp term, _contraction.py:1200-1216
+    relax: bool = False  # const.doRelax: exp(-H dt/2) / exp(+K dt/2) + renormalise, _mps_cls.py:1086-1094
     left: dict = field(default_factory=dict)
     right: dict = field(default_factory=dict)
     kprev: dict = field(default_factory=dict)
@@ -405,7 +406,8 @@ class OracleMPS:
         end = n - 1 if forward else 0
         for p in sites:
             # exp_superH_propagation_direct, _mps_cls.py:1016-1100 (:1070)
-            self.cores[p] = self._exp(-1.0j * dt / 2, self._heff(p), self.cores[p], p)
+            zs = -1.0 if self.relax else -1.0j  # _mps_cls.py:1070 vs :1088
+            self.cores[p] = self._exp(zs * dt / 2, self._heff(p), self.cores[p], p)
             if p == end:
                 break
             if forward:
@@ -415,7 +417,7 @@ class OracleMPS:
                 self.left[p + 1] = env_update_left(self.left[p], A, self.mpo[p])
                 # exp_superK_propagation_direct, _mps_cls.py:1102-1170 (:1151)
                 sval = self._exp(
-                    +1.0j * dt / 2, self._keff(self.left[p + 1], self.right[p]), sval, p
+                    -zs * dt / 2, self._keff(self.left[p + 1], self.right[p]), sval, p
                 )
                 # trans_next_psite_APsiB, _mps_cls.py:1172-1206
                 self.cores[p + 1] = np.tensordot(sval, self.cores[p + 1], axes=(1, 0))
@@ -424,7 +426,7 @@ class OracleMPS:
                 self.cores[p] = np.ascontiguousarray(B)
                 self.right[p - 1] = env_update_right(self.right[p], self.cores[p], self.mpo[p])
                 sval = self._exp(
-                    +1.0j * dt / 2, self._keff(self.left[p], self.right[p - 1]), sval, p
+                    -zs * dt / 2, self._keff(self.left[p], self.right[p - 1]), sval, p
                 )
                 self.cores[p - 1] = np.tensordot(self.cores[p - 1], sval, axes=(2, 0))
         self.center = end

@@ -297,13 +297,14 @@ class Simulator:
                 f.close()
         return ener, wf
 
-    def relax(self, stepsize=0.1, maxstep=20, improved_relax=False, restart=False, savefile_ext="_gs", loadfile_ext="",
+    def relax(self, stepsize=0.1, maxstep=20, improved=True, restart=False, savefile_ext="_gs", loadfile_ext="",
               backup_interval=10, norm=True, populations=True, observables=False, integrator="lanczos",
-              display_time_unit="fs", thresh_sil=1.0e-09, **kw):
+              display_time_unit="fs", thresh_sil=1.0e-09):
         """Imaginary-time relaxation (simulator_cls.py:95-159; exp(-H dt/2) with
-        renormalisation, _mps_cls.py:1086-1094).  Improved relaxation is a 'next' row."""
-        if improved_relax:
-            raise NotImplementedError("improved relaxation (Lanczos diagonalisation) is a 'next' row")
+        renormalisation, _mps_cls.py:1086-1094).  ``improved=True`` (the reference's
+        default: Lanczos diagonalisation of H_eff, _integrator.py:74-138) is a 'next' row."""
+        if improved:
+            raise NotImplementedError("improved relaxation (Lanczos diagonalisation of H_eff) is a 'next' row; pass improved=False")
         eng, ids = self._engine(integrator, True, thresh_sil, relax=True)
         dt_au = stepsize / units.au_in_fs
         ener = None

@@ -5,7 +5,6 @@
 namespace mitdvp {
 
 constexpr int QR_NB = 32;     // panel width
-constexpr int QR_ROWS = 128;  // rows per workgroup in the panel kernels
 
 // workspace size in complex elements for an (m x n) factorisation
 size_t qr_work_elems(int m, int n);

@@ -13,6 +13,8 @@
 // O(m n^2) goes through the MFMA zgemm kernel.
 #include "qr.h"
 
+#include <type_traits>
+
 #include "vecops.h"
 
 namespace mitdvp {
@@ -72,6 +74,7 @@ __device__ __forceinline__ House zlarfg(zc alpha, double xnorm2) {
 // the next kernel (double buffered: it is rewritten by its owner while other
 // blocks still need the old values).
 // ---------------------------------------------------------------------------
+template <int QR_ROWS>
 __global__ __launch_bounds__(256) void k_qr_panel_init(const zc* __restrict__ A, long lda, int m, int j0, int j1,
                                                        zc* __restrict__ py, zc* __restrict__ rowbuf) {
   __shared__ zc red[8][32];
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256) void k_qr_panel_init(const zc* __restrict__ A,
   }
 }
 
+template <int QR_ROWS>
 __global__ __launch_bounds__(256) void k_qr_col(zc* __restrict__ A, long lda, int m, int j, int j0, int j1,
                                                 const zc* __restrict__ py_in, int nblk, zc* __restrict__ py_out,
                                                 const zc* __restrict__ row_in, zc* __restrict__ row_out,
@@ -244,8 +248,12 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 }
 
 // ---------------------------------------------------------------------------
+// rows per workgroup in the panel kernels: enough workgroups to spread a column
+// step over the chip, few enough that summing their partials stays cheap
+static int qr_rows_for(int m) { return m <= 8192 ? 32 : (m <= 65536 ? 128 : 256); }
+
 size_t qr_work_elems(int m, int n) {
-  const int nblk = (m + QR_ROWS - 1) / QR_ROWS;
+  const int nblk = (m + 31) / 32;  // upper bound over all row-block sizes
   const int npan = (n + QR_NB - 1) / QR_NB;
   size_t e = 0;
   e += (size_t)m * QR_NB;          // Vp
@@ -262,7 +270,9 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
   if (n <= 0) return;
   const long lda = n;
-  const int nblk = (m + QR_ROWS - 1) / QR_ROWS;
+  const int rows = qr_rows_for(m);
+  const int nblk = (m + rows - 1) / rows;
+  const int nblk_max = (m + 31) / 32;
   const int npan = (n + QR_NB - 1) / QR_NB;
   zc* Vp = work;
   zc* W = Vp + (size_t)m * QR_NB;
@@ -270,8 +280,8 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   zc* G = W2 + (size_t)QR_NB * n;
   zc* T = G + (size_t)QR_NB * QR_NB;
   zc* tau = T + (size_t)npan * QR_NB * QR_NB;
-  zc* py[2] = {tau + n, tau + n + (size_t)nblk * QR_NB};
-  zc* rowb[2] = {py[1] + (size_t)nblk * QR_NB, py[1] + (size_t)nblk * QR_NB + QR_NB};
+  zc* py[2] = {tau + n, tau + n + (size_t)nblk_max * QR_NB};
+  zc* rowb[2] = {py[1] + (size_t)nblk_max * QR_NB, py[1] + (size_t)nblk_max * QR_NB + QR_NB};
   long nl = 0;
   const zc one = make_double2(1.0, 0.0), mone = make_double2(-1.0, 0.0);
 
@@ -283,14 +293,20 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
 
   for (int ip = 0; ip < npan; ++ip) {
     const int j0 = ip * QR_NB, j1 = min(n, j0 + QR_NB), nbp = j1 - j0, mp = m - j0;
-    hipLaunchKernelGGL(k_qr_panel_init, dim3(nblk), dim3(256), 0, st, A, lda, m, j0, j1, py[0], rowb[0]);
-    ++nl;
-    for (int j = j0; j < j1; ++j) {
-      const int cur = (j - j0) & 1;
-      hipLaunchKernelGGL(k_qr_col, dim3(nblk), dim3(256), 0, st, A, lda, m, j, j0, j1, py[cur], nblk, py[cur ^ 1],
-                         rowb[cur], rowb[cur ^ 1], tau);
+    auto panel = [&](auto rows_c) {
+      constexpr int R = decltype(rows_c)::value;
+      hipLaunchKernelGGL(k_qr_panel_init<R>, dim3(nblk), dim3(256), 0, st, A, lda, m, j0, j1, py[0], rowb[0]);
       ++nl;
-    }
+      for (int j = j0; j < j1; ++j) {
+        const int cur = (j - j0) & 1;
+        hipLaunchKernelGGL(k_qr_col<R>, dim3(nblk), dim3(256), 0, st, A, lda, m, j, j0, j1, py[cur], nblk, py[cur ^ 1],
+                           rowb[cur], rowb[cur ^ 1], tau);
+        ++nl;
+      }
+    };
+    if (rows == 32) panel(std::integral_constant<int, 32>{});
+    else if (rows == 128) panel(std::integral_constant<int, 128>{});
+    else panel(std::integral_constant<int, 256>{});
     HIP_CHECK(hipGetLastError());
     // compact WY: T from G = V^H V
     extract_v(j0, nbp);

@@ -329,6 +329,24 @@ def main():
         )
     save("chain_arnoldi.npz", dt_au=np.array(dt / au_in_fs), nsite=np.array(L), **o)
 
+    # (ii-b) imaginary-time relaxation (doRelax=True, exp(-H dt/2) + renormalisation,
+    # _mps_cls.py:1086-1094, :1162-1169) on the Hermitian chain
+    model = Model(basis, operators={"hamiltonian": [w.copy() for w in mpo]}, bond_dim=D)
+    model.init_HartreeProduct = [[np.array(c) for c in cores]]
+    o = {f"mpo{i}": w for i, w in enumerate(mpo)}
+    o.update({f"init{i}": c for i, c in enumerate(cores)})
+    for n in (1, 5):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_relax", model, backend="numpy", verbose=0)
+        ener, wf = sim.relax(stepsize=0.2, maxstep=n, improved=False)
+        o[f"n{n}_energy_last"] = np.array(ener)
+        o[f"n{n}_energy_final"] = np.array(wf.expectation(model.hamiltonian))
+        o[f"n{n}_norm"] = np.array(wf.norm())
+        o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(L)])
+        for i, s in enumerate(wf.ci_coef.superblock_states[0]):
+            o[f"n{n}_final{i}"] = np.array(s.data)
+    save("chain_relax.npz", dt_au=np.array(0.2 / au_in_fs), nsite=np.array(L), **o)
+
     # (iii) the reference's own exciton pin (tests/test_exiciton_propagate.py):
     # potential = diagonal 3-leg cores + one 4-leg core, kinetic on sites 0-2 only.
     au_in_cm1 = float(units.au_in_cm1)

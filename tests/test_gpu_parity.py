@@ -224,3 +224,28 @@ def test_oracle_parity_liouvillian_arnoldi():
     e0, e1 = st.expectation(), eng.expectation()
     assert abs(e0 - e1) < 1e-8 * abs(e0)
     assert abs(_fidelity(orc, st.cores, eng.get_mps()) - 1) < 1e-10
+
+
+def test_chain_relaxation_golden(golden):
+    """Imaginary-time relaxation (Simulator.relax(improved=False)) against the reference."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    g = golden("chain_relax.npz")
+    n = int(g["nsite"])
+    mpo = [g[f"mpo{i}"] for i in range(n)]
+    init = [g[f"init{i}"] for i in range(n)]
+    dt = float(g["dt_au"])
+    eng = TDVPEngine(n, relax=True)
+    eng.set_mpo(mpo)
+    eng.set_mps(init, canonicalize=True)
+    e_last = None
+    for _ in range(5):
+        e_last = eng.expectation()
+        eng.propagate(dt)
+    assert eng.krylov_stats() == list(g["n5_krylov"])
+    assert abs(e_last.real - float(g["n5_energy_last"])) < 1e-8 * abs(float(g["n5_energy_last"]))
+    assert abs(eng.expectation().real - float(g["n5_energy_final"])) < 1e-8 * abs(float(g["n5_energy_final"]))
+    assert abs(eng.norm() - 1) < 1e-12
+    ref = [g[f"n5_final{i}"] for i in range(n)]
+    assert abs(_fidelity(orc, ref, eng.get_mps()) - 1) < 1e-10

@@ -82,6 +82,24 @@ def test_chain_end_to_end(golden, name, integ, cn, steps):
             np.testing.assert_allclose(a, b, atol=1e-9)
 
 
+def test_chain_relaxation(golden):
+    """Imaginary-time relaxation (doRelax=True) against the reference."""
+    g = golden("chain_relax.npz")
+    n, mpo, init = _load_chain(g)
+    dt = float(g["dt_au"])
+    for ns in (1, 5):
+        st = orc.OracleMPS(orc.canonicalize_site0(init), mpo, relax=True)
+        e_last = None
+        for _ in range(ns):
+            e_last = st.expectation()
+            st.propagate(dt)
+        assert list(g[f"n{ns}_krylov"]) == [st.kprev[i] for i in range(n)]
+        np.testing.assert_allclose(e_last.real, float(g[f"n{ns}_energy_last"]), rtol=1e-10)
+        np.testing.assert_allclose(st.expectation().real, float(g[f"n{ns}_energy_final"]), rtol=1e-9)
+        ref = [g[f"n{ns}_final{i}"] for i in range(n)]
+        assert abs(abs(orc.overlap(ref, st.cores)) - 1) < 1e-10
+
+
 def test_synthetic_inputs_shapes():
     mpo = orc.synthetic_mpo(5, 3, 4)
     assert [w.shape for w in mpo] == [(1, 3, 3, 4)] + [(4, 3, 3, 4)] * 3 + [(4, 3, 3, 1)]
