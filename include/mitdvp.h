@@ -114,6 +114,12 @@ int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */
 int mitdvp_norm(mitdvp_engine* h, double* out);                      /* _mps_cls.py:706-716 */
 int mitdvp_site_rdm(mitdvp_engine* h, int isite, double* reim_out);  /* _mps_cls.py:1208-1436, key (isite,isite) */
+/* General reduced density, MPSCoef.get_reduced_densities / _get_pure_reduced_density
+ * (_mps_cls.py:1208-1283, :1628-1678): remain_nleg[isite] in {0,1,2} legs kept per site
+ * (2 = ket and bra, 1 = diagonal).  Two calls: with out == NULL the number of complex
+ * elements is returned in *n_out; then with a buffer of that size.  Axes: kept sites
+ * ascending, (ket, bra) per 2-leg site. */
+int mitdvp_reduced_density(mitdvp_engine* h, const int* remain_nleg, int nlen, double* reim_out, size_t* n_out);
 int mitdvp_krylov_stats(mitdvp_engine* h, int* per_site);            /* _Debug.niter_krylov, _helper.py:29 */
 
 /* -- counters: _ElpTime / _NFlops equivalents (_helper.py:33-101) ------- */

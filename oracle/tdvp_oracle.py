@@ -489,6 +489,26 @@ def site_rdm(cores: list[np.ndarray], site: int) -> np.ndarray:
     return np.einsum("ajs,aks->jk", c, np.conj(c))
 
 
+def reduced_density(cores: list[np.ndarray], remain_nleg) -> np.ndarray:
+    """``_get_pure_reduced_density`` (_mps_cls.py:1208-1283) for a site-0-centred
+    MPS: per site keep 2 legs (ket, bra), 1 leg (diagonal) or none; sites right
+    of the last kept one are right-canonical and drop out.  Axes: kept sites in
+    ascending order, (ket, bra) per 2-leg site."""
+    legs = list(remain_nleg)
+    last = max(i for i, n in enumerate(legs) if n)
+    dens = None
+    for p in range(last, -1, -1):
+        c = cores[p]
+        n = legs[p]
+        if dens is None:
+            sub = {2: "ijk,alk->iajl", 1: "ijk,ajk->iaj"}[n]
+            dens = np.einsum(sub, c, np.conj(c))
+        else:
+            sub = {2: "lmi,bna,ia...->lbmn...", 1: "lmi,bma,ia...->lbm...", 0: "lmi,bma,ia...->lb..."}[n]
+            dens = np.einsum(sub, c, np.conj(c), dens)
+    return dens[0, 0, ...]
+
+
 # --------------------------------------------------------------------------
 # synthetic inputs (SURVEY.md section 8d) -- used by tests and bench
 # --------------------------------------------------------------------------

@@ -201,13 +201,10 @@ class WFunc:
         return v.real
 
     def get_reduced_densities(self, remain_nleg):
-        """Only one-site keys, e.g. (0, 0, 0, 2) = both legs of site 3 kept
-        (properties.py:69-82)."""
-        legs = remain_nleg[0] if isinstance(remain_nleg, list) else remain_nleg
-        nz = [i for i, n in enumerate(legs) if n]
-        if len(nz) != 1 or legs[nz[0]] != 2:
-            raise NotImplementedError("only one-site reduced densities (both legs of one site) are built so far")
-        return [self.engine.site_rdm(nz[0])]
+        """``WFunc.get_reduced_densities`` (wavefunction.py:67-88): one tuple of kept legs
+        per site, e.g. (0, 0, 0, 2) = both legs of site 3, or a list of such tuples."""
+        keys = remain_nleg if isinstance(remain_nleg, list) else [remain_nleg]
+        return [self.engine.reduced_density(k) for k in keys]
 
     def get_mps(self):
         return self.engine.get_mps()
@@ -288,8 +285,11 @@ class Simulator:
                 if reduced_density is not None and istep % reduced_density[1] == 0:
                     rec = {}
                     for key in reduced_density[0]:
-                        if len(key) == 2 and key[0] == key[1]:
-                            rec[tuple(key)] = eng.site_rdm(key[0])
+                        # key (3, 3) -> remain_nleg (0, 0, 0, 2), properties.py:69-82
+                        legs = [0] * (max(key) + 1)
+                        for site in key:
+                            legs[site] += 1
+                        rec[tuple(key)] = eng.reduced_density(legs)
                     self.rdm_trace.append((t, rec))
                 eng.propagate(dt_au)
         finally:

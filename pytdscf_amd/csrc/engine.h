@@ -97,6 +97,7 @@ class Engine {
   hzc autocorr();
   double norm();
   void site_rdm(int isite, double* out);
+  void reduced_density(const int* legs, int nlen, std::vector<hzc>& out, std::vector<int>& shape);
   void krylov_stats(int* per_site) const;
 
   void counters_get(mitdvp_counters* out);

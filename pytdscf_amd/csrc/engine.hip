@@ -878,6 +878,97 @@ void Engine::site_rdm(int isite, double* out) {
   }
 }
 
+// General pure-state reduced density (_get_pure_reduced_density,
+// _mps_cls.py:1208-1283): per site keep 2 legs (ket, bra), 1 leg (diagonal) or
+// none.  Left-to-right transfer with the open physical legs folded into a batch
+// index o: T_o[a][a'] (ket bond, bra bond); sites right of the last kept one
+// are right-canonical and drop out.  Output axes: kept sites ascending, (ket,
+// bra) per 2-leg site -- the reference's order.
+void Engine::reduced_density(const int* legs, int nlen, std::vector<hzc>& out, std::vector<int>& shape) {
+  require_ready();
+  if (center_ != 0) throw ArgError("reduced density needs the centre at site 0");
+  if (nlen < 1 || nlen > L_) throw ArgError("reduced_density: bad number of sites");
+  int last = -1;
+  for (int p = 0; p < nlen; ++p) {
+    if (legs[p] < 0 || legs[p] > 2) throw ArgError("The number of legs must be less than 3.");
+    if (legs[p]) last = p;
+  }
+  if (last < 0) throw ArgError("The number of legs must be greater than 0.");
+  shape.clear();
+  const zc one = make_double2(1.0, 0.0);
+  long no = 1;
+  DevBuf T = pool_get(1);
+  HIP_CHECK(hipMemcpyAsync(T.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  for (int p = 0; p <= last; ++p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p], n = legs[p];
+    if (no > 65535) throw ArgError("reduced_density: too many open legs for one call");
+    const zc* C = site_[p].p;
+    DevBuf U = pool_get((size_t)no * dl * d * dr);
+    {  // U_o[a'][(j,s)] = sum_a T_o[a][a'] C[a][(j,s)]
+      ZgemmDesc g = zgemm_desc(T.p, C, U.p, dl, d * dr, dl);
+      g.transA = 1; g.lda = dl; g.batch = (int)no;
+      g.strideA = (long)dl * dl; g.strideB = 0; g.strideC = (long)dl * d * dr;
+      zgemm(st_, g);
+    }
+    pool_put(std::move(T));
+    if (p < last) {
+      if (n == 0) {
+        T = pool_get((size_t)no * dr * dr);
+        ZgemmDesc g = zgemm_desc(U.p, C, T.p, dr, dr, dl * d);  // T'[s][s'] = U[(a',j)][s] conj(C[(a',j)][s'])
+        g.transA = 1; g.lda = dr; g.conjB = 1; g.batch = (int)no;
+        g.strideA = (long)dl * d * dr; g.strideB = 0; g.strideC = (long)dr * dr;
+        zgemm(st_, g);
+      } else if (n == 2) {
+        const long ds = (long)d * dr;
+        DevBuf Z = pool_get((size_t)no * ds * ds);
+        ZgemmDesc g = zgemm_desc(U.p, C, Z.p, (int)ds, (int)ds, dl);  // Z[(j,s)][(j',s')]
+        g.transA = 1; g.lda = ds; g.conjB = 1; g.batch = (int)no;
+        g.strideA = (long)dl * ds; g.strideB = 0; g.strideC = ds * ds;
+        zgemm(st_, g);
+        T = pool_get((size_t)no * ds * ds);
+        permute_0213(st_, Z.p, T.p, no * d, dr, d, dr);  // (o,j,s,j',s') -> (o,j,j',s,s')
+        pool_put(std::move(Z));
+        no *= (long)d * d;
+        shape.push_back(d); shape.push_back(d);
+      } else {
+        T = pool_get((size_t)no * d * dr * dr);
+        for (int j = 0; j < d; ++j) {  // T'_(o,j)[s][s'] = sum_a' U_o[a'][j][s] conj(C[a'][j][s'])
+          ZgemmDesc g = zgemm_desc(U.p + (size_t)j * dr, C + (size_t)j * dr, T.p + (size_t)j * dr * dr, dr, dr, dl);
+          g.transA = 1; g.lda = (long)d * dr; g.ldb = (long)d * dr; g.conjB = 1; g.batch = (int)no;
+          g.strideA = (long)dl * d * dr; g.strideB = 0; g.strideC = (long)d * dr * dr;
+          zgemm(st_, g);
+        }
+        no *= d;
+        shape.push_back(d);
+      }
+    } else {
+      // last kept site: the right side is the identity -> trace over s
+      DevBuf Ut = pool_get((size_t)no * dl * d * dr), Ct = pool_get((size_t)dl * d * dr), rho = pool_get((size_t)no * d * d);
+      permute_0213(st_, U.p, Ut.p, no, dl, d, dr);  // (o,a',j,s) -> (o,j,a',s)
+      permute_0213(st_, C, Ct.p, 1, dl, d, dr);
+      ZgemmDesc g = zgemm_desc(Ut.p, Ct.p, rho.p, d, d, dl * dr);  // rho_o[j][j'] = Ut_o[j][(a',s)] conj(Ct[j'][(a',s)])
+      g.transB = 1; g.conjB = 1; g.ldb = (long)dl * dr; g.batch = (int)no;
+      g.strideA = (long)d * dl * dr; g.strideB = 0; g.strideC = (long)d * d;
+      zgemm(st_, g);
+      std::vector<hzc> h((size_t)no * d * d);
+      HIP_CHECK(hipMemcpyAsync(h.data(), rho.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      if (n == 2) {
+        out = std::move(h);
+        shape.push_back(d); shape.push_back(d);
+      } else {
+        out.resize((size_t)no * d);
+        for (long o = 0; o < no; ++o)
+          for (int j = 0; j < d; ++j) out[(size_t)o * d + j] = h[((size_t)o * d + j) * d + j];
+        shape.push_back(d);
+      }
+      pool_put(std::move(Ut)); pool_put(std::move(Ct)); pool_put(std::move(rho));
+    }
+    pool_put(std::move(U));
+  }
+  pool_put(std::move(T));
+}
+
 void Engine::krylov_stats(int* per_site) const {
   for (int i = 0; i < L_; ++i) per_site[i] = kprev_[i];
 }

@@ -8,6 +8,8 @@
 // _integrator.py:553-554).
 #include "vecops.h"
 
+#include <algorithm>
+
 namespace mitdvp {
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -226,6 +228,21 @@ __global__ __launch_bounds__(256) void k_transpose(const zc* __restrict__ in, zc
   }
 }
 
+// out[i0][i2][i1][i3] = in[i0][i1][i2][i3]
+__global__ __launch_bounds__(256) void k_permute_0213(const zc* __restrict__ in, zc* __restrict__ out, long n0, int n1,
+                                                      int n2, int n3) {
+  const long tot = n0 * n1 * n2 * n3;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const int i3 = e % n3;
+    long r = e / n3;
+    const int i1 = r % n1;  // output order: i0, i2, i1, i3
+    r /= n1;
+    const int i2 = r % n2;
+    const long i0 = r / n2;
+    out[e] = in[((i0 * n1 + i1) * n2 + i2) * n3 + i3];
+  }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -307,6 +324,12 @@ void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, in, out, rows, cols, ldi, ldo, in_bs, out_bs);
   HIP_CHECK(hipGetLastError());
+}
+
+void permute_0213(hipStream_t st, const zc* in, zc* out, long n0, int n1, int n2, int n3) {
+  const long tot = n0 * n1 * n2 * n3;
+  if (tot <= 0) return;
+  LAUNCH(k_permute_0213, (int)std::min<long>(4096, (tot + 255) / 256), st, in, out, n0, n1, n2, n3);
 }
 
 // out[s][j][a] = in[a][j][s]   (in: (na, nj, ns) C order)

@@ -38,6 +38,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //   mode 1: row = 4*(lane>>4) + reg     (the f32 16x16x4 map)
 static int g_cd_mode = -1;
 
+__device__ __forceinline__ double flip_sign(double x, unsigned mask) {
+  return __hiloint2double(__double2hiint(x) ^ (int)mask, __double2loint(x));
+}
+
 __device__ __forceinline__ int cd_row(int mode, int lk, int r) {
   return mode == 0 ? (lk + 4 * r) : (4 * lk + r);
 }
@@ -178,8 +182,8 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
       for (int j = 0; j < WN; ++j)
         acc[q][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 
-  const double sa = d.conjA ? -1.0 : 1.0;
-  const double sb = d.conjB ? -1.0 : 1.0;
+  const unsigned sa_mask = d.conjA ? 0x80000000u : 0u;
+  const unsigned sb_mask = d.conjB ? 0x80000000u : 0u;
   constexpr int NK4 = BK / 4;
   constexpr int SLOTS = NK4 * WM;                       // MFMA groups per tile
   constexpr int PER_SLOT = (2 * NP + SLOTS - 1) / SLOTS;  // side items after each group
@@ -220,10 +224,12 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
     for (int k4 = 0; k4 < NK4; ++k4) {
       if (k4 + 1 < NK4) ldfrag(st, k4 + 1, fa[(k4 + 1) & 1], fb[(k4 + 1) & 1]);
       zc a[WM], bb[WN];
+      // conjugation = flip the sign bit of the imaginary part (one 32-bit xor
+      // instead of an f64 multiply on the VALU port the MFMAs share)
 #pragma unroll
-      for (int i = 0; i < WM; ++i) { a[i] = fa[k4 & 1][i]; a[i].y *= sa; }
+      for (int i = 0; i < WM; ++i) { a[i] = fa[k4 & 1][i]; a[i].y = flip_sign(a[i].y, sa_mask); }
 #pragma unroll
-      for (int j = 0; j < WN; ++j) { bb[j] = fb[k4 & 1][j]; bb[j].y *= sb; }
+      for (int j = 0; j < WN; ++j) { bb[j] = fb[k4 & 1][j]; bb[j].y = flip_sign(bb[j].y, sb_mask); }
       double as[WM], bs[WN];
       if (M3) {
 #pragma unroll

@@ -137,6 +137,19 @@ class TDVPEngine:
         self._ck(self._lib.mitdvp_site_rdm(self._h, isite, _dp(out)))
         return out
 
+    def reduced_density(self, remain_nleg) -> np.ndarray:
+        """``get_reduced_densities`` for one key: legs kept per site (0, 1 or 2)."""
+        legs = [int(x) for x in remain_nleg]
+        arr = (C.c_int * len(legs))(*legs)
+        n = C.c_size_t(0)
+        self._ck(self._lib.mitdvp_reduced_density(self._h, arr, len(legs), None, C.byref(n)))
+        out = np.empty(n.value, dtype=np.complex128)
+        self._ck(self._lib.mitdvp_reduced_density(self._h, arr, len(legs), _dp(out), C.byref(n)))
+        shape = []
+        for p, k in enumerate(legs):
+            shape += [self.get_site_shape(p)[1]] * k
+        return out.reshape(shape)
+
     def get_site_shape(self, isite: int):
         l, n, r, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self._ck(self._lib.mitdvp_get_site_shape(self._h, isite, C.byref(l), C.byref(n), C.byref(r), C.byref(g)))

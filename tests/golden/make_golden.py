@@ -427,6 +427,10 @@ def main():
         # key (3, 3) -> remain_legs (0, 0, 0, 2), properties.py:69-82
         rd = wf.get_reduced_densities((0, 0, 0, 2))
         o[f"n{n}_rdm33"] = np.array(rd[0])
+        # further keys of the reference test: (0, 0) -> (2,), (0, 0, 3, 3) -> (2, 0, 0, 2),
+        # and diagonal-only forms (one leg per site)
+        for tag, legs in (("rdm00", (2,)), ("rdm0033", (2, 0, 0, 2)), ("rdm1", (0, 1)), ("rdm013", (1, 2, 0, 1))):
+            o[f"n{n}_{tag}"] = np.array(wf.get_reduced_densities(legs)[0])
         for i, s in enumerate(wf.ci_coef.superblock_states[0]):
             o[f"n{n}_final{i}"] = np.array(s.data)
     # the reference's own known answers (tests/test_exiciton_propagate.py:178-184)

@@ -82,6 +82,12 @@ def test_exciton_pin_through_merged_mpo(golden):
     assert e.real == pytest.approx(float(g["ref_pin_energy"]))
     np.testing.assert_allclose(rdm, g["ref_pin_rdm33"], atol=1e-9)
     np.testing.assert_allclose(rdm, g["n19_rdm33"], atol=1e-10)
+    # general reduced densities (keys of the reference test + diagonal-only forms)
+    st = orc.OracleMPS(orc.canonicalize_site0(init), mpo)
+    for _ in range(19):
+        st.propagate(dt)
+    for tag, legs in (("rdm33", (0, 0, 0, 2)), ("rdm00", (2,)), ("rdm0033", (2, 0, 0, 2)), ("rdm1", (0, 1)), ("rdm013", (1, 2, 0, 1))):
+        np.testing.assert_allclose(orc.reduced_density(st.cores, legs), g[f"n19_{tag}"], atol=1e-10)
 
 
 def test_henon_heiles_pin_through_merged_mpo(golden):
