@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
   const unsigned sb_mask = d.conjB ? 0x80000000u : 0u;
   constexpr int NK4 = BK / 4;
   constexpr int SLOTS = NK4 * WM;                       // MFMA groups per tile
-  constexpr int PER_SLOT = (2 * NP + SLOTS - 1) / SLOTS;  // side items after each group
+  // side items after each MFMA group: front-loaded (twice the even share) so that
+  // the global loads of tile k+2 are in flight for most of tile k
+  constexpr int PER_SLOT = 2 * ((2 * NP + SLOTS - 1) / SLOTS);
 
   // LDS -> register fragments of k-step k4 of a stage
   auto ldfrag = [&](const zc* st, int k4, zc (&a)[WM], zc (&bb)[WN]) {
