@@ -174,6 +174,12 @@ int mitdvp_get_gemm_mode(void);
 /* Device-resident timing of the three-stage H_eff apply at a given shape
  * with random operands (bench roofline leg).  Returns avg ms per apply. */
 int mitdvp_bench_heff(int device, int dl, int d, int dr, int ml, int mr, int reps, int warmup, double* ms_out);
+/* Size-independent self checks of the H_eff apply on device-resident random
+ * operands at a given (possibly full BASELINE) shape, without host copies:
+ *   out[0] = ||H_3m(x) - H_4m(x)|| / ||H_4m(x)||        (two complex-product forms agree)
+ *   out[1] = ||H(x + 2i y) - H(x) - 2i H(y)|| / ||H(x + 2i y)||   (linearity)
+ *   out[2] = ||H(x)||, out[3] = ms of the last apply */
+int mitdvp_heff_selfcheck(int device, int dl, int d, int dr, int ml, int mr, double out[4]);
 /* raw v_mfma_f64_16x16x4_f64 issue-rate probe: returns TFLOP/s */
 int mitdvp_mfma_peak_probe(int device, double* tflops_out);
 /* dumps the C/D lane map of v_mfma_f64_16x16x4_f64: out[64*4*2] = (row, col) */

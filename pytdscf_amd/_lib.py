@@ -125,6 +125,7 @@ def load() -> C.CDLL:
         "mitdvp_expm_dense": (i, [i, i, i, i, dp, i, dp, d, d, d, i, dp, ip]),
         "mitdvp_zgemm": (i, [i, i, i, i, i, i, i, i, dp, dp, dp, dp, dp, i, i, dp]),
         "mitdvp_bench_heff": (i, [i, i, i, i, i, i, i, i, dp]),
+        "mitdvp_heff_selfcheck": (i, [i, i, i, i, i, i, dp]),
         "mitdvp_set_gemm_mode": (i, [i]),
         "mitdvp_get_gemm_mode": (i, []),
         "mitdvp_mfma_peak_probe": (i, [i, dp]),

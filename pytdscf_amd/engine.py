@@ -255,6 +255,13 @@ def zgemm(A, B, C0=None, transA=False, conjA=False, transB=False, conjB=False, a
     return (Cm, ms.value) if reps else Cm
 
 
+def heff_selfcheck(dl, d, dr, ml, mr, device=0) -> dict:
+    """Size-independent checks of one H_eff apply on device-resident operands."""
+    out = np.zeros(4)
+    _lib.check(_lib.load().mitdvp_heff_selfcheck(device, dl, d, dr, ml, mr, _dp(out)))
+    return {"rel_3m_vs_4m": out[0], "linearity_defect": out[1], "norm_Hx": out[2], "ms": out[3]}
+
+
 def set_gemm_mode(mode: str):
     """"4m" (textbook complex product) or "3m" (Karatsuba, library default)."""
     _lib.load().mitdvp_set_gemm_mode({"4m": 0, "3m": 1}[mode.lower()])
