@@ -289,3 +289,52 @@ def test_reduced_density_vs_oracle_full_rank():
         ref = orc.reduced_density(mps, legs)
         out = eng.reduced_density(legs)
         np.testing.assert_allclose(out, ref, atol=1e-13)
+
+
+@pytest.mark.parametrize(
+    "dims,D,M",
+    [([4], 8, 1), ([3, 5], 7, 3), ([2, 5, 3, 4], 1000, 4), ([6, 2, 2, 2, 2, 6], 5, 3), ([2] * 12, 16, 5)],
+)
+def test_edge_chains_vs_oracle(dims, D, M):
+    """Single site, two sites, ragged physical dimensions, exact regime (D larger than
+    the Hilbert space) and bond dimensions that are not multiples of any tile size."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L = len(dims)
+    rng = np.random.default_rng(sum(dims) + D)
+
+    def herm(d, s):
+        g = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        return s * (g + g.conj().T) / 2
+
+    mpo = []
+    for p, d in enumerate(dims):  # H = sum_p h_p + sum_p a_p a_{p+1} (+ more coupling channels)
+        w = np.zeros((M, d, d, M), dtype=np.complex128)
+        w[0, :, :, 0] = np.eye(d)
+        w[M - 1, :, :, M - 1] = np.eye(d)
+        w[0, :, :, M - 1] = herm(d, 0.3)
+        for k in range(1, M - 1):
+            a = herm(d, 0.2)
+            w[0, :, :, k] = a
+            w[k, :, :, M - 1] = a
+        if p == 0:
+            w = w[0:1] if M > 1 else w
+        if p == L - 1:
+            w = w[:, :, :, M - 1 : M]
+        if L == 1:
+            w = herm(d, 0.3).reshape(1, d, d, 1)
+        mpo.append(np.ascontiguousarray(w))
+    mps = orc.synthetic_mps(dims, D, seed=11)
+    st = orc.OracleMPS([c.copy() for c in mps], mpo)
+    eng = TDVPEngine(L)
+    eng.set_mpo(mpo)
+    eng.set_mps(mps)
+    for _ in range(3):
+        st.propagate(0.3)
+        eng.propagate(0.3)
+    assert eng.krylov_stats() == [st.kprev[i] for i in range(L)]
+    assert abs(eng.norm() - 1) < 1e-12
+    assert abs(eng.expectation() - st.expectation()) < 1e-8 * max(abs(st.expectation()), 1e-3)
+    assert abs(eng.autocorr() - st.autocorr()) < 1e-8
+    assert abs(_fidelity(orc, st.cores, eng.get_mps()) - 1) < 1e-10
