@@ -49,12 +49,16 @@ typedef struct {
   int device;           /* HIP device ordinal                               */
   int integrator;       /* MITDVP_LANCZOS | MITDVP_ARNOLDI  (:integrator)   */
   int conserve_norm;    /* const.conserve_norm, _integrator.py:189-213      */
-  int relax;            /* 0 real time; 1 imaginary time (const.doRelax)    */
+  int relax;            /* 0 real time; 1 imaginary time (const.doRelax = True);
+                           2 improved relaxation (doRelax = "improved": Lanczos
+                           ground state of H_eff per site, _integrator.py:74-138) */
   double thresh;        /* const.thresh_exp, default 1e-9                   */
   int max_krylov;       /* 20, _integrator.py:182                           */
   int lanczos_variant;  /* 0: reference alpha_l=<v0|H|v_l> (_integrator.py:556)
                            1: orthodox alpha_l=<v_l|H|v_l>                  */
-  int reserved[8];
+  int max_diag_krylov;  /* Krylov vectors kept by the improved-relaxation solver
+                           (0 = default 64; the reference allows up to 3000)   */
+  int reserved[7];
 } mitdvp_config;
 
 /* -- lifetime ---------------------------------------------------------- */

@@ -331,6 +331,42 @@ def sil_arnoldi(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
     raise ValueError("Short Iterative Arnoldi is not converged in 20 basis.")
 
 
+def lanczos_ground_state(matvec, psi, thresh=1e-9, root=0):
+    """Lowest eigenvector of a Hermitian H_eff by Lanczos, the "improved
+    relaxation" local solver ``matrix_diagonalize_lanczos`` (_integrator.py:74-138):
+    orthodox Lanczos (alpha_l = Re<v_l|H|v_l>, :115), a tridiagonal ``eigh`` after
+    every new vector (:123), convergence on the change of the Ritz vector (:131-134).
+    Returns (psi_new, k)."""
+    shape = psi.shape
+    v = np.array(psi, dtype=np.complex128).reshape(-1)
+    ndim = v.size
+    n_iter = min(ndim, 3000)
+    alpha = np.array([], dtype=np.float64)
+    beta = np.array([0.0], dtype=np.float64)
+    V = [v]
+    psi_sv = None
+    for i in range(n_iter + 1):
+        sig = np.array(matvec(V[-1].reshape(shape))).reshape(-1)
+        alpha = np.append(alpha, np.inner(np.conj(V[-1]), sig).real)
+        sig = sig - V[-1] * alpha[-1]
+        if len(V) >= 2:
+            sig = sig - V[-2] * beta[-1]
+        beta = np.append(beta, np.linalg.norm(sig))
+        sig = sig / beta[-1] if beta[-1] != 0 else sig
+        _, vecs = scipy.linalg.eigh_tridiagonal(alpha, beta[1:-1])
+        psi_next = (np.array(V).T @ vecs[:, root].reshape(i + 1, 1)).reshape(ndim)
+        if abs(beta[-1]) < EPS:
+            return psi_next.reshape(shape), i + 1
+        if i == 0:
+            psi_sv = psi_next
+        else:
+            if np.linalg.norm(psi_next - psi_sv) < thresh or i == ndim:
+                return psi_next.reshape(shape), i + 1
+            psi_sv = psi_next
+        V.append(sig)
+    raise ValueError("Lanczos Diagonalization is not converged in 3000 basis")
+
+
 # --------------------------------------------------------------------------
 # a8-a10: sweep
 # --------------------------------------------------------------------------
@@ -350,7 +386,8 @@ class OracleMPS:
     thresh: float = 1e-9
     conserve_norm: bool = True
     shift: complex = 0.0  # coupleJ[0][0] * ovlp term, _contraction.py:1200-1216
-    relax: bool = False  # const.doRelax: exp(-H dt/2) / exp(+K dt/2) + renormalise, _mps_cls.py:1086-1094
+    relax: bool | str = False  # const.doRelax: True = exp(-H dt/2) / exp(+K dt/2) + renormalise
+    #   (_mps_cls.py:1086-1094); "improved" = Lanczos ground state of H_eff, bond step skipped (:1078-1084, :1159-1160)
     left: dict = field(default_factory=dict)
     right: dict = field(default_factory=dict)
     kprev: dict = field(default_factory=dict)
@@ -407,7 +444,12 @@ class OracleMPS:
         for p in sites:
             # exp_superH_propagation_direct, _mps_cls.py:1016-1100 (:1070)
             zs = -1.0 if self.relax else -1.0j  # _mps_cls.py:1070 vs :1088
-            self.cores[p] = self._exp(zs * dt / 2, self._heff(p), self.cores[p], p)
+            if self.relax == "improved":
+                new, k = lanczos_ground_state(self._heff(p), self.cores[p], self.thresh)
+                self.kprev[p] = k
+                self.cores[p] = new / np.linalg.norm(new)
+            else:
+                self.cores[p] = self._exp(zs * dt / 2, self._heff(p), self.cores[p], p)
             if p == end:
                 break
             if forward:
@@ -416,18 +458,20 @@ class OracleMPS:
                 self.cores[p] = A
                 self.left[p + 1] = env_update_left(self.left[p], A, self.mpo[p])
                 # exp_superK_propagation_direct, _mps_cls.py:1102-1170 (:1151)
-                sval = self._exp(
-                    -zs * dt / 2, self._keff(self.left[p + 1], self.right[p]), sval, p
-                )
+                if self.relax != "improved":
+                    sval = self._exp(
+                        -zs * dt / 2, self._keff(self.left[p + 1], self.right[p]), sval, p
+                    )
                 # trans_next_psite_APsiB, _mps_cls.py:1172-1206
                 self.cores[p + 1] = np.tensordot(sval, self.cores[p + 1], axes=(1, 0))
             else:
                 sval, B = qr_psi2sigmaB(self.cores[p])
                 self.cores[p] = np.ascontiguousarray(B)
                 self.right[p - 1] = env_update_right(self.right[p], self.cores[p], self.mpo[p])
-                sval = self._exp(
-                    -zs * dt / 2, self._keff(self.left[p], self.right[p - 1]), sval, p
-                )
+                if self.relax != "improved":
+                    sval = self._exp(
+                        -zs * dt / 2, self._keff(self.left[p], self.right[p - 1]), sval, p
+                    )
                 self.cores[p - 1] = np.tensordot(self.cores[p - 1], sval, axes=(2, 0))
         self.center = end
 

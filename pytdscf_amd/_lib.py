@@ -34,7 +34,8 @@ class Config(C.Structure):
         ("thresh", C.c_double),
         ("max_krylov", C.c_int),
         ("lanczos_variant", C.c_int),
-        ("reserved", C.c_int * 8),
+        ("max_diag_krylov", C.c_int),
+        ("reserved", C.c_int * 7),
     ]
 
 

@@ -301,11 +301,10 @@ class Simulator:
               backup_interval=10, norm=True, populations=True, observables=False, integrator="lanczos",
               display_time_unit="fs", thresh_sil=1.0e-09):
         """Imaginary-time relaxation (simulator_cls.py:95-159; exp(-H dt/2) with
-        renormalisation, _mps_cls.py:1086-1094).  ``improved=True`` (the reference's
-        default: Lanczos diagonalisation of H_eff, _integrator.py:74-138) is a 'next' row."""
-        if improved:
-            raise NotImplementedError("improved relaxation (Lanczos diagonalisation of H_eff) is a 'next' row; pass improved=False")
-        eng, ids = self._engine(integrator, True, thresh_sil, relax=True)
+        renormalisation, _mps_cls.py:1086-1094) or, with ``improved=True`` (the
+        reference's default), Lanczos diagonalisation of H_eff per site
+        (_integrator.py:74-138, _mps_cls.py:1078-1084)."""
+        eng, ids = self._engine(integrator, True, thresh_sil, relax="improved" if improved else True)
         dt_au = stepsize / units.au_in_fs
         ener = None
         for _ in range(maxstep):

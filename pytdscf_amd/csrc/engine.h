@@ -118,6 +118,9 @@ class Engine {
   // x <- exp(scale * Op) x ; returns Krylov dimension used
   template <class MV>
   int krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev);
+  // x <- lowest eigenvector of Op (improved relaxation); returns Krylov dimension used
+  template <class MV>
+  int krylov_diag(MV&& matvec, zc* x, long n);
   void gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* sigma_out);   // Psi2Asigma
   void gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc* Bt_out, zc* sigma_out);  // Psi2sigmaB
   void ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n);
@@ -141,7 +144,8 @@ class Engine {
   void pool_put(DevBuf&& b);
 
   // workspaces
-  DevBuf X_, Y_, V_, tmp1_, tmp2_, sig_, sig2_, qrwork_, red_;
+  DevBuf X_, Y_, V_, Vdiag_, tmp1_, tmp2_, sig_, sig2_, qrwork_, red_;
+  int max_diag_krylov_ = 64;
   zc* h_red_ = nullptr;  // pinned host mirror of red_
   size_t red_elems_ = 0;
   std::vector<int> kprev_;

@@ -35,6 +35,8 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (c.nsite < 1) throw ArgError("nsite must be >= 1");
   if (c.max_krylov < 1 || c.max_krylov > MAXK - 1) throw ArgError("max_krylov must be in [1, 20]");
   if (c.integrator != MITDVP_LANCZOS && c.integrator != MITDVP_ARNOLDI) throw ArgError("bad integrator");
+  if (c.relax < 0 || c.relax > 2) throw ArgError("relax must be 0, 1 or 2");
+  max_diag_krylov_ = c.max_diag_krylov > 0 ? c.max_diag_krylov : 64;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -550,6 +552,83 @@ int Engine::krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev) {
 }
 
 // ---------------------------------------------------------------------------
+// improved relaxation: lowest eigenvector of H_eff by Lanczos
+// (matrix_diagonalize_lanczos, _integrator.py:74-138): orthodox Lanczos
+// (alpha_l = Re <v_l|H|v_l>), the projected tridiagonal problem is solved on the
+// host after every new vector, convergence on the change of the Ritz vector.
+// The Ritz vector's sign is fixed by a non-negative overlap with the start
+// vector (LAPACK leaves it arbitrary; only the global phase of the state is
+// affected).  The change ||psi_k - psi_{k-1}|| is evaluated in the Lanczos
+// coefficient space (the basis is orthonormal to working accuracy).
+// ---------------------------------------------------------------------------
+template <class MV>
+int Engine::krylov_diag(MV&& matvec, zc* x, long n) {
+  const int kcap = (int)std::min<long>(n, max_diag_krylov_);
+  Vdiag_.reserve((size_t)(kcap + 1) * n);
+  zc* V = Vdiag_.p;
+  zc* alpha_p = red_.p + RED_ALPHA;
+  double* nrm_p = reinterpret_cast<double*>(red_.p + RED_NRM);
+  HIP_CHECK(hipMemcpyAsync(V, x, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  std::vector<double> alpha, beta;  // beta[i] = norm of vector i+1 before normalisation
+  std::vector<double> prev;
+  auto finalize = [&](const std::vector<double>& c) {
+    const int k = (int)c.size();
+    double* misc_d = reinterpret_cast<double*>(red_.p + RED_MISC);
+    for (int c0 = 0; c0 < k; c0 += MAXK) {  // sum_j c_j V_j in chunks of MAXK vectors
+      const int kc = std::min(MAXK, k - c0);
+      Coefs cf{};
+      for (int j = 0; j < kc; ++j) cf.c[j] = make_double2(c[c0 + j], 0.0);
+      if (c0 == 0) {
+        vec_lincomb(st_, x, V, n, kc, cf, n, nullptr);
+      } else {
+        vec_lincomb(st_, tmp1_.p, V + (size_t)c0 * n, n, kc, cf, n, nullptr);
+        vec_axpby(st_, x, tmp1_.p, n, make_double2(1.0, 0.0), make_double2(1.0, 0.0));
+      }
+    }
+    vec_sumsq(st_, x, n, misc_d);  // renormalise (get_C_sval_states_norm, _mps_cls.py:1083-1084)
+    vec_scale_inv_norm(st_, x, n, misc_d, 0.0);
+  };
+  for (int i = 0; i < kcap; ++i) {
+    zc* vi = V + (size_t)i * n;
+    zc* vn = V + (size_t)(i + 1) * n;
+    matvec(vi, vn);
+    const int slot = i % MAXK;  // scalar slots are recycled; they are read every iteration
+    vec_dot(st_, vi, vn, n, true, alpha_p + (size_t)slot * NPART);
+    const int pslot = (i + MAXK - 1) % MAXK;
+    vec_lanczos_update(st_, vn, vi, i > 0 ? V + (size_t)(i - 1) * n : nullptr, n, alpha_p + (size_t)slot * NPART,
+                       i > 0 ? nrm_p + (size_t)pslot * NPART : nullptr, nrm_p + (size_t)slot * NPART);
+    vec_scale_inv_norm(st_, vn, n, nrm_p + (size_t)slot * NPART, KRYLOV_EPS);
+    cnt_.n_launch += 3;
+    read_partials(RED_ALPHA + (size_t)slot * NPART, NPART);
+    read_partials(RED_NRM, (size_t)MAXK * NPART / 2 + 1);
+    double a = 0, b2 = 0;
+    for (int q = 0; q < NPART; ++q) a += h_red_[RED_ALPHA + (size_t)slot * NPART + q].x;
+    const double* np_ = reinterpret_cast<const double*>(h_red_ + RED_NRM) + (size_t)slot * NPART;
+    for (int q = 0; q < NPART; ++q) b2 += np_[q];
+    alpha.push_back(a);
+    beta.push_back(std::sqrt(b2));
+    const int k = i + 1;
+    std::vector<double> c = tridiag_eigvec(alpha, beta, k, 0, nullptr);
+    if (c.empty()) throw NotConverged("tridiagonal eigen-solver did not converge");
+    bool done = beta.back() < KRYLOV_EPS || k == n;
+    if (!done && i > 0) {
+      double err = 0;
+      for (int j = 0; j < k; ++j) {
+        const double dlt = c[j] - (j < (int)prev.size() ? prev[j] : 0.0);
+        err += dlt * dlt;
+      }
+      done = std::sqrt(err) < cfg.thresh;
+    }
+    if (done) {
+      finalize(c);
+      return k;
+    }
+    prev = c;
+  }
+  throw NotConverged("Lanczos Diagonalization is not converged in " + std::to_string(kcap) + " basis");
+}
+
+// ---------------------------------------------------------------------------
 // gauge moves
 // ---------------------------------------------------------------------------
 void Engine::gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* sigma_out) {
@@ -648,7 +727,7 @@ void Engine::canonicalize(double scale) {
 // ---------------------------------------------------------------------------
 // sweep
 // ---------------------------------------------------------------------------
-hzc Engine::scale_site(double dt) const { return cfg.relax ? hzc(-dt / 2, 0.0) : hzc(0.0, -dt / 2); }
+hzc Engine::scale_site(double dt) const { return cfg.relax ? hzc(-dt / 2, 0.0) : hzc(0.0, -dt / 2); }  // :1070 / :1088
 hzc Engine::scale_bond(double dt) const { return cfg.relax ? hzc(+dt / 2, 0.0) : hzc(0.0, +dt / 2); }
 
 void Engine::build_right_envs() {
@@ -673,7 +752,10 @@ void Engine::local_site_exp(int p, double dt) {
   const zc* Rb = envR_[p + 1].p;
   const hzc shift = op(0).shift;
   auto mv = [&](const zc* in, zc* out) { heff_apply(Lb, w, Rb, in, out, dl, d, dr, shift); };
-  kprev_[p] = krylov_exp(scale_site(dt), mv, site_[p].p, (long)dl * d * dr, kprev_[p]);
+  if (cfg.relax == 2)  // improved relaxation, _mps_cls.py:1078-1084
+    kprev_[p] = krylov_diag(mv, site_[p].p, (long)dl * d * dr);
+  else
+    kprev_[p] = krylov_exp(scale_site(dt), mv, site_[p].p, (long)dl * d * dr, kprev_[p]);
   cnt_.n_exp_site += 1;
 }
 
@@ -716,8 +798,10 @@ void Engine::sweep(double dt, bool forward) {
       const zc* Rb = envR_[p + 1].p;
       const int m = w.mr;
       auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dr, dr, m, shift); };
-      kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dr * dr, kprev_[p]);
-      cnt_.n_exp_bond += 1;
+      if (cfg.relax != 2) {  // improved relaxation leaves the bond matrix alone (_mps_cls.py:1159-1160)
+        kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dr * dr, kprev_[p]);
+        cnt_.n_exp_bond += 1;
+      }
       envR_ok_[p + 1] = 0;
       pool_put(std::move(envR_[p + 1]));
       // trans_next_psite_APsiB: Psi(p+1) = sigma . B(p+1)
@@ -739,8 +823,10 @@ void Engine::sweep(double dt, bool forward) {
       const zc* Rb = envR_[p].p;
       const int m = w.ml;
       auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dl, dl, m, shift); };
-      kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dl * dl, kprev_[p]);
-      cnt_.n_exp_bond += 1;
+      if (cfg.relax != 2) {
+        kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dl * dl, kprev_[p]);
+        cnt_.n_exp_bond += 1;
+      }
       envL_ok_[p] = 0;
       pool_put(std::move(envL_[p]));
       // Psi(p-1) = A(p-1) . sigma

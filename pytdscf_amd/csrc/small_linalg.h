@@ -3,6 +3,7 @@
 // (scipy.linalg.eigh_tridiagonal / eig + solve, _integrator.py:401-409,
 // :617-637); here it is self-contained C++ (no LAPACK in the C-ABI library).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <vector>
@@ -48,6 +49,78 @@ inline void jacobi_eigh(int n, std::vector<double>& a, std::vector<double>& v) {
         }
       }
   }
+}
+
+// Eigen-decomposition of a real symmetric tridiagonal matrix by QL with implicit
+// shifts (the classic tql2/tqli algorithm): d = diagonal (n), e = sub-diagonal
+// (n-1).  On return d holds the eigenvalues (unsorted) and z (row-major n x n)
+// the eigenvectors in its columns.  Returns false if an eigenvalue needs > 100 sweeps.
+inline bool tridiag_ql(int n, std::vector<double>& d, std::vector<double> e, std::vector<double>& z) {
+  z.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) z[(size_t)i * n + i] = 1.0;
+  e.resize(n, 0.0);
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 100) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          e[i + 1] = (r = std::hypot(f, g));
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          d[i + 1] = g + (p = s * r);
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = z[(size_t)k * n + i + 1];
+            z[(size_t)k * n + i + 1] = s * z[(size_t)k * n + i] + c * f;
+            z[(size_t)k * n + i] = c * z[(size_t)k * n + i] - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return true;
+}
+
+// eigenvector of the `root`-th smallest eigenvalue of T(alpha, beta), with the
+// sign fixed so that its first component is non-negative
+inline std::vector<double> tridiag_eigvec(const std::vector<double>& alpha, const std::vector<double>& beta, int k,
+                                          int root, double* eigval) {
+  std::vector<double> d(alpha.begin(), alpha.begin() + k), e(beta.begin(), beta.begin() + std::max(k - 1, 0)), z;
+  if (!tridiag_ql(k, d, e, z)) return {};
+  std::vector<int> idx(k);
+  for (int i = 0; i < k; ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
+  const int col = idx[root < 0 ? k + root : root];
+  std::vector<double> v(k);
+  for (int i = 0; i < k; ++i) v[i] = z[(size_t)i * k + col];
+  if (v[0] < 0)
+    for (auto& x : v) x = -x;
+  if (eigval) *eigval = d[col];
+  return v;
 }
 
 // coef = exp(scale * T) e0 for the real symmetric tridiagonal T(alpha, beta):

@@ -30,7 +30,7 @@ class TDVPEngine:
         device: int = 0,
         integrator: str = "lanczos",
         conserve_norm: bool = True,
-        relax: bool = False,
+        relax: bool | str = False,
         thresh: float = 1e-9,
         max_krylov: int = 20,
         lanczos_variant: str = "reference",
@@ -41,7 +41,7 @@ class TDVPEngine:
         cfg.device = device
         cfg.integrator = {"lanczos": _lib.LANCZOS, "arnoldi": _lib.ARNOLDI}[integrator]
         cfg.conserve_norm = int(bool(conserve_norm))
-        cfg.relax = int(bool(relax))
+        cfg.relax = 2 if relax == "improved" else int(bool(relax))
         cfg.thresh = thresh
         cfg.max_krylov = max_krylov
         cfg.lanczos_variant = {"reference": 0, "orthodox": 1}[lanczos_variant]

@@ -347,6 +347,22 @@ def main():
             o[f"n{n}_final{i}"] = np.array(s.data)
     save("chain_relax.npz", dt_au=np.array(0.2 / au_in_fs), nsite=np.array(L), **o)
 
+    # (ii-c) improved relaxation (doRelax="improved": matrix_diagonalize_lanczos per site,
+    # no bond propagation, _mps_cls.py:1078-1084, :1159-1160)
+    o = {f"mpo{i}": w for i, w in enumerate(mpo)}
+    o.update({f"init{i}": c for i, c in enumerate(cores)})
+    for n in (1, 3):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_irelax", model, backend="numpy", verbose=0)
+        ener, wf = sim.relax(stepsize=0.2, maxstep=n, improved=True)
+        o[f"n{n}_energy_last"] = np.array(ener)
+        o[f"n{n}_energy_final"] = np.array(wf.expectation(model.hamiltonian))
+        o[f"n{n}_norm"] = np.array(wf.norm())
+        o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(L)])
+        for i, s in enumerate(wf.ci_coef.superblock_states[0]):
+            o[f"n{n}_final{i}"] = np.array(s.data)
+    save("chain_improved_relax.npz", nsite=np.array(L), **o)
+
     # (iii) the reference's own exciton pin (tests/test_exiciton_propagate.py):
     # potential = diagonal 3-leg cores + one 4-leg core, kinetic on sites 0-2 only.
     au_in_cm1 = float(units.au_in_cm1)

@@ -109,3 +109,19 @@ def test_synthetic_inputs_shapes():
     st = orc.OracleMPS(mps, mpo)
     assert abs(st.expectation().imag) < 1e-14
     assert orc.bond_dims([3] * 5, 6) == [(1, 3), (3, 6), (6, 6), (6, 3), (3, 1)]
+
+
+def test_chain_improved_relaxation(golden):
+    """doRelax="improved" (Lanczos ground state of H_eff per site, no bond propagation)."""
+    g = golden("chain_improved_relax.npz")
+    n, mpo, init = _load_chain(g)
+    for ns in (1, 3):
+        st = orc.OracleMPS(orc.canonicalize_site0(init), mpo, relax="improved")
+        e_last = None
+        for _ in range(ns):
+            e_last = st.expectation()
+            st.propagate(0.0)
+        np.testing.assert_allclose(e_last.real, float(g[f"n{ns}_energy_last"]), rtol=1e-10)
+        np.testing.assert_allclose(st.expectation().real, float(g[f"n{ns}_energy_final"]), rtol=1e-10)
+        ref = [g[f"n{ns}_final{i}"] for i in range(n)]
+        assert abs(abs(orc.overlap(ref, st.cores)) - 1) < 1e-10  # eigenvector sign is a free global phase
