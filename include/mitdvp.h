@@ -77,7 +77,9 @@ int mitdvp_get_site(mitdvp_engine* h, int isite, double* reim_out);
  * through the host. */
 int mitdvp_init_random(mitdvp_engine* h, const int* dims, int bond_dim, uint64_t seed);
 /* alloc_superblock_random's C2sigmaB sweep for tensors given by set_site
- * with gauge "C": site 0 becomes "Psi", scaled to norm `scale`. */
+ * with gauge "C": site 0 becomes "Psi", scaled to norm `scale`; scale <= 0 keeps
+ * the state's own normalisation (Liouville space: trace-normalised start,
+ * _mps_cls.py:2695-2699). */
 int mitdvp_canonicalize(mitdvp_engine* h, double scale);
 
 /* -- operators: TensorHamiltonian.mpo[0][0] after reduction to one
@@ -124,6 +126,17 @@ int mitdvp_site_rdm(mitdvp_engine* h, int isite, double* reim_out);  /* _mps_cls
  * elements is returned in *n_out; then with a buffer of that size.  Axes: kept sites
  * ascending, (ket, bra) per 2-leg site. */
 int mitdvp_reduced_density(mitdvp_engine* h, const int* remain_nleg, int nlen, double* reim_out, size_t* n_out);
+/* Liouville space (Model(space="liouville")): the MPS is a vectorised density matrix with
+ * site dimension n*n, physical index = row*n + col (_mps_mpo.py:135-194).
+ *   mitdvp_set_trace_op_core : core O[a][out][in][f] (M_l, n, n, M_r) of a full-chain
+ *                              observable acting on the n-dimensional Hilbert-space legs
+ *   mitdvp_expect_trace      : Tr(O rho), _exp_liouville (_mps_cls.py:3769-3838)
+ *   mitdvp_partial_trace     : get_partial_trace (_mps_cls.py:1438-1510); size query with
+ *                              out == NULL like mitdvp_reduced_density; the right-most kept
+ *                              site always keeps both legs */
+int mitdvp_set_trace_op_core(mitdvp_engine* h, int op_id, int isite, const double* reim, int ml, int n, int mr);
+int mitdvp_expect_trace(mitdvp_engine* h, int op_id, double out[2]);
+int mitdvp_partial_trace(mitdvp_engine* h, const int* remain_nleg, int nlen, double* reim_out, size_t* n_out);
 int mitdvp_krylov_stats(mitdvp_engine* h, int* per_site);            /* _Debug.niter_krylov, _helper.py:29 */
 
 /* -- counters: _ElpTime / _NFlops equivalents (_helper.py:33-101) ------- */

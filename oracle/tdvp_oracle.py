@@ -78,7 +78,7 @@ def qr_psi2sigmaB(psi: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     return r.T, q.reshape(dr, d, -1).transpose(2, 1, 0)
 
 
-def canonicalize_site0(cores: list[np.ndarray], scale: float = 1.0) -> list[np.ndarray]:
+def canonicalize_site0(cores: list[np.ndarray], scale: float | None = 1.0) -> list[np.ndarray]:
     """Right->left QR sweep so sites 1.. are "B" and site 0 is "Psi".
 
     Tail of ``alloc_superblock_random`` (_mps_cls.py:2684-2699): C2sigmaB on
@@ -90,7 +90,8 @@ def canonicalize_site0(cores: list[np.ndarray], scale: float = 1.0) -> list[np.n
         sval, matB = qr_psi2sigmaB(cores[isite])
         cores[isite] = np.ascontiguousarray(matB)
         cores[isite - 1] = np.tensordot(cores[isite - 1], sval, axes=(2, 0))
-    cores[0] = cores[0] * (scale / np.linalg.norm(cores[0]))
+    if scale is not None:  # Hilbert space; in Liouville space the state keeps its (trace) normalisation, :2695-2699
+        cores[0] = cores[0] * (scale / np.linalg.norm(cores[0]))
     return cores
 
 
@@ -551,6 +552,40 @@ def reduced_density(cores: list[np.ndarray], remain_nleg) -> np.ndarray:
             sub = {2: "lmi,bna,ia...->lbmn...", 1: "lmi,bma,ia...->lbm...", 0: "lmi,bma,ia...->lb..."}[n]
             dens = np.einsum(sub, c, np.conj(c), dens)
     return dens[0, 0, ...]
+
+
+def liouville_expectation(cores: list[np.ndarray], op: list[np.ndarray]) -> complex:
+    """Tr(O rho) for a vectorised density matrix (site dims n^2, index j = row*n + col)
+    and a full-chain MPO ``op`` with n-dimensional physical legs
+    (``_exp_liouville``, _mps_cls.py:3769-3838: "ab,bcde,adcf->fe")."""
+    left = np.ones((1, 1), dtype=np.complex128)
+    for c, w in zip(cores, op):
+        i, j, k = c.shape
+        n = math.isqrt(j)
+        left = np.einsum("ab,bcde,adcf->fe", left, c.reshape(i, n, n, k), w)
+    return complex(left[0, 0])
+
+
+def liouville_partial_trace(cores: list[np.ndarray], remain_nleg) -> np.ndarray:
+    """``get_partial_trace`` (_mps_cls.py:1438-1510): trace out sites with 0 legs, keep
+    the diagonal (1 leg) or both legs (2) of the others; the right-most kept site always
+    keeps both legs."""
+    legs = list(remain_nleg)
+    center = max(i for i, n in enumerate(legs) if n)
+    resh = []
+    for c in cores:
+        i, j, k = c.shape
+        n = math.isqrt(j)
+        resh.append(c.reshape(i, n, n, k))
+    left = np.array([1.0 + 0.0j])
+    for q in range(center):
+        d = resh[q]
+        t = {0: lambda x: np.einsum("ijjl->il", x), 1: lambda x: np.einsum("ijjl->ijl", x), 2: lambda x: x}[legs[q]](d)
+        left = np.tensordot(left, t, axes=(-1, 0))
+    right = np.array([1.0 + 0.0j])
+    for q in range(len(cores) - 1, center, -1):
+        right = np.einsum("ijjl->il", resh[q]) @ right
+    return np.tensordot(left, np.tensordot(resh[center], right, axes=(-1, 0)), axes=(-1, 0))
 
 
 # --------------------------------------------------------------------------

@@ -5,7 +5,8 @@ behaviour as the reference classes cited in each docstring; all numerics go
 through ``libmitdvp.so`` (no CPU fallback).  Not supported (raise
 ``NotImplementedError`` like the reference does for unsupported combos):
 multi-state direct-product MPS, SoP/PolynomialHamiltonian, MCTDH SPFs,
-adaptive bond dimension, MPI sharding, Liouville space.
+adaptive bond dimension, MPI sharding, gates / Kraus maps / subspace projection
+in Liouville space.
 """
 
 from __future__ import annotations
@@ -123,11 +124,13 @@ class Model:
     def __init__(self, basinfo, operators, *, bond_dim=None, build_td_hamiltonian=None, space="hilbert",
                  subspace_inds=None, one_gate_to_apply=None, kraus_op=None):
         self.basinfo = basinfo if isinstance(basinfo, BasInfo) else BasInfo(basinfo)
-        if space.lower() != "hilbert":
-            raise NotImplementedError("Liouville space is a 'next' row (SURVEY 8f)")
+        if space.lower() not in ("hilbert", "liouville"):
+            raise ValueError(f"space must be 'hilbert' or 'liouville' but got {space}")
+        if subspace_inds is not None:
+            raise NotImplementedError("subspace projection in Liouville space is a 'next' row")
         if one_gate_to_apply is not None or kraus_op is not None or build_td_hamiltonian is not None:
             raise NotImplementedError("gates / Kraus operators / time-dependent Hamiltonians are 'next' rows")
-        self.space = "hilbert"
+        self.space = space.lower()
         ops = {"hamiltonian": operators} if isinstance(operators, (TensorHamiltonian, list)) else dict(operators)
         self.dims = [self.basinfo.get_nprim(0, i) for i in range(self.basinfo.get_ndof())]
         out = {}
@@ -164,7 +167,7 @@ class Model:
     def initial_cores(self):
         D = self.m_aux_max if self.m_aux_max is not None else 1
         if self.init_HartreeProduct is not None:
-            return product_state_cores(self.init_HartreeProduct[0], D)
+            return product_state_cores(self.init_HartreeProduct[0], D, space=self.space)
         if self.init_weight_VIBSTATE is not None:
             w = self.init_weight_VIBSTATE[0]
         else:
@@ -180,9 +183,10 @@ class WFunc:
     """Handle returned by ``Simulator.propagate`` (wavefunction.py:34-): the
     state lives on the GPU inside ``self.engine``."""
 
-    def __init__(self, engine: TDVPEngine, op_ids: dict):
+    def __init__(self, engine: TDVPEngine, op_ids: dict, space: str = "hilbert"):
         self.engine = engine
         self._op_ids = op_ids
+        self.space = space
 
     def norm(self):
         return self.engine.norm()
@@ -194,8 +198,13 @@ class WFunc:
         return self.engine.autocorr()
 
     def expectation(self, matOp):
-        name = matOp if isinstance(matOp, str) else getattr(matOp, "name", "hamiltonian")
-        v = self.engine.expectation(self._op_ids[name])
+        name = matOp if isinstance(matOp, str) else self._name_of(matOp)
+        if self.space == "liouville":  # Tr(O rho), _exp_liouville
+            if name == "hamiltonian":
+                raise NotImplementedError("Liouville space: the 'hamiltonian' is a super-operator; expectation values are for n-dimensional observables")
+            v = self.engine.expect_trace(self._op_ids[name])
+        else:
+            v = self.engine.expectation(self._op_ids[name])
         if abs(np.angle(v)) > 1e-2 and abs(abs(np.angle(v)) - np.pi) > 1e-2:
             warnings.warn(f"Expectation value {v} is not real, probably due to non-Hermitian operator or numerical error.")
         return v.real
@@ -204,7 +213,15 @@ class WFunc:
         """``WFunc.get_reduced_densities`` (wavefunction.py:67-88): one tuple of kept legs
         per site, e.g. (0, 0, 0, 2) = both legs of site 3, or a list of such tuples."""
         keys = remain_nleg if isinstance(remain_nleg, list) else [remain_nleg]
+        if self.space == "liouville":  # get_partial_trace, _mps_cls.py:1438-1510
+            return [self.engine.partial_trace(k) for k in keys]
         return [self.engine.reduced_density(k) for k in keys]
+
+    def _name_of(self, matOp):
+        for name, op in getattr(self, "_ops_by_name", {}).items():
+            if op is matOp:
+                return name
+        return getattr(matOp, "name", "hamiltonian")
 
     def get_mps(self):
         return self.engine.get_mps()
@@ -229,14 +246,24 @@ class Simulator:
 
     def _engine(self, integrator, conserve_norm, thresh, relax=False):
         m = self.model
+        liou = m.space == "liouville"
         eng = TDVPEngine(len(m.dims), integrator=integrator, conserve_norm=conserve_norm, thresh=thresh, relax=relax)
         ids = {"hamiltonian": 0}
         eng.set_mpo(m.hamiltonian.as_mpo(m.dims), 0, shift=m.hamiltonian.coupleJ[0][0])
         for k, (name, op) in enumerate(m.observables.items(), start=1):
-            eng.set_mpo(op.as_mpo(m.dims), k)
+            if liou:  # observables act on the n-dimensional Hilbert-space legs, site dim = n*n
+                eng.set_trace_op(op.as_mpo([int(round(d ** 0.5)) for d in m.dims]), k)
+            else:
+                eng.set_mpo(op.as_mpo(m.dims), k)
             ids[name] = k
-        eng.set_mps(m.initial_cores(), canonicalize=True, scale=1.0)
+        # Liouville space keeps the (trace) normalisation of the initial state (_mps_cls.py:2695-2699)
+        eng.set_mps(m.initial_cores(), canonicalize=True, scale=None if liou else 1.0)
         return eng, ids
+
+    def _wfunc(self, eng, ids):
+        wf = WFunc(eng, ids, self.model.space)
+        wf._ops_by_name = dict(self.model.observables, hamiltonian=self.model.hamiltonian)
+        return wf
 
     def propagate(self, stepsize=0.1, maxstep=5000, restart=False, savefile_ext="", loadfile_ext="_operate",
                   backup_interval=1000, autocorr=True, energy=True, norm=True, populations=True, observables=False,
@@ -250,8 +277,16 @@ class Simulator:
             raise ValueError(f"Invalid integrator: {integrator}")
         dt_fs = Δt if Δt is not None else stepsize
         dt_au = dt_fs / units.au_in_fs
+        liou = self.model.space == "liouville"
+        if liou:
+            if conserve_norm:
+                conserve_norm = False  # forced in Liouville space, _const_cls.py:219-224
+            if energy:
+                raise NotImplementedError("Liouville space: pass energy=False (the Hamiltonian entry is the super-operator), like tests/test_mixedstate.py:434")
+            if autocorr:
+                autocorr = False
         eng, ids = self._engine(integrator, conserve_norm, thresh_sil)
-        wf = WFunc(eng, ids)
+        wf = self._wfunc(eng, ids)
         outdir = f"{self.jobname}_prop"
         os.makedirs(outdir, exist_ok=True)
         tconv = {"fs": units.au_in_fs, "ps": units.au_in_fs * 1e-3, "au": 1.0}[display_time_unit]
@@ -277,7 +312,7 @@ class Simulator:
                 if observables and istep % observables_per_step == 0:
                     for name, k in ids.items():
                         if k:
-                            row[name] = eng.expectation(k).real
+                            row[name] = (eng.expect_trace(k) if liou else eng.expectation(k)).real
                 if row:
                     if istep == 0:
                         files["expectations"].write(f"# time [{display_time_unit}]\t" + "\t".join(f"{k:<11}" for k in row) + "\n")
@@ -289,7 +324,7 @@ class Simulator:
                         legs = [0] * (max(key) + 1)
                         for site in key:
                             legs[site] += 1
-                        rec[tuple(key)] = eng.reduced_density(legs)
+                        rec[tuple(key)] = eng.partial_trace(legs) if liou else eng.reduced_density(legs)
                     self.rdm_trace.append((t, rec))
                 eng.propagate(dt_au)
         finally:
@@ -310,7 +345,7 @@ class Simulator:
         for _ in range(maxstep):
             ener = eng.expectation(0).real
             eng.propagate(dt_au)
-        return ener, WFunc(eng, ids)
+        return ener, self._wfunc(eng, ids)
 
     def operate(self, *a, **k):
         raise NotImplementedError("operate (dipole application) is outside the accelerated path")

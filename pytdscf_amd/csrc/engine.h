@@ -55,6 +55,8 @@ struct MpoSite {
   int ml = 0, d = 0, mr = 0;
   DevBuf w2l;  // W2L[(i,t)][(c,j)] = W[c,i,j,t]   (d*mr) x (ml*d)
   DevBuf w2r;  // W2R[(i,c)][(t,j)] = W[c,i,j,t]   (d*ml) x (mr*d)
+  DevBuf wtr;  // Liouville trace operator: O2[f][(a,c,d)] = O[a,d,c,f], n = sqrt(site dim)
+  int ntr = 0, mltr = 0, mrtr = 0;
   bool set = false;
 };
 struct Operator {
@@ -98,6 +100,10 @@ class Engine {
   double norm();
   void site_rdm(int isite, double* out);
   void reduced_density(const int* legs, int nlen, std::vector<hzc>& out, std::vector<int>& shape);
+  // Liouville space (vectorised density matrices)
+  void set_trace_op_core(int op_id, int isite, const double* reim, int ml, int n, int mr);
+  hzc expect_trace(int op_id);
+  void partial_trace(const int* legs, int nlen, std::vector<hzc>& out);
   void krylov_stats(int* per_site) const;
 
   void counters_get(mitdvp_counters* out);

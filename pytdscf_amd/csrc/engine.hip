@@ -689,19 +689,28 @@ void Engine::init_random(const int* dims, int D, uint64_t seed) {
 void Engine::canonicalize(double scale) {
   require_ready();
   DevBuf spare = pool_get(V_.n / MAXK);
+  double log_scale = 0.0;
   for (int p = L_ - 1; p > 0; --p) {
     const int dl = dl_[p], d = dd_[p], dr = dr_[p];
     // C2sigmaB (_mps_cls.py:2684-2693)
     gauge_qr_right(site_[p].p, dl, d, dr, spare.p, tmp2_.p, sig_.p);
     std::swap(site_[p], spare);
     gauge_[p] = MITDVP_GAUGE_B;
-    // The overall norm is reset at the end of the sweep, so sigma is rescaled to
-    // unit Frobenius norm on the device: unnormalised (e.g. random) cores would
-    // otherwise grow geometrically along a long chain and overflow.
+    // sigma is rescaled to unit Frobenius norm on the device (unnormalised, e.g.
+    // random, cores would otherwise grow geometrically along a long chain and
+    // overflow); the factors are accumulated on the host for scale <= 0 (keep the
+    // state's own normalisation: Liouville space, _mps_cls.py:2695-2699)
     {
       double* nrm = reinterpret_cast<double*>(red_.p + RED_MISC);
       vec_sumsq(st_, sig_.p, (long)dl * dl, nrm);
       vec_scale_inv_norm(st_, sig_.p, (long)dl * dl, nrm, 1e-300);
+      if (scale <= 0.0) {
+        read_partials(RED_MISC, NPART / 2);
+        const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+        double t = 0;
+        for (int i = 0; i < NPART; ++i) t += hp[i];
+        if (t > 0) log_scale += 0.5 * std::log(t);
+      }
     }
     // site[p-1] <- site[p-1] . sigma
     const int m = dl_[p - 1] * dd_[p - 1];
@@ -718,7 +727,10 @@ void Engine::canonicalize(double scale) {
   double s = 0;
   for (int i = 0; i < NPART; ++i) s += hp[i];
   if (s == 0.0) throw ArgError("canonicalize: zero state");
-  vec_scale(st_, site_[0].p, n0, make_double2(scale / std::sqrt(s), 0.0));
+  if (scale > 0.0)
+    vec_scale(st_, site_[0].p, n0, make_double2(scale / std::sqrt(s), 0.0));
+  else
+    vec_scale(st_, site_[0].p, n0, make_double2(std::exp(log_scale), 0.0));
   gauge_[0] = MITDVP_GAUGE_PSI;
   center_ = 0;
   invalidate_env();
@@ -1053,6 +1065,130 @@ void Engine::reduced_density(const int* legs, int nlen, std::vector<hzc>& out, s
     pool_put(std::move(U));
   }
   pool_put(std::move(T));
+}
+
+// ---------------------------------------------------------------------------
+// Liouville space: the MPS is a vectorised density matrix, site dimension n*n,
+// physical index = row*n + col (reshape_mat, _mps_mpo.py:135-194)
+// ---------------------------------------------------------------------------
+void Engine::set_trace_op_core(int op_id, int isite, const double* reim, int ml, int n, int mr) {
+  if (isite < 0 || isite >= L_) throw ArgError("set_trace_op_core: bad site index");
+  if (ml < 1 || mr < 1 || n < 1) throw ArgError("set_trace_op_core: bad shape");
+  const hzc* O = reinterpret_cast<const hzc*>(reim);  // O[a][d][c][f]  (bond, out, in, bond)
+  std::vector<hzc> o2((size_t)mr * ml * n * n);
+  for (int a = 0; a < ml; ++a)
+    for (int dd = 0; dd < n; ++dd)
+      for (int c = 0; c < n; ++c)
+        for (int f = 0; f < mr; ++f)
+          o2[(size_t)f * ml * n * n + ((size_t)a * n + c) * n + dd] = O[(((size_t)a * n + dd) * n + c) * mr + f];
+  MpoSite& s = op(op_id).sites[isite];
+  s.wtr.reserve(o2.size());
+  HIP_CHECK(hipMemcpyAsync(s.wtr.p, o2.data(), o2.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  s.ntr = n; s.mltr = ml; s.mrtr = mr;
+}
+
+// Tr(O rho): left[f][e] = sum left[a][b] rho[b][c][d][e] O[a][d][c][f]   (_exp_liouville)
+hzc Engine::expect_trace(int op_id) {
+  require_ready();
+  auto it = ops_.find(op_id);
+  if (it == ops_.end()) throw ArgError("trace operator not set");
+  const zc one = make_double2(1.0, 0.0);
+  size_t mx = 1;
+  for (int p = 0; p < L_; ++p) {
+    const MpoSite& w = it->second.sites[p];
+    if (!w.ntr) throw ArgError("trace operator core not set for this site");
+    if (w.ntr * w.ntr != dd_[p]) throw ArgError("trace operator: site dimension is not n*n");
+    mx = std::max(mx, (size_t)std::max(w.mltr, w.mrtr) * dd_[p] * std::max(dl_[p], dr_[p]));
+  }
+  DevBuf left = pool_get(mx), nxt = pool_get(mx), U = pool_get(mx);
+  HIP_CHECK(hipMemcpyAsync(left.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  int ma = 1;
+  for (int p = 0; p < L_; ++p) {
+    const MpoSite& w = it->second.sites[p];
+    if (w.mltr != ma) throw ArgError("trace operator: MPO bond mismatch");
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    ZgemmDesc g1 = zgemm_desc(left.p, site_[p].p, U.p, ma, d * dr, dl);  // U[a][(c,d,e)]
+    zgemm(st_, g1);
+    ZgemmDesc g2 = zgemm_desc(w.wtr.p, U.p, nxt.p, w.mrtr, dr, ma * d);   // left'[f][e]
+    zgemm(st_, g2);
+    std::swap(left, nxt);
+    ma = w.mrtr;
+  }
+  if (ma != 1) throw ArgError("trace operator: last core must close the MPO bond");
+  hzc out;
+  HIP_CHECK(hipMemcpyAsync(&out, left.p, sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  pool_put(std::move(left)); pool_put(std::move(nxt)); pool_put(std::move(U));
+  return out;
+}
+
+// get_partial_trace (_mps_cls.py:1438-1510)
+void Engine::partial_trace(const int* legs, int nlen, std::vector<hzc>& out) {
+  require_ready();
+  if (nlen < 1 || nlen > L_) throw ArgError("partial_trace: bad number of sites");
+  int center = -1;
+  for (int p = 0; p < nlen; ++p) {
+    if (legs[p] < 0 || legs[p] > 2) throw ArgError("Invalid number of legs");
+    if (legs[p]) center = p;
+  }
+  if (center < 0) throw ArgError("No site with 2 legs found in remain_nleg");
+  std::vector<int> nn(L_);
+  size_t maxd = 1;
+  for (int p = 0; p < L_; ++p) {
+    nn[p] = (int)std::lround(std::sqrt((double)dd_[p]));
+    if (nn[p] * nn[p] != dd_[p]) throw ArgError("partial_trace: site dimension is not n*n");
+    maxd = std::max(maxd, (size_t)std::max(dl_[p], dr_[p]));
+  }
+  const zc one = make_double2(1.0, 0.0);
+  // right environment vector: sites right of the centre are traced out
+  DevBuf right = pool_get(maxd), rnext = pool_get(maxd), tq = pool_get(maxd * maxd * 0 + (size_t)maxd * maxd);
+  HIP_CHECK(hipMemcpyAsync(right.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  for (int q = L_ - 1; q > center; --q) {
+    phys_diag(st_, site_[q].p, tq.p, dl_[q], nn[q], dr_[q], true);
+    ZgemmDesc g = zgemm_desc(tq.p, right.p, rnext.p, dl_[q], 1, dr_[q]);
+    zgemm(st_, g);
+    std::swap(right, rnext);
+  }
+  // left environment with the open legs of the kept sites folded into its rows
+  long no = 1;
+  DevBuf left = pool_get(1);
+  HIP_CHECK(hipMemcpyAsync(left.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  for (int q = 0; q < center; ++q) {
+    const int dl = dl_[q], dr = dr_[q], n = nn[q];
+    const zc* M = nullptr;
+    DevBuf tmp;
+    long cols;
+    if (legs[q] == 2) {
+      M = site_[q].p;
+      cols = (long)n * n * dr;
+    } else {
+      tmp = pool_get((size_t)dl * n * dr);
+      phys_diag(st_, site_[q].p, tmp.p, dl, n, dr, legs[q] == 0);
+      M = tmp.p;
+      cols = (legs[q] == 0 ? 1L : (long)n) * dr;
+    }
+    DevBuf nl = pool_get((size_t)no * cols);
+    ZgemmDesc g = zgemm_desc(left.p, M, nl.p, (int)no, (int)cols, dl);
+    zgemm(st_, g);
+    pool_put(std::move(left));
+    left = std::move(nl);
+    no = no * cols / dr;
+    pool_put(std::move(tmp));
+  }
+  {
+    const int dl = dl_[center], dr = dr_[center], n = nn[center];
+    DevBuf wv = pool_get((size_t)dl * n * n), dm = pool_get((size_t)no * n * n);
+    ZgemmDesc g1 = zgemm_desc(site_[center].p, right.p, wv.p, dl * n * n, 1, dr);  // C (x) right
+    zgemm(st_, g1);
+    ZgemmDesc g2 = zgemm_desc(left.p, wv.p, dm.p, (int)no, n * n, dl);
+    zgemm(st_, g2);
+    out.resize((size_t)no * n * n);
+    HIP_CHECK(hipMemcpyAsync(out.data(), dm.p, out.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    pool_put(std::move(wv)); pool_put(std::move(dm));
+  }
+  pool_put(std::move(left)); pool_put(std::move(right)); pool_put(std::move(rnext)); pool_put(std::move(tq));
 }
 
 void Engine::krylov_stats(int* per_site) const {

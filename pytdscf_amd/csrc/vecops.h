@@ -27,6 +27,8 @@ void vec_randn(hipStream_t st, zc* out, long n, uint64_t seed);
 void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld);
 void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols, long ldi, long ldo, int batch,
                        long in_bs, long out_bs);
+// Liouville space: diagonal (trace = false) or trace (true) over the n x n physical index
+void phys_diag(hipStream_t st, const zc* C, zc* out, int dl, int n, int dr, bool trace);
 // out[i0][i2][i1][i3] = in[i0][i1][i2][i3]
 void permute_0213(hipStream_t st, const zc* in, zc* out, long n0, int n1, int n2, int n3);
 void transpose_rev3(hipStream_t st, const zc* in, zc* out, int na, int nj, int ns);

@@ -228,6 +228,31 @@ __global__ __launch_bounds__(256) void k_transpose(const zc* __restrict__ in, zc
   }
 }
 
+// Liouville space (site dimension n*n, physical index = row*n + col):
+//   diag: out[b][c][e] = C[b][c*n+c][e]     trace: out[b][e] = sum_c C[b][c*n+c][e]
+__global__ __launch_bounds__(256) void k_phys_diag(const zc* __restrict__ C, zc* __restrict__ out, int dl, int n, int dr,
+                                                   int trace) {
+  const long tot = trace ? (long)dl * dr : (long)dl * n * dr;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    if (trace) {
+      const int s = e % dr;
+      const long b = e / dr;
+      double re = 0, im = 0;
+      for (int c = 0; c < n; ++c) {
+        const zc v = C[(b * n * n + (long)c * n + c) * dr + s];
+        re += v.x;
+        im += v.y;
+      }
+      out[e] = make_double2(re, im);
+    } else {
+      const int s = e % dr;
+      const int c = (e / dr) % n;
+      const long b = e / ((long)dr * n);
+      out[e] = C[(b * n * n + (long)c * n + c) * dr + s];
+    }
+  }
+}
+
 // out[i0][i2][i1][i3] = in[i0][i1][i2][i3]
 __global__ __launch_bounds__(256) void k_permute_0213(const zc* __restrict__ in, zc* __restrict__ out, long n0, int n1,
                                                       int n2, int n3) {
@@ -324,6 +349,11 @@ void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, in, out, rows, cols, ldi, ldo, in_bs, out_bs);
   HIP_CHECK(hipGetLastError());
+}
+
+void phys_diag(hipStream_t st, const zc* C, zc* out, int dl, int n, int dr, bool trace) {
+  const long tot = trace ? (long)dl * dr : (long)dl * n * dr;
+  LAUNCH(k_phys_diag, (int)std::min<long>(4096, (tot + 255) / 256), st, C, out, dl, n, dr, trace ? 1 : 0);
 }
 
 void permute_0213(hipStream_t st, const zc* in, zc* out, long n0, int n1, int n2, int n3) {

@@ -78,8 +78,8 @@ class TDVPEngine:
         cores with ``canonicalize=True`` (alloc_superblock_random's QR sweep)."""
         for i, c in enumerate(cores):
             self.set_site(i, c, "C" if canonicalize else ("Psi" if i == 0 else "B"))
-        if canonicalize:
-            self._ck(self._lib.mitdvp_canonicalize(self._h, scale))
+        if canonicalize:  # scale=None: keep the state's own normalisation (Liouville space)
+            self._ck(self._lib.mitdvp_canonicalize(self._h, -1.0 if scale is None else scale))
 
     def get_site(self, isite: int) -> np.ndarray:
         l, n, r, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()
@@ -148,6 +148,34 @@ class TDVPEngine:
         shape = []
         for p, k in enumerate(legs):
             shape += [self.get_site_shape(p)[1]] * k
+        return out.reshape(shape)
+
+    # ---- Liouville space (vectorised density matrices) -------------------
+    def set_trace_op(self, cores, op_id: int):
+        """Full-chain observable with n-dimensional physical legs (site dim = n*n)."""
+        for i, w in enumerate(cores):
+            a = _c128(w)
+            if a.ndim != 4 or a.shape[1] != a.shape[2]:
+                raise ValueError("trace operator core must be (M_l, n, n, M_r)")
+            self._ck(self._lib.mitdvp_set_trace_op_core(self._h, op_id, i, _dp(a), a.shape[0], a.shape[1], a.shape[3]))
+
+    def expect_trace(self, op_id: int) -> complex:
+        out = np.zeros(2)
+        self._ck(self._lib.mitdvp_expect_trace(self._h, op_id, _dp(out)))
+        return complex(out[0], out[1])
+
+    def partial_trace(self, remain_nleg) -> np.ndarray:
+        legs = [int(x) for x in remain_nleg]
+        arr = (C.c_int * len(legs))(*legs)
+        n = C.c_size_t(0)
+        self._ck(self._lib.mitdvp_partial_trace(self._h, arr, len(legs), None, C.byref(n)))
+        out = np.empty(n.value, dtype=np.complex128)
+        self._ck(self._lib.mitdvp_partial_trace(self._h, arr, len(legs), _dp(out), C.byref(n)))
+        center = max(i for i, k in enumerate(legs) if k)
+        shape = []
+        for p in range(center + 1):
+            nn = int(round(self.get_site_shape(p)[1] ** 0.5))
+            shape += [nn] * (2 if p == center else legs[p])
         return out.reshape(shape)
 
     def get_site_shape(self, isite: int):

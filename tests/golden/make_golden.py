@@ -363,6 +363,43 @@ def main():
             o[f"n{n}_final{i}"] = np.array(s.data)
     save("chain_improved_relax.npz", nsite=np.array(L), **o)
 
+    # (ii-d) Liouville space (space="Liouville": vectorised density matrix, d = n^2 per
+    # site, trace-normalised product start, Arnoldi, conserve_norm forced False,
+    # _const_cls.py:219-224): trace expectation (_exp_liouville, _mps_cls.py:3769-3838)
+    # and partial traces (get_partial_trace, :1438-1510)
+    Ll, Dl_ = 5, 8
+    lmpo = orc.synthetic_liouvillian_mpo(Ll, 16, seed=0, gamma=0.05)
+    lbasis = [Exciton(nstate=4) for _ in range(Ll)]
+    sz = np.diag([1.0, -1.0]).reshape(1, 2, 2, 1).astype(np.complex128)
+    sx = np.array([[0.0, 1.0], [1.0, 0.0]]).reshape(1, 2, 2, 1).astype(np.complex128)
+    # two-site observable sz_1 sx_3 (identity fill-in on site 2) and a one-site sz_2
+    obs1 = TensorHamiltonian(ndof=Ll, potential=[[{((2, 2),): TensorOperator(mpo=[sz], legs=(2, 2))}]], kinetic=None, backend="numpy")
+    obs2 = TensorHamiltonian(ndof=Ll, potential=[[{((1, 1), (3, 3)): TensorOperator(mpo=[sz, sx], legs=(1, 1, 3, 3))}]], kinetic=None, backend="numpy")
+    lmodel = Model(lbasis, operators={"hamiltonian": [w.copy() for w in lmpo], "sz2": obs1, "sz1sx3": obs2}, bond_dim=Dl_, space="liouville")
+    rhos = []
+    for p in range(Ll):
+        G = crandn(2, 2)
+        rho = G @ G.conj().T
+        rhos.append((rho / np.trace(rho)).reshape(-1))
+    lmodel.init_HartreeProduct = [rhos]
+    o = {f"mpo{i}": w for i, w in enumerate(lmpo)}
+    o.update({f"rho{i}": r for i, r in enumerate(rhos)})
+    o["sz"] = sz
+    o["sx"] = sx
+    for n in (1, 3):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_liou", lmodel, backend="numpy", verbose=0)
+        _, wf = sim.propagate(stepsize=0.02, maxstep=n, integrator="arnoldi", autocorr=False, energy=False)
+        o[f"n{n}_norm"] = np.array(wf.norm())
+        o[f"n{n}_sz2"] = np.array(wf.expectation(lmodel.observables["sz2"]))
+        o[f"n{n}_sz1sx3"] = np.array(wf.expectation(lmodel.observables["sz1sx3"]))
+        for tag, legs in (("pt2", (0, 0, 2)), ("pt04", (2, 0, 0, 0, 2)), ("pt1d", (0, 1)), ("pt13", (0, 2, 0, 1))):
+            o[f"n{n}_{tag}"] = np.array(wf.get_reduced_densities(legs)[0])
+        o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(Ll)])
+        for i, s_ in enumerate(wf.ci_coef.superblock_states[0]):
+            o[f"n{n}_final{i}"] = np.array(s_.data)
+    save("chain_liouville.npz", dt_au=np.array(0.02 / au_in_fs), nsite=np.array(Ll), bond_dim=np.array(Dl_), **o)
+
     # (iii) the reference's own exciton pin (tests/test_exiciton_propagate.py):
     # potential = diagonal 3-leg cores + one 4-leg core, kinetic on sites 0-2 only.
     au_in_cm1 = float(units.au_in_cm1)

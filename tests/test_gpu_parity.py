@@ -363,3 +363,41 @@ def test_chain_improved_relaxation_golden(golden):
         assert abs(eng.norm() - 1) < 1e-12
         ref = [g[f"n{ns}_final{i}"] for i in range(n)]
         assert abs(_fidelity(orc, ref, eng.get_mps()) - 1) < 1e-9
+
+
+def test_liouville_space_golden(golden):
+    """space="Liouville" through the shell: trace-normalised start, Arnoldi,
+    conserve_norm forced off; Tr(O rho) and partial traces against the reference."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import Exciton, Model, Simulator, TensorHamiltonian, TensorOperator
+
+    g = golden("chain_liouville.npz")
+    n = int(g["nsite"])
+    mpo = [g[f"mpo{i}"] for i in range(n)]
+    obs1 = TensorHamiltonian(ndof=n, potential=[[{((2, 2),): TensorOperator(mpo=[g["sz"]], legs=(2, 2))}]], kinetic=None)
+    obs2 = TensorHamiltonian(ndof=n, potential=[[{((1, 1), (3, 3)): TensorOperator(mpo=[g["sz"], g["sx"]], legs=(1, 1, 3, 3))}]], kinetic=None)
+    model = Model([Exciton(nstate=4) for _ in range(n)], operators={"hamiltonian": mpo, "sz2": obs1, "sz1sx3": obs2},
+                  bond_dim=int(g["bond_dim"]), space="liouville")
+    model.init_HartreeProduct = [[g[f"rho{i}"] for i in range(n)]]
+    dt_fs = 0.02
+    for ns in (1, 3):
+        sim = Simulator("liou", model, backend="hip")
+        import os, tempfile
+
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                _, wf = sim.propagate(stepsize=dt_fs, maxstep=ns, integrator="arnoldi", autocorr=False, energy=False)
+            finally:
+                os.chdir(cwd)
+        assert wf.engine.krylov_stats() == list(g[f"n{ns}_krylov"])
+        assert abs(wf.norm() - float(g[f"n{ns}_norm"])) < 1e-10 * float(g[f"n{ns}_norm"])
+        assert abs(wf.expectation(model.observables["sz2"]) - float(g[f"n{ns}_sz2"])) < 1e-8 * abs(float(g[f"n{ns}_sz2"]))
+        assert abs(wf.expectation(model.observables["sz1sx3"]) - float(g[f"n{ns}_sz1sx3"])) < 1e-8 * abs(float(g[f"n{ns}_sz1sx3"]))
+        for tag, legs in (("pt2", (0, 0, 2)), ("pt04", (2, 0, 0, 0, 2)), ("pt1d", (0, 1)), ("pt13", (0, 2, 0, 1))):
+            out = wf.get_reduced_densities(legs)[0]
+            assert out.shape == g[f"n{ns}_{tag}"].shape
+            np.testing.assert_allclose(out, g[f"n{ns}_{tag}"], atol=1e-10)
+        ref = [g[f"n{ns}_final{i}"] for i in range(n)]
+        assert abs(_fidelity(orc, ref, wf.get_mps()) - 1) < 1e-10

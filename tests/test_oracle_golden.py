@@ -125,3 +125,37 @@ def test_chain_improved_relaxation(golden):
         np.testing.assert_allclose(st.expectation().real, float(g[f"n{ns}_energy_final"]), rtol=1e-10)
         ref = [g[f"n{ns}_final{i}"] for i in range(n)]
         assert abs(abs(orc.overlap(ref, st.cores)) - 1) < 1e-10  # eigenvector sign is a free global phase
+
+
+def _liouville_setup(g):
+    from pytdscf_amd.mps import product_state_cores
+    from pytdscf_amd.operators import merge_operator_terms
+
+    n = int(g["nsite"])
+    mpo = [g[f"mpo{i}"] for i in range(n)]
+    init = product_state_cores([g[f"rho{i}"] for i in range(n)], int(g["bond_dim"]), space="liouville")
+    ops = {
+        "sz2": merge_operator_terms([([g["sz"]], [2])], [2] * n),
+        "sz1sx3": merge_operator_terms([([g["sz"], g["sx"]], [1, 3])], [2] * n),
+    }
+    keys = {"pt2": (0, 0, 2), "pt04": (2, 0, 0, 0, 2), "pt1d": (0, 1), "pt13": (0, 2, 0, 1)}
+    return n, mpo, init, ops, keys
+
+
+def test_liouville_space(golden):
+    """space="Liouville": trace-normalised product start, Arnoldi, conserve_norm=False;
+    trace expectations and partial traces against the reference."""
+    g = golden("chain_liouville.npz")
+    n, mpo, init, ops, keys = _liouville_setup(g)
+    dt = float(g["dt_au"])
+    for ns in (1, 3):
+        cores = orc.canonicalize_site0(init, scale=None)  # Liouville: the state is not renormalised
+        st = orc.OracleMPS(cores, mpo, integrator="arnoldi", conserve_norm=False)
+        for _ in range(ns):
+            st.propagate(dt)
+        assert list(g[f"n{ns}_krylov"]) == [st.kprev[i] for i in range(n)]
+        np.testing.assert_allclose(st.norm(), float(g[f"n{ns}_norm"]), rtol=1e-10)
+        for name, op in ops.items():
+            np.testing.assert_allclose(orc.liouville_expectation(st.cores, op).real, float(g[f"n{ns}_{name}"]), rtol=1e-9, atol=1e-12)
+        for tag, legs in keys.items():
+            np.testing.assert_allclose(orc.liouville_partial_trace(st.cores, legs), g[f"n{ns}_{tag}"], atol=1e-11)

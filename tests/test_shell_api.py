@@ -48,7 +48,9 @@ def test_unsupported_combinations_raise():
 
     core = np.zeros((1, 2, 2, 1))
     with pytest.raises(NotImplementedError):
-        Model([Exciton(2)], [core], bond_dim=2, space="liouville")
+        Model([Exciton(4)], [np.zeros((1, 4, 4, 1))], bond_dim=2, space="liouville", subspace_inds={0: (0, 3)})
+    with pytest.raises(ValueError):
+        Model([Exciton(2)], [core], bond_dim=2, space="fock")
     with pytest.raises(ValueError):
         Model([Exciton(2), Exciton(2)], {"hamiltonian": [core]}, bond_dim=2)
     m = Model([Exciton(2)], [core], bond_dim=2)
