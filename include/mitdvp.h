@@ -126,6 +126,15 @@ int mitdvp_site_rdm(mitdvp_engine* h, int isite, double* reim_out);  /* _mps_cls
  * elements is returned in *n_out; then with a buffer of that size.  Axes: kept sites
  * ascending, (ket, bra) per 2-leg site. */
 int mitdvp_reduced_density(mitdvp_engine* h, const int* remain_nleg, int nlen, double* reim_out, size_t* n_out);
+/* SVD truncation of the bond right of the centre ("Psi") site, truncate_sigvec
+ * (_site_cls.py:586-690): keep the leading singular values whose cumulative weight
+ * sum s_k / sum s reaches 1 - p (at most max_dim if max_dim > 0); the kept values,
+ * normalised to unit 2-norm, are written to svals_out (may be NULL) and their number
+ * to *new_dim.  The engine's one-sided Jacobi SVD kernel does the decomposition. */
+int mitdvp_truncate_bond(mitdvp_engine* h, double p, int max_dim, int* new_dim, double* svals_out);
+/* kernel-level hook: A (r x c) = U diag(S) Vh with the engine's Jacobi SVD */
+int mitdvp_svd(int device, const double* A, int r, int c, double* U, double* S, double* Vh, int* sweeps);
+
 /* Liouville space (Model(space="liouville")): the MPS is a vectorised density matrix with
  * site dimension n*n, physical index = row*n + col (_mps_mpo.py:135-194).
  *   mitdvp_set_trace_op_core : core O[a][out][in][f] (M_l, n, n, M_r) of a full-chain

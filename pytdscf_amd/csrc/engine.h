@@ -8,6 +8,7 @@
 #include "../../include/mitdvp.h"
 #include "common.h"
 #include "qr.h"
+#include "svd.h"
 #include "vecops.h"
 
 namespace mitdvp {
@@ -100,6 +101,8 @@ class Engine {
   double norm();
   void site_rdm(int isite, double* out);
   void reduced_density(const int* legs, int nlen, std::vector<hzc>& out, std::vector<int>& shape);
+  // SVD truncation of the bond right of the centre site (truncate_sigvec, _site_cls.py:586-690)
+  int truncate_bond(double p, int max_dim, std::vector<double>& svals);
   // Liouville space (vectorised density matrices)
   void set_trace_op_core(int op_id, int isite, const double* reim, int ml, int n, int mr);
   hzc expect_trace(int op_id);

@@ -1068,6 +1068,67 @@ void Engine::reduced_density(const int* legs, int nlen, std::vector<hzc>& out, s
 }
 
 // ---------------------------------------------------------------------------
+// bond truncation by SVD (truncate_sigvec, _site_cls.py:586-690) at the bond
+// right of the centre site c:  Psi(c) = A sigma,  sigma = U s Vh;  keep the first
+// idx singular values with cumulative weight sum_{k<idx} s_k / sum s_k >= 1 - p
+// (and idx <= max_dim if max_dim > 0);  A <- A U,  B(c+1) <- Vh B(c+1),
+// sigma' = diag(s / ||s||).  The result is stored as Psi(c) = A sigma', B(c+1).
+// ---------------------------------------------------------------------------
+int Engine::truncate_bond(double p, int max_dim, std::vector<double>& svals) {
+  require_ready();
+  const int c = center_;
+  if (c < 0 || c >= L_ - 1) throw ArgError("truncate_bond: the centre must not be the last site");
+  if (gauge_[c + 1] != MITDVP_GAUGE_B) throw ArgError("truncate_bond: the right neighbour must be in gauge B");
+  const int dl = dl_[c], d = dd_[c], dr = dr_[c];
+  const int dn = dd_[c + 1], drn = dr_[c + 1];
+  DevBuf A = pool_get((size_t)dl * d * dr), U = pool_get((size_t)dr * dr), Vh = pool_get((size_t)dr * dr),
+         work = pool_get(svd_work_elems(dr, dr));
+  gauge_qr_left(site_[c].p, dl, d, dr, A.p, sig_.p);  // Psi2Asigma
+  std::vector<double> s(dr);
+  int sweeps = 0;
+  svd_jacobi(st_, sig_.p, dr, dr, U.p, s.data(), Vh.p, work.p, &sweeps);
+  double tot = 0;
+  for (double v : s) tot += v;
+  int idx = dr;
+  double cum = 0;
+  for (int k = 0; k < dr; ++k) {  // idx = argmax(cumsum / total >= 1 - p) + 1
+    cum += s[k];
+    if (cum / tot >= 1.0 - p) { idx = k + 1; break; }
+  }
+  if (max_dim > 0) idx = std::min(idx, max_dim);
+  double nrm2 = 0;
+  for (int k = 0; k < idx; ++k) nrm2 += s[k] * s[k];
+  svals.assign(s.begin(), s.begin() + idx);
+  for (auto& v : svals) v /= std::sqrt(nrm2);
+  // A' sigma' = A U[:, :idx] diag(s'/||s'||): scale the kept columns of U first
+  std::vector<hzc> hU((size_t)dr * dr);
+  HIP_CHECK(hipMemcpyAsync(hU.data(), U.p, hU.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  std::vector<hzc> hUs((size_t)dr * idx);
+  for (int r = 0; r < dr; ++r)
+    for (int k = 0; k < idx; ++k) hUs[(size_t)r * idx + k] = hU[(size_t)r * dr + k] * svals[k];
+  HIP_CHECK(hipMemcpyAsync(U.p, hUs.data(), hUs.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  DevBuf newc = pool_get(site_[c].n), newn = pool_get(site_[c + 1].n);
+  {
+    ZgemmDesc g = zgemm_desc(A.p, U.p, newc.p, dl * d, idx, dr);  // (dl d x dr) (dr x idx)
+    zgemm(st_, g);
+  }
+  {
+    ZgemmDesc g = zgemm_desc(Vh.p, site_[c + 1].p, newn.p, idx, dn * drn, dr);  // Vh[:idx] B
+    zgemm(st_, g);
+  }
+  HIP_CHECK(hipStreamSynchronize(st_));
+  std::swap(site_[c], newc);
+  std::swap(site_[c + 1], newn);
+  dr_[c] = idx;
+  dl_[c + 1] = idx;
+  invalidate_env();
+  pool_put(std::move(A)); pool_put(std::move(U)); pool_put(std::move(Vh)); pool_put(std::move(work));
+  pool_put(std::move(newc)); pool_put(std::move(newn));
+  return idx;
+}
+
+// ---------------------------------------------------------------------------
 // Liouville space: the MPS is a vectorised density matrix, site dimension n*n,
 // physical index = row*n + col (reshape_mat, _mps_mpo.py:135-194)
 // ---------------------------------------------------------------------------

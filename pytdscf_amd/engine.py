@@ -150,6 +150,21 @@ class TDVPEngine:
             shape += [self.get_site_shape(p)[1]] * k
         return out.reshape(shape)
 
+    def truncate_bond(self, p: float, max_dim: int = 0):
+        """SVD-truncate the bond right of the centre site (``truncate_sigvec``).
+        Returns (new bond dimension, kept singular values normalised to unit norm)."""
+        l, n, r, g = self.get_site_shape(self._center())
+        sv = np.zeros(r)
+        nd = C.c_int()
+        self._ck(self._lib.mitdvp_truncate_bond(self._h, p, max_dim, C.byref(nd), _dp(sv)))
+        return nd.value, sv[: nd.value].copy()
+
+    def _center(self) -> int:
+        for i in range(self.nsite):
+            if self.get_site_shape(i)[3] == _lib.GAUGE_PSI:
+                return i
+        raise ValueError("no centre site")
+
     # ---- Liouville space (vectorised density matrices) -------------------
     def set_trace_op(self, cores, op_id: int):
         """Full-chain observable with n-dimensional physical legs (site dim = n*n)."""
@@ -281,6 +296,17 @@ def zgemm(A, B, C0=None, transA=False, conjA=False, transB=False, conjB=False, a
         )
     )
     return (Cm, ms.value) if reps else Cm
+
+
+def svd(A, device=0):
+    """A = U diag(S) Vh with the engine's one-sided Jacobi kernel; returns (U, S, Vh, sweeps)."""
+    A = _c128(A)
+    r, c = A.shape
+    k = min(r, c)
+    U, S, Vh = np.empty((r, k), np.complex128), np.empty(k), np.empty((k, c), np.complex128)
+    sw = C.c_int()
+    _lib.check(_lib.load().mitdvp_svd(device, _dp(A), r, c, _dp(U), _dp(S), _dp(Vh), C.byref(sw)))
+    return U, S, Vh, sw.value
 
 
 def heff_selfcheck(dl, d, dr, ml, mr, device=0) -> dict:

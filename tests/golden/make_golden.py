@@ -258,6 +258,27 @@ def main():
         "unit_gauge.npz", psi=psi_g, A=np.array(a_site.data), sigA=sA, B=np.array(b_site.data), sigB=sB
     )
 
+    # bond truncation by SVD: truncate_sigvec (_site_cls.py:586-690)
+    from pytdscf._site_cls import truncate_sigvec
+
+    rng_t = np.random.default_rng(77)  # own stream: the fixtures below keep their inputs
+
+    def crandn_t(*shape):
+        return rng_t.standard_normal(shape) + 1j * rng_t.standard_normal(shape)
+
+    psi_t = crandn_t(5, 3, 7)
+    a_t, sig_t = SiteCoef(psi_t.copy(), "Psi", 1).gauge_trf("Psi2Asigma")
+    # a decaying spectrum so that the cumulative-weight criterion actually truncates
+    sig_t = sig_t * (0.5 ** np.arange(7))[None, :]
+    q_t, _ = np.linalg.qr(crandn_t(12, 7))
+    b_t = np.ascontiguousarray(q_t.T.reshape(7, 3, 4))
+    out_t = {}
+    for tag, pp in (("p1e-2", 1e-2), ("p1e-6", 1e-6), ("p0", 0.0)):
+        A2, s2, B2 = truncate_sigvec(SiteCoef(np.array(a_t.data), "A", 1), sig_t.copy(), SiteCoef(b_t.copy(), "B", 2), pp)
+        out_t[f"{tag}_sig"] = np.array(s2)
+        out_t[f"{tag}_two_site"] = np.einsum("ajk,kl,lmr->ajmr", np.array(A2.data), np.array(s2), np.array(B2.data))
+    save("unit_truncate.npz", A=np.array(a_t.data), sigma=sig_t, B=b_t, **out_t)
+
     # ------------------------------------------------------------ end-to-end
     def run_ref(basis, operators, cores, D, dt_fs, nstep, **kw):
         """Reference Simulator.propagate from explicit (full-rank) cores."""

@@ -157,3 +157,23 @@ def test_gauge_trf_rank_deficient():
     Am = A.reshape(24, 6)
     assert np.abs(Am.conj().T @ Am - np.eye(6)).max() < 1e-14
     assert np.abs(np.tensordot(A, s, axes=(2, 0)) - psi).max() < 1e-14
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 7), (33, 33), (64, 20), (20, 64), (128, 128), (257, 257)])
+def test_jacobi_svd_vs_lapack(shape):
+    """One-sided Jacobi SVD: singular values to working precision (small ones as
+    well), orthonormal factors, exact reconstruction."""
+    from pytdscf_amd import engine as E
+
+    r, c = shape
+    rng = np.random.default_rng(r * 1000 + c)
+    k = min(r, c)
+    A = crandn(rng, r, c) * (0.5 ** np.arange(c))[None, :] if c <= 40 else crandn(rng, r, c)
+    U, S, Vh, sweeps = E.svd(A)
+    Sref = np.linalg.svd(A, compute_uv=False)
+    assert np.all(np.diff(S) <= 1e-300)  # descending
+    np.testing.assert_allclose(S, Sref, rtol=1e-10, atol=1e-14 * Sref[0])
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() < 1e-13 * k
+    assert np.abs(Vh @ Vh.conj().T - np.eye(k)).max() < 1e-13 * k
+    assert np.abs((U * S) @ Vh - A).max() < 1e-13 * np.abs(A).max() * k
+    assert sweeps <= 20
