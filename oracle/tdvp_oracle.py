@@ -98,35 +98,40 @@ def canonicalize_site0(cores: list[np.ndarray], scale: float | None = 1.0) -> li
 # --------------------------------------------------------------------------
 # a3: environment update
 # --------------------------------------------------------------------------
-def env_update_left(L: np.ndarray, A: np.ndarray, W: np.ndarray) -> np.ndarray:
-    """L'[i,q,j] = sum conj(A)[m,r,i] A[n,s,j] L[m,p,n] W[p,r,s,q].
+def env_update_left(L: np.ndarray, A: np.ndarray, W: np.ndarray, bra: np.ndarray | None = None) -> np.ndarray:
+    """L'[i,q,j] = sum conj(bra)[m,r,i] A[n,s,j] L[m,p,n] W[p,r,s,q]  (bra = A unless given).
 
     "mri,nsj,mpn,prsq->iqj", _contraction.py:286-297 (gauge "A", modes 3,2),
     called from renormalize_op_psite (_mps_mpo.py:554).  GEMM order
-    L.A -> W -> conj(A) so that it is also a fair zgemm CPU baseline.
+    L.A -> W -> conj(A) so that it is also a fair zgemm CPU baseline.  A
+    separate (wider) ``bra`` tensor is the adaptive-rank case
+    (superblock_states_bra, _mps_cls.py:1950-1963): L is then (bra bond, M, ket bond).
     """
-    Dl, M, _ = L.shape
-    _, d, Dr = A.shape
+    bra = A if bra is None else bra
+    Db, M, Dk = L.shape
+    _, d, Dko = A.shape
+    Dbo = bra.shape[2]
     Mr = W.shape[3]
     # X[m,p,s,j] = sum_n L[m,p,n] A[n,s,j]
-    X = (L.reshape(Dl * M, Dl) @ A.reshape(Dl, d * Dr)).reshape(Dl, M * d, Dr)
+    X = (L.reshape(Db * M, Dk) @ A.reshape(Dk, d * Dko)).reshape(Db, M * d, Dko)
     # Y[m,(r,q),j] = sum_(p,s) W2[(r,q),(p,s)] X[m,(p,s),j]
     W2 = W.transpose(1, 3, 0, 2).reshape(d * Mr, M * d)
-    Y = np.matmul(W2, X)  # (Dl, d*Mr, Dr)
-    # L'[i,(q,j)] = sum_(m,r) conj(A)[(m,r),i] Y[(m,r),(q,j)]
-    out = A.reshape(Dl * d, Dr).conj().T @ Y.reshape(Dl * d, Mr * Dr)
-    return out.reshape(Dr, Mr, Dr)
+    Y = np.matmul(W2, X)  # (Db, d*Mr, Dko)
+    # L'[i,(q,j)] = sum_(m,r) conj(bra)[(m,r),i] Y[(m,r),(q,j)]
+    out = bra.reshape(Db * d, Dbo).conj().T @ Y.reshape(Db * d, Mr * Dko)
+    return out.reshape(Dbo, Mr, Dko)
 
 
-def env_update_right(R: np.ndarray, B: np.ndarray, W: np.ndarray) -> np.ndarray:
-    """R'[i,p,j] = sum conj(B)[i,r,m] B[j,s,n] R[m,q,n] W[p,r,s,q].
+def env_update_right(R: np.ndarray, B: np.ndarray, W: np.ndarray, bra: np.ndarray | None = None) -> np.ndarray:
+    """R'[i,p,j] = sum conj(bra)[i,r,m] B[j,s,n] R[m,q,n] W[p,r,s,q]  (bra = B unless given).
 
     "irm,jsn,mqn,prsq->ipj", _contraction.py:376-388 (gauge "B" mirror case).
     Evaluated as the mirror image of :func:`env_update_left`.
     """
     Bt = np.ascontiguousarray(B.transpose(2, 1, 0))  # [n,s,j]
     Wt = np.ascontiguousarray(W.transpose(3, 1, 2, 0))  # [q,r,s,p]
-    return env_update_left(R, Bt, Wt)
+    brat = None if bra is None else np.ascontiguousarray(bra.transpose(2, 1, 0))
+    return env_update_left(R, Bt, Wt, brat)
 
 
 # --------------------------------------------------------------------------
@@ -136,16 +141,17 @@ def heff_apply(L: np.ndarray, W: np.ndarray, R: np.ndarray, psi: np.ndarray) -> 
     """sigma[a,i,r] = sum L[a,c,b] W[c,i,j,t] R[r,t,s] psi[b,j,s].
 
     "bjs,acb,cijt,rts->air", _contraction.py:1154-1161 via
-    multiplyH_MPS_direct_MPO.dot (_contraction.py:1182-1243).
+    multiplyH_MPS_direct_MPO.dot (_contraction.py:1182-1243).  The blocks may be
+    rectangular (bra bond != ket bond: adaptive rank, tensor_shapes_out).
     """
-    Dl, Ml, _ = L.shape
-    Dr, Mr, _ = R.shape
+    Dlo, Ml, Dli = L.shape
+    Dro, Mr, Dri = R.shape
     d = psi.shape[1]
-    X = (L.reshape(Dl * Ml, Dl) @ psi.reshape(Dl, d * Dr)).reshape(Dl, Ml * d, Dr)
+    X = (L.reshape(Dlo * Ml, Dli) @ psi.reshape(Dli, d * Dri)).reshape(Dlo, Ml * d, Dri)
     W2 = W.transpose(1, 3, 0, 2).reshape(d * Mr, Ml * d)
     Y = np.matmul(W2, X)  # [a,(i,t),s]
-    out = Y.reshape(Dl * d, Mr * Dr) @ R.reshape(Dr, Mr * Dr).T
-    return out.reshape(Dl, d, Dr)
+    out = Y.reshape(Dlo * d, Mr * Dri) @ R.reshape(Dro, Mr * Dri).T
+    return out.reshape(Dlo, d, Dro)
 
 
 def heff_apply_chunked(L, W, R, psi, chunk: int) -> np.ndarray:
@@ -169,10 +175,10 @@ def keff_apply(L: np.ndarray, R: np.ndarray, sigma: np.ndarray) -> np.ndarray:
 
     "bs,acb,rcs->ar", _contraction.py:1339-1352 via multiplyK_MPS_direct_MPO.dot.
     """
-    Dl, M, _ = L.shape
-    Dr = R.shape[0]
-    X = L.reshape(Dl * M, Dl) @ sigma  # [(a,c),s]
-    return X.reshape(Dl, M * Dr) @ R.reshape(Dr, M * Dr).T
+    Dlo, M, Dli = L.shape
+    Dro, _, Dri = R.shape
+    X = L.reshape(Dlo * M, Dli) @ sigma  # [(a,c),s]
+    return X.reshape(Dlo, M * Dri) @ R.reshape(Dro, M * Dri).T
 
 
 # --------------------------------------------------------------------------
@@ -183,7 +189,7 @@ def _n_warmup(size: int, k_prev: int) -> int:
     return min(size, min(max(0, k_prev - 2), 15))
 
 
-def sil_lanczos(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
+def sil_lanczos(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True, size=None):
     """exp(scale*H) psi by the reference's short-iterative Lanczos.
 
     Follows _integrator.py:453-655 statement by statement, including the
@@ -197,7 +203,8 @@ def sil_lanczos(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
     """
     shape = psi.shape
     v0 = np.array(psi, dtype=np.complex128).reshape(-1)
-    size = v0.size
+    # _iter_info counts the UNPADDED input tensor (adaptive rank: psi is zero-padded, _integrator.py:178-186)
+    size = v0.size if size is None else size
     ndim = min(size, MAX_KRYLOV)
     n_warm = _n_warmup(size, k_prev)
     if conserve_norm:
@@ -267,7 +274,7 @@ def sil_lanczos(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
     )
 
 
-def sil_arnoldi(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
+def sil_arnoldi(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True, size=None):
     """exp(scale*H) psi by short-iterative Arnoldi, _integrator.py:287-432.
 
     Classical Gram-Schmidt against all previous vectors (_orth_step_np,
@@ -276,7 +283,8 @@ def sil_arnoldi(scale, matvec, psi, thresh=1e-9, k_prev=0, conserve_norm=True):
     """
     shape = psi.shape
     v0 = np.array(psi, dtype=np.complex128).reshape(-1)
-    size = v0.size
+    # _iter_info counts the UNPADDED input tensor (adaptive rank: psi is zero-padded, _integrator.py:178-186)
+    size = v0.size if size is None else size
     ndim = min(size, MAX_KRYLOV)
     n_warm = _n_warmup(size, k_prev)
     hessen = np.zeros((ndim + 1, ndim), dtype=np.complex128)
@@ -369,6 +377,81 @@ def lanczos_ground_state(matvec, psi, thresh=1e-9, root=0):
 
 
 # --------------------------------------------------------------------------
+# f2: adaptive bond dimension (a1TDVP) helpers
+# --------------------------------------------------------------------------
+def thin_to_full(core: np.ndarray, gauge: str, delta_rank: int) -> np.ndarray:
+    """Isometry + ``delta_rank`` further orthonormal columns (rows) of its
+    orthogonal complement, SiteCoef.thin_to_full (_site_cls.py:294-405): the
+    trailing columns of LAPACK's full QR of the isometry itself; the leading
+    ones are sign-aligned with the input, i.e. they ARE the input."""
+    l, c, r = core.shape
+    if gauge == "A":
+        dr = min(delta_rank, l * c - r)
+        mat = core.reshape(l * c, r)
+        Q, _ = scipy.linalg.qr(mat, mode="full")
+        ip = mat.T.conj() @ Q
+        unflip = np.sign(np.sign(np.diag(ip[:r, :r])) + 0.5)
+        Q = Q[:, : r + dr].copy()
+        Q[:, :r] *= unflip[np.newaxis, :]
+        return Q.reshape(l, c, r + dr)
+    dl = min(delta_rank, c * r - l)
+    mat = np.ascontiguousarray(core.reshape(l, c * r).T)
+    Q, _ = scipy.linalg.qr(mat, mode="full")
+    ip = mat.T.conj() @ Q
+    unflip = np.sign(np.sign(np.diag(ip[:l, :l])) + 0.5)
+    Q = Q[:, : l + dl].copy()
+    Q[:, :l] *= unflip[np.newaxis, :]
+    return np.ascontiguousarray(Q.T).reshape(l + dl, c, r)
+
+
+def actual_delta_rank(cores: list[np.ndarray], isite: int, gauge: str, delta_rank: int) -> int:
+    """get_actual_delta_rank (_mps_cls.py:3723-3755)."""
+    nsite = len(cores)
+    l1, c1, r1 = cores[isite].shape
+    if gauge == "A":
+        if isite == nsite - 1:
+            return 0
+        l2, c2, r2 = cores[isite + 1].shape
+        return max(min(delta_rank, min(l1 * c1 - r1, c2 * r2 - l2)), 0)
+    if isite == 0:
+        return 0
+    l2, c2, r2 = cores[isite - 1].shape
+    return max(min(delta_rank, min(c1 * r1 - l1, l2 * c2 - r2)), 0)
+
+
+def superblock_full(cores: list[np.ndarray], center: int, delta_rank: int) -> list[np.ndarray]:
+    """get_superblock_full (_mps_cls.py:3699-3720): sites left of the centre are
+    "A", right of it "B", the centre is copied."""
+    out = []
+    for i, c in enumerate(cores):
+        if i == center:
+            out.append(c.copy())
+        else:
+            g = "A" if i < center else "B"
+            out.append(thin_to_full(c, g, actual_delta_rank(cores, i, g, delta_rank)))
+    return out
+
+
+def select_rank(h_left: np.ndarray, k_sig: np.ndarray, h_right: np.ndarray, dmin: int, dmax: int, p: float):
+    """The D loop of get_rank_and_projection_error (_mps_cls.py:2083-2105):
+    f(D) = |H psi_left[..., :D]|^2 - |K sigma[:D, :D]|^2 + |H psi_right[:D, ...]|^2,
+    stop at the first D whose relative increment falls below p."""
+    prev = 0.0
+    D = dmin
+    for D in range(dmin, dmax + 1):
+        a = h_left[:, :, :D].ravel()
+        b = h_right[:D, :, :].ravel()
+        k = k_sig[:D, :D].ravel()
+        tot = float(np.vdot(a, a).real) - float(np.vdot(k, k).real) + float(np.vdot(b, b).real)
+        if D > dmin:
+            metric = (tot - prev) / tot
+            if metric < p:
+                return D - 1, metric
+        prev = tot
+    return max(dmin, D), 0.0
+
+
+# --------------------------------------------------------------------------
 # a8-a10: sweep
 # --------------------------------------------------------------------------
 @dataclass
@@ -389,6 +472,10 @@ class OracleMPS:
     shift: complex = 0.0  # coupleJ[0][0] * ovlp term, _contraction.py:1200-1216
     relax: bool | str = False  # const.doRelax: True = exp(-H dt/2) / exp(+K dt/2) + renormalise
     #   (_mps_cls.py:1086-1094); "improved" = Lanczos ground state of H_eff, bond step skipped (:1078-1084, :1159-1160)
+    adaptive: bool = False  # const.adaptive (_const_cls.py:120-124, :212-216)
+    Dmax: int = 100
+    dD: int = 10
+    p_proj: float = 1e-4
     left: dict = field(default_factory=dict)
     right: dict = field(default_factory=dict)
     kprev: dict = field(default_factory=dict)
@@ -408,10 +495,10 @@ class OracleMPS:
         for p in range(self.nsite - 1, 0, -1):
             self.right[p - 1] = env_update_right(self.right[p], self.cores[p], self.mpo[p])
 
-    def _exp(self, scale, matvec, x, site):
+    def _exp(self, scale, matvec, x, site, size=None):
         fn = sil_lanczos if self.integrator == "lanczos" else sil_arnoldi
         out, k = fn(
-            scale, matvec, x, self.thresh, self.kprev.get(site, 0), self.conserve_norm
+            scale, matvec, x, self.thresh, self.kprev.get(site, 0), self.conserve_norm, size
         )
         self.kprev[site] = k
         return out
@@ -442,7 +529,10 @@ class OracleMPS:
         n = self.nsite
         sites = range(0, n) if forward else range(n - 1, -1, -1)
         end = n - 1 if forward else 0
+        full = superblock_full(self.cores, 0 if forward else n - 1, self.dD) if self.adaptive else None
         for p in sites:
+            if self.adaptive and p != end and self._adaptive_site(p, dt, forward, full):
+                continue
             # exp_superH_propagation_direct, _mps_cls.py:1016-1100 (:1070)
             zs = -1.0 if self.relax else -1.0j  # _mps_cls.py:1070 vs :1088
             if self.relax == "improved":
@@ -475,6 +565,103 @@ class OracleMPS:
                     )
                 self.cores[p - 1] = np.tensordot(self.cores[p - 1], sval, axes=(2, 0))
         self.center = end
+
+    # ---- f2: adaptive bond dimension ---------------------------------------
+    def _adaptive_site(self, p: int, dt: float, forward: bool, full: list[np.ndarray]) -> bool:
+        """One site of an adaptive half-sweep (const.adaptive branches of
+        propagate_along_sweep, _mps_cls.py:863-987; get_adaptive_rank_and_block,
+        :2152-2286).  Returns False when the bond is already at maximal rank
+        (is_max_rank, :3757-3766): the caller then does the plain step."""
+        if self.relax or self.integrator not in ("lanczos", "arnoldi"):
+            raise NotImplementedError
+        l, c, r = self.cores[p].shape
+        W = self.mpo
+        if forward:
+            if l * c <= r or r >= self.Dmax:
+                return False
+            q = p + 1
+            env_prev = self.right[q]  # thin block right of site p+1
+            # get_op_block_full, modes "braket" and "bra" (:2111-2150)
+            env_braket = env_update_right(env_prev, full[q], W[q])
+            env_bra = env_update_right(env_prev, self.cores[q], W[q], bra=full[q])
+            dmax = min(self.Dmax, full[q].shape[0])
+            # get_psi_sigvec_psi_fullblock (:1921-1983)
+            A, sig = qr_psi2Asigma(self.cores[p])
+            psi_prime = np.tensordot(sig, self.cores[q], axes=(1, 0))
+            A_full = thin_to_full(A, "A", dmax - r)
+            sys_bra = env_update_left(self.left[p], A, W[p], bra=A_full)
+            # get_rank_and_projection_error (:1985-2105)
+            dmax = min(dmax, l * c, psi_prime.shape[1] * psi_prime.shape[2])
+            newD = r
+            if r != dmax:
+                h_left = heff_apply(self.left[p], W[p], env_bra[:dmax], self.cores[p])
+                h_right = heff_apply(sys_bra[:dmax], W[q], env_prev, psi_prime)
+                k_sig = keff_apply(sys_bra[:dmax], env_bra[:dmax], sig)
+                newD, _ = select_rank(h_left, k_sig, h_right, r, dmax, self.p_proj)
+            env_D_bra = env_bra[:newD]
+            env_D_braket = env_braket[:newD, :, :newD]
+            self.cores[q] = np.ascontiguousarray(full[q][:newD])
+            # exp_superH_propagation_direct with tensor_shapes_out=(l, c, newD): every apply
+            # sees the vector truncated to the old shape (SplitStack.split(truncate=True),
+            # _contraction.py:593-610; _integrator.py:368,382 / :524,543)
+            Lb = self.left[p]
+
+            def mv(v):
+                x = v[:, :, :r]
+                y = heff_apply(Lb, W[p], env_D_bra, x)
+                if self.shift != 0.0:
+                    y[:, :, :r] += self.shift * x
+                return y
+
+            x0 = np.zeros((l, c, newD), dtype=np.complex128)
+            x0[:, :, :r] = self.cores[p]
+            self.cores[p] = self._exp(-1.0j * dt / 2, mv, x0, p, l * c * r)
+            A, sval = qr_psi2Asigma(self.cores[p])
+            self.cores[p] = A
+            self.left[q] = env_update_left(self.left[p], A, W[p])
+            sval = self._exp(+1.0j * dt / 2, self._keff(self.left[q], env_D_braket), sval, p)
+            self.cores[q] = np.tensordot(sval, self.cores[q], axes=(1, 0))
+            return True
+        if l >= c * r or l >= self.Dmax:
+            return False
+        q = p - 1
+        env_prev = self.left[q]  # thin block left of site p-1
+        env_braket = env_update_left(env_prev, full[q], W[q])
+        env_bra = env_update_left(env_prev, self.cores[q], W[q], bra=full[q])
+        dmax = min(self.Dmax, full[q].shape[2])
+        sig, B = qr_psi2sigmaB(self.cores[p])
+        B = np.ascontiguousarray(B)
+        psi_prime = np.tensordot(self.cores[q], sig, axes=(2, 0))
+        B_full = thin_to_full(B, "B", dmax - l)
+        sys_bra = env_update_right(self.right[p], B, W[p], bra=B_full)
+        dmax = min(dmax, psi_prime.shape[0] * psi_prime.shape[1], c * r)
+        newD = l
+        if l != dmax:
+            h_left = heff_apply(env_prev, W[q], sys_bra[:dmax], psi_prime)
+            h_right = heff_apply(env_bra[:dmax], W[p], self.right[p], self.cores[p])
+            k_sig = keff_apply(env_bra[:dmax], sys_bra[:dmax], sig)
+            newD, _ = select_rank(h_left, k_sig, h_right, l, dmax, self.p_proj)
+        env_D_bra = env_bra[:newD]
+        env_D_braket = env_braket[:newD, :, :newD]
+        self.cores[q] = np.ascontiguousarray(full[q][:, :, :newD])
+        Rb = self.right[p]
+
+        def mv(v):
+            x = v[:l]
+            y = heff_apply(env_D_bra, W[p], Rb, x)
+            if self.shift != 0.0:
+                y[:l] += self.shift * x
+            return y
+
+        x0 = np.zeros((newD, c, r), dtype=np.complex128)
+        x0[:l] = self.cores[p]
+        self.cores[p] = self._exp(-1.0j * dt / 2, mv, x0, p, l * c * r)
+        sval, B = qr_psi2sigmaB(self.cores[p])
+        self.cores[p] = np.ascontiguousarray(B)
+        self.right[q] = env_update_right(self.right[p], self.cores[p], W[p])
+        sval = self._exp(+1.0j * dt / 2, self._keff(env_D_braket, self.right[q]), sval, p)
+        self.cores[q] = np.tensordot(self.cores[q], sval, axes=(2, 0))
+        return True
 
     def propagate(self, dt: float):
         """One time step = forward + backward half-sweep, MPSCoef.propagate

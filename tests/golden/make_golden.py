@@ -545,6 +545,76 @@ def main():
     save("henon_heiles.npz", dt_au=np.array(dt_h / au_in_fs), ref_pin_energy=np.array(0.018225341011652626),
          au_in_fs=np.array(au_in_fs), au_in_cm1=np.array(au_in_cm1), **o)
 
+    # (v) adaptive bond dimension (a1TDVP): Simulator.propagate(adaptive=True, ...)
+    # (_mps_cls.py:863-987, :1921-2286; the reference's own run is tests/test_a1tdvp.py,
+    # which only checks that it executes).  Own RNG stream: earlier fixtures keep their inputs.
+    rng_a = np.random.default_rng(4242)
+
+    def crandn_a(*shape):
+        return rng_a.standard_normal(shape) + 1j * rng_a.standard_normal(shape)
+
+    def run_adaptive(model, nsite, n, dt_fs, **kw):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_adapt", model, backend="numpy", verbose=0)
+        ener, wf = sim.propagate(stepsize=dt_fs, maxstep=n, adaptive=True, **kw)
+        res = {
+            f"n{n}_energy_last": np.array(ener),
+            f"n{n}_energy_final": np.array(wf.expectation(model.hamiltonian)),
+            f"n{n}_norm": np.array(wf.norm()),
+            f"n{n}_autocorr": np.array(wf._ints_wf_ovlp_mpssm(wf.ci_coef, conj=False)),
+            f"n{n}_krylov": np.array([helper._Debug.niter_krylov[i] for i in range(nsite)]),
+            f"n{n}_bonddim": np.array([s.data.shape[2] for s in wf.ci_coef.superblock_states[0][:-1]]),
+        }
+        for i, s_ in enumerate(wf.ci_coef.superblock_states[0]):
+            res[f"n{n}_final{i}"] = np.array(s_.data)
+        return res
+
+    # (v-a) synthetic chain from low-rank random cores
+    La, da, Ma, Da0 = 6, 3, 4, 2
+    mpo_a = orc.synthetic_mpo(La, da, Ma, seed=3)
+    bd_a = orc.bond_dims([da] * La, Da0)
+    cores_a = [crandn_a(dl, da, dr) for (dl, dr) in bd_a]
+    basis_a = [Exciton(nstate=da) for _ in range(La)]
+    model_a = Model(basis_a, operators={"hamiltonian": [w.copy() for w in mpo_a]}, bond_dim=Da0)
+    model_a.init_HartreeProduct = [[np.array(c) for c in cores_a]]
+    o = {f"mpo{i}": w for i, w in enumerate(mpo_a)}
+    o.update({f"init{i}": c for i, c in enumerate(cores_a)})
+    akw = dict(adaptive_Dmax=7, adaptive_dD=1, adaptive_p_proj=1.0e-8)
+    for n in (1, 3):
+        o.update(run_adaptive(model_a, La, n, 0.05, **akw))
+    save("adaptive_chain.npz", dt_au=np.array(0.05 / au_in_fs), nsite=np.array(La), bond_dim0=np.array(Da0),
+         Dmax=np.array(7), dD=np.array(1), p_proj=np.array(1.0e-8), **o)
+
+    # (v-b) the model of tests/test_a1tdvp.py (exciton + 3 modes, lambda = 1e-3) from the
+    # bond-dimension-1 Hartree product
+    pot_b = [w.copy() for w in pot]
+    lamb_b = 0.001
+    pot_b[1][0, :, 0] = J * one[1] + lamb_b * q1[1]
+    pot_b[1][1, :, 0] = lamb_b * one[1]
+    pot_b[2][1, :, 2] = lamb_b * q1[2]
+
+    def a1_model():
+        ham = TensorHamiltonian(
+            ndof=4,
+            potential=[[{(0, 1, 2, (3, 3)): TensorOperator(mpo=[w.copy() for w in pot_b], legs=(0, 1, 2, 3, 3))}]],
+            kinetic=[[{((0, 0), (1, 1), (2, 2)): TensorOperator(mpo=[w.copy() for w in kin], legs=(0, 0, 1, 1, 2, 2))}]],
+            backend="numpy",
+        )
+        m_ = Model(prim, {"hamiltonian": ham}, bond_dim=1)
+        m_.init_HartreeProduct = [
+            [ho.get_unitary()[0].tolist() for ho in prim[:3]] + [np.array([0.0, 1.0]).tolist()]
+        ]
+        return m_
+
+    o = {f"pot{i}": w for i, w in enumerate(pot_b)}
+    o.update({f"kin{i}": w for i, w in enumerate(kin)})
+    o.update({f"w{i}": np.array(ho.get_unitary()[0]) for i, ho in enumerate(prim[:3])})
+    bkw = dict(adaptive_Dmax=12, adaptive_dD=4, adaptive_p_proj=1.0e-5)
+    for n in (2, 10):
+        o.update(run_adaptive(a1_model(), 4, n, 0.1, **bkw))
+    save("adaptive_exciton.npz", dt_au=np.array(0.1 / au_in_fs), Dmax=np.array(12), dD=np.array(4),
+         p_proj=np.array(1.0e-5), **o)
+
 
 if __name__ == "__main__":
     main()
