@@ -132,6 +132,20 @@ int mitdvp_reduced_density(mitdvp_engine* h, const int* remain_nleg, int nlen, d
  * normalised to unit 2-norm, are written to svals_out (may be NULL) and their number
  * to *new_dim.  The engine's one-sided Jacobi SVD kernel does the decomposition. */
 int mitdvp_truncate_bond(mitdvp_engine* h, double p, int max_dim, int* new_dim, double* svals_out);
+/* Adaptive bond dimension (a1TDVP), Simulator.propagate(adaptive=True, adaptive_Dmax,
+ * adaptive_dD, adaptive_p_proj) -> const.adaptive / Dmax / dD / p_proj
+ * (_const_cls.py:120-124, :212-216).  While enabled, every half-sweep widens the
+ * neighbour tensors by up to dD orthogonal-complement vectors (get_superblock_full,
+ * _mps_cls.py:3699-3755), picks each bond's new rank from the projection-error
+ * functional (get_rank_and_projection_error, :1985-2105; stop when the relative
+ * increment falls below p_proj, never above Dmax) and propagates the zero-padded
+ * centre tensor (propagate_along_sweep, :863-987).  Real-time propagation only. */
+int mitdvp_set_adaptive(mitdvp_engine* h, int enable, int dmax, int dd, double p_proj);
+/* SiteCoef.thin_to_full (_site_cls.py:294-405) on caller data: gauge 0 = "A": site
+ * (l, c, r) isometric over (l c) x r -> out (l, c, r + extra); gauge 1 = "B": isometric
+ * over l x (c r) -> out (l + extra, c, r).  The added vectors are the leading ones of
+ * the orthogonal complement in LAPACK's full-mode QR of the isometry. */
+int mitdvp_thin_to_full(int device, int gauge, const double* site, int l, int c, int r, int extra, double* out);
 /* kernel-level hook: A (r x c) = U diag(S) Vh with the engine's Jacobi SVD */
 int mitdvp_svd(int device, const double* A, int r, int c, double* U, double* S, double* Vh, int* sweeps);
 

@@ -116,6 +116,8 @@ def load() -> C.CDLL:
         "mitdvp_reduced_density": (i, [vp, ip, i, dp, C.POINTER(C.c_size_t)]),
         "mitdvp_truncate_bond": (i, [vp, d, i, ip, dp]),
         "mitdvp_svd": (i, [i, dp, i, i, dp, dp, dp, ip]),
+        "mitdvp_set_adaptive": (i, [vp, i, i, i, d]),
+        "mitdvp_thin_to_full": (i, [i, i, dp, i, i, i, i, dp]),
         "mitdvp_set_trace_op_core": (i, [vp, i, i, dp, i, i, i]),
         "mitdvp_expect_trace": (i, [vp, i, dp]),
         "mitdvp_partial_trace": (i, [vp, ip, i, dp, C.POINTER(C.c_size_t)]),

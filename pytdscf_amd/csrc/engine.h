@@ -120,19 +120,29 @@ class Engine {
   void heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
                   hzc shift);
   void keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift);
+  // rectangular blocks (bra bond != ket bond), no shift term: the adaptive-rank applies
+  void heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dlo, int dli, int d,
+                       int dro, int dri);
+  void keff_apply_rect(const zc* L, const zc* R, const zc* sig, zc* out, int dlo, int dli, int dro, int dri, int m);
+  void env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const zc* w2, zc* env_out, int dbi, int dki,
+                       int min_, int d, int dbo, int dko, int mout);
   // generic environment update: env_in (din, min, din), T (din, d, dout),
   // W2 ((d*mout) x (min*d)) -> env_out (dout, mout, dout)
   void env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
                   int mout);
   // x <- exp(scale * Op) x ; returns Krylov dimension used
   template <class MV>
-  int krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev);
+  int krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev, long nsize = -1);
   // x <- lowest eigenvector of Op (improved relaxation); returns Krylov dimension used
   template <class MV>
   int krylov_diag(MV&& matvec, zc* x, long n);
   void gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* sigma_out);   // Psi2Asigma
   void gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc* Bt_out, zc* sigma_out);  // Psi2sigmaB
-  void ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n);
+  void ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n, int qr_next = 0);
+  // adaptive bond dimension (a1TDVP, const.adaptive / Dmax / dD / p_proj, _const_cls.py:120-124)
+  void set_adaptive(bool on, int dmax, int dd, double p_proj);
+  void thin_to_full_A(const zc* A, int l, int c, int r, int e, zc* out);
+  void thin_to_full_B(const zc* B, int l, int c, int r, int e, zc* out);
   hipStream_t stream() const { return st_; }
   const MpoSite& mpo(int op_id, int isite);
   mitdvp_config cfg;
@@ -165,6 +175,17 @@ class Engine {
   void* coll_user_ = nullptr;
   bool shard_range(int n, int& a0, int& a1) const;
   void collective(int op, zc* p, size_t elems);
+
+  // adaptive bond dimension
+  bool adaptive_ = false;
+  int ad_dmax_ = 100, ad_dd_ = 10;
+  double ad_p_ = 1e-4;
+  std::vector<DevBuf> full_;  // widened neighbour tensors of the current half-sweep (get_superblock_full)
+  std::vector<int> fdl_, fdr_;
+  void adaptive_prepare();
+  void build_superblock_full(bool forward);
+  int select_rank(const zc* hl, long hl_rows, const zc* ks, const zc* hr, long hr_cols, int dmin, int dmax);
+  bool adaptive_site(int p, double dt, bool forward, DevBuf& spare);
 
   // counters
   mitdvp_counters cnt_{};

@@ -82,6 +82,7 @@ DevBuf Engine::pool_get(size_t elems) {
 }
 void Engine::pool_put(DevBuf&& b) {
   if (b.p) pool_.push_back(std::move(b));
+  if (pool_.size() > 48) pool_.erase(pool_.begin());  // adaptive ranks: block sizes drift, drop the oldest
 }
 
 void Engine::timer_begin(int kind) {
@@ -208,7 +209,7 @@ void Engine::invalidate_env() {
   }
 }
 
-void Engine::ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n) {
+void Engine::ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n, int qr_next) {
   X_.reserve(max_x);
   Y_.reserve(max_y);
   V_.reserve((size_t)MAXK * max_site);
@@ -217,7 +218,7 @@ void Engine::ensure_work(long max_site, long max_x, long max_y, int max_qr_m, in
   const size_t dd = (size_t)max_qr_n * max_qr_n;
   sig_.reserve(std::max<size_t>(dd, 1));
   sig2_.reserve(std::max<size_t>(dd, 1));
-  qrwork_.reserve(qr_work_elems(max_qr_m, max_qr_n));
+  qrwork_.reserve(qr_work_elems(max_qr_m, max_qr_n, qr_next));
 }
 
 void Engine::size_workspaces() {
@@ -292,99 +293,123 @@ void Engine::collective(int op, zc* p, size_t elems) {
   cnt_.collective_bytes += (double)(elems * sizeof(zc));
 }
 
-void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
-                        hzc shift) {
+// The blocks may be rectangular (bra bond != ket bond): L (dlo, ml, dli), R (dro, mr, dri),
+// psi (dli, d, dri) -> out (dlo, d, dro).  That is the adaptive-rank case
+// (tensor_shapes_out, _contraction.py:455-477); the plain sweep has dlo == dli, dro == dri.
+void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dlo, int dli,
+                             int d, int dro, int dri) {
   const int ml = w.ml, mr = w.mr;
   int a0, a1;
-  const bool sharded = shard_range(dl, a0, a1);
+  const bool sharded = shard_range(dlo, a0, a1);
   const int na = a1 - a0;
   timer_begin(10);
   {  // X[(a,c)][(j,s)] = L[(a,c)][b] psi[b][(j,s)]
-    ZgemmDesc g = zgemm_desc(L + (size_t)a0 * ml * dl, psi, X_.p, na * ml, d * dr, dl);
+    ZgemmDesc g = zgemm_desc(L + (size_t)a0 * ml * dli, psi, X_.p, na * ml, d * dri, dli);
     zgemm(st_, g);
   }
   timer_end();
   timer_begin(11);
   {  // Y_a[(i,t)][s] = W2L[(i,t)][(c,j)] X_a[(c,j)][s]
-    ZgemmDesc g = zgemm_desc(w.w2l.p, X_.p, Y_.p, d * mr, dr, ml * d);
-    g.batch = na; g.strideA = 0; g.strideB = (long)ml * d * dr; g.strideC = (long)d * mr * dr;
+    ZgemmDesc g = zgemm_desc(w.w2l.p, X_.p, Y_.p, d * mr, dri, ml * d);
+    g.batch = na; g.strideA = 0; g.strideB = (long)ml * d * dri; g.strideC = (long)d * mr * dri;
     zgemm(st_, g);
   }
   timer_end();
   timer_begin(12);
   {  // out[(a,i)][r] = Y[(a,i)][(t,s)] R[r][(t,s)]
-    ZgemmDesc g = zgemm_desc(Y_.p, R, out + (size_t)a0 * d * dr, na * d, dr, mr * dr);
-    g.transB = 1; g.ldb = (long)mr * dr;
+    ZgemmDesc g = zgemm_desc(Y_.p, R, out + (size_t)a0 * d * dro, na * d, dro, mr * dri);
+    g.transB = 1; g.ldb = (long)mr * dri;
     zgemm(st_, g);
   }
   timer_end();
-  if (sharded) collective(COLL_ALLGATHER, out, (size_t)dl * d * dr);
-  if (shift != hzc(0.0, 0.0))
-    vec_axpby(st_, out, psi, (long)dl * d * dr, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
+  if (sharded) collective(COLL_ALLGATHER, out, (size_t)dlo * d * dro);
   cnt_.n_launch += 3;
   cnt_.n_heff += 1;
-  cnt_.heff_flops += 8.0 * ((double)na * dl * ml * d * dr + (double)na * dr * ml * mr * d * d + (double)na * dr * dr * mr * d);
+  cnt_.heff_flops += 8.0 * ((double)na * dli * ml * d * dri + (double)na * dri * ml * mr * d * d + (double)na * dro * dri * mr * d);
 }
 
-void Engine::keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift) {
+void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
+                        hzc shift) {
+  heff_apply_rect(L, w, R, psi, out, dl, dl, d, dr, dr);
+  if (shift != hzc(0.0, 0.0))
+    vec_axpby(st_, out, psi, (long)dl * d * dr, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
+}
+
+// L (dlo, m, dli), R (dro, m, dri), sig (dli, dri) -> out (dlo, dro)
+void Engine::keff_apply_rect(const zc* L, const zc* R, const zc* sig, zc* out, int dlo, int dli, int dro, int dri,
+                             int m) {
   int a0, a1;
-  const bool sharded = shard_range(d1, a0, a1);
+  const bool sharded = shard_range(dlo, a0, a1);
   const int na = a1 - a0;
   timer_begin(2);
   {  // X[(a,c)][s] = L[(a,c)][b] sig[b][s]
-    ZgemmDesc g = zgemm_desc(L + (size_t)a0 * m * d1, sig, X_.p, na * m, d2, d1);
+    ZgemmDesc g = zgemm_desc(L + (size_t)a0 * m * dli, sig, X_.p, na * m, dri, dli);
     zgemm(st_, g);
   }
   {  // out[a][r] = X[a][(c,s)] R[r][(c,s)]
-    ZgemmDesc g = zgemm_desc(X_.p, R, out + (size_t)a0 * d2, na, d2, m * d2);
-    g.transB = 1; g.ldb = (long)m * d2;
+    ZgemmDesc g = zgemm_desc(X_.p, R, out + (size_t)a0 * dro, na, dro, m * dri);
+    g.transB = 1; g.ldb = (long)m * dri;
     zgemm(st_, g);
   }
   timer_end();
-  if (sharded) collective(COLL_ALLGATHER, out, (size_t)d1 * d2);
-  if (shift != hzc(0.0, 0.0))
-    vec_axpby(st_, out, sig, (long)d1 * d2, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
+  if (sharded) collective(COLL_ALLGATHER, out, (size_t)dlo * dro);
   cnt_.n_launch += 2;
   cnt_.n_keff += 1;
-  cnt_.keff_flops += 8.0 * ((double)na * d1 * m * d2 + (double)na * d2 * d2 * m);
+  cnt_.keff_flops += 8.0 * ((double)na * dli * m * dri + (double)na * dro * dri * m);
+}
+
+void Engine::keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift) {
+  keff_apply_rect(L, R, sig, out, d1, d1, d2, d2, m);
+  if (shift != hzc(0.0, 0.0))
+    vec_axpby(st_, out, sig, (long)d1 * d2, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
+}
+
+// env_in (dbi, min, dki), ket tensor Tk (dki, d, dko), bra tensor Tb (dbi, d, dbo),
+// W2 ((d*mout) x (min*d)) -> env_out (dbo, mout, dko).  Tb != Tk is the adaptive-rank
+// "bra" block (superblock_states_bra, _mps_cls.py:1950-1963).
+void Engine::env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const zc* w2, zc* env_out, int dbi, int dki,
+                             int min_, int d, int dbo, int dko, int mout) {
+  int m0, m1;
+  const bool sharded = shard_range(dbi, m0, m1);
+  const int nm = m1 - m0;
+  timer_begin(1);
+  {  // X[(m,p)][(s,j)] = env[(m,p)][n] Tk[n][(s,j)]
+    ZgemmDesc g = zgemm_desc(env_in + (size_t)m0 * min_ * dki, Tk, X_.p, nm * min_, d * dko, dki);
+    zgemm(st_, g);
+  }
+  {  // Y_m[(r,q)][j] = W2[(r,q)][(p,s)] X_m[(p,s)][j]
+    ZgemmDesc g = zgemm_desc(w2, X_.p, Y_.p, d * mout, dko, min_ * d);
+    g.batch = nm; g.strideA = 0; g.strideB = (long)min_ * d * dko; g.strideC = (long)d * mout * dko;
+    zgemm(st_, g);
+  }
+  {  // env'[i][(q,j)] = conj(Tb)[(m,r)][i] Y[(m,r)][(q,j)]   (sum over this rank's m)
+    ZgemmDesc g = zgemm_desc(Tb + (size_t)m0 * d * dbo, Y_.p, env_out, dbo, mout * dko, nm * d);
+    g.transA = 1; g.conjA = 1; g.lda = dbo;
+    zgemm(st_, g);
+  }
+  timer_end();
+  if (sharded) collective(COLL_ALLREDUCE, env_out, (size_t)dbo * mout * dko);
+  cnt_.n_launch += 3;
+  cnt_.n_env += 1;
+  cnt_.env_flops += 8.0 * ((double)nm * dki * min_ * d * dko + (double)nm * dko * min_ * mout * d * d +
+                           (double)nm * dbo * dko * mout * d);
 }
 
 void Engine::env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
                         int mout) {
-  int m0, m1;
-  const bool sharded = shard_range(din, m0, m1);
-  const int nm = m1 - m0;
-  timer_begin(1);
-  {  // X[(m,p)][(s,j)] = env[(m,p)][n] T[n][(s,j)]
-    ZgemmDesc g = zgemm_desc(env_in + (size_t)m0 * min_ * din, T, X_.p, nm * min_, d * dout, din);
-    zgemm(st_, g);
-  }
-  {  // Y_m[(r,q)][j] = W2[(r,q)][(p,s)] X_m[(p,s)][j]
-    ZgemmDesc g = zgemm_desc(w2, X_.p, Y_.p, d * mout, dout, min_ * d);
-    g.batch = nm; g.strideA = 0; g.strideB = (long)min_ * d * dout; g.strideC = (long)d * mout * dout;
-    zgemm(st_, g);
-  }
-  {  // env'[i][(q,j)] = conj(T)[(m,r)][i] Y[(m,r)][(q,j)]   (sum over this rank's m)
-    ZgemmDesc g = zgemm_desc(T + (size_t)m0 * d * dout, Y_.p, env_out, dout, mout * dout, nm * d);
-    g.transA = 1; g.conjA = 1; g.lda = dout;
-    zgemm(st_, g);
-  }
-  timer_end();
-  if (sharded) collective(COLL_ALLREDUCE, env_out, (size_t)dout * mout * dout);
-  cnt_.n_launch += 3;
-  cnt_.n_env += 1;
-  cnt_.env_flops += 8.0 * ((double)nm * din * min_ * d * dout + (double)nm * dout * min_ * mout * d * d +
-                           (double)nm * dout * dout * mout * d);
+  env_update_rect(env_in, T, T, w2, env_out, din, din, min_, d, dout, dout, mout);
 }
 
 // ---------------------------------------------------------------------------
 // local propagator: x <- exp(scale*Op) x
 // ---------------------------------------------------------------------------
 template <class MV>
-int Engine::krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev) {
-  const int ndim = (int)std::min<long>(n, cfg.max_krylov);
-  // _iter_info (_integrator.py:178-186)
-  const int n_warm = (int)std::min<long>(n, std::min(std::max(0, k_prev - 2), 15));
+int Engine::krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev, long nsize) {
+  // nsize: element count of the UNPADDED input tensor (adaptive rank: x is zero-padded to
+  // the output shape but _iter_info still counts psi_states, _integrator.py:178-186, :524)
+  if (nsize <= 0) nsize = n;
+  const int ndim = (int)std::min<long>(nsize, cfg.max_krylov);
+  const int n_warm = (int)std::min<long>(nsize, std::min(std::max(0, k_prev - 2), 15));
   const bool lanczos = cfg.integrator == MITDVP_LANCZOS;
   const bool cn = cfg.conserve_norm != 0;
   zc* V = V_.p;
@@ -463,7 +488,7 @@ int Engine::krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev) {
     timer_end();
     cnt_.n_launch += 3;
 
-    const bool last_possible = (l + 1 == n);
+    const bool last_possible = (l + 1 == nsize);
     if (l < n_warm && !last_possible && l + 1 < ndim) continue;  // warm-up: no host sync (:578-579)
 
     // ---- bring the scalars of iterations [next_unread, l] to the host -------
@@ -486,7 +511,7 @@ int Engine::krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev) {
         for (int j = 0; j <= q; ++j) hess[(size_t)j * ndim + q] = sum_z(RED_H + ((size_t)q * MAXK + j) * NPART);
         if (b > KRYLOV_EPS && q + 1 < ndim + 1) hess[(size_t)(q + 1) * ndim + q] = b;
       }
-      if (b < KRYLOV_EPS || q + 1 == n) {  // Krylov space exhausted (:569, :392)
+      if (b < KRYLOV_EPS || q + 1 == nsize) {  // Krylov space exhausted (:569, :392)
         ld = q;
         exhausted = true;
         break;
@@ -785,8 +810,14 @@ void Engine::sweep(double dt, bool forward) {
     for (int b = 1; b < L_; ++b)
       if (!envL_ok_[b]) throw ArgError("backward sweep needs the left environments of a forward sweep");
   const hzc shift = op(0).shift;
+  if (adaptive_) {
+    if (cfg.relax) throw ArgError("adaptive bond dimension is implemented for real-time propagation only");
+    adaptive_prepare();
+    build_superblock_full(forward);
+  }
   DevBuf spare = pool_get(V_.n / MAXK);
   for (int p = begin; forward ? p <= end : p >= end; p += forward ? 1 : -1) {
+    if (adaptive_ && p != end && adaptive_site(p, dt, forward, spare)) continue;
     local_site_exp(p, dt);  // exp_superH_propagation_direct
     if (p == end) break;
     const MpoSite& w = mpo(0, p);
@@ -851,6 +882,325 @@ void Engine::sweep(double dt, bool forward) {
     }
   }
   pool_put(std::move(spare));
+}
+
+// ---------------------------------------------------------------------------
+// adaptive bond dimension (a1TDVP): const.adaptive branches of
+// propagate_along_sweep (_mps_cls.py:863-987), get_adaptive_rank_and_block
+// (:2152-2286), get_rank_and_projection_error (:1985-2105), thin_to_full
+// (_site_cls.py:294-405).  Every block that the reference builds twice ("bra"
+// and "braket") is built once here from the widened neighbour tensor and
+// sliced: the leading columns / rows of the widened tensor ARE the thin tensor.
+// ---------------------------------------------------------------------------
+void Engine::set_adaptive(bool on, int dmax, int dd, double p_proj) {
+  if (on && (dmax < 1 || dd < 0 || !(p_proj >= 0.0))) throw ArgError("set_adaptive: need Dmax >= 1, dD >= 0, p_proj >= 0");
+  adaptive_ = on; ad_dmax_ = dmax; ad_dd_ = dd; ad_p_ = p_proj;
+}
+
+// workspaces for the largest shapes the bonds can reach during this sweep
+void Engine::adaptive_prepare() {
+  std::vector<long> cap(L_ + 1, 1);  // cap[b]: largest possible dimension of the bond left of site b
+  {
+    std::vector<double> lp(L_ + 1, 1.0), rp(L_ + 1, 1.0);
+    for (int b = 1; b <= L_; ++b) lp[b] = std::min(1e15, lp[b - 1] * dd_[b - 1]);
+    for (int b = L_ - 1; b >= 0; --b) rp[b] = std::min(1e15, rp[b + 1] * dd_[b]);
+    for (int b = 0; b <= L_; ++b) cap[b] = (long)std::min(lp[b], rp[b]);
+  }
+  auto bound = [&](int b) -> long {  // bond left of site b, widened tensors included
+    const long cur = b == 0 ? 1 : (b == L_ ? 1 : dl_[b]);
+    if (b == 0 || b == L_) return 1;
+    return std::min<long>(cap[b], std::max<long>(cur, ad_dmax_) + ad_dd_);
+  };
+  long ms = 1, mx = 1, my = 1;
+  int qm = 1, qn = 1;
+  for (int p = 0; p < L_; ++p) {
+    const long bl = bound(p), br = bound(p + 1);
+    ms = std::max(ms, bl * dd_[p] * br);
+    qm = std::max<long>(qm, std::max(bl, br) * dd_[p]);
+    qn = std::max<long>(qn, std::max(bl, br));
+    const MpoSite& w = mpo(0, p);
+    const long mm = std::max(w.ml, w.mr);
+    mx = std::max(mx, bl * br * dd_[p] * mm);
+    my = mx;
+  }
+  ensure_work(ms, mx, my, qm, qn, ad_dd_ + 1);
+  for (int p = 0; p < L_; ++p) site_[p].grow_preserve((size_t)ms, (size_t)dl_[p] * dd_[p] * dr_[p], st_);
+  if (full_.size() != (size_t)L_) { full_.clear(); full_.resize(L_); fdl_.assign(L_, 0); fdr_.assign(L_, 0); }
+}
+
+// (l, c, r) isometry over (l c) x r -> (l, c, r + e): e more orthonormal columns
+void Engine::thin_to_full_A(const zc* A, int l, int c, int r, int e, zc* out) {
+  const size_t n = (size_t)l * c * r;
+  if (e == 0) {
+    HIP_CHECK(hipMemcpyAsync(out, A, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+    return;
+  }
+  HIP_CHECK(hipMemcpyAsync(tmp1_.p, A, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  long nl = 0;
+  timer_begin(3);
+  qr_householder(st_, tmp1_.p, l * c, r, out, nullptr, qrwork_.p, &nl, e);
+  timer_end();
+  // sign alignment (_site_cls.py:321-335): the leading columns equal the input
+  copy2d(st_, out, r + e, A, r, (long)l * c, r, 0, make_double2(1.0, 0.0), false);
+  cnt_.n_launch += nl + 1;
+  cnt_.n_qr += 1;
+}
+
+// (l, c, r) isometry over l x (c r) -> (l + e, c, r): e more orthonormal rows
+void Engine::thin_to_full_B(const zc* B, int l, int c, int r, int e, zc* out) {
+  const size_t n = (size_t)l * c * r;
+  if (e > 0) {
+    const int m = c * r;
+    transpose_batched(st_, B, tmp1_.p, l, m, m, l, 1, 0, 0);  // mat = B.reshape(l, c r).T, _site_cls.py:357
+    long nl = 0;
+    timer_begin(3);
+    qr_householder(st_, tmp1_.p, m, l, tmp2_.p, nullptr, qrwork_.p, &nl, e);
+    timer_end();
+    transpose_batched(st_, tmp2_.p, out, m, l + e, l + e, m, 1, 0, 0);
+    cnt_.n_launch += nl + 2;
+    cnt_.n_qr += 1;
+  }
+  HIP_CHECK(hipMemcpyAsync(out, B, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+}
+
+// get_superblock_full / get_actual_delta_rank (_mps_cls.py:3699-3755)
+void Engine::build_superblock_full(bool forward) {
+  for (int q = 0; q < L_; ++q) {
+    if (q == (forward ? 0 : L_ - 1)) continue;
+    const int l1 = dl_[q], c1 = dd_[q], r1 = dr_[q];
+    pool_put(std::move(full_[q]));
+    if (forward) {  // gauge B, neighbour q-1
+      const int l2 = dl_[q - 1], c2 = dd_[q - 1], r2 = dr_[q - 1];
+      const long e = std::max<long>(0, std::min<long>(ad_dd_, std::min((long)c1 * r1 - l1, (long)l2 * c2 - r2)));
+      full_[q] = pool_get((size_t)(l1 + e) * c1 * r1);
+      thin_to_full_B(site_[q].p, l1, c1, r1, (int)e, full_[q].p);
+      fdl_[q] = l1 + (int)e; fdr_[q] = r1;
+    } else {  // gauge A, neighbour q+1
+      const int l2 = dl_[q + 1], c2 = dd_[q + 1], r2 = dr_[q + 1];
+      const long e = std::max<long>(0, std::min<long>(ad_dd_, std::min((long)l1 * c1 - r1, (long)c2 * r2 - l2)));
+      full_[q] = pool_get((size_t)l1 * c1 * (r1 + e));
+      thin_to_full_A(site_[q].p, l1, c1, r1, (int)e, full_[q].p);
+      fdl_[q] = l1; fdr_[q] = r1 + (int)e;
+    }
+  }
+}
+
+// the D loop of get_rank_and_projection_error (_mps_cls.py:2083-2105):
+// f(D) = |H psi_left[..., :D]|^2 - |K sigma[:D, :D]|^2 + |H psi_right[:D, ...]|^2
+int Engine::select_rank(const zc* hl, long hl_rows, const zc* ks, const zc* hr, long hr_cols, int dmin, int dmax) {
+  DevBuf prof = pool_get((size_t)(3 * dmax) / 2 + 2);
+  double* pd = reinterpret_cast<double*>(prof.p);
+  col_sumsq(st_, hl, hl_rows, dmax, pd);
+  row_sumsq(st_, hr, dmax, hr_cols, pd + dmax);
+  shell_sumsq(st_, ks, dmax, pd + 2 * (size_t)dmax);
+  std::vector<double> h(3 * (size_t)dmax);
+  HIP_CHECK(hipMemcpyAsync(h.data(), pd, h.size() * sizeof(double), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  cnt_.n_launch += 3;
+  pool_put(std::move(prof));
+  double a = 0, b = 0, k = 0, prev = 0;
+  for (int D = 1; D <= dmax; ++D) {
+    a += h[D - 1]; b += h[(size_t)dmax + D - 1]; k += h[2 * (size_t)dmax + D - 1];
+    if (D < dmin) continue;
+    const double tot = a - k + b;
+    if (D > dmin) {
+      const double metric = (tot - prev) / tot;
+      if (metric < ad_p_) return D - 1;
+    }
+    prev = tot;
+  }
+  return dmax;
+}
+
+// one site of an adaptive half-sweep; false: the bond is at maximal rank
+// (is_max_rank, _mps_cls.py:3757-3766) and the caller does the plain step
+bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
+  const hzc shift = op(0).shift;
+  const zc one = make_double2(1.0, 0.0);
+  const zc zshift = make_double2(shift.real(), shift.imag());
+  const bool has_shift = shift != hzc(0.0, 0.0);
+  const int l = dl_[p], c = dd_[p], r = dr_[p];
+  const MpoSite& wp = mpo(0, p);
+  if (c != wp.d) throw ArgError("MPO physical dimension differs from the site tensor's");
+  long nl = 0;
+  if (forward) {
+    if ((long)l * c <= r || r >= ad_dmax_) return false;
+    const int q = p + 1;
+    const MpoSite& wq = mpo(0, q);
+    const int cq = dd_[q], rq = dr_[q], Df = fdl_[q], M = wp.mr;
+    // environment right of site p from the widened B(q): "braket", and its ket-thin slice "bra"
+    DevBuf fm = pool_get((size_t)Df * cq * rq);
+    transpose_rev3(st_, full_[q].p, fm.p, Df, cq, rq);
+    DevBuf env_braket = pool_get((size_t)Df * M * Df);
+    env_update(envR_[q + 1].p, fm.p, wq.w2r.p, env_braket.p, rq, wq.mr, cq, Df, M);
+    pool_put(std::move(fm));
+    DevBuf env_bra = pool_get((size_t)Df * M * r);
+    copy2d(st_, env_bra.p, r, env_braket.p, Df, (long)Df * M, r, 0, one, false);
+    int dmax = std::min(ad_dmax_, Df);
+    // get_psi_sigvec_psi_fullblock: Psi = A sigma, Psi' = sigma B(q), widened A
+    DevBuf A = pool_get((size_t)l * c * r);
+    gauge_qr_left(site_[p].p, l, c, r, A.p, sig_.p);
+    DevBuf psip = pool_get((size_t)r * cq * rq);
+    {
+      ZgemmDesc g = zgemm_desc(sig_.p, site_[q].p, psip.p, r, cq * rq, r);
+      zgemm(st_, g);
+    }
+    const int ea = (int)std::min<long>(dmax - r, (long)l * c - r);
+    DevBuf Afull = pool_get((size_t)l * c * (r + ea));
+    thin_to_full_A(A.p, l, c, r, ea, Afull.p);
+    DevBuf sys_bra = pool_get((size_t)(r + ea) * M * r);
+    env_update_rect(envL_[p].p, A.p, Afull.p, wp.w2l.p, sys_bra.p, l, l, wp.ml, c, r + ea, r, M);
+    pool_put(std::move(A));
+    pool_put(std::move(Afull));
+    dmax = (int)std::min<long>(dmax, std::min((long)l * c, (long)cq * rq));
+    int newD = r;
+    if (r != dmax) {
+      DevBuf hl = pool_get((size_t)l * c * dmax), hr = pool_get((size_t)dmax * cq * rq), ks = pool_get((size_t)dmax * dmax);
+      heff_apply_rect(envL_[p].p, wp, env_bra.p, site_[p].p, hl.p, l, l, c, dmax, r);
+      heff_apply_rect(sys_bra.p, wq, envR_[q + 1].p, psip.p, hr.p, dmax, r, cq, rq, rq);
+      keff_apply_rect(sys_bra.p, env_bra.p, sig_.p, ks.p, dmax, r, dmax, r, M);
+      newD = select_rank(hl.p, (long)l * c, ks.p, hr.p, (long)cq * rq, r, dmax);
+      pool_put(std::move(hl)); pool_put(std::move(hr)); pool_put(std::move(ks));
+    }
+    pool_put(std::move(psip));
+    pool_put(std::move(sys_bra));
+    // blocks at the chosen rank: bra = leading newD*M rows of env_bra, braket = [:newD, :, :newD]
+    DevBuf envD_braket = pool_get((size_t)newD * M * newD);
+    copy2d(st_, envD_braket.p, newD, env_braket.p, Df, (long)newD * M, newD, 0, one, false);
+    pool_put(std::move(env_braket));
+    // B(q) <- widened B(q)[:newD]
+    HIP_CHECK(hipMemcpyAsync(site_[q].p, full_[q].p, (size_t)newD * cq * rq * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+    dl_[q] = newD;
+    // exp(-i H dt/2) on the zero-padded centre tensor; every apply sees the vector cut
+    // back to the old shape (SplitStack.split(truncate=True), _contraction.py:593-610)
+    copy2d(st_, spare.p, newD, site_[p].p, r, (long)l * c, r, newD, one, false);
+    std::swap(site_[p], spare);
+    dr_[p] = newD;
+    {
+      const zc* Lb = envL_[p].p;
+      const zc* Rb = env_bra.p;
+      auto mv = [&](const zc* in, zc* out) {
+        copy2d(st_, tmp2_.p, r, in, newD, (long)l * c, r, 0, one, false);
+        heff_apply_rect(Lb, wp, Rb, tmp2_.p, out, l, l, c, newD, r);
+        if (has_shift) copy2d(st_, out, newD, tmp2_.p, r, (long)l * c, r, 0, zshift, true);
+        cnt_.n_launch += has_shift ? 2 : 1;
+      };
+      kprev_[p] = krylov_exp(scale_site(dt), mv, site_[p].p, (long)l * c * newD, kprev_[p], (long)l * c * r);
+      cnt_.n_exp_site += 1;
+    }
+    pool_put(std::move(env_bra));
+    // from here on the plain step at the new rank
+    timer_begin(3);
+    qr_householder(st_, site_[p].p, l * c, newD, spare.p, sig_.p, qrwork_.p, &nl);
+    timer_end();
+    cnt_.n_launch += nl; cnt_.n_qr += 1;
+    cnt_.qr_flops += 4.0 * (4.0 * (double)l * c * newD * newD - 4.0 * (double)newD * newD * newD / 3.0);
+    std::swap(site_[p], spare);
+    gauge_[p] = MITDVP_GAUGE_A;
+    pool_put(std::move(envL_[q]));
+    envL_[q] = pool_get((size_t)newD * M * newD);
+    env_update(envL_[p].p, site_[p].p, wp.w2l.p, envL_[q].p, l, wp.ml, c, newD, M);
+    envL_ok_[q] = 1;
+    {
+      const zc* Lb = envL_[q].p;
+      const zc* Rb = envD_braket.p;
+      auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, newD, newD, M, shift); };
+      kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)newD * newD, kprev_[p]);
+      cnt_.n_exp_bond += 1;
+    }
+    pool_put(std::move(envD_braket));
+    envR_ok_[q] = 0;
+    pool_put(std::move(envR_[q]));
+    ZgemmDesc g = zgemm_desc(sig_.p, site_[q].p, spare.p, newD, cq * rq, newD);
+    zgemm(st_, g);
+    cnt_.n_launch += 1;
+    std::swap(site_[q], spare);
+    gauge_[q] = MITDVP_GAUGE_PSI;
+    center_ = q;
+    return true;
+  }
+  // ---- backward: the mirror image ------------------------------------------
+  if (l >= (long)c * r || l >= ad_dmax_) return false;
+  const int q = p - 1;
+  const MpoSite& wq = mpo(0, q);
+  const int lq = dl_[q], cq = dd_[q], Df = fdr_[q], M = wp.ml;
+  DevBuf env_braket = pool_get((size_t)Df * M * Df);
+  env_update(envL_[q].p, full_[q].p, wq.w2l.p, env_braket.p, lq, wq.ml, cq, Df, M);
+  DevBuf env_bra = pool_get((size_t)Df * M * l);
+  copy2d(st_, env_bra.p, l, env_braket.p, Df, (long)Df * M, l, 0, one, false);
+  int dmax = std::min(ad_dmax_, Df);
+  DevBuf B = pool_get((size_t)l * c * r), Bt = pool_get((size_t)l * c * r);
+  gauge_qr_right(site_[p].p, l, c, r, B.p, Bt.p, sig_.p);
+  DevBuf psip = pool_get((size_t)lq * cq * l);
+  {
+    ZgemmDesc g = zgemm_desc(site_[q].p, sig_.p, psip.p, lq * cq, l, l);
+    zgemm(st_, g);
+  }
+  const int eb = (int)std::min<long>(dmax - l, (long)c * r - l);
+  DevBuf Bfull = pool_get((size_t)(l + eb) * c * r), Bfull_t = pool_get((size_t)(l + eb) * c * r);
+  thin_to_full_B(B.p, l, c, r, eb, Bfull.p);
+  transpose_rev3(st_, Bfull.p, Bfull_t.p, l + eb, c, r);
+  DevBuf sys_bra = pool_get((size_t)(l + eb) * M * l);
+  env_update_rect(envR_[p + 1].p, Bt.p, Bfull_t.p, wp.w2r.p, sys_bra.p, r, r, wp.mr, c, l + eb, l, M);
+  pool_put(std::move(B)); pool_put(std::move(Bt)); pool_put(std::move(Bfull)); pool_put(std::move(Bfull_t));
+  dmax = (int)std::min<long>(dmax, std::min((long)lq * cq, (long)c * r));
+  int newD = l;
+  if (l != dmax) {
+    DevBuf hl = pool_get((size_t)lq * cq * dmax), hr = pool_get((size_t)dmax * c * r), ks = pool_get((size_t)dmax * dmax);
+    heff_apply_rect(envL_[q].p, wq, sys_bra.p, psip.p, hl.p, lq, lq, cq, dmax, l);
+    heff_apply_rect(env_bra.p, wp, envR_[p + 1].p, site_[p].p, hr.p, dmax, l, c, r, r);
+    keff_apply_rect(env_bra.p, sys_bra.p, sig_.p, ks.p, dmax, l, dmax, l, M);
+    newD = select_rank(hl.p, (long)lq * cq, ks.p, hr.p, (long)c * r, l, dmax);
+    pool_put(std::move(hl)); pool_put(std::move(hr)); pool_put(std::move(ks));
+  }
+  pool_put(std::move(psip));
+  pool_put(std::move(sys_bra));
+  DevBuf envD_braket = pool_get((size_t)newD * M * newD);
+  copy2d(st_, envD_braket.p, newD, env_braket.p, Df, (long)newD * M, newD, 0, one, false);
+  pool_put(std::move(env_braket));
+  // A(q) <- widened A(q)[:, :, :newD]
+  copy2d(st_, site_[q].p, newD, full_[q].p, Df, (long)lq * cq, newD, 0, one, false);
+  dr_[q] = newD;
+  // zero-padded centre tensor (newD, c, r): the old tensor is the leading block
+  HIP_CHECK(hipMemcpyAsync(spare.p, site_[p].p, (size_t)l * c * r * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  if (newD > l) HIP_CHECK(hipMemsetAsync(spare.p + (size_t)l * c * r, 0, (size_t)(newD - l) * c * r * sizeof(zc), st_));
+  std::swap(site_[p], spare);
+  dl_[p] = newD;
+  {
+    const zc* Lb = env_bra.p;
+    const zc* Rb = envR_[p + 1].p;
+    auto mv = [&](const zc* in, zc* out) {
+      heff_apply_rect(Lb, wp, Rb, in, out, newD, l, c, r, r);
+      if (has_shift) vec_axpby(st_, out, in, (long)l * c * r, zshift, one);
+    };
+    kprev_[p] = krylov_exp(scale_site(dt), mv, site_[p].p, (long)newD * c * r, kprev_[p], (long)l * c * r);
+    cnt_.n_exp_site += 1;
+  }
+  pool_put(std::move(env_bra));
+  gauge_qr_right(site_[p].p, newD, c, r, spare.p, tmp2_.p, sig_.p);
+  std::swap(site_[p], spare);
+  gauge_[p] = MITDVP_GAUGE_B;
+  pool_put(std::move(envR_[p]));
+  envR_[p] = pool_get((size_t)newD * M * newD);
+  env_update(envR_[p + 1].p, tmp2_.p, wp.w2r.p, envR_[p].p, r, wp.mr, c, newD, M);
+  envR_ok_[p] = 1;
+  {
+    const zc* Lb = envD_braket.p;
+    const zc* Rb = envR_[p].p;
+    auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, newD, newD, M, shift); };
+    kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)newD * newD, kprev_[p]);
+    cnt_.n_exp_bond += 1;
+  }
+  pool_put(std::move(envD_braket));
+  envL_ok_[p] = 0;
+  pool_put(std::move(envL_[p]));
+  ZgemmDesc g = zgemm_desc(site_[q].p, sig_.p, spare.p, lq * cq, newD, newD);
+  zgemm(st_, g);
+  cnt_.n_launch += 1;
+  std::swap(site_[q], spare);
+  gauge_[q] = MITDVP_GAUGE_PSI;
+  center_ = q;
+  return true;
 }
 
 void Engine::step(double dt) {

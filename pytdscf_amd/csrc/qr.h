@@ -7,9 +7,11 @@ namespace mitdvp {
 constexpr int QR_NB = 32;     // panel width
 
 // workspace size in complex elements for an (m x n) factorisation
-size_t qr_work_elems(int m, int n);
+size_t qr_work_elems(int m, int n, int next = 0);
 // A (m x n, row-major, ld = n, m >= n) is overwritten by the reflectors;
-// Q (m x n, ld = n) and R (n x n, ld = n, zero below the diagonal) are written.
-void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch);
+// Q (m x (n+next), ld = n+next) and R (n x n, ld = n, zero below the diagonal; may be
+// null) are written.  next > 0 appends the first `next` columns of the orthogonal
+// complement exactly as LAPACK's full-mode Q orders them (H_1..H_n applied to e_{n+1}..).
+void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next = 0);
 
 }  // namespace mitdvp

@@ -252,12 +252,12 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 // step over the chip, few enough that summing their partials stays cheap
 static int qr_rows_for(int m) { return m <= 8192 ? 32 : (m <= 65536 ? 128 : 256); }
 
-size_t qr_work_elems(int m, int n) {
+size_t qr_work_elems(int m, int n, int next) {
   const int nblk = (m + 31) / 32;  // upper bound over all row-block sizes
   const int npan = (n + QR_NB - 1) / QR_NB;
   size_t e = 0;
   e += (size_t)m * QR_NB;          // Vp
-  e += 2 * (size_t)QR_NB * n;      // W, W2
+  e += 2 * (size_t)QR_NB * (n + next);  // W, W2
   e += (size_t)QR_NB * QR_NB;      // G
   e += (size_t)npan * QR_NB * QR_NB;  // T
   e += n;                          // tau
@@ -266,9 +266,11 @@ size_t qr_work_elems(int m, int n) {
   return e;
 }
 
-void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch) {
+void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next) {
   if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
+  if (next < 0 || n + next > m) throw ArgError("qr: more orthogonal-complement columns requested than exist");
   if (n <= 0) return;
+  const int nqt = n + next;  // columns of Q: the thin factor and `next` columns of LAPACK's full Q
   const long lda = n;
   const int rows = qr_rows_for(m);
   const int nblk = (m + rows - 1) / rows;
@@ -276,8 +278,8 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   const int npan = (n + QR_NB - 1) / QR_NB;
   zc* Vp = work;
   zc* W = Vp + (size_t)m * QR_NB;
-  zc* W2 = W + (size_t)QR_NB * n;
-  zc* G = W2 + (size_t)QR_NB * n;
+  zc* W2 = W + (size_t)QR_NB * nqt;
+  zc* G = W2 + (size_t)QR_NB * nqt;
   zc* T = G + (size_t)QR_NB * QR_NB;
   zc* tau = T + (size_t)npan * QR_NB * QR_NB;
   zc* py[2] = {tau + n, tau + n + (size_t)nblk_max * QR_NB};
@@ -335,25 +337,28 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     }
   }
   // R
-  hipLaunchKernelGGL(k_qr_extract_r, dim3(vec_blocks((long)n * n)), dim3(256), 0, st, A, lda, n, R);
-  ++nl;
-  // Q = H_1 ... H_k [I; 0]  (zungqr, block reflectors applied in reverse)
-  set_identity(st, Q, m, n, n);
+  if (R) {
+    hipLaunchKernelGGL(k_qr_extract_r, dim3(vec_blocks((long)n * n)), dim3(256), 0, st, A, lda, n, R);
+    ++nl;
+  }
+  // Q = H_1 ... H_k I[:, :n+next]  (zungqr, block reflectors applied in reverse); columns
+  // n.. are the leading columns of the orthogonal complement in LAPACK's "full" Q
+  set_identity(st, Q, m, nqt, nqt);
   ++nl;
   for (int ip = npan - 1; ip >= 0; --ip) {
     const int j0 = ip * QR_NB, j1 = min(n, j0 + QR_NB), nbp = j1 - j0, mp = m - j0;
-    const int nq = n - j0;
+    const int nq = nqt - j0;
     extract_v(j0, nbp);
     zc* Tp = T + (size_t)ip * QR_NB * QR_NB;
-    zc* Q2 = Q + (long)j0 * n + j0;
+    zc* Q2 = Q + (long)j0 * nqt + j0;
     ZgemmDesc w = zgemm_desc(Vp, Q2, W, nbp, nq, mp);  // W = V^H Q2
-    w.transA = 1; w.conjA = 1; w.lda = nbp; w.ldb = n; w.ldc = nq;
+    w.transA = 1; w.conjA = 1; w.lda = nbp; w.ldb = nqt; w.ldc = nq;
     zgemm(st, w);
     ZgemmDesc w2 = zgemm_desc(Tp, W, W2, nbp, nq, nbp);  // W2 = T W
     w2.lda = nbp; w2.ldb = nq; w2.ldc = nq;
     zgemm(st, w2);
     ZgemmDesc u = zgemm_desc(Vp, W2, Q2, mp, nq, nbp);  // Q2 -= V W2
-    u.lda = nbp; u.ldb = nq; u.ldc = n; u.alpha = mone; u.beta = one;
+    u.lda = nbp; u.ldb = nq; u.ldc = nqt; u.alpha = mone; u.beta = one;
     zgemm(st, u);
     nl += 3;
   }

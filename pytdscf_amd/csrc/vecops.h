@@ -25,6 +25,13 @@ void vec_axpby(hipStream_t st, zc* y, const zc* x, long n, zc a, zc b);
 void vec_scale(hipStream_t st, zc* y, long n, zc a);
 void vec_randn(hipStream_t st, zc* out, long n, uint64_t seed);
 void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld);
+// dst[r][c] = a * src[r][c] (+ dst[r][c]) for c < cols; columns cols..zero_to-1 of dst are zeroed
+void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
+            bool accumulate);
+// norm profiles for the adaptive-rank functional (plain device arrays, no partials)
+void col_sumsq(hipStream_t st, const zc* x, long rows, int cols, double* out /*[cols]*/);
+void row_sumsq(hipStream_t st, const zc* x, int rows, long cols, double* out /*[rows]*/);
+void shell_sumsq(hipStream_t st, const zc* x, int n, double* out /*[n]*/);
 void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols, long ldi, long ldo, int batch,
                        long in_bs, long out_bs);
 // Liouville space: diagonal (trace = false) or trace (true) over the n x n physical index

@@ -298,6 +298,75 @@ __global__ __launch_bounds__(256) void k_identity(zc* __restrict__ out, int rows
 }
 
 // ---------------------------------------------------------------------------
+// adaptive bond dimension: strided block copies and the norm profiles of the
+// rank-selection functional f(D) (_mps_cls.py:2083-2105)
+// ---------------------------------------------------------------------------
+// dst[r][c] = a * src[r][c] (+ dst[r][c] if acc); dst columns >= cols are zero-filled up to zcols
+__global__ __launch_bounds__(256) void k_copy2d(zc* __restrict__ dst, long ldd, const zc* __restrict__ src, long lds,
+                                                long rows, int cols, int zcols, zc a, int acc) {
+  const int w = zcols > cols ? zcols : cols;
+  const long n = rows * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / w;
+    const int c = (int)(i % w);
+    if (c < cols) {
+      const zc v = src[r * lds + c];
+      zc o = make_double2(a.x * v.x - a.y * v.y, a.x * v.y + a.y * v.x);
+      if (acc) { const zc d = dst[r * ldd + c]; o.x += d.x; o.y += d.y; }
+      dst[r * ldd + c] = o;
+    } else {
+      dst[r * ldd + c] = make_double2(0.0, 0.0);
+    }
+  }
+}
+
+// out[c] = sum_r |x[r][c]|^2 : one workgroup per column (fixed summation order)
+__global__ __launch_bounds__(256) void k_col_sumsq(const zc* __restrict__ x, long rows, int cols,
+                                                   double* __restrict__ out) {
+  __shared__ double sh[5];
+  const int c = blockIdx.x;
+  double a = 0;
+  for (long r = threadIdx.x; r < rows; r += 256) {
+    const zc v = x[r * cols + c];
+    a += v.x * v.x + v.y * v.y;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) out[c] = a;
+}
+
+// out[r] = sum_c |x[r][c]|^2
+__global__ __launch_bounds__(256) void k_row_sumsq(const zc* __restrict__ x, int rows, long cols,
+                                                   double* __restrict__ out) {
+  __shared__ double sh[5];
+  const zc* xr = x + (long)blockIdx.x * cols;
+  double a = 0;
+  for (long c = threadIdx.x; c < cols; c += 256) {
+    const zc v = xr[c];
+    a += v.x * v.x + v.y * v.y;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
+// out[t] = sum over the "shell" max(i, j) == t of |x[i][j]|^2  (square n x n):
+// |x[:D, :D]|^2 = sum_{t < D} out[t]
+__global__ __launch_bounds__(256) void k_shell_sumsq(const zc* __restrict__ x, int n, double* __restrict__ out) {
+  __shared__ double sh[5];
+  const int t = blockIdx.x;
+  double a = 0;
+  for (int j = threadIdx.x; j <= t; j += 256) {  // row t, columns 0..t
+    const zc v = x[(long)t * n + j];
+    a += v.x * v.x + v.y * v.y;
+  }
+  for (int i = threadIdx.x; i < t; i += 256) {  // column t, rows 0..t-1
+    const zc v = x[(long)i * n + t];
+    a += v.x * v.x + v.y * v.y;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) out[t] = a;
+}
+
+// ---------------------------------------------------------------------------
 // host wrappers
 // ---------------------------------------------------------------------------
 int vec_blocks(long n) {
@@ -340,6 +409,22 @@ void vec_scale(hipStream_t st, zc* y, long n, zc a) { LAUNCH(k_scale, vec_blocks
 void vec_randn(hipStream_t st, zc* out, long n, uint64_t seed) { LAUNCH(k_randn, vec_blocks(n), st, out, n, seed); }
 void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld) {
   LAUNCH(k_identity, vec_blocks((long)rows * cols), st, out, rows, cols, ld);
+}
+
+void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
+            bool accumulate) {
+  const long n = rows * (long)std::max(cols, zero_to);
+  if (n <= 0) return;
+  LAUNCH(k_copy2d, vec_blocks(n), st, dst, ldd, src, lds, rows, cols, zero_to, a, accumulate ? 1 : 0);
+}
+void col_sumsq(hipStream_t st, const zc* x, long rows, int cols, double* out) {
+  if (cols > 0) LAUNCH(k_col_sumsq, cols, st, x, rows, cols, out);
+}
+void row_sumsq(hipStream_t st, const zc* x, int rows, long cols, double* out) {
+  if (rows > 0) LAUNCH(k_row_sumsq, rows, st, x, rows, cols, out);
+}
+void shell_sumsq(hipStream_t st, const zc* x, int n, double* out) {
+  if (n > 0) LAUNCH(k_shell_sumsq, n, st, x, n, out);
 }
 
 void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols, long ldi, long ldo, int batch,

@@ -150,6 +150,16 @@ class TDVPEngine:
             shape += [self.get_site_shape(p)[1]] * k
         return out.reshape(shape)
 
+    def set_adaptive(self, enable: bool = True, Dmax: int = 20, dD: int = 5, p_proj: float = 1.0e-4) -> None:
+        """Adaptive bond dimension (``Simulator.propagate(adaptive=True, adaptive_Dmax=...,
+        adaptive_dD=..., adaptive_p_proj=...)``): ranks grow by up to ``dD`` per half-sweep
+        where the projection error asks for it, never above ``Dmax``."""
+        self._ck(self._lib.mitdvp_set_adaptive(self._h, int(bool(enable)), int(Dmax), int(dD), float(p_proj)))
+
+    def bond_dims(self) -> list[int]:
+        """Current bond dimensions (``WFunc.bonddim``)."""
+        return [self.get_site_shape(i)[2] for i in range(self.nsite - 1)]
+
     def truncate_bond(self, p: float, max_dim: int = 0):
         """SVD-truncate the bond right of the centre site (``truncate_sigvec``).
         Returns (new bond dimension, kept singular values normalised to unit norm)."""
@@ -296,6 +306,19 @@ def zgemm(A, B, C0=None, transA=False, conjA=False, transB=False, conjB=False, a
         )
     )
     return (Cm, ms.value) if reps else Cm
+
+
+def thin_to_full(site, gauge: str, delta_rank: int, device=0) -> np.ndarray:
+    """``SiteCoef.thin_to_full``: widen an "A" (or "B") isometry by ``delta_rank``
+    orthonormal columns (rows) of its orthogonal complement (capped at its dimension)."""
+    site = _c128(site)
+    l, c, r = site.shape
+    if gauge not in ("A", "B"):
+        raise ValueError(f"Invalid gauge: {gauge}")
+    extra = min(int(delta_rank), l * c - r if gauge == "A" else c * r - l)
+    out = np.empty((l, c, r + extra) if gauge == "A" else (l + extra, c, r), np.complex128)
+    _lib.check(_lib.load().mitdvp_thin_to_full(device, 0 if gauge == "A" else 1, _dp(site), l, c, r, extra, _dp(out)))
+    return out
 
 
 def svd(A, device=0):
