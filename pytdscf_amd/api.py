@@ -197,6 +197,10 @@ class WFunc:
     def autocorr(self):
         return self.engine.autocorr()
 
+    def bonddim(self):
+        """Bond dimensions of the MPS (wavefunction.py:151-167)."""
+        return self.engine.bond_dims()
+
     def expectation(self, matOp):
         name = matOp if isinstance(matOp, str) else self._name_of(matOp)
         if self.space == "liouville":  # Tr(O rho), _exp_liouville
@@ -271,8 +275,8 @@ class Simulator:
                   energy_per_step=1, norm_per_step=1, populations_per_step=1, parallel_split_indices=None,
                   adaptive=False, adaptive_Dmax=20, adaptive_dD=5, adaptive_p_proj=1.0e-04, adaptive_p_svd=1.0e-07,
                   integrator="lanczos", display_time_unit="fs", conserve_norm=True):
-        if restart or adaptive or parallel_split_indices is not None:
-            raise NotImplementedError("restart / adaptive / MPI sharding are 'next' rows (SURVEY 8f)")
+        if restart or parallel_split_indices is not None:
+            raise NotImplementedError("restart / MPI site sharding are 'next' rows (SURVEY 8f)")
         if integrator not in ("lanczos", "arnoldi"):
             raise ValueError(f"Invalid integrator: {integrator}")
         dt_fs = Δt if Δt is not None else stepsize
@@ -286,11 +290,14 @@ class Simulator:
             if autocorr:
                 autocorr = False
         eng, ids = self._engine(integrator, conserve_norm, thresh_sil)
+        if adaptive:  # const.adaptive / Dmax / dD / p_proj (_const_cls.py:212-216); p_svd is unused there too (:968-983)
+            eng.set_adaptive(True, Dmax=adaptive_Dmax, dD=adaptive_dD, p_proj=adaptive_p_proj)
         wf = self._wfunc(eng, ids)
         outdir = f"{self.jobname}_prop"
         os.makedirs(outdir, exist_ok=True)
         tconv = {"fs": units.au_in_fs, "ps": units.au_in_fs * 1e-3, "au": 1.0}[display_time_unit]
-        files = {k: open(os.path.join(outdir, f"{k}.dat"), "w") for k in ("autocorr", "populations", "expectations")}
+        names = ("autocorr", "populations", "expectations") + (("bonddim",) if adaptive else ())
+        files = {k: open(os.path.join(outdir, f"{k}.dat"), "w") for k in names}
         self.rdm_trace = []
         ener = None
         try:
@@ -317,6 +324,11 @@ class Simulator:
                     if istep == 0:
                         files["expectations"].write(f"# time [{display_time_unit}]\t" + "\t".join(f"{k:<11}" for k in row) + "\n")
                     files["expectations"].write(f"{t:6.9f}\t" + "".join(f"{v:6.9f}\t" for v in row.values()) + "\n")
+                if adaptive:  # properties.py:255-262, :344-356
+                    bd = eng.bond_dims()
+                    if istep == 0:
+                        files["bonddim"].write(f"# time [{display_time_unit}]\t" + "\t".join(f"{i}" for i in range(len(bd))) + "\n")
+                    files["bonddim"].write(f"{t:6.9f}\t" + "\t".join(f"{b}" for b in bd) + "\n")
                 if reduced_density is not None and istep % reduced_density[1] == 0:
                     rec = {}
                     for key in reduced_density[0]:

@@ -31,19 +31,21 @@ from oracle import tdvp_oracle as orc
 from pytdscf_amd import TDVPEngine
 from pytdscf_amd.dist import Comm, attach_parallel
 comm = Comm()
-L, d, M, D = 8, 4, 5, 48            # 48 = 2 * 24 = 3 * 16: shards for 2 and 3 ranks
+L, d, M, D = 8, 4, 5, {D}           # 48 = 2 * 24 = 3 * 16: shards for 2 and 3 ranks
 mpo = orc.synthetic_mpo(L, d, M, seed=3)
 mps = orc.synthetic_mps([d] * L, D, seed=4)
 eng = TDVPEngine(L, device=0, integrator={integ!r}, conserve_norm={cn})
 eng.set_mpo(mpo)
 eng.set_mps(mps)
 attach_parallel(eng, comm)
+if {adaptive}:
+    eng.set_adaptive(True, Dmax=32, dD=8, p_proj=1e-9)
 e0 = eng.expectation()
 for _ in range(2):
     eng.propagate(0.4)
 out = dict(rank=comm.rank, e0=[e0.real, e0.imag], e=[eng.expectation().real, eng.expectation().imag],
            norm=eng.norm(), ac=[eng.autocorr().real, eng.autocorr().imag], k=eng.krylov_stats(),
-           ncoll=eng.counters()["n_collectives"])
+           ncoll=eng.counters()["n_collectives"], bd=eng.bond_dims())
 np.save({out!r} + f".rank{{comm.rank}}.npy", np.concatenate([c.reshape(-1) for c in eng.get_mps()]))
 print("RESULT " + json.dumps(out), flush=True)
 comm.barrier()
@@ -51,12 +53,12 @@ comm.close()
 """
 
 
-def _run(world, tmp_path, integ="lanczos", cn=True, backend_env=None):
+def _run(world, tmp_path, integ="lanczos", cn=True, backend_env=None, D=48, adaptive=False):
     import json
 
     script = tmp_path / f"w{world}.py"
     out = str(tmp_path / f"mps_w{world}")
-    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, integ=integ, cn=cn, out=out)))
+    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, integ=integ, cn=cn, out=out, D=D, adaptive=adaptive)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                MITDVP_DIST_BACKEND="gloo")
     if backend_env:
@@ -93,6 +95,21 @@ def test_bond_sharded_arnoldi(tmp_path):
     res, vecs = _run(2, tmp_path, integ="arnoldi", cn=False)
     assert res[0]["k"] == ref[0]["k"]
     assert np.abs(vecs[0] - vref[0]).max() < 1e-10 and np.array_equal(vecs[0], vecs[1])
+
+
+def test_bond_sharded_adaptive(tmp_path):
+    """Adaptive bond dimension under bond sharding: the rank decisions are taken from
+    replicated data, so every rank grows the same bonds; blocks whose leading dimension
+    is not divisible by the world size stay replicated."""
+    ref, vref = _run(1, tmp_path, D=16, adaptive=True)
+    res, vecs = _run(2, tmp_path, D=16, adaptive=True)
+    assert max(ref[0]["bd"]) > 16 and all(r["ncoll"] > 0 for r in res)
+    for r, v in zip(res, vecs):
+        assert r["bd"] == ref[0]["bd"] and r["k"] == ref[0]["k"]
+        assert abs(r["norm"] - 1) < 1e-12
+        assert abs(complex(*r["ac"]) - complex(*ref[0]["ac"])) < 1e-9
+        assert v.shape == vref[0].shape and np.abs(v - vref[0]).max() < 1e-8
+    assert np.array_equal(vecs[0], vecs[1])
 
 
 def test_nccl_device_collectives_world1(tmp_path):

@@ -91,3 +91,35 @@ def test_henon_heiles_script_on_gpu(golden, tmp_path, monkeypatch):
     assert pytest.approx(ener_calc) == 0.018225341011652626
     ref = [g["n3_final0"], g["n3_final1"]]
     assert abs(abs(orc.overlap(ref, wf.get_mps())) - 1) < 1e-9
+
+
+@pytest.mark.gpu
+def test_a1tdvp_script_on_gpu(golden, tmp_path, monkeypatch):
+    """tests/test_a1tdvp.py of the reference through the shell: the exciton model from
+    bond dimension 1 with ``propagate(adaptive=True, ...)``.  The reference's test only
+    checks that it runs; here the ranks are pinned to its golden run as well."""
+    from pytdscf_amd import Exciton, HarmonicOscillator as HO, Model, Simulator, TensorHamiltonian, TensorOperator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("adaptive_exciton.npz")
+    prim_info = [HO(8, f, units="cm-1") for f in (1000, 2000, 3000)] + [Exciton(nstate=2, names=["S0", "S1"])]
+    pot = [g[f"pot{i}"] for i in range(4)]
+    kin = [g[f"kin{i}"] for i in range(3)]
+    hamiltonian = TensorHamiltonian(
+        ndof=4,
+        potential=[[{(0, 1, 2, (3, 3)): TensorOperator(mpo=pot, legs=(0, 1, 2, 3, 3))}]],
+        kinetic=[[{((0, 0), (1, 1), (2, 2)): TensorOperator(mpo=kin, legs=(0, 0, 1, 1, 2, 2))}]],
+        backend="hip",
+    )
+    model = Model(prim_info, {"hamiltonian": hamiltonian}, bond_dim=1)
+    model.init_HartreeProduct = [[ho.get_unitary()[0].tolist() for ho in prim_info[:3]] + [np.array([0.0, 1.0]).tolist()]]
+    simulator = Simulator("a1tdvp", model, backend="hip")
+    ener, wf = simulator.propagate(
+        stepsize=0.1, maxstep=10, adaptive=True, adaptive_Dmax=int(g["Dmax"]), adaptive_dD=int(g["dD"]),
+        adaptive_p_proj=float(g["p_proj"]),
+    )
+    assert wf.bonddim() == list(g["n10_bonddim"])
+    assert ener == pytest.approx(float(g["n10_energy_last"]), rel=1e-5)
+    assert abs(wf.norm() - 1) < 1e-12
+    lines = open(tmp_path / "a1tdvp_prop" / "bonddim.dat").read().splitlines()
+    assert len(lines) == 11 and lines[1].split()[1:] == ["1", "1", "1"] and lines[-1].split()[1:] == ["5", "5", "2"]
