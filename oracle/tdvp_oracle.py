@@ -452,6 +452,53 @@ def select_rank(h_left: np.ndarray, k_sig: np.ndarray, h_right: np.ndarray, dmin
 
 
 # --------------------------------------------------------------------------
+# f3: one-site gates between the half-sweeps (apply_one_gate)
+# --------------------------------------------------------------------------
+def canonicalize_A(cores: list[np.ndarray], lo: int, hi: int) -> None:
+    """canonicalizeA on cores[lo..hi] (_mps_cls.py:3539-3567): A(lo) .. A(hi-1) Psi(hi), in place."""
+    sval = None
+    for i in range(lo, hi + 1):
+        if sval is not None:
+            cores[i] = np.tensordot(sval, cores[i], axes=(1, 0))
+        if i != hi:
+            cores[i], sval = qr_psi2Asigma(cores[i])
+
+
+def canonicalize_B(cores: list[np.ndarray], lo: int, hi: int) -> None:
+    """canonicalizeB on cores[lo..hi] (_mps_cls.py:3570-3598): Psi(lo) B(lo+1) .. B(hi), in place."""
+    sval = None
+    for i in range(hi, lo - 1, -1):
+        if sval is not None:
+            cores[i] = np.tensordot(cores[i], sval, axes=(2, 0))
+        if i != lo:
+            sval, B = qr_psi2sigmaB(cores[i])
+            cores[i] = np.ascontiguousarray(B)
+
+
+def apply_one_gate(cores: list[np.ndarray], center: int, gates: dict, conj: bool = False, power: int = 1) -> None:
+    """MPSCoef.apply_one_gate (_mps_cls.py:2314-2373, :2420-2451): U[d', b] on the
+    physical leg of the listed sites, then re-orthogonalisation towards ``center``
+    (which must be the current "Psi" site) over the span of the touched sites."""
+    changed = []
+    for isite, U in sorted(gates.items()):
+        U = np.asarray(U, dtype=np.complex128)
+        if U.ndim == 1:  # diagonal core, key (isite,)
+            U = np.diag(U)
+        if conj:
+            U = U.conj()
+        if power != 1:
+            U = np.linalg.matrix_power(U, power)
+        cores[isite] = np.einsum("abc,db->adc", cores[isite], U)
+        if isite != center:
+            changed.append(isite)
+    if changed:
+        if max(changed) > center:
+            canonicalize_B(cores, center, max(changed))
+        if min(changed) < center:
+            canonicalize_A(cores, min(changed), center)
+
+
+# --------------------------------------------------------------------------
 # a8-a10: sweep
 # --------------------------------------------------------------------------
 @dataclass
@@ -472,6 +519,7 @@ class OracleMPS:
     shift: complex = 0.0  # coupleJ[0][0] * ovlp term, _contraction.py:1200-1216
     relax: bool | str = False  # const.doRelax: True = exp(-H dt/2) / exp(+K dt/2) + renormalise
     #   (_mps_cls.py:1086-1094); "improved" = Lanczos ground state of H_eff, bond step skipped (:1078-1084, :1159-1160)
+    gates: dict | None = None  # Model(one_gate_to_apply=...): {site: U (d x d) or diagonal (d,)}, applied between the half-sweeps
     adaptive: bool = False  # const.adaptive (_const_cls.py:120-124, :212-216)
     Dmax: int = 100
     dD: int = 10
@@ -670,6 +718,10 @@ class OracleMPS:
         if len(self.right) < self.nsite:
             self.build_right_envs()
         self.sweep(dt, True)
+        if self.gates:  # _mps_cls.py:489-490; op_sys_sites = None -> all left blocks are rebuilt (:2370)
+            apply_one_gate(self.cores, self.nsite - 1, self.gates)
+            for p in range(self.nsite - 1):
+                self.left[p + 1] = env_update_left(self.left[p], self.cores[p], self.mpo[p])
         self.sweep(dt, False)
 
     # ---- a11: observables -------------------------------------------------

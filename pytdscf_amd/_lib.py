@@ -12,7 +12,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmitdvp.so")
+LIB_PATH = os.environ.get("MITDVP_LIB") or os.path.join(_HERE, "csrc", "libmitdvp.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mitdvp.h")
 
 OK, EINVAL, EHIP, ENOTCONV, ESTATE, ENOMEM = 0, -1, -2, -3, -4, -5

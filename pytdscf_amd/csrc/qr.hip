@@ -118,6 +118,19 @@ __global__ __launch_bounds__(256) void k_qr_col(zc* __restrict__ A, long lda, in
   const int c = j0 + tx;
   const int r0 = blockIdx.x * QR_ROWS;
   const int jj = j - j0;
+  // every global load of this kernel is issued up front (one memory latency instead of
+  // three dependent ones): the block's rows of the panel, the exported row j, the partials
+  zc xs[QR_ROWS / 8], as_[QR_ROWS / 8];
+#pragma unroll
+  for (int q = 0; q < QR_ROWS / 8; ++q) {
+    const int i = r0 + ty + 8 * q;
+    const bool ok = i < m && i >= j && c < j1 && c >= j;
+    const long ii = ok ? i : j;
+    xs[q] = A[ii * lda + j];
+    as_[q] = A[ii * lda + (ok ? c : j)];
+  }
+  const zc alpha_in = row_in[jj];
+  const zc rowc_in = row_in[tx];
   // (1) y_c = sum over blocks of the partials of column j
   {
     double sr = 0, si = 0;
@@ -137,25 +150,16 @@ __global__ __launch_bounds__(256) void k_qr_col(zc* __restrict__ A, long lda, in
   }
   __syncthreads();
   // (2) reflector scalars
-  const House h = zlarfg(row_in[jj], ysum[jj].x);
+  const House h = zlarfg(alpha_in, ysum[jj].x);
   const bool active = c > j && c < j1;
   // w_c = conj(scale) y_c + A[j,c]
   zc f = make_double2(0.0, 0.0);
   if (active) {
-    const zc w = zadd(zmul(zconj(h.scale), ysum[tx]), row_in[tx]);
+    const zc w = zadd(zmul(zconj(h.scale), ysum[tx]), rowc_in);
     f = zmul(zconj(h.tau), w);
   }
   // (3) update the block's rows; (4) partial y of column j+1
   const bool have_next = j + 1 < j1;
-  zc xs[QR_ROWS / 8], as_[QR_ROWS / 8];
-#pragma unroll
-  for (int q = 0; q < QR_ROWS / 8; ++q) {
-    const int i = r0 + ty + 8 * q;
-    const bool ok = i < m && i >= j && c < j1 && c >= j;
-    const long ii = ok ? i : j;
-    xs[q] = A[ii * lda + j];
-    as_[q] = A[ii * lda + (ok ? c : j)];
-  }
 #pragma unroll
   for (int q = 0; q < QR_ROWS / 8; ++q) {
     const int i = r0 + ty + 8 * q;

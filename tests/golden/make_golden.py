@@ -615,6 +615,78 @@ def main():
     save("adaptive_exciton.npz", dt_au=np.array(0.1 / au_in_fs), Dmax=np.array(12), dD=np.array(4),
          p_proj=np.array(1.0e-5), **o)
 
+    # (vi) one-site gates between the half-sweeps: Model(one_gate_to_apply=...) ->
+    # MPSCoef.propagate -> apply_one_gate(reorth_center=nsite-1) (_mps_cls.py:489-490, :2314-2373)
+    rng_g = np.random.default_rng(991)
+
+    def crandn_g(*shape):
+        return rng_g.standard_normal(shape) + 1j * rng_g.standard_normal(shape)
+
+    # (vi-a) Hilbert space: unitary kicks, a full (4-leg) gate on site 1 and a diagonal (3-leg) one on site 4
+    Lg, dg, Mg, Dg = 6, 3, 4, 6
+    mpo_g = orc.synthetic_mpo(Lg, dg, Mg, seed=5)
+    cores_g = [crandn_g(dl, dg, dr) for (dl, dr) in orc.bond_dims([dg] * Lg, Dg)]
+    Hk = crandn_g(dg, dg)
+    from scipy.linalg import expm as _expm
+    U1 = _expm(-0.3j * (Hk + Hk.conj().T))
+    U4 = np.exp(1j * rng_g.standard_normal(dg))
+    gate_h = TensorHamiltonian(
+        ndof=Lg,
+        potential=[[{((1, 1),): TensorOperator(mpo=[U1[None, :, :, None]], legs=(1, 1)),
+                     (4,): TensorOperator(mpo=[U4[None, :, None]], legs=(4,))}]],
+        kinetic=None, backend="numpy",
+    )
+    model_g = Model([Exciton(nstate=dg) for _ in range(Lg)], operators={"hamiltonian": [w.copy() for w in mpo_g]},
+                    bond_dim=Dg, one_gate_to_apply=gate_h)
+    model_g.init_HartreeProduct = [[np.array(c) for c in cores_g]]
+    o = {f"mpo{i}": w for i, w in enumerate(mpo_g)}
+    o.update({f"init{i}": c for i, c in enumerate(cores_g)})
+    o["U1"] = U1
+    o["U4"] = U4
+    for n in (1, 3):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_gate", model_g, backend="numpy", verbose=0)
+        ener, wf = sim.propagate(stepsize=0.05, maxstep=n)
+        o[f"n{n}_energy_last"] = np.array(ener)
+        o[f"n{n}_energy_final"] = np.array(wf.expectation(model_g.hamiltonian))
+        o[f"n{n}_norm"] = np.array(wf.norm())
+        o[f"n{n}_autocorr"] = np.array(wf._ints_wf_ovlp_mpssm(wf.ci_coef, conj=False))
+        o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(Lg)])
+        for i, s_ in enumerate(wf.ci_coef.superblock_states[0]):
+            o[f"n{n}_final{i}"] = np.array(s_.data)
+    save("gate_chain.npz", dt_au=np.array(0.05 / au_in_fs), nsite=np.array(Lg), **o)
+
+    # (vi-b) Liouville space: a one-site super-gate exp(D dt) of a Lindblad dissipator on site 2
+    # (tests/test_mixedstate.py:373-388 pattern) on top of the Liouvillian chain of (ii-d)
+    Lm = crandn_g(2, 2) * 0.3
+    E2_ = np.eye(2)
+    Dsup = np.kron(Lm, Lm.conj()) - 0.5 * (np.kron(Lm.conj().T @ Lm, E2_) + np.kron(E2_, Lm.T @ Lm.conj()))
+    Gsup = _expm(Dsup * 0.5)
+    gate_l = TensorHamiltonian(
+        ndof=Ll, potential=[[{((2, 2),): TensorOperator(mpo=[Gsup[None, :, :, None]], legs=(2, 2))}]], kinetic=None, backend="numpy",
+    )
+    lmodel_g = Model(lbasis, operators={"hamiltonian": [w.copy() for w in lmpo], "sz2": obs1, "sz1sx3": obs2}, bond_dim=Dl_,
+                     space="liouville", one_gate_to_apply=gate_l)
+    lmodel_g.init_HartreeProduct = [rhos]
+    o = {f"mpo{i}": w for i, w in enumerate(lmpo)}
+    o.update({f"rho{i}": r for i, r in enumerate(rhos)})
+    o["sz"] = sz
+    o["sx"] = sx
+    o["G2"] = Gsup
+    for n in (1, 3):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_lgate", lmodel_g, backend="numpy", verbose=0)
+        _, wf = sim.propagate(stepsize=0.02, maxstep=n, integrator="arnoldi", autocorr=False, energy=False)
+        o[f"n{n}_norm"] = np.array(wf.norm())
+        o[f"n{n}_sz2"] = np.array(wf.expectation(lmodel_g.observables["sz2"]))
+        o[f"n{n}_sz1sx3"] = np.array(wf.expectation(lmodel_g.observables["sz1sx3"]))
+        for tag, legs in (("pt2", (0, 0, 2)), ("pt13", (0, 2, 0, 1))):
+            o[f"n{n}_{tag}"] = np.array(wf.get_reduced_densities(legs)[0])
+        o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(Ll)])
+        for i, s_ in enumerate(wf.ci_coef.superblock_states[0]):
+            o[f"n{n}_final{i}"] = np.array(s_.data)
+    save("gate_liouville.npz", dt_au=np.array(0.02 / au_in_fs), nsite=np.array(Ll), bond_dim=np.array(Dl_), **o)
+
 
 if __name__ == "__main__":
     main()

@@ -217,3 +217,42 @@ def test_adaptive_exciton_model(golden):
         np.testing.assert_allclose(st.autocorr(), complex(g[f"n{ns}_autocorr"]), atol=1e-4)
         ref = [g[f"n{ns}_final{i}"] for i in range(4)]
         assert abs(abs(orc.overlap(ref, st.cores)) - 1) < 1e-7
+
+
+def test_one_gate_between_half_sweeps(golden):
+    """Model(one_gate_to_apply=...): a full and a diagonal one-site gate applied after the
+    forward half-sweep, re-orthogonalisation towards the last site, all left blocks rebuilt."""
+    g = golden("gate_chain.npz")
+    n, mpo, init = _load_chain(g)
+    dt = float(g["dt_au"])
+    for ns in (1, 3):
+        st = orc.OracleMPS(orc.canonicalize_site0(init), mpo, gates={1: g["U1"], 4: g["U4"]})
+        e_last = None
+        for _ in range(ns):
+            e_last = st.expectation()
+            st.propagate(dt)
+        assert [st.kprev[i] for i in range(n)] == list(g[f"n{ns}_krylov"])
+        np.testing.assert_allclose(e_last.real, float(g[f"n{ns}_energy_last"]), rtol=1e-10)
+        np.testing.assert_allclose(st.norm(), float(g[f"n{ns}_norm"]), rtol=1e-12)
+        np.testing.assert_allclose(st.autocorr(), complex(g[f"n{ns}_autocorr"]), rtol=1e-9, atol=1e-12)
+        for i in range(n):
+            np.testing.assert_allclose(st.cores[i], g[f"n{ns}_final{i}"], atol=1e-10)
+
+
+def test_liouville_supergate(golden):
+    """Liouville space with a one-site super-gate exp(D dt) (tests/test_mixedstate.py:373-413)."""
+    g = golden("gate_liouville.npz")
+    n, mpo, init, ops, keys = _liouville_setup(g)
+    dt = float(g["dt_au"])
+    for ns in (1, 3):
+        cores = orc.canonicalize_site0(init, scale=None)
+        st = orc.OracleMPS(cores, mpo, integrator="arnoldi", conserve_norm=False, gates={2: g["G2"]})
+        for _ in range(ns):
+            st.propagate(dt)
+        assert list(g[f"n{ns}_krylov"]) == [st.kprev[i] for i in range(n)]
+        np.testing.assert_allclose(st.norm(), float(g[f"n{ns}_norm"]), rtol=1e-10)
+        for name, op in ops.items():
+            np.testing.assert_allclose(orc.liouville_expectation(st.cores, op).real, float(g[f"n{ns}_{name}"]), rtol=1e-9, atol=1e-12)
+        for tag in ("pt2", "pt13"):
+            np.testing.assert_allclose(orc.liouville_partial_trace(st.cores, keys[tag]), g[f"n{ns}_{tag}"], atol=1e-11)
+        # (the product start leaves rank-deficient bonds: tensors are gauge-noisy, observables are not)
