@@ -41,7 +41,7 @@ enum {
 };
 
 enum { MITDVP_LANCZOS = 0, MITDVP_ARNOLDI = 1 };
-enum { MITDVP_GAUGE_PSI = 0, MITDVP_GAUGE_A = 1, MITDVP_GAUGE_B = 2 };
+enum { MITDVP_GAUGE_C = -1 /* no gauge */, MITDVP_GAUGE_PSI = 0, MITDVP_GAUGE_A = 1, MITDVP_GAUGE_B = 2 };
 
 /* const.set_runtype(...) flags that reach the sweep (_const_cls.py:102-252). */
 typedef struct {
@@ -132,6 +132,18 @@ int mitdvp_reduced_density(mitdvp_engine* h, const int* remain_nleg, int nlen, d
  * normalised to unit 2-norm, are written to svals_out (may be NULL) and their number
  * to *new_dim.  The engine's one-sided Jacobi SVD kernel does the decomposition. */
 int mitdvp_truncate_bond(mitdvp_engine* h, double p, int max_dim, int* new_dim, double* svals_out);
+/* One-site gates, Model(one_gate_to_apply=TensorHamiltonian of single-site operators):
+ *   mitdvp_set_gate    : register U[d_out][d_in] (d x d, row-major, interleaved re/im) for a
+ *                        site; NULL removes it.  While gates are registered mitdvp_step applies
+ *                        them between its two half-sweeps with the last site as
+ *                        re-orthogonalisation centre (MPSCoef.propagate, _mps_cls.py:489-490).
+ *   mitdvp_apply_gates : MPSCoef.apply_one_gate (_mps_cls.py:2314-2373, :2420-2451) now, with
+ *                        the current centre site as reorth_center (WFunc.apply_one_gate,
+ *                        wavefunction.py:588-598, uses the resting centre 0): U on the physical
+ *                        leg, canonicalizeB / canonicalizeA over the touched span (:3539-3598),
+ *                        environment blocks that saw a touched site dropped (op_sys_sites = None). */
+int mitdvp_set_gate(mitdvp_engine* h, int isite, const double* U_reim, int d);
+int mitdvp_apply_gates(mitdvp_engine* h);
 /* Adaptive bond dimension (a1TDVP), Simulator.propagate(adaptive=True, adaptive_Dmax,
  * adaptive_dD, adaptive_p_proj) -> const.adaptive / Dmax / dD / p_proj
  * (_const_cls.py:120-124, :212-216).  While enabled, every half-sweep widens the

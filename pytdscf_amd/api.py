@@ -5,8 +5,7 @@ behaviour as the reference classes cited in each docstring; all numerics go
 through ``libmitdvp.so`` (no CPU fallback).  Not supported (raise
 ``NotImplementedError`` like the reference does for unsupported combos):
 multi-state direct-product MPS, SoP/PolynomialHamiltonian, MCTDH SPFs,
-adaptive bond dimension, MPI sharding, gates / Kraus maps / subspace projection
-in Liouville space.
+MPI site sharding, Kraus maps, subspace projection in Liouville space.
 """
 
 from __future__ import annotations
@@ -88,6 +87,25 @@ class TensorHamiltonian:
     def apply_backend(self, backend):
         self.backend = backend
 
+    def one_site_gates(self, dims):
+        """``{site: U}`` of a gate operator (every key acts on one site; diagonal 3-leg
+        or full 4-leg core with unit bonds), what ``apply_one_gate`` reads from
+        ``mpo.calc_point`` (_mps_cls.py:2346-2361, :2420-2451)."""
+        gates = {}
+        for key, op in self.terms.items():
+            if len(op.tensor_decomposed) != 1:
+                raise ValueError(f"a gate operator acts on one site per key, got {key}")
+            core, site = op.tensor_decomposed[0], op.sites[0]
+            if site in gates:
+                raise ValueError("Multiple one gate on same site is not supported. Contract gates in advance!")
+            if core.shape[0] != 1 or core.shape[-1] != 1:
+                raise ValueError("a gate core must have unit MPO bonds")
+            U = np.diag(core[0, :, 0]) if core.ndim == 3 else core[0, :, :, 0]
+            if U.shape[0] != dims[site]:
+                raise ValueError(f"gate on site {site} has dimension {U.shape[0]}, the basis {dims[site]}")
+            gates[site] = np.asarray(U, dtype=np.complex128)
+        return gates
+
 
 class BasInfo:
     """``BasInfo(prim_info)`` -- model_cls.py:323-.  prim_info[istate][idof]."""
@@ -128,8 +146,11 @@ class Model:
             raise ValueError(f"space must be 'hilbert' or 'liouville' but got {space}")
         if subspace_inds is not None:
             raise NotImplementedError("subspace projection in Liouville space is a 'next' row")
-        if one_gate_to_apply is not None or kraus_op is not None or build_td_hamiltonian is not None:
-            raise NotImplementedError("gates / Kraus operators / time-dependent Hamiltonians are 'next' rows")
+        if kraus_op is not None or build_td_hamiltonian is not None:
+            raise NotImplementedError("Kraus operators / time-dependent Hamiltonians are 'next' rows")
+        if one_gate_to_apply is not None and not isinstance(one_gate_to_apply, TensorHamiltonian):
+            raise TypeError("one_gate_to_apply must be a TensorHamiltonian of one-site operators")
+        self.one_gate_to_apply = one_gate_to_apply
         self.space = space.lower()
         ops = {"hamiltonian": operators} if isinstance(operators, (TensorHamiltonian, list)) else dict(operators)
         self.dims = [self.basinfo.get_nprim(0, i) for i in range(self.basinfo.get_ndof())]
@@ -201,6 +222,18 @@ class WFunc:
         """Bond dimensions of the MPS (wavefunction.py:151-167)."""
         return self.engine.bond_dims()
 
+    def apply_one_gate(self, matOp, reorth_center: int = 0):
+        """``WFunc.apply_one_gate`` (wavefunction.py:588-598): one-site operators applied
+        to the resting state; ``reorth_center`` must be the current centre site."""
+        eng = self.engine
+        if reorth_center != eng._center():
+            raise ValueError(f"reorth_center={reorth_center} is not the centre site of the MPS ({eng._center()})")
+        dims = [eng.get_site_shape(i)[1] for i in range(eng.nsite)]
+        keep = dict(getattr(eng, "_step_gates", {}))
+        eng.set_gates(matOp.one_site_gates(dims))
+        eng.apply_gates()
+        eng.set_gates(keep)
+
     def expectation(self, matOp):
         name = matOp if isinstance(matOp, str) else self._name_of(matOp)
         if self.space == "liouville":  # Tr(O rho), _exp_liouville
@@ -262,6 +295,8 @@ class Simulator:
             ids[name] = k
         # Liouville space keeps the (trace) normalisation of the initial state (_mps_cls.py:2695-2699)
         eng.set_mps(m.initial_cores(), canonicalize=True, scale=None if liou else 1.0)
+        if m.one_gate_to_apply is not None:  # applied between the half-sweeps of every step (_mps_cls.py:489-490)
+            eng.set_gates(m.one_gate_to_apply.one_site_gates(m.dims))
         return eng, ids
 
     def _wfunc(self, eng, ids):

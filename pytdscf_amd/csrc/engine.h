@@ -139,6 +139,9 @@ class Engine {
   void gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* sigma_out);   // Psi2Asigma
   void gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc* Bt_out, zc* sigma_out);  // Psi2sigmaB
   void ensure_work(long max_site, long max_x, long max_y, int max_qr_m, int max_qr_n, int qr_next = 0);
+  // one-site gates applied between the half-sweeps of every step / on demand
+  void set_gate(int isite, const double* reim, int d);
+  void apply_gates();
   // adaptive bond dimension (a1TDVP, const.adaptive / Dmax / dD / p_proj, _const_cls.py:120-124)
   void set_adaptive(bool on, int dmax, int dd, double p_proj);
   void thin_to_full_A(const zc* A, int l, int c, int r, int e, zc* out);
@@ -175,6 +178,10 @@ class Engine {
   void* coll_user_ = nullptr;
   bool shard_range(int n, int& a0, int& a1) const;
   void collective(int op, zc* p, size_t elems);
+
+  struct Gate { DevBuf u; int d = 0; };
+  std::map<int, Gate> gates_;
+  void build_left_envs();
 
   // adaptive bond dimension
   bool adaptive_ = false;

@@ -781,6 +781,92 @@ void Engine::build_right_envs() {
   }
 }
 
+void Engine::build_left_envs() {
+  // construct_op_sites(begin=0, end=L-1): needed when a gate / Kraus map re-orthogonalised
+  // sites after the forward half-sweep (op_sys_sites = None, _mps_cls.py:2370)
+  for (int p = 0; p < L_ - 1; ++p) {
+    if (envL_ok_[p + 1]) continue;
+    if (!envL_ok_[p]) throw ArgError("internal: left environment chain broken");
+    if (gauge_[p] != MITDVP_GAUGE_A) throw ArgError("sites left of the centre must be in gauge A");
+    const MpoSite& w = mpo(0, p);
+    pool_put(std::move(envL_[p + 1]));
+    envL_[p + 1] = pool_get((size_t)dr_[p] * w.mr * dr_[p]);
+    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl_[p], w.ml, dd_[p], dr_[p], w.mr);
+    envL_ok_[p + 1] = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one-site gates (Model(one_gate_to_apply=...), MPSCoef.apply_one_gate,
+// _mps_cls.py:2314-2373, :2420-2451): out[a, d', c] = sum_b U[d', b] site[a, b, c],
+// then re-orthogonalisation towards the current centre over the touched span
+// (canonicalizeB / canonicalizeA, :3539-3598); the environment blocks that saw a
+// touched site are dropped and rebuilt by the next half-sweep.
+// ---------------------------------------------------------------------------
+void Engine::set_gate(int isite, const double* reim, int d) {
+  if (isite < 0 || isite >= L_) throw ArgError("set_gate: bad site index");
+  if (!reim) { gates_.erase(isite); return; }
+  if (d < 1) throw ArgError("set_gate: bad dimension");
+  std::vector<zc> h((size_t)d * d);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = make_double2(reim[2 * i], reim[2 * i + 1]);
+  Gate& g = gates_[isite];
+  g.d = d;
+  g.u.reserve(h.size());
+  HIP_CHECK(hipMemcpyAsync(g.u.p, h.data(), h.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void Engine::apply_gates() {
+  if (gates_.empty()) return;
+  require_ready();
+  if (center_ < 0) throw ArgError("apply_gates: the MPS has no centre (Psi) site");
+  DevBuf spare = pool_get(V_.n / MAXK);
+  int lo = L_, hi = -1;
+  for (auto& kv : gates_) {
+    const int p = kv.first;
+    const Gate& g = kv.second;
+    const int l = dl_[p], d = dd_[p], r = dr_[p];
+    if (g.d != d) throw ArgError("gate dimension differs from the site's physical dimension");
+    ZgemmDesc z = zgemm_desc(g.u.p, site_[p].p, spare.p, d, r, d);
+    z.batch = l; z.strideA = 0; z.strideB = (long)d * r; z.strideC = (long)d * r;
+    zgemm(st_, z);
+    cnt_.n_launch += 1;
+    std::swap(site_[p], spare);
+    if (p != center_) {
+      gauge_[p] = MITDVP_GAUGE_C;
+      lo = std::min(lo, p); hi = std::max(hi, p);
+    }
+  }
+  const int c0 = center_;
+  if (hi > c0) {  // canonicalizeB(superblock[centre : hi + 1])
+    for (int p = hi; p > c0; --p) {
+      gauge_qr_right(site_[p].p, dl_[p], dd_[p], dr_[p], spare.p, tmp2_.p, sig_.p);
+      std::swap(site_[p], spare);
+      gauge_[p] = MITDVP_GAUGE_B;
+      const int m = dl_[p - 1] * dd_[p - 1];
+      ZgemmDesc z = zgemm_desc(site_[p - 1].p, sig_.p, spare.p, m, dl_[p], dl_[p]);
+      zgemm(st_, z);
+      cnt_.n_launch += 1;
+      std::swap(site_[p - 1], spare);
+    }
+    for (int b = 1; b <= hi; ++b) { envR_ok_[b] = 0; pool_put(std::move(envR_[b])); }
+  }
+  if (lo < c0) {  // canonicalizeA(superblock[lo : centre + 1])
+    for (int p = lo; p < c0; ++p) {
+      gauge_qr_left(site_[p].p, dl_[p], dd_[p], dr_[p], spare.p, sig_.p);
+      std::swap(site_[p], spare);
+      gauge_[p] = MITDVP_GAUGE_A;
+      ZgemmDesc z = zgemm_desc(sig_.p, site_[p + 1].p, spare.p, dr_[p], dd_[p + 1] * dr_[p + 1], dr_[p]);
+      zgemm(st_, z);
+      cnt_.n_launch += 1;
+      std::swap(site_[p + 1], spare);
+    }
+    for (int b = lo + 1; b < L_; ++b) { envL_ok_[b] = 0; pool_put(std::move(envL_[b])); }
+  }
+  gauge_[c0] = MITDVP_GAUGE_PSI;
+  pool_put(std::move(spare));
+}
+
 void Engine::local_site_exp(int p, double dt) {
   const MpoSite& w = mpo(0, p);
   if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
@@ -806,9 +892,7 @@ void Engine::sweep(double dt, bool forward) {
   const int begin = forward ? 0 : L_ - 1, end = forward ? L_ - 1 : 0;
   if (center_ != begin) throw ArgError("sweep must start at the centre (Psi) site");
   if (forward) build_right_envs();
-  else
-    for (int b = 1; b < L_; ++b)
-      if (!envL_ok_[b]) throw ArgError("backward sweep needs the left environments of a forward sweep");
+  else build_left_envs();
   const hzc shift = op(0).shift;
   if (adaptive_) {
     if (cfg.relax) throw ArgError("adaptive bond dimension is implemented for real-time propagation only");
@@ -1205,6 +1289,7 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
 
 void Engine::step(double dt) {
   sweep(dt, true);
+  apply_gates();  // Model(one_gate_to_apply=...), _mps_cls.py:489-490 (reorth_center = nsite - 1)
   sweep(dt, false);
 }
 

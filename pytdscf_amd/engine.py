@@ -150,6 +150,26 @@ class TDVPEngine:
             shape += [self.get_site_shape(p)[1]] * k
         return out.reshape(shape)
 
+    def set_gates(self, gates: dict | None) -> None:
+        """Register one-site gates ``{site: U}`` (``Model(one_gate_to_apply=...)``): U is
+        d x d (U[d_out, d_in]) or a length-d diagonal; ``propagate`` applies them between its
+        half-sweeps.  ``None`` / ``{}`` removes all gates."""
+        for i in range(self.nsite):
+            self._ck(self._lib.mitdvp_set_gate(self._h, i, None, 0))
+        self._step_gates = dict(gates or {})
+        for site, U in (gates or {}).items():
+            U = np.asarray(U, dtype=np.complex128)
+            if U.ndim == 1:
+                U = np.diag(U)
+            if U.ndim != 2 or U.shape[0] != U.shape[1]:
+                raise ValueError("a gate must be a square matrix or a diagonal")
+            U = np.ascontiguousarray(U)
+            self._ck(self._lib.mitdvp_set_gate(self._h, int(site), _dp(U), U.shape[0]))
+
+    def apply_gates(self) -> None:
+        """``apply_one_gate`` now, re-orthogonalising towards the current centre site."""
+        self._ck(self._lib.mitdvp_apply_gates(self._h))
+
     def set_adaptive(self, enable: bool = True, Dmax: int = 20, dD: int = 5, p_proj: float = 1.0e-4) -> None:
         """Adaptive bond dimension (``Simulator.propagate(adaptive=True, adaptive_Dmax=...,
         adaptive_dD=..., adaptive_p_proj=...)``): ranks grow by up to ``dD`` per half-sweep

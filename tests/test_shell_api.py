@@ -123,3 +123,36 @@ def test_a1tdvp_script_on_gpu(golden, tmp_path, monkeypatch):
     assert abs(wf.norm() - 1) < 1e-12
     lines = open(tmp_path / "a1tdvp_prop" / "bonddim.dat").read().splitlines()
     assert len(lines) == 11 and lines[1].split()[1:] == ["1", "1", "1"] and lines[-1].split()[1:] == ["5", "5", "2"]
+
+
+def test_one_gate_model_validation():
+    from pytdscf_amd import Exciton, Model, TensorHamiltonian, TensorOperator
+
+    core = np.zeros((1, 2, 2, 1))
+    g2 = TensorHamiltonian(2, potential=[[{((0, 0),): TensorOperator(mpo=[np.eye(2)[None, :, :, None]], legs=(0, 0)),
+                                           (0,): TensorOperator(mpo=[np.ones(2)[None, :, None]], legs=(0,))}]], kinetic=None)
+    m = Model([Exciton(2), Exciton(2)], {"hamiltonian": [core, core]}, bond_dim=2, one_gate_to_apply=g2)
+    with pytest.raises(ValueError, match="Multiple one gate"):
+        m.one_gate_to_apply.one_site_gates(m.dims)
+    with pytest.raises(TypeError):
+        Model([Exciton(2), Exciton(2)], {"hamiltonian": [core, core]}, bond_dim=2, one_gate_to_apply=[core])
+
+
+@pytest.mark.gpu
+def test_supergate_script_on_gpu(golden, tmp_path, monkeypatch):
+    """tests/test_mixedstate.py::test_vectorised_density_matrix(supergate=True) pattern through
+    the shell: Liouville-space Model with one_gate_to_apply, pinned to the reference's run."""
+    from pytdscf_amd import Exciton, Model, Simulator, TensorHamiltonian, TensorOperator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("gate_liouville.npz")
+    n = int(g["nsite"])
+    gate = TensorHamiltonian(n, potential=[[{((2, 2),): TensorOperator(mpo=[g["G2"][None, :, :, None]], legs=(2, 2))}]], kinetic=None, backend="hip")
+    sz2 = TensorHamiltonian(n, potential=[[{((2, 2),): TensorOperator(mpo=[g["sz"]], legs=(2, 2))}]], kinetic=None, backend="hip")
+    model = Model([Exciton(nstate=4) for _ in range(n)], operators={"hamiltonian": [g[f"mpo{i}"] for i in range(n)], "sz2": sz2},
+                  bond_dim=int(g["bond_dim"]), space="Liouville", one_gate_to_apply=gate)
+    model.init_HartreeProduct = [[g[f"rho{i}"] for i in range(n)]]
+    sim = Simulator("supergate", model, backend="hip")
+    _, wf = sim.propagate(stepsize=0.02, maxstep=3, integrator="arnoldi", autocorr=False, energy=False, conserve_norm=False)
+    assert wf.expectation(model.observables["sz2"]) == pytest.approx(float(g["n3_sz2"]), rel=1e-8)
+    np.testing.assert_allclose(wf.get_reduced_densities((0, 0, 2))[0], g["n3_pt2"], atol=1e-10)
