@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (spec), 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     # name: (L, d, D, M, dt_au, integrator, description)
@@ -196,7 +197,12 @@ def main():
         eng.sweep(0.0, False)
     eng.norm()
     eng.counters_reset()
-    eng.set_profiling(True)
+    # Per-phase HIP-event timing (roofline / breakdown) costs two event records per phase:
+    # nothing at C4 (0.01 %), a third of the run in the launch-bound small-bond regime.  There
+    # the timed region runs unprofiled and the same number of sweeps is repeated afterwards,
+    # profiled, only for the breakdown.
+    profile_in_timed = D >= 128
+    eng.set_profiling(profile_in_timed)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -213,6 +219,13 @@ def main():
         value = args.steps / el
     else:
         value, el = replica_throughput(comm, float(args.steps), el_rank)
+    if not profile_in_timed:
+        eng.counters_reset()
+        eng.set_profiling(True)
+        for i in range(args.steps):
+            eng.sweep(dt, forward)
+            forward = not forward
+        eng.norm()
     cnt = eng.counters()
     eng.set_profiling(False)
 
@@ -220,6 +233,11 @@ def main():
         kh = cnt["n_heff"] / max(cnt["n_exp_site"], 1)
         kk = cnt["n_keff"] / max(cnt["n_exp_bond"], 1)
         ach = cnt["heff_flops"] / max(cnt["heff_ms"], 1e-9) / 1e9  # TFLOP/s
+        # small-bond regime (C2, D < 128): the apply is memory / latency bound, the
+        # roofline that applies is HBM: algorithmic bytes B_H per apply over the apply time
+        small = D < 128
+        bytes_apply = 16.0 * (2 * D * d * D + 2 * D * D * M + M * d * d * M)  # interior site, SURVEY 8d B_H
+        ach_gbs = bytes_apply * cnt["n_heff"] / max(cnt["heff_ms"], 1e-9) / 1e6  # GB/s
         out = {
             "metric": "tdvp_sweeps_per_sec",
             "value": value,
@@ -247,7 +265,20 @@ def main():
                 "collectives": int(cnt["n_collectives"]),
                 "collective_GB": cnt["collective_bytes"] / 1e9,
             },
-            "roofline": {
+            "roofline": ({
+                "bound": "hbm",
+                "kernel": "H_eff apply (3 zgemm launches) in the small-bond regime",
+                "achieved": ach_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_apply": bytes_apply,
+                "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
+                "n_apply": cnt["n_heff"],
+                "tflops": ach,
+                "note": "launch/latency bound: a site is a few hundred KB, every apply is three dependent launches of a few microseconds",
+            } if small else {
                 "bound": "mfma",
                 "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)" + (" -- per GPU, this rank's bond shard" if mode == "tp" else ""),
                 "achieved": ach,
@@ -262,10 +293,11 @@ def main():
                 "complex_product": gemm_mode,
                 "note": ("3M (Karatsuba) complex product: 6 real flop executed per 8 algorithmic; executed-MFMA "
                          "rate = 0.75 x achieved") if gemm_mode == "3m" else "4M complex product: executed = algorithmic flops",
-            },
+            }),
             "breakdown_ms": {
                 "heff": cnt["heff_ms"], "env": cnt["env_ms"], "keff": cnt["keff_ms"], "qr": cnt["qr_ms"],
                 "krylov_vec": cnt["krylov_vec_ms"], "wall": 1e3 * el,
+                "phases_from": "the timed sweeps" if profile_in_timed else "a profiled repeat of the timed sweeps (event overhead kept out of the timed region)",
                 "env_tflops": cnt["env_flops"] / max(cnt["env_ms"], 1e-9) / 1e9,
                 "keff_tflops": cnt["keff_flops"] / max(cnt["keff_ms"], 1e-9) / 1e9,
                 "qr_tflops": cnt["qr_flops"] / max(cnt["qr_ms"], 1e-9) / 1e9,
