@@ -235,6 +235,9 @@ int mitdvp_heff_selfcheck(int device, int dl, int d, int dr, int ml, int mr, dou
 /* raw v_mfma_f64_16x16x4_f64 issue-rate probe: returns TFLOP/s */
 int mitdvp_mfma_peak_probe(int device, double* tflops_out);
 /* dumps the C/D lane map of v_mfma_f64_16x16x4_f64: out[64*4*2] = (row, col) */
+/* shader-clock probe: out[0] = shader cycles, out[1] = 100 MHz reference ticks spent by a
+ * single-wavefront dependent-FMA loop of `iters` iterations (clock in MHz = 100 * out[0] / out[1]). */
+int mitdvp_clock_probe(int device, long iters, double* cycles_ticks_out);
 int mitdvp_mfma_layout_probe(int device, int* out);
 
 #ifdef __cplusplus

@@ -118,6 +118,7 @@ def load() -> C.CDLL:
         "mitdvp_svd": (i, [i, dp, i, i, dp, dp, dp, ip]),
         "mitdvp_set_adaptive": (i, [vp, i, i, i, d]),
         "mitdvp_set_gate": (i, [vp, i, dp, i]),
+        "mitdvp_clock_probe": (i, [i, C.c_long, dp]),
         "mitdvp_apply_gates": (i, [vp]),
         "mitdvp_thin_to_full": (i, [i, i, dp, i, i, i, i, dp]),
         "mitdvp_set_trace_op_core": (i, [vp, i, i, dp, i, i, i]),

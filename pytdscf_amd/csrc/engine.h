@@ -179,6 +179,7 @@ class Engine {
   bool shard_range(int n, int& a0, int& a1) const;
   void collective(int op, zc* p, size_t elems);
 
+  bool small_kernels_ = true;  // MITDVP_SMALL_KERNELS=0: always the general multi-launch kernels (A/B testing)
   struct Gate { DevBuf u; int d = 0; };
   std::map<int, Gate> gates_;
   void build_left_envs();

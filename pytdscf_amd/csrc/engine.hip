@@ -15,6 +15,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -37,6 +38,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (c.integrator != MITDVP_LANCZOS && c.integrator != MITDVP_ARNOLDI) throw ArgError("bad integrator");
   if (c.relax < 0 || c.relax > 2) throw ArgError("relax must be 0, 1 or 2");
   max_diag_krylov_ = c.max_diag_krylov > 0 ? c.max_diag_krylov : 64;
+  if (const char* e = std::getenv("MITDVP_SMALL_KERNELS")) small_kernels_ = std::atoi(e) != 0;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -475,18 +477,26 @@ int Engine::krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev, long n
     zc* vn = V + (size_t)(l + 1) * ldv;
     matvec(vl, vn);
     timer_begin(4);
-    if (lanczos) {
-      // alpha_l = <v0 | H v_l> (reference, :556) or <v_l | H v_l> (orthodox)
-      vec_dot(st_, cfg.lanczos_variant == 0 ? V : vl, vn, n, true, alpha_p + (size_t)l * NPART);
-      vec_lanczos_update(st_, vn, vl, l > 0 ? V + (size_t)(l - 1) * ldv : nullptr, n, alpha_p + (size_t)l * NPART,
-                         l > 0 ? nrm_p + (size_t)(l - 1) * NPART : nullptr, nrm_p + (size_t)l * NPART);
+    if (lanczos && n <= SMALL_VEC_N && small_kernels_) {
+      // small-bond regime: dot, update, norm and normalisation in one single-workgroup launch
+      vec_lanczos_step_small(st_, vn, cfg.lanczos_variant == 0 ? V : vl, vl, l > 0 ? V + (size_t)(l - 1) * ldv : nullptr, n,
+                             alpha_p + (size_t)l * NPART, l > 0 ? nrm_p + (size_t)(l - 1) * NPART : nullptr,
+                             nrm_p + (size_t)l * NPART, KRYLOV_EPS);
+      cnt_.n_launch += 1;
     } else {
-      vec_multi_dot(st_, V, ldv, l + 1, vn, n, h_p + (size_t)l * MAXK * NPART);
-      vec_arnoldi_update(st_, vn, V, ldv, l + 1, n, h_p + (size_t)l * MAXK * NPART, nrm_p + (size_t)l * NPART);
+      if (lanczos) {
+        // alpha_l = <v0 | H v_l> (reference, :556) or <v_l | H v_l> (orthodox)
+        vec_dot(st_, cfg.lanczos_variant == 0 ? V : vl, vn, n, true, alpha_p + (size_t)l * NPART);
+        vec_lanczos_update(st_, vn, vl, l > 0 ? V + (size_t)(l - 1) * ldv : nullptr, n, alpha_p + (size_t)l * NPART,
+                           l > 0 ? nrm_p + (size_t)(l - 1) * NPART : nullptr, nrm_p + (size_t)l * NPART);
+      } else {
+        vec_multi_dot(st_, V, ldv, l + 1, vn, n, h_p + (size_t)l * MAXK * NPART);
+        vec_arnoldi_update(st_, vn, V, ldv, l + 1, n, h_p + (size_t)l * MAXK * NPART, nrm_p + (size_t)l * NPART);
+      }
+      vec_scale_inv_norm(st_, vn, n, nrm_p + (size_t)l * NPART, KRYLOV_EPS);
+      cnt_.n_launch += 3;
     }
-    vec_scale_inv_norm(st_, vn, n, nrm_p + (size_t)l * NPART, KRYLOV_EPS);
     timer_end();
-    cnt_.n_launch += 3;
 
     const bool last_possible = (l + 1 == nsize);
     if (l < n_warm && !last_possible && l + 1 < ndim) continue;  // warm-up: no host sync (:578-579)

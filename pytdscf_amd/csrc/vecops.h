@@ -7,6 +7,9 @@ namespace mitdvp {
 constexpr int NPART = 256;  // partial sums written by every reduction kernel
 constexpr int MAXK = 21;    // Krylov vectors kept: ndim (<= 20) + 1
 
+constexpr int SMALL_VEC_EPT = 16;                 // elements per thread of the single-workgroup kernels
+constexpr long SMALL_VEC_N = 1024L * SMALL_VEC_EPT;  // longest vector they take
+
 struct Coefs {
   zc c[MAXK];
 };
@@ -16,6 +19,10 @@ void vec_dot(hipStream_t st, const zc* x, const zc* y, long n, bool conj_x, zc* 
 void vec_sumsq(hipStream_t st, const zc* x, long n, double* out_p /*[NPART]*/);
 void vec_lanczos_update(hipStream_t st, zc* v, const zc* vm1, const zc* vm2 /*nullable*/, long n,
                         const zc* alpha_p, const double* betaprev_p, double* out_p);
+// one Lanczos vector step (dot with x, three-term update, norm, normalisation) in one
+// single-workgroup launch; n <= SMALL_VEC_N; same partial layout as the three separate kernels
+void vec_lanczos_step_small(hipStream_t st, zc* w, const zc* x, const zc* vl, const zc* vm2 /*nullable*/, long n,
+                            zc* alpha_p, const double* betaprev_p, double* nrm_p, double eps);
 void vec_scale_inv_norm(hipStream_t st, zc* v, long n, const double* nrm_p, double eps);
 void vec_multi_dot(hipStream_t st, const zc* V, long ldv, int k, const zc* v, long n, zc* out_p /*[k][NPART]*/);
 void vec_arnoldi_update(hipStream_t st, zc* v, const zc* V, long ldv, int k, long n, const zc* h_p, double* out_p);
@@ -38,6 +45,7 @@ void transpose_batched(hipStream_t st, const zc* in, zc* out, int rows, int cols
 void phys_diag(hipStream_t st, const zc* C, zc* out, int dl, int n, int dr, bool trace);
 // out[i0][i2][i1][i3] = in[i0][i1][i2][i3]
 void permute_0213(hipStream_t st, const zc* in, zc* out, long n0, int n1, int n2, int n3);
+void clock_probe(hipStream_t st, long iters, double* host_out3 /* shader cycles, 100 MHz ticks, dummy */);
 void transpose_rev3(hipStream_t st, const zc* in, zc* out, int na, int nj, int ns);
 
 }  // namespace mitdvp

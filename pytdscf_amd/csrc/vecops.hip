@@ -298,6 +298,86 @@ __global__ __launch_bounds__(256) void k_identity(zc* __restrict__ out, int rows
 }
 
 // ---------------------------------------------------------------------------
+// Small-bond regime: the whole Lanczos vector step of one Krylov iteration in ONE
+// single-workgroup launch (dot, three-term update, norm, normalisation) -- the
+// vector (<= 16384 elements) lives in registers between the passes.  Replaces three
+// dependent launches of a few microseconds each; the partial arrays are written in
+// the same layout ([0] = value, rest 0) so that every consumer stays unchanged.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_1024(double v, double* sh /*[17]*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+__global__ __launch_bounds__(1024) void k_lanczos_step_small(zc* __restrict__ w, const zc* __restrict__ x,
+                                                             const zc* __restrict__ vl, const zc* __restrict__ vm2,
+                                                             int n, zc* __restrict__ alpha_p,
+                                                             const double* __restrict__ betaprev_p,
+                                                             double* __restrict__ nrm_p, double eps) {
+  __shared__ double sh[17];
+  zc wv[SMALL_VEC_EPT];
+  double re = 0, im = 0;
+#pragma unroll
+  for (int e = 0; e < SMALL_VEC_EPT; ++e) {
+    const int i = threadIdx.x + e * 1024;
+    if (i < n) {
+      const zc b = w[i], a = x[i];
+      wv[e] = b;
+      re += a.x * b.x + a.y * b.y;  // conj(x) * w
+      im += a.x * b.y - a.y * b.x;
+    }
+  }
+  re = block_sum_1024(re, sh);
+  im = block_sum_1024(im, sh);
+  double bp = 0.0;
+  if (vm2) {
+    double t = threadIdx.x < NPART ? betaprev_p[threadIdx.x] : 0.0;
+    bp = sqrt(block_sum_1024(t, sh));
+  }
+  double s = 0;
+#pragma unroll
+  for (int e = 0; e < SMALL_VEC_EPT; ++e) {
+    const int i = threadIdx.x + e * 1024;
+    if (i < n) {
+      zc v = wv[e];
+      const zc a = vl[i];
+      v.x -= re * a.x - im * a.y;
+      v.y -= re * a.y + im * a.x;
+      if (vm2) {
+        const zc c = vm2[i];
+        v.x -= bp * c.x;
+        v.y -= bp * c.y;
+      }
+      wv[e] = v;
+      s += v.x * v.x + v.y * v.y;
+    }
+  }
+  s = block_sum_1024(s, sh);
+  const double beta = sqrt(s);
+  const double inv = beta >= eps ? 1.0 / beta : 1.0;  // exhausted Krylov space: left as is
+#pragma unroll
+  for (int e = 0; e < SMALL_VEC_EPT; ++e) {
+    const int i = threadIdx.x + e * 1024;
+    if (i < n) w[i] = make_double2(wv[e].x * inv, wv[e].y * inv);
+  }
+  if (threadIdx.x < NPART) {
+    alpha_p[threadIdx.x] = threadIdx.x == 0 ? make_double2(re, im) : make_double2(0.0, 0.0);
+    nrm_p[threadIdx.x] = threadIdx.x == 0 ? s : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // adaptive bond dimension: strided block copies and the norm profiles of the
 // rank-selection functional f(D) (_mps_cls.py:2083-2105)
 // ---------------------------------------------------------------------------
@@ -390,6 +470,13 @@ void vec_lanczos_update(hipStream_t st, zc* v, const zc* vm1, const zc* vm2, lon
                         const double* betaprev_p, double* out_p) {
   LAUNCH(k_lanczos_update, NPART, st, v, vm1, vm2, n, alpha_p, betaprev_p, NPART, out_p);
 }
+void vec_lanczos_step_small(hipStream_t st, zc* w, const zc* x, const zc* vl, const zc* vm2, long n, zc* alpha_p,
+                            const double* betaprev_p, double* nrm_p, double eps) {
+  if (n > SMALL_VEC_N) throw ArgError("vec_lanczos_step_small: vector too long");
+  hipLaunchKernelGGL(k_lanczos_step_small, dim3(1), dim3(1024), 0, st, w, x, vl, vm2, (int)n, alpha_p, betaprev_p, nrm_p,
+                     eps);
+  HIP_CHECK(hipGetLastError());
+}
 void vec_scale_inv_norm(hipStream_t st, zc* v, long n, const double* nrm_p, double eps) {
   LAUNCH(k_scale_inv_norm, vec_blocks(n), st, v, n, nrm_p, NPART, eps);
 }
@@ -409,6 +496,31 @@ void vec_scale(hipStream_t st, zc* y, long n, zc a) { LAUNCH(k_scale, vec_blocks
 void vec_randn(hipStream_t st, zc* out, long n, uint64_t seed) { LAUNCH(k_randn, vec_blocks(n), st, out, n, seed); }
 void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld) {
   LAUNCH(k_identity, vec_blocks((long)rows * cols), st, out, rows, cols, ld);
+}
+
+// shader clock seen by a short single-workgroup kernel: cycles of s_memtime per 100 MHz
+// tick of s_memrealtime over a dependent FMA chain (what the small-bond regime runs at)
+__global__ void k_clock_probe(long iters, double* out) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  const unsigned long long r0 = wall_clock64();
+  double x = 1.0 + threadIdx.x * 1e-9;
+  for (long i = 0; i < iters; ++i) x = x * 1.0000001 + 1e-12;
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long r1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    out[0] = (double)(t1 - t0);
+    out[1] = (double)(r1 - r0);
+    out[2] = x;
+  }
+}
+void clock_probe(hipStream_t st, long iters, double* host_out3) {
+  double* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, 3 * sizeof(double)));
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, st, iters, d);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(host_out3, d, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  (void)hipFree(d);
 }
 
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,

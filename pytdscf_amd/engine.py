@@ -341,6 +341,13 @@ def thin_to_full(site, gauge: str, delta_rank: int, device=0) -> np.ndarray:
     return out
 
 
+def clock_probe(iters: int = 200000, device=0) -> dict:
+    """Shader clock seen by a short single-wavefront kernel (MHz) and its duration (us)."""
+    out = np.zeros(2)
+    _lib.check(_lib.load().mitdvp_clock_probe(device, int(iters), _dp(out)))
+    return {"mhz": 100.0 * out[0] / max(out[1], 1.0), "us": out[1] / 100.0, "cycles_per_iter": out[0] / iters}
+
+
 def svd(A, device=0):
     """A = U diag(S) Vh with the engine's one-sided Jacobi kernel; returns (U, S, Vh, sweeps)."""
     A = _c128(A)
