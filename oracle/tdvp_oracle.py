@@ -499,6 +499,55 @@ def apply_one_gate(cores: list[np.ndarray], center: int, gates: dict, conj: bool
 
 
 # --------------------------------------------------------------------------
+# f3: Kraus maps on purified states between the half-sweeps (apply_kraus)
+# --------------------------------------------------------------------------
+def kraus_single_site(B: np.ndarray, A: np.ndarray) -> np.ndarray:
+    """_kraus_contract_single_site_np (kraus.py:146-228): the site's physical index is
+    (d, K) = (system, ancilla); C[(m,n,x),(k,K)] = sum_d B[k,x,d] A[m,d,K,n], the ancilla
+    index (k,K) is cut back to K by an SVD (U S kept), result (m, x K, n)."""
+    k, x, d = B.shape
+    m, dK, n = A.shape
+    K = dK // d
+    C = np.einsum("kxd,mdKn->mnxkK", B, A.reshape(m, d, K, n)).reshape(m * n * x, k * K)
+    U, S, _ = scipy.linalg.svd(C, full_matrices=False)
+    out = U[:, :K] * S[np.newaxis, :K]
+    return np.ascontiguousarray(out.reshape(m, n, x * K).swapaxes(1, 2))
+
+
+def kraus_two_site(B: np.ndarray, A1: np.ndarray, A2: np.ndarray):
+    """_kraus_contract_two_site_np (kraus.py:281-358): system site A1 (m,d,l), ancilla
+    site A2 (l,K,n); the Kraus index is absorbed into the ancilla by one SVD, the two
+    sites are split again by a second one (bond dimension l kept)."""
+    k, x, d = B.shape
+    m, _, l = A1.shape
+    _, K, n = A2.shape
+    C = np.einsum("kxd,mdl,lKn->mxnkK", B, A1, A2).reshape(m * x * n, k * K)
+    U, S, _ = scipy.linalg.svd(C, full_matrices=False)
+    U = U[:, :K] * S[np.newaxis, :K]
+    C = np.ascontiguousarray(U.reshape(m, x, n, K).swapaxes(2, 3)).reshape(m * x, K * n)
+    U, S, Vh = scipy.linalg.svd(C, full_matrices=False)
+    return (U[:, :l] * S[np.newaxis, :l]).reshape(m, x, -1), Vh[:l].reshape(-1, K, n)
+
+
+def apply_kraus(cores: list[np.ndarray], center: int, kraus: dict) -> None:
+    """MPSCoef.apply_kraus (_mps_cls.py:2375-2418): keys (site,) or (site, site + 1)."""
+    lo, hi = len(cores), -1
+    for sites, B in kraus.items():
+        B = np.asarray(B, dtype=np.complex128)
+        if len(sites) == 1:
+            cores[sites[0]] = kraus_single_site(B, cores[sites[0]])
+        elif len(sites) == 2 and sites[0] + 1 == sites[1]:
+            cores[sites[0]], cores[sites[1]] = kraus_two_site(B, cores[sites[0]], cores[sites[1]])
+        else:
+            raise ValueError(f"site_inds={sites} is not yet implemented")
+        lo, hi = min(lo, sites[0]), max(hi, sites[-1])
+    if hi > center:
+        canonicalize_B(cores, center, hi)
+    if lo < center:
+        canonicalize_A(cores, lo, center)
+
+
+# --------------------------------------------------------------------------
 # a8-a10: sweep
 # --------------------------------------------------------------------------
 @dataclass
@@ -520,6 +569,7 @@ class OracleMPS:
     relax: bool | str = False  # const.doRelax: True = exp(-H dt/2) / exp(+K dt/2) + renormalise
     #   (_mps_cls.py:1086-1094); "improved" = Lanczos ground state of H_eff, bond step skipped (:1078-1084, :1159-1160)
     gates: dict | None = None  # Model(one_gate_to_apply=...): {site: U (d x d) or diagonal (d,)}, applied between the half-sweeps
+    kraus: dict | None = None  # Model(kraus_op=...): {(site,) | (site, site+1): B (k, d, d)}, after the gates
     adaptive: bool = False  # const.adaptive (_const_cls.py:120-124, :212-216)
     Dmax: int = 100
     dD: int = 10
@@ -718,8 +768,11 @@ class OracleMPS:
         if len(self.right) < self.nsite:
             self.build_right_envs()
         self.sweep(dt, True)
-        if self.gates:  # _mps_cls.py:489-490; op_sys_sites = None -> all left blocks are rebuilt (:2370)
-            apply_one_gate(self.cores, self.nsite - 1, self.gates)
+        if self.gates or self.kraus:  # _mps_cls.py:489-492; op_sys_sites = None -> all left blocks are rebuilt (:2370)
+            if self.gates:
+                apply_one_gate(self.cores, self.nsite - 1, self.gates)
+            if self.kraus:
+                apply_kraus(self.cores, self.nsite - 1, self.kraus)
             for p in range(self.nsite - 1):
                 self.left[p + 1] = env_update_left(self.left[p], self.cores[p], self.mpo[p])
         self.sweep(dt, False)

@@ -687,6 +687,70 @@ def main():
             o[f"n{n}_final{i}"] = np.array(s_.data)
     save("gate_liouville.npz", dt_au=np.array(0.02 / au_in_fs), nsite=np.array(Ll), bond_dim=np.array(Dl_), **o)
 
+    # (vii) Kraus maps on purified states: Model(kraus_op=...) -> apply_kraus after the forward
+    # half-sweep (_mps_cls.py:491-492, :2375-2418; kraus.py).  tests/test_mixedstate.py:560-700
+    # pattern with a synthetic chain: (a) the system site carries the ancilla index (d*K),
+    # (b) a separate ancilla site right of the system site and a two-site map.
+    from pytdscf.kraus import lindblad_to_kraus, trace_kraus_dim
+
+    rng_k = np.random.default_rng(31337)
+
+    def crandn_k(*shape):
+        return rng_k.standard_normal(shape) + 1j * rng_k.standard_normal(shape)
+
+    dk, Kk, Lk, Mk, Dk = 3, 4, 4, 4, 8
+    # real Lindblad operators like the reference's tests (its Kraus self-check assumes them)
+    Lops = [0.4 * rng_k.standard_normal((dk, dk)), 0.3 * rng_k.standard_normal((dk, dk))]
+    dt_k = 0.05
+    Bk = np.array(lindblad_to_kraus([x.copy() for x in Lops], 0.5))
+    base = orc.synthetic_mpo(Lk, dk, Mk, seed=9)
+    for p_ in range(Lk):  # weak non-Hermitian part so that Arnoldi / conserve_norm=False matter
+        base[p_][0, :, :, base[p_].shape[3] - 1] += -0.01j * np.eye(dk)
+    # (a) single-site map on site 1 whose physical index is (system, ancilla)
+    mpo_k = [w.copy() for w in base]
+    mpo_k[1] = np.einsum("aijb,kl->aikjlb", base[1], np.eye(Kk)).reshape(base[1].shape[0], dk * Kk, dk * Kk, base[1].shape[3])
+    dims_k = [dk, dk * Kk, dk, dk]
+    # full-rank random cores (a product start leaves rank-deficient bonds whose rounding noise the
+    # bond propagation feeds back at ~1e-6, in the reference itself: no parity target)
+    w_k = [crandn_k(a_, dd_, b_) for dd_, (a_, b_) in zip(dims_k, orc.bond_dims(dims_k, Dk))]
+    model_k = Model([Exciton(nstate=dd_) for dd_ in dims_k], operators={"hamiltonian": [w.copy() for w in mpo_k]},
+                    kraus_op={(1,): Bk.copy()}, bond_dim=Dk)
+    model_k.init_HartreeProduct = [[w.copy() for w in w_k]]
+    o = {f"mpo{i}": w for i, w in enumerate(mpo_k)}
+    o.update({f"w{i}": w for i, w in enumerate(w_k)})
+    o["B"] = Bk
+    for n in (1, 4):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_kraus1", model_k, backend="numpy", verbose=0)
+        _, wf = sim.propagate(stepsize=dt_k, maxstep=n, integrator="arnoldi", conserve_norm=False, autocorr=False, energy=False)
+        o[f"n{n}_norm"] = np.array(wf.norm())
+        o[f"n{n}_rdm1"] = trace_kraus_dim(np.array(wf.get_reduced_densities((0, 2))[0]), dk)
+        o[f"n{n}_rdm2"] = np.array(wf.get_reduced_densities((0, 0, 2))[0])
+        o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(Lk)])
+    save("kraus_single.npz", dt_au=np.array(dt_k / au_in_fs), bond_dim=np.array(Dk), d=np.array(dk), K=np.array(Kk), **o)
+
+    # (b) two-site map: system site 1 (d), ancilla site 2 (K) with identity Hamiltonian cores
+    Mb = base[1].shape[3]
+    anc = np.einsum("ab,ij->aijb", np.eye(Mb), np.eye(Kk)).astype(np.complex128)
+    mpo_k2 = [base[0].copy(), base[1].copy(), anc, base[2].copy(), base[3].copy()]
+    dims_k2 = [dk, dk, Kk, dk, dk]
+    w_k2 = [crandn_k(a_, dd_, b_) for dd_, (a_, b_) in zip(dims_k2, orc.bond_dims(dims_k2, Dk))]
+    model_k2 = Model([Exciton(nstate=dd_) for dd_ in dims_k2], operators={"hamiltonian": [w.copy() for w in mpo_k2]},
+                     kraus_op={(1, 2): Bk.copy()}, bond_dim=Dk)
+    model_k2.init_HartreeProduct = [[w.copy() for w in w_k2]]
+    o = {f"mpo{i}": w for i, w in enumerate(mpo_k2)}
+    o.update({f"w{i}": w for i, w in enumerate(w_k2)})
+    o["B"] = Bk
+    for n in (1, 4):
+        helper._Debug.niter_krylov.clear()
+        sim = Simulator("gold_kraus2", model_k2, backend="numpy", verbose=0)
+        _, wf = sim.propagate(stepsize=dt_k, maxstep=n, integrator="arnoldi", conserve_norm=False, autocorr=False, energy=False)
+        o[f"n{n}_norm"] = np.array(wf.norm())
+        o[f"n{n}_rdm1"] = np.array(wf.get_reduced_densities((0, 2))[0])
+        o[f"n{n}_rdm3"] = np.array(wf.get_reduced_densities((0, 0, 0, 2))[0])
+        o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(Lk + 1)])
+    save("kraus_two_site.npz", dt_au=np.array(dt_k / au_in_fs), bond_dim=np.array(Dk), d=np.array(dk), K=np.array(Kk), **o)
+
 
 if __name__ == "__main__":
     main()

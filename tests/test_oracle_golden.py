@@ -256,3 +256,30 @@ def test_liouville_supergate(golden):
         for tag in ("pt2", "pt13"):
             np.testing.assert_allclose(orc.liouville_partial_trace(st.cores, keys[tag]), g[f"n{ns}_{tag}"], atol=1e-11)
         # (the product start leaves rank-deficient bonds: tensors are gauge-noisy, observables are not)
+
+
+def _kraus_case(g):
+    n = len([k for k in g.files if k.startswith("mpo")])
+    return n, [g[f"mpo{i}"] for i in range(n)], [g[f"w{i}"] for i in range(n)], float(g["dt_au"]), int(g["d"]), int(g["K"])
+
+
+@pytest.mark.parametrize("name,key", [("kraus_single.npz", (1,)), ("kraus_two_site.npz", (1, 2))])
+def test_kraus_maps_on_purified_states(golden, name, key):
+    """Model(kraus_op=...): the Kraus index is absorbed into the ancilla by an SVD after every
+    forward half-sweep (single-site form: ancilla inside the physical index; two-site form:
+    separate ancilla site).  Ancilla-traced reduced densities against the reference."""
+    g = golden(name)
+    n, mpo, init, dt, d, K = _kraus_case(g)
+    for ns in (1, 4):
+        st = orc.OracleMPS(orc.canonicalize_site0(init), mpo, integrator="arnoldi", conserve_norm=False, kraus={key: g["B"]})
+        for _ in range(ns):
+            st.propagate(dt)
+        assert [st.kprev[i] for i in range(n)] == list(g[f"n{ns}_krylov"])
+        np.testing.assert_allclose(st.norm(), float(g[f"n{ns}_norm"]), rtol=1e-10)
+        r1 = orc.reduced_density(st.cores, (0, 2))
+        if len(key) == 1:  # trace_kraus_dim (kraus.py:434-455)
+            r1 = np.einsum("dKxK->dx", r1.reshape(d, K, d, K))
+        np.testing.assert_allclose(r1, g[f"n{ns}_rdm1"], atol=1e-10)
+        other = "rdm2" if len(key) == 1 else "rdm3"
+        legs = (0, 0, 2) if len(key) == 1 else (0, 0, 0, 2)
+        np.testing.assert_allclose(orc.reduced_density(st.cores, legs), g[f"n{ns}_{other}"], atol=1e-10)
