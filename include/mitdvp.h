@@ -144,6 +144,19 @@ int mitdvp_truncate_bond(mitdvp_engine* h, double p, int max_dim, int* new_dim, 
  *                        environment blocks that saw a touched site dropped (op_sys_sites = None). */
 int mitdvp_set_gate(mitdvp_engine* h, int isite, const double* U_reim, int d);
 int mitdvp_apply_gates(mitdvp_engine* h);
+/* Kraus maps on purified states, Model(kraus_op={(site,): B} or {(site, site+1): B}) with
+ * B (k, d, d) = the Kraus operators B_q[x][d'] (kraus.py:17-123):
+ *   mitdvp_set_kraus   : register B for `isite` (NULL removes it).  two_site = 0: the site's
+ *                        physical index is (system d, ancilla K), K = dim / d
+ *                        (_kraus_contract_single_site_np, kraus.py:146-228); two_site = 1: system
+ *                        site `isite` (dimension d) and ancilla site `isite + 1`
+ *                        (_kraus_contract_two_site_np, :281-358; the bond between them is
+ *                        re-split by the engine's Jacobi SVD).  mitdvp_step applies the maps after
+ *                        the gates, between its half-sweeps (MPSCoef.propagate, _mps_cls.py:491-492).
+ *   mitdvp_apply_kraus : MPSCoef.apply_kraus (_mps_cls.py:2375-2418) now, re-orthogonalising
+ *                        towards the current centre site. */
+int mitdvp_set_kraus(mitdvp_engine* h, int isite, int two_site, const double* B_reim, int k, int d);
+int mitdvp_apply_kraus(mitdvp_engine* h);
 /* Adaptive bond dimension (a1TDVP), Simulator.propagate(adaptive=True, adaptive_Dmax,
  * adaptive_dD, adaptive_p_proj) -> const.adaptive / Dmax / dD / p_proj
  * (_const_cls.py:120-124, :212-216).  While enabled, every half-sweep widens the

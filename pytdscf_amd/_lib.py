@@ -118,6 +118,8 @@ def load() -> C.CDLL:
         "mitdvp_svd": (i, [i, dp, i, i, dp, dp, dp, ip]),
         "mitdvp_set_adaptive": (i, [vp, i, i, i, d]),
         "mitdvp_set_gate": (i, [vp, i, dp, i]),
+        "mitdvp_set_kraus": (i, [vp, i, i, dp, i, i]),
+        "mitdvp_apply_kraus": (i, [vp]),
         "mitdvp_clock_probe": (i, [i, C.c_long, dp]),
         "mitdvp_apply_gates": (i, [vp]),
         "mitdvp_thin_to_full": (i, [i, i, dp, i, i, i, i, dp]),

@@ -5,7 +5,7 @@ behaviour as the reference classes cited in each docstring; all numerics go
 through ``libmitdvp.so`` (no CPU fallback).  Not supported (raise
 ``NotImplementedError`` like the reference does for unsupported combos):
 multi-state direct-product MPS, SoP/PolynomialHamiltonian, MCTDH SPFs,
-MPI site sharding, Kraus maps, subspace projection in Liouville space.
+MPI site sharding, subspace projection in Liouville space.
 """
 
 from __future__ import annotations
@@ -146,8 +146,11 @@ class Model:
             raise ValueError(f"space must be 'hilbert' or 'liouville' but got {space}")
         if subspace_inds is not None:
             raise NotImplementedError("subspace projection in Liouville space is a 'next' row")
-        if kraus_op is not None or build_td_hamiltonian is not None:
-            raise NotImplementedError("Kraus operators / time-dependent Hamiltonians are 'next' rows")
+        if build_td_hamiltonian is not None:
+            raise NotImplementedError("time-dependent Hamiltonians are a 'next' row")
+        if kraus_op is not None and not isinstance(kraus_op, dict):
+            raise TypeError("kraus_op must be a dict {(site,) | (site, site + 1): array (k, d, d)}")
+        self.kraus_op = kraus_op
         if one_gate_to_apply is not None and not isinstance(one_gate_to_apply, TensorHamiltonian):
             raise TypeError("one_gate_to_apply must be a TensorHamiltonian of one-site operators")
         self.one_gate_to_apply = one_gate_to_apply
@@ -297,6 +300,8 @@ class Simulator:
         eng.set_mps(m.initial_cores(), canonicalize=True, scale=None if liou else 1.0)
         if m.one_gate_to_apply is not None:  # applied between the half-sweeps of every step (_mps_cls.py:489-490)
             eng.set_gates(m.one_gate_to_apply.one_site_gates(m.dims))
+        if m.kraus_op:  # after the gates, _mps_cls.py:491-492
+            eng.set_kraus(m.kraus_op)
         return eng, ids
 
     def _wfunc(self, eng, ids):

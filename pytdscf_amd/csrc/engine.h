@@ -142,6 +142,10 @@ class Engine {
   // one-site gates applied between the half-sweeps of every step / on demand
   void set_gate(int isite, const double* reim, int d);
   void apply_gates();
+  // Kraus maps on purified states (single-site: ancilla inside the physical index; two-site:
+  // ancilla on the next site), applied after the gates between the half-sweeps / on demand
+  void set_kraus(int isite, int two_site, const double* reim, int k, int d);
+  void apply_kraus();
   // adaptive bond dimension (a1TDVP, const.adaptive / Dmax / dD / p_proj, _const_cls.py:120-124)
   void set_adaptive(bool on, int dmax, int dd, double p_proj);
   void thin_to_full_A(const zc* A, int l, int c, int r, int e, zc* out);
@@ -182,6 +186,10 @@ class Engine {
   bool small_kernels_ = true;  // MITDVP_SMALL_KERNELS=0: always the general multi-launch kernels (A/B testing)
   struct Gate { DevBuf u; int d = 0; };
   std::map<int, Gate> gates_;
+  struct KrausOp { DevBuf b; int k = 0, d = 0; bool two_site = false; };
+  std::map<int, KrausOp> kraus_;
+  void kraus_core(const zc* theta, int m, int d, int K, int n, const KrausOp& op, zc* out);
+  void recanonicalize(int lo, int hi, DevBuf& spare);
   void build_left_envs();
 
   // adaptive bond dimension

@@ -847,8 +847,16 @@ void Engine::apply_gates() {
       lo = std::min(lo, p); hi = std::max(hi, p);
     }
   }
+  recanonicalize(lo, hi, spare);
+  pool_put(std::move(spare));
+}
+
+// canonicalizeB(superblock[centre : hi + 1]) and canonicalizeA(superblock[lo : centre + 1])
+// (_mps_cls.py:3539-3598) after sites in [lo, hi] were modified; the environment blocks that
+// contain a modified site are dropped (op_sys_sites = None, :2370, :2417)
+void Engine::recanonicalize(int lo, int hi, DevBuf& spare) {
   const int c0 = center_;
-  if (hi > c0) {  // canonicalizeB(superblock[centre : hi + 1])
+  if (hi > c0) {
     for (int p = hi; p > c0; --p) {
       gauge_qr_right(site_[p].p, dl_[p], dd_[p], dr_[p], spare.p, tmp2_.p, sig_.p);
       std::swap(site_[p], spare);
@@ -861,7 +869,7 @@ void Engine::apply_gates() {
     }
     for (int b = 1; b <= hi; ++b) { envR_ok_[b] = 0; pool_put(std::move(envR_[b])); }
   }
-  if (lo < c0) {  // canonicalizeA(superblock[lo : centre + 1])
+  if (lo < c0) {
     for (int p = lo; p < c0; ++p) {
       gauge_qr_left(site_[p].p, dl_[p], dd_[p], dr_[p], spare.p, sig_.p);
       std::swap(site_[p], spare);
@@ -874,6 +882,104 @@ void Engine::apply_gates() {
     for (int b = lo + 1; b < L_; ++b) { envL_ok_[b] = 0; pool_put(std::move(envL_[b])); }
   }
   gauge_[c0] = MITDVP_GAUGE_PSI;
+}
+
+// ---------------------------------------------------------------------------
+// Kraus maps on purified states (Model(kraus_op=...), MPSCoef.apply_kraus,
+// _mps_cls.py:2375-2418; kraus.py:146-358).  theta (m, d*K, n) has the physical index
+// (system d, ancilla K); C[(m,n,x),(k,K)] = sum_d B[k,x,d] theta[m,d,K,n] and the ancilla
+// index (k,K) is cut back to K keeping "U S" of the leading singular values.  One-sided
+// Jacobi on the k*K ROWS of C^T delivers exactly that factor (the rotated rows are
+// s_i q_i), so neither U, V nor a normalisation is formed.
+// ---------------------------------------------------------------------------
+void Engine::set_kraus(int isite, int two_site, const double* reim, int k, int d) {
+  if (isite < 0 || isite >= L_ || (two_site && isite + 1 >= L_)) throw ArgError("set_kraus: bad site index");
+  if (!reim) { kraus_.erase(isite); return; }
+  if (k < 1 || d < 1) throw ArgError("set_kraus: bad Kraus tensor shape");
+  std::vector<zc> h((size_t)k * d * d);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = make_double2(reim[2 * i], reim[2 * i + 1]);
+  KrausOp& o = kraus_[isite];
+  o.k = k; o.d = d; o.two_site = two_site != 0;
+  o.b.reserve(h.size());
+  HIP_CHECK(hipMemcpyAsync(o.b.p, h.data(), h.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void Engine::kraus_core(const zc* theta, int m, int d, int K, int n, const KrausOp& op, zc* out) {
+  const int k = op.k, x = d;
+  const size_t tot = (size_t)m * k * x * K * n;
+  DevBuf T = pool_get(tot), M = pool_get(tot);
+  {  // T[m][(k,x)][(K,n)] = B[(k,x)][d] theta[m][d][(K,n)]
+    ZgemmDesc z = zgemm_desc(op.b.p, theta, T.p, k * x, K * n, d);
+    z.batch = m; z.strideA = 0; z.strideB = (long)d * K * n; z.strideC = (long)k * x * K * n;
+    zgemm(st_, z);
+  }
+  {  // M[(k,K)][(m,x,n)] = T[m][k][x][K][n]
+    const int dims[5] = {k, K, m, x, n};
+    const long str[5] = {(long)x * K * n, (long)n, (long)k * x * K * n, (long)K * n, 1};
+    permute5(st_, T.p, M.p, dims, str, nullptr);
+  }
+  const int nr = k * K, nc = m * x * n;
+  DevBuf wk = pool_get((size_t)nr + 8 + (size_t)(nr + 1) / 2);
+  int* idx_dev = reinterpret_cast<int*>(wk.p + nr / 2 + 4);
+  std::vector<double> S(nr);
+  int sweeps = 0;
+  svd_rows_us(st_, M.p, nr, nc, S.data(), idx_dev, wk.p, &sweeps);
+  {  // out[m][x][K''][n] = M[idx[K'']][(m,x,n)]
+    const int dims[5] = {m, x, K, n, 1};
+    const long str[5] = {(long)x * n, (long)n, (long)nc, 1, 0};
+    permute5(st_, M.p, out, dims, str, idx_dev);
+  }
+  HIP_CHECK(hipStreamSynchronize(st_));  // idx lives in wk
+  cnt_.n_launch += 3 + (long)sweeps * (nr + (nr & 1) - 1);
+  pool_put(std::move(T)); pool_put(std::move(M)); pool_put(std::move(wk));
+}
+
+void Engine::apply_kraus() {
+  if (kraus_.empty()) return;
+  require_ready();
+  if (center_ < 0) throw ArgError("apply_kraus: the MPS has no centre (Psi) site");
+  DevBuf spare = pool_get(V_.n / MAXK);
+  int lo = L_, hi = -1;
+  for (auto& kv : kraus_) {
+    const int p = kv.first;
+    const KrausOp& op = kv.second;
+    if (!op.two_site) {
+      const int l = dl_[p], dim = dd_[p], r = dr_[p];
+      if (dim % op.d != 0) throw ArgError("Kraus contract: dK must be divisible by d");
+      kraus_core(site_[p].p, l, op.d, dim / op.d, r, op, spare.p);
+      std::swap(site_[p], spare);
+      gauge_[p] = MITDVP_GAUGE_C;
+      lo = std::min(lo, p); hi = std::max(hi, p);
+      continue;
+    }
+    const int q = p + 1;
+    const int m = dl_[p], d = dd_[p], l = dr_[p], K = dd_[q], n = dr_[q];
+    if (d != op.d) throw ArgError("two-site Kraus map: the system site's dimension differs from the Kraus operators'");
+    DevBuf theta = pool_get((size_t)m * d * K * n), c2 = pool_get((size_t)m * d * K * n);
+    {  // theta[m][d][(K,n)] = A1[(m,d)][l] A2[l][(K,n)]
+      ZgemmDesc z = zgemm_desc(site_[p].p, site_[q].p, theta.p, m * d, K * n, l);
+      zgemm(st_, z);
+    }
+    kraus_core(theta.p, m, d, K, n, op, c2.p);  // (m, x, K, n) = matrix (m x) x (K n)
+    const int rr = m * d, cc = K * n, kk = std::min(rr, cc), lnew = std::min(l, kk);
+    DevBuf U = pool_get((size_t)rr * kk), Vh = pool_get((size_t)kk * cc), wk = pool_get(svd_work_elems(rr, cc));
+    std::vector<double> S(kk);
+    svd_jacobi(st_, c2.p, rr, cc, U.p, S.data(), Vh.p, wk.p, nullptr);
+    // A1 = U[:, :l] S[:l], A2 = Vh[:l]  (kraus.py:338-353)
+    copy2d(st_, site_[p].p, lnew, U.p, kk, rr, lnew, 0, make_double2(1.0, 0.0), false);
+    double* sdev = reinterpret_cast<double*>(wk.p);
+    HIP_CHECK(hipMemcpyAsync(sdev, S.data(), lnew * sizeof(double), hipMemcpyHostToDevice, st_));
+    scale_cols(st_, site_[p].p, rr, lnew, lnew, sdev);
+    HIP_CHECK(hipMemcpyAsync(site_[q].p, Vh.p, (size_t)lnew * cc * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    dr_[p] = lnew; dl_[q] = lnew;
+    gauge_[p] = MITDVP_GAUGE_C; gauge_[q] = MITDVP_GAUGE_C;
+    lo = std::min(lo, p); hi = std::max(hi, q);
+    cnt_.n_launch += 6;
+    pool_put(std::move(theta)); pool_put(std::move(c2)); pool_put(std::move(U)); pool_put(std::move(Vh)); pool_put(std::move(wk));
+  }
+  recanonicalize(lo, hi, spare);
   pool_put(std::move(spare));
 }
 
@@ -1300,6 +1406,7 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
 void Engine::step(double dt) {
   sweep(dt, true);
   apply_gates();  // Model(one_gate_to_apply=...), _mps_cls.py:489-490 (reorth_center = nsite - 1)
+  apply_kraus();  // Model(kraus_op=...), :491-492
   sweep(dt, false);
 }
 

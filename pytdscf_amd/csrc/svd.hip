@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_jacobi_step(zc* __restrict__ M, zc* __r
     }
   };
   rot(x, y, ncol);
-  rot(W + (size_t)p * nrow, W + (size_t)q * nrow, nrow);
+  if (W) rot(W + (size_t)p * nrow, W + (size_t)q * nrow, nrow);
 }
 
 // row norms -> s[i]
@@ -115,6 +115,48 @@ __global__ __launch_bounds__(256) void k_svd_gather(const zc* __restrict__ M, co
   }
 }
 
+// Orthogonalise the rows of M (nr x nc) in place by Jacobi rotations (optionally accumulating
+// them in W); returns the number of sweeps.  off_dev: one device word for the convergence flag.
+static int jacobi_rows(hipStream_t st, zc* M, zc* W, int nr, int nc, unsigned long long* off_dev) {
+  const int np = nr + (nr & 1);
+  int sweeps = 0;
+  if (nr <= 1) return 0;
+  for (; sweeps < 60; ++sweeps) {
+    HIP_CHECK(hipMemsetAsync(off_dev, 0, sizeof(unsigned long long), st));
+    for (int round = 0; round < np - 1; ++round)
+      hipLaunchKernelGGL(k_jacobi_step, dim3(np / 2), dim3(256), 0, st, M, W, nr, nc, np, round, off_dev);
+    HIP_CHECK(hipGetLastError());
+    unsigned long long bits = 0;
+    HIP_CHECK(hipMemcpyAsync(&bits, off_dev, sizeof(bits), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    double off;
+    static_assert(sizeof(double) == sizeof(unsigned long long), "bit cast");
+    std::memcpy(&off, &bits, sizeof(off));
+    if (off <= 1e-30) return sweeps + 1;  // every |<x,y>| <= 1e-15 ||x|| ||y||
+  }
+  throw NotConverged("Jacobi SVD did not converge in 60 sweeps");
+}
+
+// Rows of M -> mutually orthogonal rows s_i q_i (the "U S" factor of M^T = Q^T S W^*), their
+// norms (host, descending) and the sorting permutation (device idx, nr ints).  This is all a
+// rank truncation "keep U S of the leading singular values" needs (Kraus maps, kraus.py:195-207).
+void svd_rows_us(hipStream_t st, zc* M, int nr, int nc, double* S_host, int* idx_dev, zc* work, int* sweeps_out) {
+  double* s_dev = reinterpret_cast<double*>(work);
+  unsigned long long* off_dev = reinterpret_cast<unsigned long long*>(work + (nr + 1) / 2 + 1);
+  const int sw = jacobi_rows(st, M, nullptr, nr, nc, off_dev);
+  hipLaunchKernelGGL(k_row_norms, dim3(nr), dim3(256), 0, st, M, nc, s_dev);
+  std::vector<double> s(nr);
+  HIP_CHECK(hipMemcpyAsync(s.data(), s_dev, nr * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  std::vector<int> idx(nr);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return s[a] > s[b]; });
+  HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), nr * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (int k = 0; k < nr; ++k) S_host[k] = s[idx[k]];
+  if (sweeps_out) *sweeps_out = sw;
+}
+
 size_t svd_work_elems(int r, int c) {
   const int nr = std::min(r, c), nc = std::max(r, c);
   return (size_t)nr * nc + (size_t)nr * nr + nr /*s*/ + nr /*idx*/ + 8 + (size_t)nr * nr + (size_t)nr * nc;
@@ -135,24 +177,7 @@ void svd_jacobi(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host
   if (tr) transpose_batched(st, A, M, r, c, c, r, 1, 0, 0);
   else HIP_CHECK(hipMemcpyAsync(M, A, (size_t)r * c * sizeof(zc), hipMemcpyDeviceToDevice, st));
   set_identity(st, W, nr, nr, nr);
-  const int np = nr + (nr & 1);
-  int sweeps = 0;
-  if (nr > 1) {
-    for (; sweeps < 60; ++sweeps) {
-      HIP_CHECK(hipMemsetAsync(off_dev, 0, sizeof(unsigned long long), st));
-      for (int round = 0; round < np - 1; ++round)
-        hipLaunchKernelGGL(k_jacobi_step, dim3(np / 2), dim3(256), 0, st, M, W, nr, nc, np, round, off_dev);
-      HIP_CHECK(hipGetLastError());
-      unsigned long long bits = 0;
-      HIP_CHECK(hipMemcpyAsync(&bits, off_dev, sizeof(bits), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      double off;
-      static_assert(sizeof(double) == sizeof(unsigned long long), "bit cast");
-      std::memcpy(&off, &bits, sizeof(off));
-      if (off <= 1e-30) { ++sweeps; break; }  // every |<x,y>| <= 1e-15 ||x|| ||y||
-    }
-    if (sweeps >= 60) throw NotConverged("Jacobi SVD did not converge in 60 sweeps");
-  }
+  const int sweeps = jacobi_rows(st, M, W, nr, nc, off_dev);
   hipLaunchKernelGGL(k_row_norms, dim3(nr), dim3(256), 0, st, M, nc, s_dev);
   std::vector<double> s(nr);
   HIP_CHECK(hipMemcpyAsync(s.data(), s_dev, nr * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -46,6 +46,9 @@ void phys_diag(hipStream_t st, const zc* C, zc* out, int dl, int n, int dr, bool
 // out[i0][i2][i1][i3] = in[i0][i1][i2][i3]
 void permute_0213(hipStream_t st, const zc* in, zc* out, long n0, int n1, int n2, int n3);
 void clock_probe(hipStream_t st, long iters, double* host_out3 /* shader cycles, 100 MHz ticks, dummy */);
+// out (C order, dims[0..4]) = in gathered with in_strides; map2 (device, nullable) replaces index 2
+void permute5(hipStream_t st, const zc* in, zc* out, const int dims[5], const long in_strides[5], const int* map2);
+void scale_cols(hipStream_t st, zc* x, long rows, int cols, long ld, const double* sc_dev);
 void transpose_rev3(hipStream_t st, const zc* in, zc* out, int na, int nj, int ns);
 
 }  // namespace mitdvp

@@ -268,6 +268,40 @@ __global__ __launch_bounds__(256) void k_permute_0213(const zc* __restrict__ in,
   }
 }
 
+// out (C order over dims d0..d4) [i0..i4] = in[sum_j i_j * stride_j]; an optional index map
+// replaces i2 (row gather by sorted index)
+struct Perm5 {
+  int d[5];
+  long s[5];
+};
+__global__ __launch_bounds__(256) void k_permute5(const zc* __restrict__ in, zc* __restrict__ out, Perm5 p,
+                                                  const int* __restrict__ map2) {
+  const long tot = (long)p.d[0] * p.d[1] * p.d[2] * p.d[3] * p.d[4];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    long r = e;
+    const int i4 = r % p.d[4]; r /= p.d[4];
+    const int i3 = r % p.d[3]; r /= p.d[3];
+    int i2 = r % p.d[2]; r /= p.d[2];
+    const int i1 = r % p.d[1];
+    const long i0 = r / p.d[1];
+    if (map2) i2 = map2[i2];
+    out[e] = in[i0 * p.s[0] + i1 * p.s[1] + i2 * p.s[2] + i3 * p.s[3] + i4 * p.s[4]];
+  }
+}
+
+// x[r][c] *= s[c]  (real scale per column)
+__global__ __launch_bounds__(256) void k_scale_cols(zc* __restrict__ x, long rows, int cols, long ld,
+                                                    const double* __restrict__ sc) {
+  const long tot = rows * cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const long r = e / cols;
+    const int c = (int)(e % cols);
+    zc v = x[r * ld + c];
+    v.x *= sc[c]; v.y *= sc[c];
+    x[r * ld + c] = v;
+  }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -557,6 +591,17 @@ void permute_0213(hipStream_t st, const zc* in, zc* out, long n0, int n1, int n2
   const long tot = n0 * n1 * n2 * n3;
   if (tot <= 0) return;
   LAUNCH(k_permute_0213, (int)std::min<long>(4096, (tot + 255) / 256), st, in, out, n0, n1, n2, n3);
+}
+
+void permute5(hipStream_t st, const zc* in, zc* out, const int dims[5], const long in_strides[5], const int* map2) {
+  Perm5 p;
+  long tot = 1;
+  for (int i = 0; i < 5; ++i) { p.d[i] = dims[i]; p.s[i] = in_strides[i]; tot *= dims[i]; }
+  if (tot <= 0) return;
+  LAUNCH(k_permute5, (int)std::min<long>(4096, (tot + 255) / 256), st, in, out, p, map2);
+}
+void scale_cols(hipStream_t st, zc* x, long rows, int cols, long ld, const double* sc_dev) {
+  if (rows * cols > 0) LAUNCH(k_scale_cols, vec_blocks(rows * cols), st, x, rows, cols, ld, sc_dev);
 }
 
 // out[s][j][a] = in[a][j][s]   (in: (na, nj, ns) C order)

@@ -170,6 +170,27 @@ class TDVPEngine:
         """``apply_one_gate`` now, re-orthogonalising towards the current centre site."""
         self._ck(self._lib.mitdvp_apply_gates(self._h))
 
+    def set_kraus(self, kraus: dict | None) -> None:
+        """Register Kraus maps ``{(site,): B}`` / ``{(site, site + 1): B}`` with B of shape
+        (k, d, d) (``Model(kraus_op=...)``); ``propagate`` applies them after the gates,
+        between its half-sweeps.  ``None`` / ``{}`` removes all maps."""
+        for i in range(self.nsite):
+            self._ck(self._lib.mitdvp_set_kraus(self._h, i, 0, None, 0, 0))
+        for sites, B in (kraus or {}).items():
+            sites = tuple(int(x) for x in (sites if isinstance(sites, (tuple, list)) else (sites,)))
+            B = np.ascontiguousarray(np.asarray(B, dtype=np.complex128))
+            if B.ndim != 3 or B.shape[1] != B.shape[2]:
+                raise ValueError("a Kraus tensor must have shape (k, d, d)")
+            if len(sites) == 2 and sites[0] + 1 != sites[1]:
+                raise ValueError(f"site_inds={sites} is not nearest neighbour")
+            if len(sites) not in (1, 2):
+                raise ValueError(f"site_inds={sites} is not yet implemented")
+            self._ck(self._lib.mitdvp_set_kraus(self._h, sites[0], int(len(sites) == 2), _dp(B), B.shape[0], B.shape[1]))
+
+    def apply_kraus(self) -> None:
+        """``apply_kraus`` now, re-orthogonalising towards the current centre site."""
+        self._ck(self._lib.mitdvp_apply_kraus(self._h))
+
     def set_adaptive(self, enable: bool = True, Dmax: int = 20, dD: int = 5, p_proj: float = 1.0e-4) -> None:
         """Adaptive bond dimension (``Simulator.propagate(adaptive=True, adaptive_Dmax=...,
         adaptive_dD=..., adaptive_p_proj=...)``): ranks grow by up to ``dD`` per half-sweep
