@@ -1,6 +1,8 @@
-// capi.inc -- extern "C" surface declared in include/mitdvp.h (included at the
-// end of engine.hip so the templates above are visible).
+// capi.hip -- extern "C" surface declared in include/mitdvp.h.
 #include <mutex>
+
+#include "engine_internal.h"
+#include "engine_krylov.inc"
 
 struct mitdvp_engine {
   std::unique_ptr<mitdvp::Engine> e;

@@ -1,0 +1,405 @@
+// engine_obs.hip -- observables evaluated on the device-resident MPS: norm, expectation
+// values, autocorrelation, reduced densities, SVD bond truncation, Liouville-space traces.
+#include "engine_internal.h"
+
+namespace mitdvp {
+
+// ---------------------------------------------------------------------------
+// observables
+// ---------------------------------------------------------------------------
+double Engine::norm() {
+  if (center_ < 0) throw ArgError("no centre site");
+  const long n = (long)dl_[center_] * dd_[center_] * dr_[center_];
+  vec_sumsq(st_, site_[center_].p, n, reinterpret_cast<double*>(red_.p + RED_MISC));
+  read_partials(RED_MISC, NPART / 2);
+  const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+  double s = 0;
+  for (int i = 0; i < NPART; ++i) s += hp[i];
+  return std::sqrt(s);
+}
+
+hzc Engine::expect(int op_id) {
+  require_ready();
+  if (center_ != 0) throw ArgError("expectation needs the centre at site 0 (psite = 0)");
+  Operator& o = op(op_id);
+  const zc* R1 = nullptr;
+  DevBuf ra, rb;
+  bool cached = (op_id == 0);
+  for (int b = 1; b < L_ && cached; ++b) cached = envR_ok_[b];
+  if (L_ == 1) {
+    R1 = envR_[1].p;
+  } else if (cached) {
+    R1 = envR_[1].p;
+  } else {
+    // fresh right environments (_mps_cls.py:570-576)
+    size_t mx = 1;
+    for (int p = 1; p < L_; ++p) mx = std::max(mx, (size_t)dl_[p] * mpo(op_id, p).ml * dl_[p]);
+    ra = pool_get(mx);
+    rb = pool_get(mx);
+    const zc* cur = envR_[L_].p;
+    for (int p = L_ - 1; p >= 1; --p) {
+      const MpoSite& w = mpo(op_id, p);
+      if (gauge_[p] != MITDVP_GAUGE_B) throw ArgError("sites right of the centre must be in gauge B");
+      transpose_rev3(st_, site_[p].p, tmp1_.p, dl_[p], dd_[p], dr_[p]);
+      env_update(cur, tmp1_.p, w.w2r.p, ra.p, dr_[p], w.mr, dd_[p], dl_[p], w.ml);
+      cur = ra.p;
+      std::swap(ra, rb);  // result now lives in rb
+    }
+    R1 = cur;
+  }
+  const MpoSite& w0 = mpo(op_id, 0);
+  heff_apply(envL_[0].p, w0, R1, site_[0].p, tmp2_.p, dl_[0], dd_[0], dr_[0], o.shift);
+  const long n0 = (long)dl_[0] * dd_[0] * dr_[0];
+  vec_dot(st_, site_[0].p, tmp2_.p, n0, true, red_.p + RED_MISC);
+  read_partials(RED_MISC, NPART);
+  double re = 0, im = 0;
+  for (int i = 0; i < NPART; ++i) { re += h_red_[RED_MISC + i].x; im += h_red_[RED_MISC + i].y; }
+  pool_put(std::move(ra));
+  pool_put(std::move(rb));
+  return hzc(re, im);
+}
+
+hzc Engine::autocorr() {
+  require_ready();
+  // <Psi^*|Psi>: block = einsum("abc,abk->ck", bra, einsum("ibk,ai->abk", ket, block))
+  // with bra = ket unconjugated (wavefunction.py:226-257 with conj=False)
+  const zc one = make_double2(1.0, 0.0);
+  HIP_CHECK(hipMemcpyAsync(sig_.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  zc* T = sig_.p;
+  zc* Tn = sig2_.p;
+  for (int p = 0; p < L_; ++p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    ZgemmDesc u = zgemm_desc(T, site_[p].p, tmp1_.p, dl, d * dr, dl);  // U[m][(s,j)] = T[m][n] C[n][(s,j)]
+    zgemm(st_, u);
+    ZgemmDesc t = zgemm_desc(site_[p].p, tmp1_.p, Tn, dr, dr, dl * d);  // T'[i][j] = C[(m,s)][i] U[(m,s)][j]
+    t.transA = 1; t.lda = dr;
+    zgemm(st_, t);
+    std::swap(T, Tn);
+  }
+  hzc out;
+  HIP_CHECK(hipMemcpyAsync(&out, T, sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  return out;
+}
+
+void Engine::site_rdm(int isite, double* out) {
+  require_ready();
+  if (center_ != 0) throw ArgError("reduced density needs the centre at site 0");
+  if (isite < 0 || isite >= L_) throw ArgError("bad site index");
+  // T[a][a'] = sum over sites < isite of ket (x) conj(bra); sites > isite are right-canonical
+  const zc one = make_double2(1.0, 0.0);
+  HIP_CHECK(hipMemcpyAsync(sig_.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  zc* T = sig_.p;
+  zc* Tn = sig2_.p;
+  for (int p = 0; p <= isite; ++p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    // U[a'][(j,s)] = sum_a T[a][a'] C[a][(j,s)]
+    ZgemmDesc u = zgemm_desc(T, site_[p].p, tmp1_.p, dl, d * dr, dl);
+    u.transA = 1; u.lda = dl;
+    zgemm(st_, u);
+    if (p < isite) {
+      // T'[s][s'] = sum_(a',j) U[(a',j)][s] conj(C[(a',j)][s'])
+      ZgemmDesc t = zgemm_desc(tmp1_.p, site_[p].p, Tn, dr, dr, dl * d);
+      t.transA = 1; t.lda = dr; t.conjB = 1;
+      zgemm(st_, t);
+      std::swap(T, Tn);
+    } else {
+      // rho_a'[j][j'] = sum_s U[a'][j][s] conj(C[a'][j'][s]); summed over a' on the host
+      DevBuf rho = pool_get((size_t)dl * d * d);
+      ZgemmDesc r = zgemm_desc(tmp1_.p, site_[p].p, rho.p, d, d, dr);
+      r.transB = 1; r.conjB = 1; r.ldb = dr; r.ldc = d;
+      r.batch = dl; r.strideA = (long)d * dr; r.strideB = (long)d * dr; r.strideC = (long)d * d;
+      zgemm(st_, r);
+      std::vector<hzc> h((size_t)dl * d * d);
+      HIP_CHECK(hipMemcpyAsync(h.data(), rho.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      pool_put(std::move(rho));
+      hzc* o = reinterpret_cast<hzc*>(out);
+      for (int e = 0; e < d * d; ++e) o[e] = hzc(0, 0);
+      for (int a = 0; a < dl; ++a)
+        for (int e = 0; e < d * d; ++e) o[e] += h[(size_t)a * d * d + e];
+    }
+  }
+}
+
+// General pure-state reduced density (_get_pure_reduced_density,
+// _mps_cls.py:1208-1283): per site keep 2 legs (ket, bra), 1 leg (diagonal) or
+// none.  Left-to-right transfer with the open physical legs folded into a batch
+// index o: T_o[a][a'] (ket bond, bra bond); sites right of the last kept one
+// are right-canonical and drop out.  Output axes: kept sites ascending, (ket,
+// bra) per 2-leg site -- the reference's order.
+void Engine::reduced_density(const int* legs, int nlen, std::vector<hzc>& out, std::vector<int>& shape) {
+  require_ready();
+  if (center_ != 0) throw ArgError("reduced density needs the centre at site 0");
+  if (nlen < 1 || nlen > L_) throw ArgError("reduced_density: bad number of sites");
+  int last = -1;
+  for (int p = 0; p < nlen; ++p) {
+    if (legs[p] < 0 || legs[p] > 2) throw ArgError("The number of legs must be less than 3.");
+    if (legs[p]) last = p;
+  }
+  if (last < 0) throw ArgError("The number of legs must be greater than 0.");
+  shape.clear();
+  const zc one = make_double2(1.0, 0.0);
+  long no = 1;
+  DevBuf T = pool_get(1);
+  HIP_CHECK(hipMemcpyAsync(T.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  for (int p = 0; p <= last; ++p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p], n = legs[p];
+    if (no > 65535) throw ArgError("reduced_density: too many open legs for one call");
+    const zc* C = site_[p].p;
+    DevBuf U = pool_get((size_t)no * dl * d * dr);
+    {  // U_o[a'][(j,s)] = sum_a T_o[a][a'] C[a][(j,s)]
+      ZgemmDesc g = zgemm_desc(T.p, C, U.p, dl, d * dr, dl);
+      g.transA = 1; g.lda = dl; g.batch = (int)no;
+      g.strideA = (long)dl * dl; g.strideB = 0; g.strideC = (long)dl * d * dr;
+      zgemm(st_, g);
+    }
+    pool_put(std::move(T));
+    if (p < last) {
+      if (n == 0) {
+        T = pool_get((size_t)no * dr * dr);
+        ZgemmDesc g = zgemm_desc(U.p, C, T.p, dr, dr, dl * d);  // T'[s][s'] = U[(a',j)][s] conj(C[(a',j)][s'])
+        g.transA = 1; g.lda = dr; g.conjB = 1; g.batch = (int)no;
+        g.strideA = (long)dl * d * dr; g.strideB = 0; g.strideC = (long)dr * dr;
+        zgemm(st_, g);
+      } else if (n == 2) {
+        const long ds = (long)d * dr;
+        DevBuf Z = pool_get((size_t)no * ds * ds);
+        ZgemmDesc g = zgemm_desc(U.p, C, Z.p, (int)ds, (int)ds, dl);  // Z[(j,s)][(j',s')]
+        g.transA = 1; g.lda = ds; g.conjB = 1; g.batch = (int)no;
+        g.strideA = (long)dl * ds; g.strideB = 0; g.strideC = ds * ds;
+        zgemm(st_, g);
+        T = pool_get((size_t)no * ds * ds);
+        permute_0213(st_, Z.p, T.p, no * d, dr, d, dr);  // (o,j,s,j',s') -> (o,j,j',s,s')
+        pool_put(std::move(Z));
+        no *= (long)d * d;
+        shape.push_back(d); shape.push_back(d);
+      } else {
+        T = pool_get((size_t)no * d * dr * dr);
+        for (int j = 0; j < d; ++j) {  // T'_(o,j)[s][s'] = sum_a' U_o[a'][j][s] conj(C[a'][j][s'])
+          ZgemmDesc g = zgemm_desc(U.p + (size_t)j * dr, C + (size_t)j * dr, T.p + (size_t)j * dr * dr, dr, dr, dl);
+          g.transA = 1; g.lda = (long)d * dr; g.ldb = (long)d * dr; g.conjB = 1; g.batch = (int)no;
+          g.strideA = (long)dl * d * dr; g.strideB = 0; g.strideC = (long)d * dr * dr;
+          zgemm(st_, g);
+        }
+        no *= d;
+        shape.push_back(d);
+      }
+    } else {
+      // last kept site: the right side is the identity -> trace over s
+      DevBuf Ut = pool_get((size_t)no * dl * d * dr), Ct = pool_get((size_t)dl * d * dr), rho = pool_get((size_t)no * d * d);
+      permute_0213(st_, U.p, Ut.p, no, dl, d, dr);  // (o,a',j,s) -> (o,j,a',s)
+      permute_0213(st_, C, Ct.p, 1, dl, d, dr);
+      ZgemmDesc g = zgemm_desc(Ut.p, Ct.p, rho.p, d, d, dl * dr);  // rho_o[j][j'] = Ut_o[j][(a',s)] conj(Ct[j'][(a',s)])
+      g.transB = 1; g.conjB = 1; g.ldb = (long)dl * dr; g.batch = (int)no;
+      g.strideA = (long)d * dl * dr; g.strideB = 0; g.strideC = (long)d * d;
+      zgemm(st_, g);
+      std::vector<hzc> h((size_t)no * d * d);
+      HIP_CHECK(hipMemcpyAsync(h.data(), rho.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      if (n == 2) {
+        out = std::move(h);
+        shape.push_back(d); shape.push_back(d);
+      } else {
+        out.resize((size_t)no * d);
+        for (long o = 0; o < no; ++o)
+          for (int j = 0; j < d; ++j) out[(size_t)o * d + j] = h[((size_t)o * d + j) * d + j];
+        shape.push_back(d);
+      }
+      pool_put(std::move(Ut)); pool_put(std::move(Ct)); pool_put(std::move(rho));
+    }
+    pool_put(std::move(U));
+  }
+  pool_put(std::move(T));
+}
+
+// ---------------------------------------------------------------------------
+// bond truncation by SVD (truncate_sigvec, _site_cls.py:586-690) at the bond
+// right of the centre site c:  Psi(c) = A sigma,  sigma = U s Vh;  keep the first
+// idx singular values with cumulative weight sum_{k<idx} s_k / sum s_k >= 1 - p
+// (and idx <= max_dim if max_dim > 0);  A <- A U,  B(c+1) <- Vh B(c+1),
+// sigma' = diag(s / ||s||).  The result is stored as Psi(c) = A sigma', B(c+1).
+// ---------------------------------------------------------------------------
+int Engine::truncate_bond(double p, int max_dim, std::vector<double>& svals) {
+  require_ready();
+  const int c = center_;
+  if (c < 0 || c >= L_ - 1) throw ArgError("truncate_bond: the centre must not be the last site");
+  if (gauge_[c + 1] != MITDVP_GAUGE_B) throw ArgError("truncate_bond: the right neighbour must be in gauge B");
+  const int dl = dl_[c], d = dd_[c], dr = dr_[c];
+  const int dn = dd_[c + 1], drn = dr_[c + 1];
+  DevBuf A = pool_get((size_t)dl * d * dr), U = pool_get((size_t)dr * dr), Vh = pool_get((size_t)dr * dr),
+         work = pool_get(svd_work_elems(dr, dr));
+  gauge_qr_left(site_[c].p, dl, d, dr, A.p, sig_.p);  // Psi2Asigma
+  std::vector<double> s(dr);
+  int sweeps = 0;
+  svd_jacobi(st_, sig_.p, dr, dr, U.p, s.data(), Vh.p, work.p, &sweeps);
+  double tot = 0;
+  for (double v : s) tot += v;
+  int idx = dr;
+  double cum = 0;
+  for (int k = 0; k < dr; ++k) {  // idx = argmax(cumsum / total >= 1 - p) + 1
+    cum += s[k];
+    if (cum / tot >= 1.0 - p) { idx = k + 1; break; }
+  }
+  if (max_dim > 0) idx = std::min(idx, max_dim);
+  double nrm2 = 0;
+  for (int k = 0; k < idx; ++k) nrm2 += s[k] * s[k];
+  svals.assign(s.begin(), s.begin() + idx);
+  for (auto& v : svals) v /= std::sqrt(nrm2);
+  // A' sigma' = A U[:, :idx] diag(s'/||s'||): scale the kept columns of U first
+  std::vector<hzc> hU((size_t)dr * dr);
+  HIP_CHECK(hipMemcpyAsync(hU.data(), U.p, hU.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  std::vector<hzc> hUs((size_t)dr * idx);
+  for (int r = 0; r < dr; ++r)
+    for (int k = 0; k < idx; ++k) hUs[(size_t)r * idx + k] = hU[(size_t)r * dr + k] * svals[k];
+  HIP_CHECK(hipMemcpyAsync(U.p, hUs.data(), hUs.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  DevBuf newc = pool_get(site_[c].n), newn = pool_get(site_[c + 1].n);
+  {
+    ZgemmDesc g = zgemm_desc(A.p, U.p, newc.p, dl * d, idx, dr);  // (dl d x dr) (dr x idx)
+    zgemm(st_, g);
+  }
+  {
+    ZgemmDesc g = zgemm_desc(Vh.p, site_[c + 1].p, newn.p, idx, dn * drn, dr);  // Vh[:idx] B
+    zgemm(st_, g);
+  }
+  HIP_CHECK(hipStreamSynchronize(st_));
+  std::swap(site_[c], newc);
+  std::swap(site_[c + 1], newn);
+  dr_[c] = idx;
+  dl_[c + 1] = idx;
+  invalidate_env();
+  pool_put(std::move(A)); pool_put(std::move(U)); pool_put(std::move(Vh)); pool_put(std::move(work));
+  pool_put(std::move(newc)); pool_put(std::move(newn));
+  return idx;
+}
+
+// ---------------------------------------------------------------------------
+// Liouville space: the MPS is a vectorised density matrix, site dimension n*n,
+// physical index = row*n + col (reshape_mat, _mps_mpo.py:135-194)
+// ---------------------------------------------------------------------------
+void Engine::set_trace_op_core(int op_id, int isite, const double* reim, int ml, int n, int mr) {
+  if (isite < 0 || isite >= L_) throw ArgError("set_trace_op_core: bad site index");
+  if (ml < 1 || mr < 1 || n < 1) throw ArgError("set_trace_op_core: bad shape");
+  const hzc* O = reinterpret_cast<const hzc*>(reim);  // O[a][d][c][f]  (bond, out, in, bond)
+  std::vector<hzc> o2((size_t)mr * ml * n * n);
+  for (int a = 0; a < ml; ++a)
+    for (int dd = 0; dd < n; ++dd)
+      for (int c = 0; c < n; ++c)
+        for (int f = 0; f < mr; ++f)
+          o2[(size_t)f * ml * n * n + ((size_t)a * n + c) * n + dd] = O[(((size_t)a * n + dd) * n + c) * mr + f];
+  MpoSite& s = op(op_id).sites[isite];
+  s.wtr.reserve(o2.size());
+  HIP_CHECK(hipMemcpyAsync(s.wtr.p, o2.data(), o2.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  s.ntr = n; s.mltr = ml; s.mrtr = mr;
+}
+
+// Tr(O rho): left[f][e] = sum left[a][b] rho[b][c][d][e] O[a][d][c][f]   (_exp_liouville)
+hzc Engine::expect_trace(int op_id) {
+  require_ready();
+  auto it = ops_.find(op_id);
+  if (it == ops_.end()) throw ArgError("trace operator not set");
+  const zc one = make_double2(1.0, 0.0);
+  size_t mx = 1;
+  for (int p = 0; p < L_; ++p) {
+    const MpoSite& w = it->second.sites[p];
+    if (!w.ntr) throw ArgError("trace operator core not set for this site");
+    if (w.ntr * w.ntr != dd_[p]) throw ArgError("trace operator: site dimension is not n*n");
+    mx = std::max(mx, (size_t)std::max(w.mltr, w.mrtr) * dd_[p] * std::max(dl_[p], dr_[p]));
+  }
+  DevBuf left = pool_get(mx), nxt = pool_get(mx), U = pool_get(mx);
+  HIP_CHECK(hipMemcpyAsync(left.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  int ma = 1;
+  for (int p = 0; p < L_; ++p) {
+    const MpoSite& w = it->second.sites[p];
+    if (w.mltr != ma) throw ArgError("trace operator: MPO bond mismatch");
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+    ZgemmDesc g1 = zgemm_desc(left.p, site_[p].p, U.p, ma, d * dr, dl);  // U[a][(c,d,e)]
+    zgemm(st_, g1);
+    ZgemmDesc g2 = zgemm_desc(w.wtr.p, U.p, nxt.p, w.mrtr, dr, ma * d);   // left'[f][e]
+    zgemm(st_, g2);
+    std::swap(left, nxt);
+    ma = w.mrtr;
+  }
+  if (ma != 1) throw ArgError("trace operator: last core must close the MPO bond");
+  hzc out;
+  HIP_CHECK(hipMemcpyAsync(&out, left.p, sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  pool_put(std::move(left)); pool_put(std::move(nxt)); pool_put(std::move(U));
+  return out;
+}
+
+// get_partial_trace (_mps_cls.py:1438-1510)
+void Engine::partial_trace(const int* legs, int nlen, std::vector<hzc>& out) {
+  require_ready();
+  if (nlen < 1 || nlen > L_) throw ArgError("partial_trace: bad number of sites");
+  int center = -1;
+  for (int p = 0; p < nlen; ++p) {
+    if (legs[p] < 0 || legs[p] > 2) throw ArgError("Invalid number of legs");
+    if (legs[p]) center = p;
+  }
+  if (center < 0) throw ArgError("No site with 2 legs found in remain_nleg");
+  std::vector<int> nn(L_);
+  size_t maxd = 1;
+  for (int p = 0; p < L_; ++p) {
+    nn[p] = (int)std::lround(std::sqrt((double)dd_[p]));
+    if (nn[p] * nn[p] != dd_[p]) throw ArgError("partial_trace: site dimension is not n*n");
+    maxd = std::max(maxd, (size_t)std::max(dl_[p], dr_[p]));
+  }
+  const zc one = make_double2(1.0, 0.0);
+  // right environment vector: sites right of the centre are traced out
+  DevBuf right = pool_get(maxd), rnext = pool_get(maxd), tq = pool_get(maxd * maxd * 0 + (size_t)maxd * maxd);
+  HIP_CHECK(hipMemcpyAsync(right.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  for (int q = L_ - 1; q > center; --q) {
+    phys_diag(st_, site_[q].p, tq.p, dl_[q], nn[q], dr_[q], true);
+    ZgemmDesc g = zgemm_desc(tq.p, right.p, rnext.p, dl_[q], 1, dr_[q]);
+    zgemm(st_, g);
+    std::swap(right, rnext);
+  }
+  // left environment with the open legs of the kept sites folded into its rows
+  long no = 1;
+  DevBuf left = pool_get(1);
+  HIP_CHECK(hipMemcpyAsync(left.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  for (int q = 0; q < center; ++q) {
+    const int dl = dl_[q], dr = dr_[q], n = nn[q];
+    const zc* M = nullptr;
+    DevBuf tmp;
+    long cols;
+    if (legs[q] == 2) {
+      M = site_[q].p;
+      cols = (long)n * n * dr;
+    } else {
+      tmp = pool_get((size_t)dl * n * dr);
+      phys_diag(st_, site_[q].p, tmp.p, dl, n, dr, legs[q] == 0);
+      M = tmp.p;
+      cols = (legs[q] == 0 ? 1L : (long)n) * dr;
+    }
+    DevBuf nl = pool_get((size_t)no * cols);
+    ZgemmDesc g = zgemm_desc(left.p, M, nl.p, (int)no, (int)cols, dl);
+    zgemm(st_, g);
+    pool_put(std::move(left));
+    left = std::move(nl);
+    no = no * cols / dr;
+    pool_put(std::move(tmp));
+  }
+  {
+    const int dl = dl_[center], dr = dr_[center], n = nn[center];
+    DevBuf wv = pool_get((size_t)dl * n * n), dm = pool_get((size_t)no * n * n);
+    ZgemmDesc g1 = zgemm_desc(site_[center].p, right.p, wv.p, dl * n * n, 1, dr);  // C (x) right
+    zgemm(st_, g1);
+    ZgemmDesc g2 = zgemm_desc(left.p, wv.p, dm.p, (int)no, n * n, dl);
+    zgemm(st_, g2);
+    out.resize((size_t)no * n * n);
+    HIP_CHECK(hipMemcpyAsync(out.data(), dm.p, out.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    pool_put(std::move(wv)); pool_put(std::move(dm));
+  }
+  pool_put(std::move(left)); pool_put(std::move(right)); pool_put(std::move(rnext)); pool_put(std::move(tq));
+}
+
+void Engine::krylov_stats(int* per_site) const {
+  for (int i = 0; i < L_; ++i) per_site[i] = kprev_[i];
+}
+
+}  // namespace mitdvp
