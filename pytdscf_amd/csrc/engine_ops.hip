@@ -267,6 +267,10 @@ void Engine::build_superblock_full(bool forward) {
     if (q == (forward ? 0 : L_ - 1)) continue;
     const int l1 = dl_[q], c1 = dd_[q], r1 = dr_[q];
     pool_put(std::move(full_[q]));
+    // A bond already at Dmax cannot grow (is_max_rank at the neighbouring site, whose own bond
+    // towards q does not change before it is processed): its widened tensor is never read.
+    // Once every bond is saturated an adaptive sweep costs what a plain one does.
+    if ((forward ? l1 : r1) >= ad_dmax_) { fdl_[q] = l1; fdr_[q] = r1; continue; }
     if (forward) {  // gauge B, neighbour q-1
       const int l2 = dl_[q - 1], c2 = dd_[q - 1], r2 = dr_[q - 1];
       const long e = std::max<long>(0, std::min<long>(ad_dd_, std::min((long)c1 * r1 - l1, (long)l2 * c2 - r2)));
