@@ -284,7 +284,31 @@ class Simulator:
             raise NotImplementedError("proj_gs")
         self.jobname, self.model, self.t2_trick, self.verbose = jobname, model, t2_trick, verbose
 
-    def _engine(self, integrator, conserve_norm, thresh, relax=False):
+    # ---- checkpoint / restart (simulator_cls.py:413-418, :500-506, :577-589) ------------
+    # The reference pickles its WFunc object graph with dill (wf_{jobname}{ext}.pkl); that
+    # format is the reference's classes, so the shell keeps the same file stem, extensions
+    # and call sites but stores the site tensors + gauge tags as wf_{jobname}{ext}.npz.
+    def _wf_path(self, ext):
+        return f"wf_{self.jobname}{ext}.npz"
+
+    def save_wavefunction(self, wf, ext=""):
+        eng = wf.engine
+        gauges = np.array([eng.get_site_shape(i)[3] for i in range(eng.nsite)])
+        np.savez(self._wf_path(ext), nsite=np.array(eng.nsite), gauges=gauges, space=np.array(self.model.space),
+                 **{f"site{i}": c for i, c in enumerate(eng.get_mps())})
+
+    def _load_cores(self, ext):
+        path = self._wf_path(ext)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"restart=True but {path} does not exist")
+        z = np.load(path)
+        n = int(z["nsite"])
+        if n != len(self.model.dims) or [z[f"site{i}"].shape[1] for i in range(n)] != list(self.model.dims):
+            raise ValueError(f"{path} does not match the model's sites")
+        names = {0: "Psi", 1: "A", 2: "B", -1: "C"}
+        return [z[f"site{i}"] for i in range(n)], [names[int(g)] for g in z["gauges"]]
+
+    def _engine(self, integrator, conserve_norm, thresh, relax=False, restart_ext=None):
         m = self.model
         liou = m.space == "liouville"
         eng = TDVPEngine(len(m.dims), integrator=integrator, conserve_norm=conserve_norm, thresh=thresh, relax=relax)
@@ -297,7 +321,14 @@ class Simulator:
                 eng.set_mpo(op.as_mpo(m.dims), k)
             ids[name] = k
         # Liouville space keeps the (trace) normalisation of the initial state (_mps_cls.py:2695-2699)
-        eng.set_mps(m.initial_cores(), canonicalize=True, scale=None if liou else 1.0)
+        if restart_ext is None:
+            eng.set_mps(m.initial_cores(), canonicalize=True, scale=None if liou else 1.0)
+        else:  # const.doRestart: continue from the saved state, gauges as saved
+            cores, gauges = self._load_cores(restart_ext)
+            if gauges.count("Psi") != 1 or gauges.index("Psi") != 0 or any(g != "B" for g in gauges[1:]):
+                raise ValueError("the saved wavefunction is not in the site-0-centred canonical form")
+            for i, (c, g_) in enumerate(zip(cores, gauges)):
+                eng.set_site(i, c, g_)
         if m.one_gate_to_apply is not None:  # applied between the half-sweeps of every step (_mps_cls.py:489-490)
             eng.set_gates(m.one_gate_to_apply.one_site_gates(m.dims))
         if m.kraus_op:  # after the gates, _mps_cls.py:491-492
@@ -315,8 +346,8 @@ class Simulator:
                   energy_per_step=1, norm_per_step=1, populations_per_step=1, parallel_split_indices=None,
                   adaptive=False, adaptive_Dmax=20, adaptive_dD=5, adaptive_p_proj=1.0e-04, adaptive_p_svd=1.0e-07,
                   integrator="lanczos", display_time_unit="fs", conserve_norm=True):
-        if restart or parallel_split_indices is not None:
-            raise NotImplementedError("restart / MPI site sharding are 'next' rows (SURVEY 8f)")
+        if parallel_split_indices is not None:
+            raise NotImplementedError("MPI site sharding (approximate real-space parallel TDVP) is not part of the engine; see DESIGN.md section 7")
         if integrator not in ("lanczos", "arnoldi"):
             raise ValueError(f"Invalid integrator: {integrator}")
         dt_fs = Δt if Δt is not None else stepsize
@@ -329,7 +360,7 @@ class Simulator:
                 raise NotImplementedError("Liouville space: pass energy=False (the Hamiltonian entry is the super-operator), like tests/test_mixedstate.py:434")
             if autocorr:
                 autocorr = False
-        eng, ids = self._engine(integrator, conserve_norm, thresh_sil)
+        eng, ids = self._engine(integrator, conserve_norm, thresh_sil, restart_ext=loadfile_ext if restart else None)
         if adaptive:  # const.adaptive / Dmax / dD / p_proj (_const_cls.py:212-216); p_svd is unused there too (:968-983)
             eng.set_adaptive(True, Dmax=adaptive_Dmax, dD=adaptive_dD, p_proj=adaptive_p_proj)
         wf = self._wfunc(eng, ids)
@@ -378,7 +409,10 @@ class Simulator:
                             legs[site] += 1
                         rec[tuple(key)] = eng.partial_trace(legs) if liou else eng.reduced_density(legs)
                     self.rdm_trace.append((t, rec))
+                if istep % backup_interval == backup_interval - 1:
+                    self.save_wavefunction(wf, savefile_ext)
                 eng.propagate(dt_au)
+            self.save_wavefunction(wf, savefile_ext)
         finally:
             for f in files.values():
                 f.close()
@@ -391,13 +425,18 @@ class Simulator:
         renormalisation, _mps_cls.py:1086-1094) or, with ``improved=True`` (the
         reference's default), Lanczos diagonalisation of H_eff per site
         (_integrator.py:74-138, _mps_cls.py:1078-1084)."""
-        eng, ids = self._engine(integrator, True, thresh_sil, relax="improved" if improved else True)
+        eng, ids = self._engine(integrator, True, thresh_sil, relax="improved" if improved else True,
+                                restart_ext=loadfile_ext if restart else None)
+        wf = self._wfunc(eng, ids)
         dt_au = stepsize / units.au_in_fs
         ener = None
-        for _ in range(maxstep):
+        for istep in range(maxstep):
             ener = eng.expectation(0).real
+            if istep % backup_interval == backup_interval - 1:
+                self.save_wavefunction(wf, savefile_ext)
             eng.propagate(dt_au)
-        return ener, self._wfunc(eng, ids)
+        self.save_wavefunction(wf, savefile_ext)
+        return ener, wf
 
     def operate(self, *a, **k):
         raise NotImplementedError("operate (dipole application) is outside the accelerated path")

@@ -177,3 +177,28 @@ def test_kraus_script_on_gpu(golden, tmp_path, monkeypatch):
     assert wf.norm() == pytest.approx(float(g["n4_norm"]), rel=1e-9)
     r1 = wf.get_reduced_densities((0, 2))[0]
     np.testing.assert_allclose(np.einsum("dKxK->dx", r1.reshape(d, K, d, K)), g["n4_rdm1"], atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_restart_from_saved_wavefunction(golden, tmp_path, monkeypatch):
+    """relax(savefile_ext="_gs") -> propagate(restart=True, loadfile_ext="_gs") and a propagation
+    continued from its own checkpoint equal the uninterrupted runs (simulator_cls.py:413-418, :500-506)."""
+    from pytdscf_amd import Simulator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("exciton.npz")
+    sim = Simulator("ckpt", _exciton_model(g), backend="hip")
+    e_all, wf_all = sim.propagate(stepsize=0.1, maxstep=6, savefile_ext="_all")
+    ref = wf_all.get_mps()
+    sim2 = Simulator("ckpt", _exciton_model(g), backend="hip")
+    sim2.propagate(stepsize=0.1, maxstep=3, savefile_ext="_half")
+    assert (tmp_path / "wf_ckpt_half.npz").exists()
+    e2, wf2 = sim2.propagate(stepsize=0.1, maxstep=3, restart=True, loadfile_ext="_half", savefile_ext="_rest")
+    assert e2 == pytest.approx(e_all, rel=1e-9)
+    assert abs(abs(orc.overlap(ref, wf2.get_mps())) - 1) < 1e-9
+    with pytest.raises(FileNotFoundError):
+        sim2.propagate(stepsize=0.1, maxstep=1, restart=True, loadfile_ext="_nope")
+    # ground state by relaxation, then real time from it: the energy stays the relaxed one
+    e_gs, _ = sim2.relax(stepsize=2.0, maxstep=6, improved=True, savefile_ext="_gs")
+    e0, _ = sim2.propagate(stepsize=0.1, maxstep=2, restart=True, loadfile_ext="_gs")
+    assert e0 == pytest.approx(e_gs, abs=1e-6)
