@@ -157,6 +157,14 @@ int mitdvp_apply_gates(mitdvp_engine* h);
  *                        towards the current centre site. */
 int mitdvp_set_kraus(mitdvp_engine* h, int isite, int two_site, const double* B_reim, int k, int d);
 int mitdvp_apply_kraus(mitdvp_engine* h);
+/* Simulator.operate (simulator_cls.py:286-331, :356-360): variational application of operator
+ * op_id to the state, WFunc.apply_dipole (wavefunction.py:303-351) -> MPSCoef.apply_dipole
+ * (_mps_cls.py:421-450, :718-796, :2733-2778): at most maxstep double sweeps in which every site
+ * tensor is replaced by the mixed-environment apply (bra = new state, ket = initial state),
+ * stopped when |1 - |<phi_i|phi_{i-1}>|| < conv_tol (1e-8 in the reference).  On return the
+ * engine holds phi ~ O|psi> / ||O|psi>|| (site-0 centred); *norm_out is the norm of the last
+ * apply (the value Simulator.operate returns), *iters_out the number of double sweeps done. */
+int mitdvp_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, double* norm_out, int* iters_out);
 /* Adaptive bond dimension (a1TDVP), Simulator.propagate(adaptive=True, adaptive_Dmax,
  * adaptive_dD, adaptive_p_proj) -> const.adaptive / Dmax / dD / p_proj
  * (_const_cls.py:120-124, :212-216).  While enabled, every half-sweep widens the

@@ -813,6 +813,63 @@ def overlap(bra: list[np.ndarray], ket: list[np.ndarray], conj_bra: bool = True)
     return complex(T[0, 0])
 
 
+# --------------------------------------------------------------------------
+# Simulator.operate: variational application of an MPO to the state
+# --------------------------------------------------------------------------
+def operate(cores0: list[np.ndarray], mpo: list[np.ndarray], maxstep: int = 10, conv_tol: float = 1.0e-8, shift: complex = 0.0):
+    """WFunc.apply_dipole (wavefunction.py:303-351) for the MPS standard method:
+    fit phi ~ O|psi_0> / ||O|psi_0>|| in the bond dimensions of psi_0 by sweeps in which every
+    site tensor is replaced by the mixed-environment apply (bra = phi, ket = psi_0),
+    MPSCoef.apply_dipole / apply_dipole_along_sweep / apply_superOp_direct
+    (_mps_cls.py:421-450, :718-796, :2733-2778).  Returns (norm, cores of phi, iterations)."""
+    n = len(cores0)
+    ket = [np.array(c, dtype=np.complex128) for c in cores0]
+    bra = [c.copy() for c in ket]
+    mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
+    one = np.ones((1, 1, 1), dtype=np.complex128)
+    # construct_op_sites with superblock_states_ket: right blocks from the initial bra / ket pair
+    right = {n - 1: one}
+    for p in range(n - 1, 0, -1):
+        right[p - 1] = env_update_right(right[p], ket[p], mpo[p], bra=bra[p])
+    left = {0: one}
+    norm = 0.0
+
+    def site(p):
+        nonlocal norm
+        y = heff_apply(left[p], mpo[p], right[p], ket[p])
+        if shift != 0.0:
+            y = y + shift * ket[p]  # coupleJ * ovlp term (both states share the bond dimensions)
+        norm = float(np.linalg.norm(y))
+        bra[p] = y / norm
+
+    it = 0
+    for it in range(1, maxstep + 1):
+        prev = [c.copy() for c in bra]
+        for p in range(n):  # ->
+            site(p)
+            if p == n - 1:
+                break
+            bra[p], sv = qr_psi2Asigma(bra[p])
+            bra[p + 1] = np.tensordot(sv, bra[p + 1], axes=(1, 0))
+            ket[p], sv = qr_psi2Asigma(ket[p])
+            ket[p + 1] = np.tensordot(sv, ket[p + 1], axes=(1, 0))
+            left[p + 1] = env_update_left(left[p], ket[p], mpo[p], bra=bra[p])
+        for p in range(n - 1, -1, -1):  # <-
+            site(p)
+            if p == 0:
+                break
+            sv, B = qr_psi2sigmaB(bra[p])
+            bra[p] = np.ascontiguousarray(B)
+            bra[p - 1] = np.tensordot(bra[p - 1], sv, axes=(2, 0))
+            sv, B = qr_psi2sigmaB(ket[p])
+            ket[p] = np.ascontiguousarray(B)
+            ket[p - 1] = np.tensordot(ket[p - 1], sv, axes=(2, 0))
+            right[p - 1] = env_update_right(right[p], ket[p], mpo[p], bra=bra[p])
+        if abs(1 - abs(overlap(bra, prev))) < conv_tol:  # _is_converged, wavefunction.py:285-301
+            break
+    return norm, bra, it
+
+
 def site_rdm(cores: list[np.ndarray], site: int) -> np.ndarray:
     """One-site reduced density matrix rho[j,j'] of a site-0-centred MPS
     (what ``get_reduced_densities`` returns for key (site, site),

@@ -5,7 +5,8 @@ behaviour as the reference classes cited in each docstring; all numerics go
 through ``libmitdvp.so`` (no CPU fallback).  Not supported (raise
 ``NotImplementedError`` like the reference does for unsupported combos):
 multi-state direct-product MPS, SoP/PolynomialHamiltonian, MCTDH SPFs,
-MPI site sharding, subspace projection in Liouville space.
+MPI site sharding, subspace projection in Liouville space.  ``Simulator.relax``, ``.operate`` and
+``.propagate`` chain through ``restart=True`` like in the reference's spectrum workflow.
 """
 
 from __future__ import annotations
@@ -438,5 +439,15 @@ class Simulator:
         self.save_wavefunction(wf, savefile_ext)
         return ener, wf
 
-    def operate(self, *a, **k):
-        raise NotImplementedError("operate (dipole application) is outside the accelerated path")
+    def operate(self, maxstep=10, restart=False, savefile_ext="_operate", loadfile_ext="_gs", verbose=2):
+        """``Simulator.operate`` (simulator_cls.py:286-331, :356-360): apply the Model's
+        "hamiltonian" entry (e.g. a dipole operator) to the wavefunction variationally
+        (``WFunc.apply_dipole``, at most ``maxstep`` double sweeps, converged when
+        |1 - |<phi_i|phi_(i-1)>|| < 1e-8); returns (norm of O|Psi>, WFunc) and saves the state."""
+        eng, ids = self._engine("lanczos", True, 1.0e-9, restart_ext=loadfile_ext if restart else None)
+        norm, iters = eng.operate(0, maxstep)
+        if iters >= maxstep:
+            warnings.warn(f"Operate O|Ψ> is not converged in {maxstep - 1} iterations")
+        wf = self._wfunc(eng, ids)
+        self.save_wavefunction(wf, savefile_ext)
+        return norm, wf

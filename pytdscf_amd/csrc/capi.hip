@@ -167,6 +167,13 @@ int mitdvp_apply_kraus(mitdvp_engine* h) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] { h->e->apply_kraus(); });
 }
+int mitdvp_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, double* norm_out, int* iters_out) {
+  if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
+  return guard(h, [&] {
+    const double n = h->e->operate(op_id, maxstep, conv_tol, iters_out);
+    if (norm_out) *norm_out = n;
+  });
+}
 int mitdvp_set_adaptive(mitdvp_engine* h, int enable, int dmax, int dd, double p_proj) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] { h->e->set_adaptive(enable != 0, dmax, dd, p_proj); });

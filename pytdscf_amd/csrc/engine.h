@@ -146,6 +146,8 @@ class Engine {
   // ancilla on the next site), applied after the gates between the half-sweeps / on demand
   void set_kraus(int isite, int two_site, const double* reim, int k, int d);
   void apply_kraus();
+  // Simulator.operate: variational application of operator op_id to the state (returns the norm)
+  double operate(int op_id, int maxstep, double conv_tol, int* iters_out);
   // adaptive bond dimension (a1TDVP, const.adaptive / Dmax / dD / p_proj, _const_cls.py:120-124)
   void set_adaptive(bool on, int dmax, int dd, double p_proj);
   void thin_to_full_A(const zc* A, int l, int c, int r, int e, zc* out);

@@ -505,4 +505,122 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// Simulator.operate: fit phi ~ O|psi_0> / ||O|psi_0>|| in the bond dimensions of psi_0
+// (WFunc.apply_dipole, wavefunction.py:303-351; MPSCoef.apply_dipole /
+// apply_dipole_along_sweep / apply_superOp_direct, _mps_cls.py:421-450, :718-796,
+// :2733-2778).  Every site tensor of phi is replaced by the mixed-environment apply
+// (bra = phi, ket = psi_0); both states move their centre together; the mixed blocks are
+// environment updates with different bra and ket tensors.  On return the engine's state
+// is phi (site-0 centred, normalised); the norm of the last apply is returned.
+// ---------------------------------------------------------------------------
+double Engine::operate(int op_id, int maxstep, double conv_tol, int* iters_out) {
+  require_ready();
+  if (center_ != 0) throw ArgError("operate needs the centre at site 0");
+  if (maxstep < 1) throw ArgError("operate: maxstep must be >= 1");
+  Operator& o = op(op_id);
+  const hzc shift = o.shift;
+  const zc one = make_double2(1.0, 0.0);
+  const size_t cap = V_.n / MAXK;
+  std::vector<DevBuf> ket(L_), prev(L_), mixL(L_ + 1), mixR(L_ + 1);
+  for (int p = 0; p < L_; ++p) {
+    const size_t e = (size_t)dl_[p] * dd_[p] * dr_[p];
+    ket[p] = pool_get(cap);
+    prev[p] = pool_get(e);
+    HIP_CHECK(hipMemcpyAsync(ket[p].p, site_[p].p, e * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  }
+  mixL[0] = pool_get(1); mixR[L_] = pool_get(1);
+  HIP_CHECK(hipMemcpyAsync(mixL[0].p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipMemcpyAsync(mixR[L_].p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  DevBuf spare = pool_get(cap), kt = pool_get(cap), bt = pool_get(cap);
+  // right blocks of the initial bra / ket pair (construct_op_sites with superblock_states_ket)
+  for (int p = L_ - 1; p >= 1; --p) {
+    const MpoSite& w = mpo(op_id, p);
+    transpose_rev3(st_, ket[p].p, kt.p, dl_[p], dd_[p], dr_[p]);
+    transpose_rev3(st_, site_[p].p, bt.p, dl_[p], dd_[p], dr_[p]);
+    mixR[p] = pool_get((size_t)dl_[p] * w.ml * dl_[p]);
+    env_update_rect(mixR[p + 1].p, kt.p, bt.p, w.w2r.p, mixR[p].p, dr_[p], dr_[p], w.mr, dd_[p], dl_[p], dl_[p], w.ml);
+  }
+  double nrm = 0.0;
+  auto apply_site = [&](int p) {  // apply_superOp_direct
+    const MpoSite& w = mpo(op_id, p);
+    if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
+    heff_apply(mixL[p].p, w, mixR[p + 1].p, ket[p].p, site_[p].p, dl_[p], dd_[p], dr_[p], shift);
+    const long n = (long)dl_[p] * dd_[p] * dr_[p];
+    vec_sumsq(st_, site_[p].p, n, reinterpret_cast<double*>(red_.p + RED_MISC));
+    read_partials(RED_MISC, NPART / 2);
+    const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+    double s2 = 0;
+    for (int i = 0; i < NPART; ++i) s2 += hp[i];
+    nrm = std::sqrt(s2);
+    if (!(nrm > 0.0)) throw ArgError("operate: the operator annihilates the state");
+    vec_scale(st_, site_[p].p, n, make_double2(1.0 / nrm, 0.0));
+    gauge_[p] = MITDVP_GAUGE_PSI;
+  };
+  int it = 0;
+  for (it = 1; it <= maxstep; ++it) {
+    for (int p = 0; p < L_; ++p)
+      HIP_CHECK(hipMemcpyAsync(prev[p].p, site_[p].p, (size_t)dl_[p] * dd_[p] * dr_[p] * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+    for (int p = 0; p < L_; ++p) {  // ->
+      apply_site(p);
+      if (p == L_ - 1) break;
+      const MpoSite& w = mpo(op_id, p);
+      const int l = dl_[p], d = dd_[p], r = dr_[p];
+      gauge_qr_left(site_[p].p, l, d, r, spare.p, sig_.p);  // phi: Psi -> A (its sigma goes into a tensor that is replaced next)
+      std::swap(site_[p], spare);
+      gauge_[p] = MITDVP_GAUGE_A;
+      gauge_qr_left(ket[p].p, l, d, r, spare.p, sig_.p);    // psi_0: Psi -> A sigma, sigma into the next site
+      std::swap(ket[p], spare);
+      ZgemmDesc g = zgemm_desc(sig_.p, ket[p + 1].p, spare.p, r, dd_[p + 1] * dr_[p + 1], r);
+      zgemm(st_, g);
+      std::swap(ket[p + 1], spare);
+      pool_put(std::move(mixL[p + 1]));
+      mixL[p + 1] = pool_get((size_t)r * w.mr * r);
+      env_update_rect(mixL[p].p, ket[p].p, site_[p].p, w.w2l.p, mixL[p + 1].p, l, l, w.ml, d, r, r, w.mr);
+    }
+    for (int p = L_ - 1; p >= 0; --p) {  // <-
+      apply_site(p);
+      if (p == 0) break;
+      const MpoSite& w = mpo(op_id, p);
+      const int l = dl_[p], d = dd_[p], r = dr_[p];
+      gauge_qr_right(site_[p].p, l, d, r, spare.p, bt.p, sig_.p);
+      std::swap(site_[p], spare);
+      gauge_[p] = MITDVP_GAUGE_B;
+      gauge_qr_right(ket[p].p, l, d, r, spare.p, kt.p, sig_.p);
+      std::swap(ket[p], spare);
+      ZgemmDesc g = zgemm_desc(ket[p - 1].p, sig_.p, spare.p, dl_[p - 1] * dd_[p - 1], l, l);
+      zgemm(st_, g);
+      std::swap(ket[p - 1], spare);
+      pool_put(std::move(mixR[p]));
+      mixR[p] = pool_get((size_t)l * w.ml * l);
+      env_update_rect(mixR[p + 1].p, kt.p, bt.p, w.w2r.p, mixR[p].p, r, r, w.mr, d, l, l, w.ml);
+    }
+    // _is_converged (wavefunction.py:285-301): |1 - |<phi_i | phi_{i-1}>|| < conv_tol
+    HIP_CHECK(hipMemcpyAsync(sig_.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+    zc* T = sig_.p;
+    zc* Tn = sig2_.p;
+    for (int p = 0; p < L_; ++p) {
+      const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+      ZgemmDesc u = zgemm_desc(T, prev[p].p, tmp1_.p, dl, d * dr, dl);
+      zgemm(st_, u);
+      ZgemmDesc t = zgemm_desc(site_[p].p, tmp1_.p, Tn, dr, dr, dl * d);
+      t.transA = 1; t.conjA = 1; t.lda = dr;
+      zgemm(st_, t);
+      std::swap(T, Tn);
+    }
+    hzc ov;
+    HIP_CHECK(hipMemcpyAsync(&ov, T, sizeof(zc), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    if (std::fabs(1.0 - std::abs(ov)) < conv_tol) break;
+    if (it == maxstep) break;
+  }
+  center_ = 0;
+  invalidate_env();
+  for (auto* v : {&ket, &prev, &mixL, &mixR})
+    for (auto& b : *v) pool_put(std::move(b));
+  pool_put(std::move(spare)); pool_put(std::move(kt)); pool_put(std::move(bt));
+  if (iters_out) *iters_out = std::min(it, maxstep);
+  return nrm;
+}
+
 }  // namespace mitdvp

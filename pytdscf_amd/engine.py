@@ -150,6 +150,13 @@ class TDVPEngine:
             shape += [self.get_site_shape(p)[1]] * k
         return out.reshape(shape)
 
+    def operate(self, op_id: int = 0, maxstep: int = 10, conv_tol: float = 1.0e-8):
+        """``Simulator.operate``: replace the state by O|psi> / ||O|psi>|| fitted in the current
+        bond dimensions; returns (norm of the last apply, double sweeps done)."""
+        nrm, it = C.c_double(), C.c_int()
+        self._ck(self._lib.mitdvp_operate(self._h, op_id, maxstep, conv_tol, C.byref(nrm), C.byref(it)))
+        return nrm.value, it.value
+
     def set_gates(self, gates: dict | None) -> None:
         """Register one-site gates ``{site: U}`` (``Model(one_gate_to_apply=...)``): U is
         d x d (U[d_out, d_in]) or a length-d diagonal; ``propagate`` applies them between its

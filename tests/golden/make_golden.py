@@ -751,6 +751,30 @@ def main():
         o[f"n{n}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(Lk + 1)])
     save("kraus_two_site.npz", dt_au=np.array(dt_k / au_in_fs), bond_dim=np.array(Dk), d=np.array(dk), K=np.array(Kk), **o)
 
+    # (viii) Simulator.operate: variational application of an operator (the Model's "hamiltonian"
+    # entry, simulator_cls.py:356-360) to the state -> WFunc.apply_dipole (wavefunction.py:303-351)
+    rng_o = np.random.default_rng(60606)
+
+    def crandn_o(*shape):
+        return rng_o.standard_normal(shape) + 1j * rng_o.standard_normal(shape)
+
+    Lo, do, Mo, Do = 6, 3, 3, 5
+    dip = orc.synthetic_mpo(Lo, do, Mo, seed=21)
+    for p_ in range(Lo):  # a "dipole": make the local terms O(1) so that O|psi> is far from |psi>
+        dip[p_][0, :, :, dip[p_].shape[3] - 1] += crandn_o(do, do)
+    cores_o = [crandn_o(dl, do, dr) for (dl, dr) in orc.bond_dims([do] * Lo, Do)]
+    model_o = Model([Exciton(nstate=do) for _ in range(Lo)], operators={"hamiltonian": [w.copy() for w in dip]}, bond_dim=Do)
+    model_o.init_HartreeProduct = [[np.array(c) for c in cores_o]]
+    o = {f"mpo{i}": w for i, w in enumerate(dip)}
+    o.update({f"init{i}": c for i, c in enumerate(cores_o)})
+    for n in (1, 10):
+        sim = Simulator("gold_operate", model_o, backend="numpy", verbose=0)
+        nrm, wf = sim.operate(maxstep=n)
+        o[f"n{n}_norm"] = np.array(nrm)
+        for i, s_ in enumerate(wf.ci_coef.superblock_states[0]):
+            o[f"n{n}_final{i}"] = np.array(s_.data)
+    save("operate_chain.npz", nsite=np.array(Lo), bond_dim=np.array(Do), **o)
+
 
 if __name__ == "__main__":
     main()

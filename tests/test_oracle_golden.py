@@ -283,3 +283,15 @@ def test_kraus_maps_on_purified_states(golden, name, key):
         other = "rdm2" if len(key) == 1 else "rdm3"
         legs = (0, 0, 2) if len(key) == 1 else (0, 0, 0, 2)
         np.testing.assert_allclose(orc.reduced_density(st.cores, legs), g[f"n{ns}_{other}"], atol=1e-10)
+
+
+def test_operate_variational_application(golden):
+    """Simulator.operate / WFunc.apply_dipole: norm and tensors after 1 and 10 double sweeps."""
+    g = golden("operate_chain.npz")
+    n, mpo, init = _load_chain(g)
+    for ns in (1, 10):
+        nrm, bra, it = orc.operate(orc.canonicalize_site0(init), mpo, maxstep=ns)
+        assert it == ns
+        np.testing.assert_allclose(nrm, float(g[f"n{ns}_norm"]), rtol=1e-12)
+        for i in range(n):
+            np.testing.assert_allclose(bra[i], g[f"n{ns}_final{i}"], atol=1e-11)

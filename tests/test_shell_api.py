@@ -202,3 +202,34 @@ def test_restart_from_saved_wavefunction(golden, tmp_path, monkeypatch):
     e_gs, _ = sim2.relax(stepsize=2.0, maxstep=6, improved=True, savefile_ext="_gs")
     e0, _ = sim2.propagate(stepsize=0.1, maxstep=2, restart=True, loadfile_ext="_gs")
     assert e0 == pytest.approx(e_gs, abs=1e-6)
+
+
+@pytest.mark.gpu
+def test_relax_operate_propagate_workflow(golden, tmp_path, monkeypatch):
+    """The reference's spectrum workflow (tests/test_harmonic_dvr_func_full_mpssm_jax.py):
+    relax -> operate(restart=True) with a "dipole" Model -> propagate(restart=True)."""
+    from pytdscf_amd import Exciton, Model, Simulator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("operate_chain.npz")
+    n = int(g["nsite"])
+    basis = [Exciton(nstate=3) for _ in range(n)]
+    ham = orc.synthetic_mpo(n, 3, 4, seed=0)
+    dip = [g[f"mpo{i}"] for i in range(n)]
+    m_h = Model(basis, operators={"hamiltonian": ham}, bond_dim=int(g["bond_dim"]))
+    m_h.init_HartreeProduct = [[g[f"init{i}"] for i in range(n)]]
+    m_d = Model(basis, operators={"hamiltonian": dip}, bond_dim=int(g["bond_dim"]))
+    e_gs, wf_gs = Simulator("wfl", m_h, backend="hip").relax(stepsize=2.0, maxstep=4, improved=True)
+    gs = wf_gs.get_mps()
+    norm, wf_op = Simulator("wfl", m_d, backend="hip").operate(restart=True, maxstep=10)
+    n_o, ref, _ = orc.operate(gs, dip, maxstep=10)
+    assert norm == pytest.approx(n_o, rel=1e-9)
+    assert abs(abs(orc.overlap(ref, wf_op.get_mps())) - 1) < 1e-9
+    assert (tmp_path / "wf_wfl_operate.npz").exists()
+    _, wf_t = Simulator("wfl", m_h, backend="hip").propagate(stepsize=0.05, maxstep=2, restart=True)  # loadfile_ext="_operate"
+    from pytdscf_amd import units
+
+    st = orc.OracleMPS([c.copy() for c in ref], ham)
+    for _ in range(2):
+        st.propagate(0.05 / units.au_in_fs)
+    assert abs(abs(orc.overlap(st.cores, wf_t.get_mps())) - 1) < 1e-8
