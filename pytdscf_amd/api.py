@@ -414,6 +414,12 @@ class Simulator:
                     self.save_wavefunction(wf, savefile_ext)
                 eng.propagate(dt_au)
             self.save_wavefunction(wf, savefile_ext)
+            if reduced_density is not None and self.rdm_trace:
+                # the reference writes reduced_density.nc (netCDF4, properties.py:156-209); same
+                # content as arrays: time[t] and rho_{key}[t, ...] per requested key
+                keys = list(self.rdm_trace[0][1])
+                np.savez(os.path.join(outdir, "reduced_density.npz"), time=np.array([t for t, _ in self.rdm_trace]),
+                         **{f"rho_{k}": np.array([r[k] for _, r in self.rdm_trace]) for k in keys})
         finally:
             for f in files.values():
                 f.close()

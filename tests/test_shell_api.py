@@ -73,6 +73,9 @@ def test_exciton_script_on_gpu(golden, tmp_path, monkeypatch):
     assert abs(wf.norm() - 1) < 1e-12
     lines = open(tmp_path / "LVC_Exciton_test_prop" / "autocorr.dat").read().splitlines()
     assert lines[0].startswith("# time [fs]") and len(lines) == 21
+    z = np.load(tmp_path / "LVC_Exciton_test_prop" / "reduced_density.npz")
+    assert z["time"].shape == (20,) and z["rho_(3, 3)"].shape == (20, 2, 2)
+    np.testing.assert_allclose(z["rho_(3, 3)"][-1], g["ref_pin_rdm33"], atol=1e-9)
 
 
 @pytest.mark.gpu
