@@ -174,7 +174,14 @@ def main():
     if mode == "tp":
         from pytdscf_amd.dist import attach_parallel
 
-        attach_parallel(eng, comm)
+        try:
+            attach_parallel(eng, comm)  # includes a collective self-test with a verdict common to all ranks
+        except RuntimeError as e:
+            # every rank gets here together: run N independent trajectories instead
+            if rank == 0:
+                print(f"[bench] {e}; falling back to independent replicas", file=sys.stderr, flush=True)
+            mode = "replicas"
+            eng.init_random([d] * L, D, seed=1 + rank)
     e0 = eng.expectation().real  # also builds nothing persistent; forces setup to finish
 
     def note(msg):

@@ -1,11 +1,10 @@
 """Multi-GPU plumbing: one process per GPU under ``torch.distributed``
 (backend "nccl" = RCCL on ROCm; "gloo" on CPU-only hosts for tests).
 
-Round 1 shards nothing on the data path (the serial sweep is a dependency
-chain): ranks run independent replicas and only
-synchronise around the timed region.  This module is the whole N>1 surface:
-rendezvous, barrier, max-over-ranks of the elapsed time, and the replica
-throughput aggregation used by bench.py."""
+This module is the whole N>1 surface: rendezvous, barrier, max-over-ranks of
+the elapsed time, the replica throughput aggregation used by bench.py, and
+``attach_parallel``: the collectives of the bond-sharded (tensor-parallel)
+execution of one sweep over several GPUs."""
 
 from __future__ import annotations
 
@@ -51,6 +50,15 @@ class Comm:
 
         t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def min_over_ranks(self, x: float) -> float:
+        if self.dist is None:
+            return float(x)
+        import torch
+
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return float(t.item())
 
     def sum_over_ranks(self, x: float) -> float:
@@ -145,6 +153,19 @@ def attach_parallel(engine, comm: Comm, host_staged: bool | None = None):
 
             traceback.print_exc(file=sys.stderr)
             return 1
+
+    # self-test of both collectives on a small device buffer before the engine relies on them;
+    # every rank learns the common verdict, so all take the same decision afterwards
+    probe = torch.full((world * 8,), -1.0, dtype=torch.float64, device=dev)
+    probe[rank * 8 : (rank + 1) * 8] = float(rank + 1)
+    ok = cb(None, 0, probe.data_ptr(), probe.numel() * 8) == 0
+    want = torch.arange(1, world + 1, dtype=torch.float64).repeat_interleave(8)
+    ok = ok and bool(torch.equal(probe.cpu(), want))
+    probe.fill_(float(rank + 1))
+    ok = ok and cb(None, 1, probe.data_ptr(), probe.numel() * 8) == 0
+    ok = ok and bool(torch.all(probe.cpu() == world * (world + 1) / 2))
+    if comm.min_over_ranks(1.0 if ok else 0.0) < 1.0:
+        raise RuntimeError("bond-sharded mode: the collective self-test failed on at least one rank")
 
     fn = _lib.COLLECTIVE_FN(cb)
     engine._collective_cb = fn  # keep the trampoline alive as long as the engine
