@@ -54,3 +54,19 @@ def test_expm_tridiag_and_dense(shim, k):
     out = np.zeros(2 * k)
     shim.sl_expm_col0(_dp(m), k, _dp(out))
     np.testing.assert_allclose(out[0::2] + 1j * out[1::2], scipy.linalg.expm(G)[:, 0], atol=1e-12, rtol=1e-12)
+
+
+def test_host_algebra_under_address_and_ub_sanitizers(tmp_path):
+    """The host-side algebra compiled with -fsanitize=address,undefined and run standalone
+    (GPU sanitizers are unavailable on the pool; this is the part of the library that can be)."""
+    exe = tmp_path / "sl_san"
+    src = os.path.join(HERE, "helpers", "small_linalg_sanitize.cpp")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", src, "-o", str(exe)],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr or ""):
+        pytest.skip("sanitizer runtime not installed: " + r.stderr.splitlines()[-1])
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", LD_PRELOAD=""))
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "0 failures" in run.stdout
