@@ -175,7 +175,12 @@ def main():
         from pytdscf_amd.dist import attach_parallel
 
         try:
-            attach_parallel(eng, comm)  # includes a collective self-test with a verdict common to all ranks
+            if os.environ.get("MITDVP_COLLECTIVES", "torch") == "native":
+                from pytdscf_amd.dist import attach_parallel_native
+
+                attach_parallel_native(eng, comm)  # the library's own RCCL calls on the engine's stream
+            else:
+                attach_parallel(eng, comm)  # includes a collective self-test with a verdict common to all ranks
         except RuntimeError as e:
             # every rank gets here together: run N independent trajectories instead
             if rank == 0:

@@ -115,6 +115,16 @@ int mitdvp_invalidate_env(mitdvp_engine* h);
 typedef int (*mitdvp_collective_fn)(void* user, int op, void* dev_ptr, size_t nbytes);
 int mitdvp_set_parallel(mitdvp_engine* h, int nranks, int rank, mitdvp_collective_fn fn, void* user);
 
+/* The same bond-sharded mode with the collectives issued by the library itself: RCCL
+ * (librccl, resolved with dlopen on first use) on the engine's own HIP stream, stream-ordered,
+ * no host synchronisation per collective.  One rank creates the 128-byte ncclUniqueId with
+ * mitdvp_rccl_unique_id and distributes it out of band (torch.distributed, MPI, a file);
+ * every rank then calls mitdvp_set_parallel_rccl.  mitdvp_rccl_selftest runs one all-gather and
+ * one all-reduce on a small device buffer and returns the number of wrong values. */
+int mitdvp_rccl_unique_id(char out[128]);
+int mitdvp_set_parallel_rccl(mitdvp_engine* h, int nranks, int rank, const char id[128]);
+int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches);
+
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */

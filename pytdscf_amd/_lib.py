@@ -118,6 +118,9 @@ def load() -> C.CDLL:
         "mitdvp_svd": (i, [i, dp, i, i, dp, dp, dp, ip]),
         "mitdvp_set_adaptive": (i, [vp, i, i, i, d]),
         "mitdvp_set_gate": (i, [vp, i, dp, i]),
+        "mitdvp_rccl_unique_id": (i, [C.c_char_p]),
+        "mitdvp_set_parallel_rccl": (i, [vp, i, i, C.c_char_p]),
+        "mitdvp_rccl_selftest": (i, [vp, ip]),
         "mitdvp_operate": (i, [vp, i, i, d, dp, ip]),
         "mitdvp_set_kraus": (i, [vp, i, i, dp, i, i]),
         "mitdvp_apply_kraus": (i, [vp]),

@@ -167,6 +167,17 @@ int mitdvp_apply_kraus(mitdvp_engine* h) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] { h->e->apply_kraus(); });
 }
+int mitdvp_rccl_unique_id(char out[128]) {
+  return guard(nullptr, [&] { mitdvp::Engine::rccl_unique_id(out); });
+}
+int mitdvp_set_parallel_rccl(mitdvp_engine* h, int nranks, int rank, const char id[128]) {
+  if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
+  return guard(h, [&] { h->e->set_parallel_rccl(nranks, rank, id); });
+}
+int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches) {
+  if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
+  return guard(h, [&] { *mismatches = h->e->rccl_selftest(); });
+}
 int mitdvp_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, double* norm_out, int* iters_out) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] {

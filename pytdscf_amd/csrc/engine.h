@@ -113,6 +113,10 @@ class Engine {
   void counters_reset();
   void set_profiling(bool on) { profiling_ = on; }
   void set_parallel(int nranks, int rank, CollFn fn, void* user);
+  // native RCCL collectives on the engine's stream (librccl resolved with dlopen)
+  static void rccl_unique_id(char out[128]);
+  void set_parallel_rccl(int nranks, int rank, const char id_bytes[128]);
+  int rccl_selftest();
 
   std::string last_error;
 
@@ -181,6 +185,7 @@ class Engine {
   // bond-sharded multi-GPU execution
   int nranks_ = 1, rank_ = 0;
   CollFn coll_ = nullptr;
+  void* rccl_comm_ = nullptr;  // ncclComm_t when the native path is active
   void* coll_user_ = nullptr;
   bool shard_range(int n, int& a0, int& a1) const;
   void collective(int op, zc* p, size_t elems);

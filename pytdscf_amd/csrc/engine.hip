@@ -14,6 +14,7 @@
 // its convergence test.
 #include "engine_internal.h"
 #include "engine_krylov.inc"
+#include "rccl_dyn.h"
 
 namespace mitdvp {
 
@@ -49,6 +50,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
 
 Engine::~Engine() {
   if (st_) (void)hipStreamSynchronize(st_);
+  if (rccl_comm_) (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(rccl_comm_));
   for (auto& t : pending_) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& e : evpool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h_red_) (void)hipHostFree(h_red_);
@@ -261,6 +263,7 @@ void Engine::require_ready() {
 void Engine::set_parallel(int nranks, int rank, CollFn fn, void* user) {
   if (nranks < 1 || rank < 0 || rank >= nranks) throw ArgError("set_parallel: bad rank / nranks");
   if (nranks > 1 && !fn) throw ArgError("set_parallel: a collective callback is required for nranks > 1");
+  if (rccl_comm_) { (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(rccl_comm_)); rccl_comm_ = nullptr; }
   nranks_ = nranks; rank_ = rank; coll_ = fn; coll_user_ = user;
 }
 
@@ -273,11 +276,72 @@ bool Engine::shard_range(int n, int& a0, int& a1) const {
 }
 
 void Engine::collective(int op, zc* p, size_t elems) {
-  HIP_CHECK(hipStreamSynchronize(st_));
-  const int rc = coll_(coll_user_, op, p, elems * sizeof(zc));
-  if (rc != 0) throw HipError("collective callback failed (rc=" + std::to_string(rc) + ")");
+  if (rccl_comm_) {
+    // native path: stream-ordered RCCL collectives on the engine's own stream -- no host
+    // synchronisation, the Krylov loop stays asynchronous between its convergence checks
+    const RcclApi& r = RcclApi::get();
+    ncclComm_t comm = static_cast<ncclComm_t>(rccl_comm_);
+    const size_t n = elems * 2;  // float64 values
+    if (op == COLL_ALLGATHER) {
+      const size_t chunk = n / nranks_;
+      double* base = reinterpret_cast<double*>(p);
+      rccl_check(r.all_gather(base + (size_t)rank_ * chunk, base, chunk, ncclDouble, comm, st_), "ncclAllGather");
+    } else {
+      rccl_check(r.all_reduce(p, p, n, ncclDouble, ncclSum, comm, st_), "ncclAllReduce");
+    }
+  } else {
+    HIP_CHECK(hipStreamSynchronize(st_));
+    const int rc = coll_(coll_user_, op, p, elems * sizeof(zc));
+    if (rc != 0) throw HipError("collective callback failed (rc=" + std::to_string(rc) + ")");
+  }
   cnt_.n_collectives += 1;
   cnt_.collective_bytes += (double)(elems * sizeof(zc));
+}
+
+// RCCL communicator owned by the engine (one process per GPU; `id` = the 128 bytes of an
+// ncclUniqueId created on one rank by rccl_unique_id() and distributed out of band)
+void Engine::rccl_unique_id(char out[128]) {
+  ncclUniqueId id;
+  rccl_check(RcclApi::get().get_unique_id(&id), "ncclGetUniqueId");
+  static_assert(sizeof(id.internal) == 128, "ncclUniqueId size");
+  std::memcpy(out, id.internal, 128);
+}
+
+void Engine::set_parallel_rccl(int nranks, int rank, const char id_bytes[128]) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) throw ArgError("set_parallel_rccl: bad rank / nranks");
+  const RcclApi& r = RcclApi::get();
+  if (rccl_comm_) { (void)r.comm_destroy(static_cast<ncclComm_t>(rccl_comm_)); rccl_comm_ = nullptr; }
+  ncclUniqueId id;
+  std::memcpy(id.internal, id_bytes, 128);
+  ncclComm_t comm = nullptr;
+  rccl_check(r.comm_init_rank(&comm, nranks, id, rank), "ncclCommInitRank");
+  rccl_comm_ = comm;
+  nranks_ = nranks; rank_ = rank; coll_ = nullptr; coll_user_ = nullptr;
+}
+
+// both collectives on a small device buffer: returns 0 when the gathered / reduced values are right
+int Engine::rccl_selftest() {
+  if (!rccl_comm_) throw ArgError("rccl_selftest: no RCCL communicator (call set_parallel_rccl)");
+  const int per = 8;
+  std::vector<hzc> h((size_t)nranks_ * per, hzc(-1.0, -1.0));
+  for (int i = 0; i < per; ++i) h[(size_t)rank_ * per + i] = hzc(rank_ + 1.0, 0.5);
+  DevBuf b = pool_get(h.size());
+  HIP_CHECK(hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  collective(COLL_ALLGATHER, b.p, h.size());
+  HIP_CHECK(hipMemcpyAsync(h.data(), b.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  int bad = 0;
+  for (int r = 0; r < nranks_; ++r)
+    for (int i = 0; i < per; ++i) bad += h[(size_t)r * per + i] != hzc(r + 1.0, 0.5);
+  for (auto& x : h) x = hzc(rank_ + 1.0, 1.0);
+  HIP_CHECK(hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  collective(COLL_ALLREDUCE, b.p, h.size());
+  HIP_CHECK(hipMemcpyAsync(h.data(), b.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  const hzc want(nranks_ * (nranks_ + 1) / 2.0, (double)nranks_);
+  for (auto& x : h) bad += x != want;
+  pool_put(std::move(b));
+  return bad;
 }
 
 // The blocks may be rectangular (bra bond != ket bond): L (dlo, ml, dli), R (dro, mr, dri),

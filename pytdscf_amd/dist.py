@@ -100,6 +100,29 @@ class _DevPtr:
         }
 
 
+def attach_parallel_native(engine, comm: Comm):
+    """Bond-sharded mode with the library's own RCCL collectives on the engine's stream
+    (``mitdvp_set_parallel_rccl``): torch.distributed only carries the 128-byte ncclUniqueId
+    from rank 0 to the others and the verdict of the self-test."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    if comm.world == 1:
+        return
+    ident = C.create_string_buffer(128)
+    if comm.rank == 0:
+        _lib.check(lib.mitdvp_rccl_unique_id(ident))
+    box = [ident.raw]
+    comm.dist.broadcast_object_list(box, src=0)
+    _lib.check(lib.mitdvp_set_parallel_rccl(engine._h, comm.world, comm.rank, box[0]), engine._h)
+    bad = C.c_int(-1)
+    _lib.check(lib.mitdvp_rccl_selftest(engine._h, C.byref(bad)), engine._h)
+    if comm.min_over_ranks(1.0 if bad.value == 0 else 0.0) < 1.0:
+        raise RuntimeError("bond-sharded mode (native RCCL): the collective self-test failed on at least one rank")
+
+
 def attach_parallel(engine, comm: Comm, host_staged: bool | None = None):
     """Put ``engine`` (a TDVPEngine living on this rank's GPU) into bond-sharded
     mode over ``comm``.  All ranks must hold the same replicated state and issue

@@ -139,3 +139,33 @@ def test_nccl_device_collectives_world1(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout + p.stderr
+
+
+def test_native_rccl_collectives_world1(tmp_path):
+    """The library's own RCCL path (dlopen'ed librccl, communicator owned by the engine,
+    collectives on the engine's stream) at world size 1: unique id, communicator, all-gather and
+    all-reduce self-test.  More ranks need more GPUs than the test box has."""
+    script = tmp_path / "r.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, ctypes as C
+        sys.path.insert(0, {ROOT!r})
+        from oracle import tdvp_oracle as orc
+        from pytdscf_amd import TDVPEngine, _lib
+        lib = _lib.load()
+        ident = C.create_string_buffer(128)
+        _lib.check(lib.mitdvp_rccl_unique_id(ident))
+        assert any(ident.raw)
+        eng = TDVPEngine(4)
+        eng.set_mpo(orc.synthetic_mpo(4, 3, 3, seed=1))
+        eng.set_mps(orc.synthetic_mps([3] * 4, 4), canonicalize=True)
+        _lib.check(lib.mitdvp_set_parallel_rccl(eng._h, 1, 0, ident.raw), eng._h)
+        bad = C.c_int(-1)
+        _lib.check(lib.mitdvp_rccl_selftest(eng._h, C.byref(bad)), eng._h)
+        assert bad.value == 0, bad.value
+        eng.propagate(0.1)
+        assert abs(eng.norm() - 1) < 1e-12 and eng.counters()["n_collectives"] == 2
+        eng.close()
+        print("OK")
+    """))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout + p.stderr
