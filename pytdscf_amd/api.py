@@ -146,9 +146,9 @@ class Model:
         if space.lower() not in ("hilbert", "liouville"):
             raise ValueError(f"space must be 'hilbert' or 'liouville' but got {space}")
         if subspace_inds is not None:
-            raise NotImplementedError("subspace projection in Liouville space is a 'next' row")
+            raise NotImplementedError("subspace projection of Liouville-space sites (subspace_inds) is not implemented (DESIGN.md section 9)")
         if build_td_hamiltonian is not None:
-            raise NotImplementedError("time-dependent Hamiltonians are a 'next' row")
+            raise NotImplementedError("time-dependent Hamiltonians (const.doTDHamil is never enabled by the reference either)")
         if kraus_op is not None and not isinstance(kraus_op, dict):
             raise TypeError("kraus_op must be a dict {(site,) | (site, site + 1): array (k, d, d)}")
         self.kraus_op = kraus_op
