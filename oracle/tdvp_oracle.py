@@ -826,19 +826,23 @@ def operate(cores0: list[np.ndarray], mpo: list[np.ndarray], maxstep: int = 10, 
     ket = [np.array(c, dtype=np.complex128) for c in cores0]
     bra = [c.copy() for c in ket]
     mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
+    # the scalar term coupleJ * ovlp (_contraction.py:1200-1216) goes through the OVERLAP blocks of
+    # the bra / ket pair, which are not identities here (phi != psi_0): carry it as a second
+    # operator chain with identity cores
+    ops = [mpo] + ([[np.eye(c.shape[1], dtype=np.complex128)[None, :, :, None] for c in ket]] if shift != 0.0 else [])
+    coef = [1.0, shift]
     one = np.ones((1, 1, 1), dtype=np.complex128)
     # construct_op_sites with superblock_states_ket: right blocks from the initial bra / ket pair
-    right = {n - 1: one}
-    for p in range(n - 1, 0, -1):
-        right[p - 1] = env_update_right(right[p], ket[p], mpo[p], bra=bra[p])
-    left = {0: one}
+    right = [{n - 1: one} for _ in ops]
+    for k, w in enumerate(ops):
+        for p in range(n - 1, 0, -1):
+            right[k][p - 1] = env_update_right(right[k][p], ket[p], w[p], bra=bra[p])
+    left = [{0: one} for _ in ops]
     norm = 0.0
 
     def site(p):
         nonlocal norm
-        y = heff_apply(left[p], mpo[p], right[p], ket[p])
-        if shift != 0.0:
-            y = y + shift * ket[p]  # coupleJ * ovlp term (both states share the bond dimensions)
+        y = sum(coef[k] * heff_apply(left[k][p], w[p], right[k][p], ket[p]) for k, w in enumerate(ops))
         norm = float(np.linalg.norm(y))
         bra[p] = y / norm
 
@@ -853,7 +857,8 @@ def operate(cores0: list[np.ndarray], mpo: list[np.ndarray], maxstep: int = 10, 
             bra[p + 1] = np.tensordot(sv, bra[p + 1], axes=(1, 0))
             ket[p], sv = qr_psi2Asigma(ket[p])
             ket[p + 1] = np.tensordot(sv, ket[p + 1], axes=(1, 0))
-            left[p + 1] = env_update_left(left[p], ket[p], mpo[p], bra=bra[p])
+            for k, w in enumerate(ops):
+                left[k][p + 1] = env_update_left(left[k][p], ket[p], w[p], bra=bra[p])
         for p in range(n - 1, -1, -1):  # <-
             site(p)
             if p == 0:
@@ -864,7 +869,8 @@ def operate(cores0: list[np.ndarray], mpo: list[np.ndarray], maxstep: int = 10, 
             sv, B = qr_psi2sigmaB(ket[p])
             ket[p] = np.ascontiguousarray(B)
             ket[p - 1] = np.tensordot(ket[p - 1], sv, axes=(2, 0))
-            right[p - 1] = env_update_right(right[p], ket[p], mpo[p], bra=bra[p])
+            for k, w in enumerate(ops):
+                right[k][p - 1] = env_update_right(right[k][p], ket[p], w[p], bra=bra[p])
         if abs(1 - abs(overlap(bra, prev))) < conv_tol:  # _is_converged, wavefunction.py:285-301
             break
     return norm, bra, it

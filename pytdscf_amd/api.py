@@ -23,25 +23,45 @@ from .operators import merge_operator_terms
 
 
 class TensorOperator:
-    """``TensorOperator(mpo=[cores], legs=(...))`` -- dvr_operator_cls.py:92-180.
+    """``TensorOperator(mpo=[cores], legs=(...))`` or a dense grid tensor
+    (``shape=`` / ``tensor=``, ``only_diag``) that is decomposed into MPO cores on
+    demand -- dvr_operator_cls.py:92-180, :359-485.
 
-    Only the already-decomposed form (``mpo=``) is part of the hot-path
-    boundary; dense-tensor decomposition is setup-time work of the reference.
     ``legs``: one entry per diagonal 3-leg core, two equal entries per 4-leg core.
+    Dense tensors: ``only_diag=True`` -- a function on the DVR grid, shape (n_1, .., n_f),
+    decomposed by a tensor-train SVD sweep (``decompose``, the reference's ``_SVD``:
+    left-to-right SVDs, ranks cut by the contribution ``rate`` or a bond dimension cap);
+    a one-site tensor (vector or matrix) becomes a single core.
     """
 
     def __init__(self, *, shape=None, tensor=None, only_diag=False, legs=None, name=None, mpo=None):
-        if mpo is None:
-            raise NotImplementedError("pytdscf_amd ingests finished MPO cores (mpo=...); TT decomposition is setup-time work")
-        self.tensor_decomposed = [np.asarray(c) for c in mpo]
-        self.only_diag = all(c.ndim == 3 for c in self.tensor_decomposed)
-        if legs is None:
-            legs = []
-            for i, c in enumerate(self.tensor_decomposed):
-                legs += [i] if c.ndim == 3 else [i, i]
-        self.legs = tuple(legs)
         self.name = name
-        self.bond_dimension = [1] + [c.shape[-1] for c in self.tensor_decomposed]
+        if mpo is not None:
+            self.tensor_decomposed = [np.asarray(c) for c in mpo]
+            self.only_diag = all(c.ndim == 3 for c in self.tensor_decomposed)
+            if legs is None:
+                legs = []
+                for i, c in enumerate(self.tensor_decomposed):
+                    legs += [i] if c.ndim == 3 else [i, i]
+            self.legs = tuple(legs)
+            self.bond_dimension = [1] + [c.shape[-1] for c in self.tensor_decomposed]
+            self._set_sites()
+            return
+        if tensor is None:
+            if shape is None:
+                raise ValueError("TensorOperator needs mpo=, tensor= or shape=")
+            tensor = np.zeros(tuple(shape), dtype=np.float64)
+        self.tensor_orig = np.array(tensor)
+        self.shape = self.tensor_orig.shape
+        self.only_diag = bool(only_diag)
+        if legs is None:
+            legs = tuple(range(len(self.shape))) if self.only_diag else tuple(i // 2 for i in range(len(self.shape)))
+        self.legs = tuple(legs)
+        if not self.only_diag and len(set(self.legs)) > 1:
+            raise NotImplementedError("dense non-diagonal multi-site tensors: pass finished MPO cores (mpo=...)")
+        self.sites = sorted(set(int(x) for x in self.legs))
+
+    def _set_sites(self):
         sites, it = [], iter(self.legs)
         for c in self.tensor_decomposed:
             s = next(it)
@@ -49,6 +69,58 @@ class TensorOperator:
                 raise ValueError("4-leg core needs two equal consecutive legs")
             sites.append(int(s))
         self.sites = sites
+
+    def decompose(self, bond_dimension=None, decompose_type="SVD", rate=None, square_sum=True, overwrite=False):
+        """MPO cores of a dense tensor (dvr_operator_cls.py:423-485).  Tensor-train SVD for
+        both ``decompose_type`` values (the reference's "QRD" is the exact, untruncated
+        decomposition: that is rate=None, no bond cap here); ranks are cut where the
+        cumulative (squared, if ``square_sum``) singular values reach ``rate``."""
+        if hasattr(self, "tensor_decomposed") and not overwrite:
+            return self.tensor_decomposed
+        if rate is not None and not 0.0 < rate < 1.0:
+            raise ValueError(f"Contribution rate must be in (0.0, 1.0), but {rate}")
+        if decompose_type.lower() not in ("svd", "sv", "qrd", "qr"):
+            raise ValueError('decompose_type must be "QRD" or "SVD"')
+        if decompose_type.lower() in ("qrd", "qr"):
+            rate, bond_dimension = None, None
+        t = self.tensor_orig
+        if len(set(self.legs)) == 1:  # one site: a diagonal (vector) or a matrix
+            self.tensor_decomposed = [t.reshape((1,) + t.shape + (1,))]
+        else:
+            nsite = t.ndim
+            caps = [bond_dimension] * (nsite - 1) if isinstance(bond_dimension, int) else (
+                list(bond_dimension)[1:-1] if bond_dimension is not None else [None] * (nsite - 1))
+            cores, r, rank = [], t.reshape(1, -1), 1
+            for i, n in enumerate(self.shape[:-1]):
+                mat = r.reshape(rank * n, -1)
+                U, sv, Vh = np.linalg.svd(mat, full_matrices=False)
+                keep = len(sv)
+                if caps[i] is not None:
+                    keep = min(keep, int(caps[i]))
+                if rate is not None:
+                    w = sv**2 if square_sum else sv
+                    tot, cum, k = w.sum(), 0.0, 0
+                    while k < keep and (tot == 0.0 or cum / tot < rate):
+                        cum += w[k]
+                        k += 1
+                    keep = max(k, 1)
+                cores.append(U[:, :keep].reshape(rank, n, keep))
+                r = sv[:keep, None] * Vh[:keep]
+                rank = keep
+            cores.append(r.reshape(rank, self.shape[-1], 1))
+            self.tensor_decomposed = cores
+        self.bond_dimension = [1] + [c.shape[-1] for c in self.tensor_decomposed]
+        if self.only_diag or len(set(self.legs)) > 1:
+            self.legs = tuple(self.legs)
+        self._set_sites()
+        return self.tensor_decomposed
+
+    def get_tensor_full(self):
+        """Dense tensor restored from the cores (dvr_operator_cls.py:267-277, :547-554)."""
+        out = self.tensor_decomposed[0]
+        for c in self.tensor_decomposed[1:]:
+            out = np.tensordot(out, c, axes=(out.ndim - 1, 0))
+        return out.reshape(out.shape[1:-1])
 
 
 def _as_term_dict(x):
@@ -80,6 +152,9 @@ class TensorHamiltonian:
             if k in self.terms:
                 raise ValueError(f"operator key {k} given twice")
             self.terms[k] = v
+        for op in self.terms.values():  # dense grid tensors -> MPO cores (hamiltonian_cls.py:705-722)
+            if not hasattr(op, "tensor_decomposed"):
+                op.decompose(bond_dimension=bond_dimension, decompose_type=decompose_type, rate=rate)
         self.coupleJ = [[0.0]]  # hamiltonian_cls.py:337-358 scalar couplings
 
     def as_mpo(self, dims):

@@ -522,16 +522,32 @@ double Engine::operate(int op_id, int maxstep, double conv_tol, int* iters_out) 
   const hzc shift = o.shift;
   const zc one = make_double2(1.0, 0.0);
   const size_t cap = V_.n / MAXK;
-  std::vector<DevBuf> ket(L_), prev(L_), mixL(L_ + 1), mixR(L_ + 1);
+  std::vector<DevBuf> ket(L_), prev(L_), mixL(L_ + 1), mixR(L_ + 1), ovL(L_ + 1), ovR(L_ + 1);
+  // The scalar term coupleJ * ovlp (_contraction.py:1200-1216) goes through the OVERLAP blocks of
+  // the bra / ket pair, which are not identities here (phi != psi_0): it is carried as a second
+  // operator chain whose cores are identities (bond dimension 1).
+  const bool has_shift = shift != hzc(0.0, 0.0);
+  std::map<int, MpoSite> idw;
+  auto ident = [&](int d) -> const MpoSite& {
+    MpoSite& w = idw[d];
+    if (!w.set) {
+      w.ml = 1; w.mr = 1; w.d = d;
+      w.w2l.reserve((size_t)d * d); w.w2r.reserve((size_t)d * d);
+      set_identity(st_, w.w2l.p, d, d, d);
+      set_identity(st_, w.w2r.p, d, d, d);
+      w.set = true;
+    }
+    return w;
+  };
   for (int p = 0; p < L_; ++p) {
     const size_t e = (size_t)dl_[p] * dd_[p] * dr_[p];
     ket[p] = pool_get(cap);
     prev[p] = pool_get(e);
     HIP_CHECK(hipMemcpyAsync(ket[p].p, site_[p].p, e * sizeof(zc), hipMemcpyDeviceToDevice, st_));
   }
-  mixL[0] = pool_get(1); mixR[L_] = pool_get(1);
-  HIP_CHECK(hipMemcpyAsync(mixL[0].p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
-  HIP_CHECK(hipMemcpyAsync(mixR[L_].p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  mixL[0] = pool_get(1); mixR[L_] = pool_get(1); ovL[0] = pool_get(1); ovR[L_] = pool_get(1);
+  for (DevBuf* b : {&mixL[0], &mixR[L_], &ovL[0], &ovR[L_]})
+    HIP_CHECK(hipMemcpyAsync(b->p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
   DevBuf spare = pool_get(cap), kt = pool_get(cap), bt = pool_get(cap);
   // right blocks of the initial bra / ket pair (construct_op_sites with superblock_states_ket)
   for (int p = L_ - 1; p >= 1; --p) {
@@ -540,13 +556,21 @@ double Engine::operate(int op_id, int maxstep, double conv_tol, int* iters_out) 
     transpose_rev3(st_, site_[p].p, bt.p, dl_[p], dd_[p], dr_[p]);
     mixR[p] = pool_get((size_t)dl_[p] * w.ml * dl_[p]);
     env_update_rect(mixR[p + 1].p, kt.p, bt.p, w.w2r.p, mixR[p].p, dr_[p], dr_[p], w.mr, dd_[p], dl_[p], dl_[p], w.ml);
+    if (has_shift) {
+      ovR[p] = pool_get((size_t)dl_[p] * dl_[p]);
+      env_update_rect(ovR[p + 1].p, kt.p, bt.p, ident(dd_[p]).w2r.p, ovR[p].p, dr_[p], dr_[p], 1, dd_[p], dl_[p], dl_[p], 1);
+    }
   }
   double nrm = 0.0;
   auto apply_site = [&](int p) {  // apply_superOp_direct
     const MpoSite& w = mpo(op_id, p);
     if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
-    heff_apply(mixL[p].p, w, mixR[p + 1].p, ket[p].p, site_[p].p, dl_[p], dd_[p], dr_[p], shift);
+    heff_apply(mixL[p].p, w, mixR[p + 1].p, ket[p].p, site_[p].p, dl_[p], dd_[p], dr_[p], hzc(0.0, 0.0));
     const long n = (long)dl_[p] * dd_[p] * dr_[p];
+    if (has_shift) {
+      heff_apply_rect(ovL[p].p, ident(dd_[p]), ovR[p + 1].p, ket[p].p, spare.p, dl_[p], dl_[p], dd_[p], dr_[p], dr_[p]);
+      vec_axpby(st_, site_[p].p, spare.p, n, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
+    }
     vec_sumsq(st_, site_[p].p, n, reinterpret_cast<double*>(red_.p + RED_MISC));
     read_partials(RED_MISC, NPART / 2);
     const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
@@ -577,6 +601,11 @@ double Engine::operate(int op_id, int maxstep, double conv_tol, int* iters_out) 
       pool_put(std::move(mixL[p + 1]));
       mixL[p + 1] = pool_get((size_t)r * w.mr * r);
       env_update_rect(mixL[p].p, ket[p].p, site_[p].p, w.w2l.p, mixL[p + 1].p, l, l, w.ml, d, r, r, w.mr);
+      if (has_shift) {
+        pool_put(std::move(ovL[p + 1]));
+        ovL[p + 1] = pool_get((size_t)r * r);
+        env_update_rect(ovL[p].p, ket[p].p, site_[p].p, ident(d).w2l.p, ovL[p + 1].p, l, l, 1, d, r, r, 1);
+      }
     }
     for (int p = L_ - 1; p >= 0; --p) {  // <-
       apply_site(p);
@@ -594,6 +623,11 @@ double Engine::operate(int op_id, int maxstep, double conv_tol, int* iters_out) 
       pool_put(std::move(mixR[p]));
       mixR[p] = pool_get((size_t)l * w.ml * l);
       env_update_rect(mixR[p + 1].p, kt.p, bt.p, w.w2r.p, mixR[p].p, r, r, w.mr, d, l, l, w.ml);
+      if (has_shift) {
+        pool_put(std::move(ovR[p]));
+        ovR[p] = pool_get((size_t)l * l);
+        env_update_rect(ovR[p + 1].p, kt.p, bt.p, ident(d).w2r.p, ovR[p].p, r, r, 1, d, l, l, 1);
+      }
     }
     // _is_converged (wavefunction.py:285-301): |1 - |<phi_i | phi_{i-1}>|| < conv_tol
     HIP_CHECK(hipMemcpyAsync(sig_.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
@@ -616,7 +650,7 @@ double Engine::operate(int op_id, int maxstep, double conv_tol, int* iters_out) 
   }
   center_ = 0;
   invalidate_env();
-  for (auto* v : {&ket, &prev, &mixL, &mixR})
+  for (auto* v : {&ket, &prev, &mixL, &mixR, &ovL, &ovR})
     for (auto& b : *v) pool_put(std::move(b));
   pool_put(std::move(spare)); pool_put(std::move(kt)); pool_put(std::move(bt));
   if (iters_out) *iters_out = std::min(it, maxstep);

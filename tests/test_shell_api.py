@@ -236,3 +236,83 @@ def test_relax_operate_propagate_workflow(golden, tmp_path, monkeypatch):
     for _ in range(2):
         st.propagate(0.05 / units.au_in_fs)
     assert abs(abs(orc.overlap(st.cores, wf_t.get_mps())) - 1) < 1e-8
+
+
+def _harmonic_prims():
+    from pytdscf_amd import HarmonicOscillator
+
+    return [HarmonicOscillator(5, 1500, 0.0), HarmonicOscillator(5, 2000, 0.0), HarmonicOscillator(5, 2500, 0.0)]
+
+
+def test_grid_tensor_decomposition_and_kinetic_mpo():
+    """construct_fulldimensional / construct_kinetic_operator / TensorOperator.decompose: the
+    MPO restores the grid function within the contribution rate; the kinetic MPO is the sum of
+    the one-site second-derivative matrices."""
+    from pytdscf_amd import TensorHamiltonian, TensorOperator
+    from pytdscf_amd.dvr_operator_cls import construct_fulldimensional, construct_kinetic_mpo, construct_kinetic_operator
+    from pytdscf_amd.operators import mpo_to_dense
+
+    prims = _harmonic_prims()
+    f = lambda a, b, c: 0.3 * a * a + 0.1 * a * b - 0.2 * np.sin(c) * b + 0.05 * a * b * c  # noqa: E731
+    op = construct_fulldimensional(dvr_prims=prims, func=f, ref_ene=0.01)[(0, 1, 2)]
+    ref = op.tensor_orig.copy()
+    cores = op.decompose(decompose_type="SVD", rate=0.999999999999)
+    assert [c.ndim for c in cores] == [3, 3, 3] and cores[0].shape[0] == 1 and cores[-1].shape[-1] == 1
+    np.testing.assert_allclose(op.get_tensor_full(), ref, atol=1e-6 * abs(ref).max())
+    low = TensorOperator(tensor=ref, only_diag=True).decompose(bond_dimension=1)
+    assert all(c.shape[0] == 1 and c.shape[2] == 1 for c in low)
+    with pytest.raises(ValueError):
+        TensorOperator(tensor=ref, only_diag=True).decompose(rate=1.5)
+    kin = construct_kinetic_mpo(prims)
+    dense = mpo_to_dense(kin)
+    t = [-0.5 * p.get_2nd_derivative_matrix_dvr() for p in prims]
+    eye = np.eye(5)
+    want = np.kron(np.kron(t[0], eye), eye) + np.kron(np.kron(eye, t[1]), eye) + np.kron(np.kron(eye, eye), t[2])
+    np.testing.assert_allclose(dense, want, atol=1e-13)
+    sop = construct_kinetic_operator(prims, forms="sop")
+    h = TensorHamiltonian(3, potential=None, kinetic=[[sop]])
+    np.testing.assert_allclose(mpo_to_dense(h.as_mpo([5, 5, 5])), want, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_reference_relax_operate_propagate_pins(tmp_path, monkeypatch):
+    """tests/test_harmonic_dvr_func_full_mpssm_jax.py of the reference, the three functions in
+    sequence, re-typed against the shell: relax -> operate(restart=True) -> propagate(restart=True)
+    with the reference's own known answers."""
+    from pytdscf_amd import BasInfo, Model, Simulator, TensorHamiltonian, units
+    from pytdscf_amd.dvr_operator_cls import construct_fulldimensional, construct_kinetic_operator
+
+    monkeypatch.chdir(tmp_path)
+    prim_info = [_harmonic_prims()]
+    basinfo = BasInfo(prim_info)
+
+    def PES(q1, q2, q3):
+        return ((1500 / units.au_in_cm1) ** 2 / 2 * q1**2 + (2000 / units.au_in_cm1) ** 2 / 2 * q2**2
+                + (2500 / units.au_in_cm1) ** 2 / 2 * q3**2)
+
+    def DMS(q1, q2, q3):
+        return 0.1 * q1 + 0.1 * q2 + 0.1 * q3
+
+    def ham():
+        potential = [[construct_fulldimensional(dvr_prims=prim_info[0], func=PES)]]
+        kinetic = [[construct_kinetic_operator(dvr_prims=prim_info[0])]]
+        return TensorHamiltonian(ndof=3, potential=potential, kinetic=kinetic, decompose_type="SVD", rate=0.9999999, backend="hip")
+
+    jobname = "harmonic_dvr_hip"
+    model = Model(basinfo, {"hamiltonian": ham()})
+    model.m_aux_max = 4
+    ener_calc, wf = Simulator(jobname, model, backend="hip").relax(maxstep=3, stepsize=0.1)
+    assert pytest.approx(ener_calc) == 0.013669005758739458
+
+    dip = TensorHamiltonian(ndof=3, potential=[[construct_fulldimensional(dvr_prims=prim_info[0], func=DMS)]], kinetic=None,
+                            decompose_type="SVD", rate=0.9999999, backend="hip")
+    dip.coupleJ = [[1.0]]  # scalar term
+    model = Model(basinfo, {"hamiltonian": dip})
+    model.m_aux_max = 4
+    norm_calc, wf = Simulator(jobname, model, backend="hip").operate(restart=True, maxstep=5)
+    assert pytest.approx(norm_calc) == 1.6490051381599562
+
+    model = Model(basinfo, {"hamiltonian": ham()})
+    model.m_aux_max = 4
+    ener_calc, wf = Simulator(jobname, model, backend="hip").propagate(maxstep=3, stepsize=0.1, restart=True)
+    assert pytest.approx(ener_calc) == 0.019185297685193108
