@@ -695,6 +695,10 @@ class OracleMPS:
                 h_left = heff_apply(self.left[p], W[p], env_bra[:dmax], self.cores[p])
                 h_right = heff_apply(sys_bra[:dmax], W[q], env_prev, psi_prime)
                 k_sig = keff_apply(sys_bra[:dmax], env_bra[:dmax], sig)
+                if self.shift != 0.0:  # coupleJ * ovlp: the overlap blocks <full|thin> are [1; 0] embeddings
+                    h_left[:, :, :r] += self.shift * self.cores[p]
+                    h_right[:r] += self.shift * psi_prime
+                    k_sig[:r, :r] += self.shift * sig
                 newD, _ = select_rank(h_left, k_sig, h_right, r, dmax, self.p_proj)
             env_D_bra = env_bra[:newD]
             env_D_braket = env_braket[:newD, :, :newD]
@@ -738,6 +742,10 @@ class OracleMPS:
             h_left = heff_apply(env_prev, W[q], sys_bra[:dmax], psi_prime)
             h_right = heff_apply(env_bra[:dmax], W[p], self.right[p], self.cores[p])
             k_sig = keff_apply(env_bra[:dmax], sys_bra[:dmax], sig)
+            if self.shift != 0.0:
+                h_left[:, :, :l] += self.shift * psi_prime
+                h_right[:l] += self.shift * self.cores[p]
+                k_sig[:l, :l] += self.shift * sig
             newD, _ = select_rank(h_left, k_sig, h_right, l, dmax, self.p_proj)
         env_D_bra = env_bra[:newD]
         env_D_braket = env_braket[:newD, :, :newD]

@@ -361,6 +361,11 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
       heff_apply_rect(envL_[p].p, wp, env_bra.p, site_[p].p, hl.p, l, l, c, dmax, r);
       heff_apply_rect(sys_bra.p, wq, envR_[q + 1].p, psip.p, hr.p, dmax, r, cq, rq, rq);
       keff_apply_rect(sys_bra.p, env_bra.p, sig_.p, ks.p, dmax, r, dmax, r, M);
+      if (has_shift) {  // coupleJ * ovlp: the overlap blocks <widened|thin> are [1; 0] embeddings
+        copy2d(st_, hl.p, dmax, site_[p].p, r, (long)l * c, r, 0, zshift, true);
+        vec_axpby(st_, hr.p, psip.p, (long)r * cq * rq, zshift, one);
+        copy2d(st_, ks.p, dmax, sig_.p, r, r, r, 0, zshift, true);
+      }
       newD = select_rank(hl.p, (long)l * c, ks.p, hr.p, (long)cq * rq, r, dmax);
       pool_put(std::move(hl)); pool_put(std::move(hr)); pool_put(std::move(ks));
     }
@@ -452,6 +457,11 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
     heff_apply_rect(envL_[q].p, wq, sys_bra.p, psip.p, hl.p, lq, lq, cq, dmax, l);
     heff_apply_rect(env_bra.p, wp, envR_[p + 1].p, site_[p].p, hr.p, dmax, l, c, r, r);
     keff_apply_rect(env_bra.p, sys_bra.p, sig_.p, ks.p, dmax, l, dmax, l, M);
+    if (has_shift) {
+      copy2d(st_, hl.p, dmax, psip.p, l, (long)lq * cq, l, 0, zshift, true);
+      vec_axpby(st_, hr.p, site_[p].p, (long)l * c * r, zshift, one);
+      copy2d(st_, ks.p, dmax, sig_.p, l, l, l, 0, zshift, true);
+    }
     newD = select_rank(hl.p, (long)lq * cq, ks.p, hr.p, (long)c * r, l, dmax);
     pool_put(std::move(hl)); pool_put(std::move(hr)); pool_put(std::move(ks));
   }

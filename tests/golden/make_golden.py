@@ -775,6 +775,20 @@ def main():
             o[f"n{n}_final{i}"] = np.array(s_.data)
     save("operate_chain.npz", nsite=np.array(Lo), bond_dim=np.array(Do), **o)
 
+    # (ix) adaptive bond dimension with a scalar term (coupleJ): the ovlp term enters the H_eff /
+    # K_eff applies of the rank-selection functional through the <widened|thin> overlap blocks
+    ham_s = TensorHamiltonian(La, potential=[[{tuple((i, i) for i in range(La)): TensorOperator(mpo=[w.copy() for w in mpo_a])}]],
+                              kinetic=None, backend="numpy")
+    ham_s.coupleJ = [[0.7]]
+    model_s = Model(basis_a, operators={"hamiltonian": ham_s}, bond_dim=Da0)
+    model_s.init_HartreeProduct = [[np.array(c) for c in cores_a]]
+    o = {f"mpo{i}": w for i, w in enumerate(mpo_a)}
+    o.update({f"init{i}": c for i, c in enumerate(cores_a)})
+    for n in (1, 3):
+        o.update(run_adaptive(model_s, La, n, 0.05, **akw))
+    save("adaptive_chain_shift.npz", dt_au=np.array(0.05 / au_in_fs), nsite=np.array(La), bond_dim0=np.array(Da0),
+         Dmax=np.array(7), dD=np.array(1), p_proj=np.array(1.0e-8), coupleJ=np.array(0.7), **o)
+
 
 if __name__ == "__main__":
     main()

@@ -66,15 +66,16 @@ def _run_engine(mpo, init, dt, ns, kw, integrator="lanczos", conserve_norm=True,
     return eng, e_last
 
 
-def test_adaptive_chain_golden(golden):
-    g = golden("adaptive_chain.npz")
+@pytest.mark.parametrize("name", ["adaptive_chain.npz", "adaptive_chain_shift.npz"])
+def test_adaptive_chain_golden(golden, name):
+    g = golden(name)
     n = int(g["nsite"])
     mpo = [g[f"mpo{i}"] for i in range(n)]
     init = [g[f"init{i}"] for i in range(n)]
     dt = float(g["dt_au"])
     kw = dict(Dmax=int(g["Dmax"]), dD=int(g["dD"]), p_proj=float(g["p_proj"]))
     for ns in (1, 3):
-        eng, e_last = _run_engine(mpo, init, dt, ns, kw)
+        eng, e_last = _run_engine(mpo, init, dt, ns, kw, shift=float(g["coupleJ"]) if "coupleJ" in g.files else 0.0)
         assert eng.bond_dims() == list(g[f"n{ns}_bonddim"])
         assert eng.krylov_stats() == list(g[f"n{ns}_krylov"])
         el = float(g[f"n{ns}_energy_last"])

@@ -165,14 +165,18 @@ def _adaptive_kw(g):
     return dict(adaptive=True, Dmax=int(g["Dmax"]), dD=int(g["dD"]), p_proj=float(g["p_proj"]))
 
 
-def test_adaptive_chain(golden):
+@pytest.mark.parametrize("name", ["adaptive_chain.npz", "adaptive_chain_shift.npz"])
+def test_adaptive_chain(golden, name):
     """Adaptive bond dimension (a1TDVP) on a well-conditioned chain: rank 2 random
-    cores grow to (3, 7, 7, 6, 3); same ranks, Krylov counts and tensors as the reference."""
-    g = golden("adaptive_chain.npz")
+    cores grow to (3, 7, 7, 6, 3); same ranks, Krylov counts and tensors as the reference.
+    With a scalar term (coupleJ = 0.7) the rank decisions change ((3, 5, 5, 4, 3)): the term
+    enters the rank-selection applies through the <widened|thin> overlap blocks."""
+    g = golden(name)
     n, mpo, init = _load_chain(g)
     dt = float(g["dt_au"])
     for ns in (1, 3):
-        st = orc.OracleMPS(orc.canonicalize_site0(init), mpo, **_adaptive_kw(g))
+        st = orc.OracleMPS(orc.canonicalize_site0(init), mpo, shift=float(g["coupleJ"]) if "coupleJ" in g.files else 0.0,
+                           **_adaptive_kw(g))
         e_last = None
         for _ in range(ns):
             e_last = st.expectation()
