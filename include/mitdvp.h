@@ -128,6 +128,11 @@ int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches);
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */
+/* Autocorrelation without the t/2 trick (Simulator(t2_trick=False): Properties._get_autocorr,
+ * properties.py:222-232, wf_zero._ints_wf_ovlp_mpo): keep a device copy of the current state, later
+ * return <copy|current state> (bra conjugated). */
+int mitdvp_save_reference(mitdvp_engine* h);
+int mitdvp_overlap_reference(mitdvp_engine* h, double out[2]);
 int mitdvp_norm(mitdvp_engine* h, double* out);                      /* _mps_cls.py:706-716 */
 int mitdvp_site_rdm(mitdvp_engine* h, int isite, double* reim_out);  /* _mps_cls.py:1208-1436, key (isite,isite) */
 /* General reduced density, MPSCoef.get_reduced_densities / _get_pure_reduced_density

@@ -118,6 +118,8 @@ def load() -> C.CDLL:
         "mitdvp_svd": (i, [i, dp, i, i, dp, dp, dp, ip]),
         "mitdvp_set_adaptive": (i, [vp, i, i, i, d]),
         "mitdvp_set_gate": (i, [vp, i, dp, i]),
+        "mitdvp_save_reference": (i, [vp]),
+        "mitdvp_overlap_reference": (i, [vp, dp]),
         "mitdvp_rccl_unique_id": (i, [C.c_char_p]),
         "mitdvp_set_parallel_rccl": (i, [vp, i, i, C.c_char_p]),
         "mitdvp_rccl_selftest": (i, [vp, ip]),

@@ -450,8 +450,10 @@ class Simulator:
         try:
             for istep in range(maxstep):
                 t = istep * dt_au * tconv
+                if autocorr and istep == 0 and not self.t2_trick:
+                    eng.save_reference()  # wf_init = deepcopy(wf), simulator_cls.py:386-393
                 if autocorr and istep % autocorr_per_step == 0:
-                    a = eng.autocorr()
+                    a = eng.autocorr() if self.t2_trick else eng.overlap_reference()
                     if istep == 0:
                         files["autocorr"].write(f"# time [{display_time_unit}]\t auto-correlation\n")
                     files["autocorr"].write(f"{(2 * t if self.t2_trick else t):6.9f}\t{a.real: 6.9f}{a.imag:+6.9f}j\n")

@@ -178,6 +178,17 @@ int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] { *mismatches = h->e->rccl_selftest(); });
 }
+int mitdvp_save_reference(mitdvp_engine* h) {
+  if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
+  return guard(h, [&] { h->e->save_reference(); });
+}
+int mitdvp_overlap_reference(mitdvp_engine* h, double out[2]) {
+  if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
+  return guard(h, [&] {
+    const mitdvp::hzc v = h->e->overlap_reference();
+    out[0] = v.real(); out[1] = v.imag();
+  });
+}
 int mitdvp_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, double* norm_out, int* iters_out) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] {

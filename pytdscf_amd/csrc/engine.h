@@ -98,6 +98,8 @@ class Engine {
   // observables
   hzc expect(int op_id);
   hzc autocorr();
+  void save_reference();     // keep a copy of the current state ...
+  hzc overlap_reference();   // ... and <copy|current state> later (autocorrelation without the t/2 trick)
   double norm();
   void site_rdm(int isite, double* out);
   void reduced_density(const int* legs, int nlen, std::vector<hzc>& out, std::vector<int>& shape);
@@ -193,6 +195,8 @@ class Engine {
   bool small_kernels_ = true;  // MITDVP_SMALL_KERNELS=0: always the general multi-launch kernels (A/B testing)
   struct Gate { DevBuf u; int d = 0; };
   std::map<int, Gate> gates_;
+  std::vector<DevBuf> ref_;
+  std::vector<int> ref_l_, ref_r_;
   struct KrausOp { DevBuf b; int k = 0, d = 0; bool two_site = false; };
   std::map<int, KrausOp> kraus_;
   void kraus_core(const zc* theta, int m, int d, int K, int n, const KrausOp& op, zc* out);

@@ -82,6 +82,45 @@ hzc Engine::autocorr() {
   return out;
 }
 
+// <Psi(0)|Psi(t)> for runs without the t/2 trick (Properties._get_autocorr, properties.py:222-232,
+// wf_zero._ints_wf_ovlp_mpo): the state is copied once, later states are overlapped with it
+void Engine::save_reference() {
+  require_ready();
+  ref_.clear(); ref_.resize(L_);
+  ref_l_ = dl_; ref_r_ = dr_;
+  for (int p = 0; p < L_; ++p) {
+    const size_t e = (size_t)dl_[p] * dd_[p] * dr_[p];
+    ref_[p].reserve(e);
+    HIP_CHECK(hipMemcpyAsync(ref_[p].p, site_[p].p, e * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  }
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+hzc Engine::overlap_reference() {
+  require_ready();
+  if ((int)ref_.size() != L_) throw ArgError("overlap_reference: no reference state saved");
+  // T'[i][j] = sum conj(ref)[(m,s)][i] (T[m][n] C[n][(s,j)]);  bond dimensions may differ (adaptive runs)
+  const zc one = make_double2(1.0, 0.0);
+  size_t mx = 1;
+  for (int p = 0; p < L_; ++p) mx = std::max(mx, (size_t)std::max(ref_l_[p], ref_r_[p]) * dd_[p] * std::max(dl_[p], dr_[p]));
+  DevBuf T = pool_get(mx), Tn = pool_get(mx), U = pool_get(mx);
+  HIP_CHECK(hipMemcpyAsync(T.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+  for (int p = 0; p < L_; ++p) {
+    const int dl = dl_[p], d = dd_[p], dr = dr_[p], rl = ref_l_[p], rr = ref_r_[p];
+    ZgemmDesc u = zgemm_desc(T.p, site_[p].p, U.p, rl, d * dr, dl);
+    zgemm(st_, u);
+    ZgemmDesc t = zgemm_desc(ref_[p].p, U.p, Tn.p, rr, dr, rl * d);
+    t.transA = 1; t.conjA = 1; t.lda = rr;
+    zgemm(st_, t);
+    std::swap(T, Tn);
+  }
+  hzc out;
+  HIP_CHECK(hipMemcpyAsync(&out, T.p, sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  pool_put(std::move(T)); pool_put(std::move(Tn)); pool_put(std::move(U));
+  return out;
+}
+
 void Engine::site_rdm(int isite, double* out) {
   require_ready();
   if (center_ != 0) throw ArgError("reduced density needs the centre at site 0");

@@ -126,6 +126,16 @@ class TDVPEngine:
         self._ck(self._lib.mitdvp_autocorr(self._h, _dp(out)))
         return complex(out[0], out[1])
 
+    def save_reference(self) -> None:
+        """Keep a device copy of the current state (the t = 0 state of a run without the t/2 trick)."""
+        self._ck(self._lib.mitdvp_save_reference(self._h))
+
+    def overlap_reference(self) -> complex:
+        """<saved state | current state>."""
+        out = np.zeros(2)
+        self._ck(self._lib.mitdvp_overlap_reference(self._h, _dp(out)))
+        return complex(out[0], out[1])
+
     def norm(self) -> float:
         out = C.c_double()
         self._ck(self._lib.mitdvp_norm(self._h, C.byref(out)))

@@ -458,3 +458,33 @@ def test_long_trace_against_oracle():
     assert eng.krylov_stats() == [st.kprev[i] for i in range(L)]
     assert abs(_fidelity(orc, st.cores, eng.get_mps()) - 1) < 1e-10
     eng.close()
+
+
+def test_overlap_with_saved_reference_state():
+    """<Psi(0)|Psi(t)> (autocorrelation without the t/2 trick) against the oracle, also when the
+    bond dimensions of Psi(t) have grown adaptively since the copy was taken."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L, d, M, D = 6, 3, 4, 2
+    mpo = orc.synthetic_mpo(L, d, M, seed=6)
+    rng = np.random.default_rng(2)
+    init = [rng.standard_normal((a, d, b)) + 1j * rng.standard_normal((a, d, b)) for a, b in orc.bond_dims([d] * L, D)]
+    c0 = orc.canonicalize_site0(init)
+    kw = dict(Dmax=6, dD=2, p_proj=1e-9)
+    st = orc.OracleMPS([c.copy() for c in c0], mpo, adaptive=True, **kw)
+    eng = TDVPEngine(L)
+    eng.set_mpo(mpo)
+    eng.set_mps(init, canonicalize=True)
+    eng.set_adaptive(True, **kw)
+    with pytest.raises(ValueError):
+        eng.overlap_reference()
+    eng.save_reference()
+    assert abs(eng.overlap_reference() - 1) < 1e-12
+    for _ in range(3):
+        st.propagate(0.6)
+        eng.propagate(0.6)
+        ref = orc.overlap(c0, st.cores)
+        assert abs(eng.overlap_reference() - ref) < 1e-9 * abs(ref)
+    assert max(eng.bond_dims()) > D
+    eng.close()

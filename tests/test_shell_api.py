@@ -316,3 +316,26 @@ def test_reference_relax_operate_propagate_pins(tmp_path, monkeypatch):
     model.m_aux_max = 4
     ener_calc, wf = Simulator(jobname, model, backend="hip").propagate(maxstep=3, stepsize=0.1, restart=True)
     assert pytest.approx(ener_calc) == 0.019185297685193108
+
+
+@pytest.mark.gpu
+def test_autocorr_without_t2_trick(golden, tmp_path, monkeypatch):
+    """Simulator(t2_trick=False): autocorr.dat holds <Psi(0)|Psi(t)> at t (not 2t).  (The
+    reference's Properties asserts in this mode -- properties.py:62 -- so the pin is the oracle.)"""
+    from pytdscf_amd import Exciton, Model, Simulator, units
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("chain_lanczos.npz")
+    n = int(g["nsite"])
+    mpo = [g[f"mpo{i}"] for i in range(n)]
+    init = [g[f"init{i}"] for i in range(n)]
+    model = Model([Exciton(nstate=3) for _ in range(n)], operators={"hamiltonian": mpo}, bond_dim=6)
+    model.init_HartreeProduct = [init]
+    Simulator("not2", model, backend="hip", t2_trick=False).propagate(stepsize=0.05, maxstep=3)
+    rows = [l.split() for l in open(tmp_path / "not2_prop" / "autocorr.dat").read().splitlines()[1:]]
+    c0 = orc.canonicalize_site0(init)
+    st = orc.OracleMPS([c.copy() for c in c0], mpo)
+    for i, (t, a) in enumerate(rows):
+        assert float(t) == pytest.approx(i * 0.05, abs=1e-9)
+        assert complex(a.replace(" ", "")) == pytest.approx(orc.overlap(c0, st.cores), abs=2e-9)
+        st.propagate(0.05 / units.au_in_fs)
