@@ -61,7 +61,10 @@ typedef struct {
   int reserved[7];
 } mitdvp_config;
 
-/* -- lifetime ---------------------------------------------------------- */
+/* -- lifetime ----------------------------------------------------------
+ * Threading: a handle owns one HIP stream and all its device memory and must be driven by one host
+ * thread at a time; different handles are independent and may be driven concurrently from different
+ * threads (an ensemble of trajectories on one GPU). */
 int mitdvp_create(const mitdvp_config* cfg, mitdvp_engine** out);
 void mitdvp_destroy(mitdvp_engine* h);
 const char* mitdvp_last_error(const mitdvp_engine* h); /* h may be NULL */

@@ -75,6 +75,8 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
 int zgemm_default_mode();
 void zgemm_set_default_mode(int m);
 double mfma_peak_probe(hipStream_t st);
+// frees the split-K workspace that belongs to a stream (call before destroying the stream)
+void zgemm_release_stream(hipStream_t st);
 void mfma_layout_probe(hipStream_t st, int* host_out);
 
 }  // namespace mitdvp

@@ -54,7 +54,7 @@ Engine::~Engine() {
   for (auto& t : pending_) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& e : evpool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h_red_) (void)hipHostFree(h_red_);
-  if (st_) (void)hipStreamDestroy(st_);
+  if (st_) { zgemm_release_stream(st_); (void)hipStreamDestroy(st_); }
 }
 
 // ---------------------------------------------------------------------------

@@ -27,6 +27,9 @@
 
 #include "common.h"
 
+#include <map>
+#include <mutex>
+
 namespace mitdvp {
 
 extern __shared__ zc smem_dyn[];
@@ -440,12 +443,11 @@ static void launch_one(hipStream_t st, const ZgemmDesc& d, dim3 grid, int ntm, i
   constexpr int B_SZ = TB ? BN * (BK + 1) : BK * BN;
   constexpr size_t lds = 2 * (size_t)(A_SZ + B_SZ) * sizeof(zc);
   auto kern = zgemm_kernel<WM, WN, BK, TA, TB, M3>;
-  static bool attr_set = false;  // one flag per instantiation
-  if (!attr_set) {
+  static std::once_flag attr_once;  // one flag per instantiation
+  std::call_once(attr_once, [&] {
     if (lds > 65536)
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, ntm, ntn, g_cd_mode);
 }
 
@@ -493,8 +495,29 @@ __global__ __launch_bounds__(256) void zgemm_splitk_reduce(const zc* __restrict_
   }
 }
 
-static zc* g_splitk_ws = nullptr;  // grows on demand; one stream per device assumed
-static size_t g_splitk_elems = 0;
+// split-K partial slabs: one workspace PER STREAM (several engines, each with its own stream, may
+// run concurrently from different host threads), grown on demand, released with the stream
+struct SplitKWs { zc* p = nullptr; size_t n = 0; };
+static std::mutex g_splitk_mu;
+static std::map<hipStream_t, SplitKWs> g_splitk;
+
+static zc* splitk_workspace(hipStream_t st, size_t need) {
+  std::lock_guard<std::mutex> lk(g_splitk_mu);
+  SplitKWs& w = g_splitk[st];
+  if (need > w.n) {
+    if (w.p) { HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipFree(w.p)); w.p = nullptr; w.n = 0; }
+    HIP_CHECK(hipMalloc(&w.p, need * sizeof(zc)));
+    w.n = need;
+  }
+  return w.p;
+}
+void zgemm_release_stream(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_splitk_mu);
+  auto it = g_splitk.find(st);
+  if (it == g_splitk.end()) return;
+  if (it->second.p) (void)hipFree(it->second.p);
+  g_splitk.erase(it);
+}
 
 static void launch_tiles(hipStream_t st, const ZgemmDesc& d, int cfg, int m3) {
   if (m3) {
@@ -518,7 +541,10 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
   if (d.K < 0) throw ArgError("zgemm: negative K");
   if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
-  if (g_cd_mode < 0) mfma_layout_probe(st, nullptr);
+  {
+    static std::once_flag probe_once;  // several engines may issue their first GEMM concurrently
+    std::call_once(probe_once, [&] { if (g_cd_mode < 0) mfma_layout_probe(st, nullptr); });
+  }
   int cfg = d.tile_cfg;
   const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
   auto tiles = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
@@ -539,13 +565,9 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
       kc = (kc + 15) / 16 * 16;
       splits = (d.K + kc - 1) / kc;
       const size_t need = (size_t)splits * d.M * d.N;
-      if (need > g_splitk_elems) {
-        if (g_splitk_ws) { HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipFree(g_splitk_ws)); }
-        HIP_CHECK(hipMalloc(&g_splitk_ws, need * sizeof(zc)));
-        g_splitk_elems = need;
-      }
+      zc* ws = splitk_workspace(st, need);
       ZgemmDesc p = d;
-      p.C = g_splitk_ws;
+      p.C = ws;
       p.ldc = d.N;
       p.strideA = p.strideB = 0;
       p.strideC = (long)d.M * d.N;
@@ -556,7 +578,7 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
       launch_tiles(st, p, cfg, m3);
       const long tot = (long)d.M * d.N;
       const int nb = (int)std::min<long>(1024, (tot + 255) / 256);
-      hipLaunchKernelGGL(zgemm_splitk_reduce, dim3(nb), dim3(256), 0, st, g_splitk_ws, splits, d.M, d.N, d.C, d.ldc,
+      hipLaunchKernelGGL(zgemm_splitk_reduce, dim3(nb), dim3(256), 0, st, ws, splits, d.M, d.N, d.C, d.ldc,
                          d.alpha, d.beta);
       HIP_CHECK(hipGetLastError());
       return;
