@@ -339,3 +339,32 @@ def test_autocorr_without_t2_trick(golden, tmp_path, monkeypatch):
         assert float(t) == pytest.approx(i * 0.05, abs=1e-9)
         assert complex(a.replace(" ", "")) == pytest.approx(orc.overlap(c0, st.cores), abs=2e-9)
         st.propagate(0.05 / units.au_in_fs)
+
+
+@pytest.mark.gpu
+def test_henon_heiles_reference_script_unchanged(tmp_path, monkeypatch):
+    """tests/test_henon_heiles.py of the reference, NumPy case, typed as it is there (only the
+    package name differs): construct_nMR_recursive + construct_kinetic_mpo + Model + Simulator."""
+    import pytdscf_amd as pytdscf
+    from pytdscf_amd import HarmonicOscillator as HO, Model, Simulator, units
+    from pytdscf_amd.dvr_operator_cls import construct_kinetic_mpo, construct_nMR_recursive
+
+    monkeypatch.chdir(tmp_path)
+    assert pytdscf.units is units
+    backend, ω, λ, f, N, m, Δt = "hip", 2000, 1.0e-03, 2, 5, 4, 0.001
+    dvr_prims = [HO(N, ω) for _ in range(f)]
+    ω_au = ω / units.au_in_cm1
+    func = {}
+    func[(0,)] = lambda Q1: pow(ω_au, 2) / 2 * Q1**2
+    func[(0, 1)] = lambda Q1, Q2: λ * pow(ω_au, 3 / 2) * (Q1**2 * Q2)
+    func[(1,)] = lambda Qf: pow(ω_au, 2) / 2 * Qf**2 - λ * pow(ω_au, 3 / 2) / 3 * Qf**3
+    potential_mpo = construct_nMR_recursive(dvr_prims, nMR=2, func=func, rate=0.99999999999)
+    kinetic_mpo = construct_kinetic_mpo(dvr_prims)
+    operators = {"potential": potential_mpo, "kinetic": kinetic_mpo}
+    model = Model(dvr_prims, operators=operators, bond_dim=m)
+    vib_gs = [1.0] + [0.0] * (N - 1)
+    vib_es = [0.0, 1.0] + [0.0] * (N - 2)
+    model.init_weight_VIBSTATE = [[vib_es] + [vib_gs] * (f - 1)]
+    simulator = Simulator(jobname="henon_heiles", model=model, backend=backend)
+    ener_calc, wf = simulator.propagate(maxstep=3, stepsize=Δt)
+    assert pytest.approx(ener_calc) == 0.018225341011652626
