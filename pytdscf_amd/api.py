@@ -19,7 +19,7 @@ import numpy as np
 from . import units
 from .engine import TDVPEngine
 from .mps import product_state_cores
-from .operators import merge_operator_terms
+from .operators import compress_mpo, merge_operator_terms
 
 
 class TensorOperator:
@@ -157,8 +157,12 @@ class TensorHamiltonian:
                 op.decompose(bond_dimension=bond_dimension, decompose_type=decompose_type, rate=rate)
         self.coupleJ = [[0.0]]  # hamiltonian_cls.py:337-358 scalar couplings
 
-    def as_mpo(self, dims):
-        return merge_operator_terms([(op.tensor_decomposed, op.sites) for op in self.terms.values()], dims)
+    def as_mpo(self, dims, compress=True):
+        """One full-chain 4-leg MPO: exact direct sum of the operator terms, then a lossless
+        rounding (``compress_mpo``, singular values below 1e-13 relative dropped) that removes
+        the linear dependencies the direct sum introduces."""
+        mpo = merge_operator_terms([(op.tensor_decomposed, op.sites) for op in self.terms.values()], dims)
+        return compress_mpo(mpo) if compress and len(mpo) > 1 else mpo
 
     def apply_backend(self, backend):
         self.backend = backend

@@ -88,6 +88,30 @@ def merge_operator_terms(terms, dims) -> list[np.ndarray]:
     return out
 
 
+def compress_mpo(mpo, tol: float = 1.0e-13) -> list[np.ndarray]:
+    """Tensor-train rounding of a full-chain 4-leg MPO: right-to-left QR sweep, then
+    left-to-right SVDs dropping singular values below ``tol`` times the largest one.  With the
+    default tolerance this only removes exact linear dependencies (the direct sum of operator
+    terms repeats identity channels), i.e. the operator is unchanged to rounding while the bond
+    dimension M -- the cost of an apply grows like M^2 -- shrinks.  The reference's counterpart
+    are the SVD sweeps of ``_mpo_cls.py:601-912`` (``sweep_compress_twodot``)."""
+    cs = [np.array(w, dtype=np.complex128) for w in mpo]
+    shp = [c.shape for c in cs]
+    cs = [c.reshape(c.shape[0], c.shape[1] * c.shape[2], c.shape[3]) for c in cs]
+    for i in range(len(cs) - 1, 0, -1):
+        r, n, rr = cs[i].shape
+        q, t = np.linalg.qr(cs[i].reshape(r, n * rr).T)
+        cs[i] = q.T.reshape(-1, n, rr)
+        cs[i - 1] = np.tensordot(cs[i - 1], t.T, axes=(2, 0))
+    for i in range(len(cs) - 1):
+        r, n, rr = cs[i].shape
+        u, sv, vh = np.linalg.svd(cs[i].reshape(r * n, rr), full_matrices=False)
+        k = max(int((sv > tol * sv[0]).sum()), 1) if sv[0] > 0 else 1
+        cs[i] = u[:, :k].reshape(r, n, k)
+        cs[i + 1] = np.tensordot(sv[:k, None] * vh[:k], cs[i + 1], axes=(1, 0))
+    return [np.ascontiguousarray(c.reshape(c.shape[0], s[1], s[2], c.shape[2])) for c, s in zip(cs, shp)]
+
+
 def mpo_to_dense(mpo) -> np.ndarray:
     """Dense matrix of a (small) MPO -- test helper."""
     t = mpo[0]

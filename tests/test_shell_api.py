@@ -25,8 +25,13 @@ def test_model_reduction_cpu(golden):
     """Model -> (one MPO, initial cores) reproduces the reference pins through the oracle."""
     g = golden("exciton.npz")
     model = _exciton_model(g)
-    mpo = model.hamiltonian.as_mpo(model.dims)
-    assert [w.shape for w in mpo] == [(1, 8, 8, 5), (5, 8, 8, 6), (6, 8, 8, 4), (4, 2, 2, 1)]
+    raw = model.hamiltonian.as_mpo(model.dims, compress=False)
+    assert [w.shape for w in raw] == [(1, 8, 8, 5), (5, 8, 8, 6), (6, 8, 8, 4), (4, 2, 2, 1)]
+    mpo = model.hamiltonian.as_mpo(model.dims)  # lossless rounding of the direct sum
+    assert [w.shape for w in mpo] == [(1, 8, 8, 4), (4, 8, 8, 5), (5, 8, 8, 3), (3, 2, 2, 1)]
+    from pytdscf_amd.operators import mpo_to_dense
+
+    np.testing.assert_allclose(mpo_to_dense(mpo), mpo_to_dense(raw), atol=1e-15)
     st = orc.OracleMPS(orc.canonicalize_site0(model.initial_cores()), mpo)
     e = None
     for _ in range(20):
