@@ -29,13 +29,14 @@ void Engine::apply_gates() {
   if (gates_.empty()) return;
   require_ready();
   if (center_ < 0) throw ArgError("apply_gates: the MPS has no centre (Psi) site");
+  for (auto& kv : gates_)  // validate everything before the state is touched
+    if (kv.second.d != dd_[kv.first]) throw ArgError("gate dimension differs from the site's physical dimension");
   DevBuf spare = pool_get(V_.n / MAXK);
   int lo = L_, hi = -1;
   for (auto& kv : gates_) {
     const int p = kv.first;
     const Gate& g = kv.second;
     const int l = dl_[p], d = dd_[p], r = dr_[p];
-    if (g.d != d) throw ArgError("gate dimension differs from the site's physical dimension");
     ZgemmDesc z = zgemm_desc(g.u.p, site_[p].p, spare.p, d, r, d);
     z.batch = l; z.strideA = 0; z.strideB = (long)d * r; z.strideC = (long)d * r;
     zgemm(st_, z);
@@ -138,6 +139,12 @@ void Engine::apply_kraus() {
   if (kraus_.empty()) return;
   require_ready();
   if (center_ < 0) throw ArgError("apply_kraus: the MPS has no centre (Psi) site");
+  for (auto& kv : kraus_) {  // validate everything before the state is touched
+    const KrausOp& op = kv.second;
+    if (!op.two_site && dd_[kv.first] % op.d != 0) throw ArgError("Kraus contract: dK must be divisible by d");
+    if (op.two_site && dd_[kv.first] != op.d)
+      throw ArgError("two-site Kraus map: the system site's dimension differs from the Kraus operators'");
+  }
   DevBuf spare = pool_get(V_.n / MAXK);
   int lo = L_, hi = -1;
   for (auto& kv : kraus_) {
@@ -145,7 +152,6 @@ void Engine::apply_kraus() {
     const KrausOp& op = kv.second;
     if (!op.two_site) {
       const int l = dl_[p], dim = dd_[p], r = dr_[p];
-      if (dim % op.d != 0) throw ArgError("Kraus contract: dK must be divisible by d");
       kraus_core(site_[p].p, l, op.d, dim / op.d, r, op, spare.p);
       std::swap(site_[p], spare);
       gauge_[p] = MITDVP_GAUGE_C;
@@ -154,7 +160,6 @@ void Engine::apply_kraus() {
     }
     const int q = p + 1;
     const int m = dl_[p], d = dd_[p], l = dr_[p], K = dd_[q], n = dr_[q];
-    if (d != op.d) throw ArgError("two-site Kraus map: the system site's dimension differs from the Kraus operators'");
     DevBuf theta = pool_get((size_t)m * d * K * n), c2 = pool_get((size_t)m * d * K * n);
     {  // theta[m][d][(K,n)] = A1[(m,d)][l] A2[l][(K,n)]
       ZgemmDesc z = zgemm_desc(site_[p].p, site_[q].p, theta.p, m * d, K * n, l);
