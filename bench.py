@@ -318,7 +318,17 @@ def main():
         }
         if not args.no_cpu_baseline and args.gpus == 1:
             nthr = os.cpu_count() or 1
+            try:  # the threads the BLAS behind NumPy actually runs (OpenBLAS caps at its build-time maximum)
+                import numpy  # noqa: F401
+                import threadpoolctl
+
+                blas = [x["num_threads"] for x in threadpoolctl.threadpool_info() if x.get("user_api") == "blas"]
+                if blas:
+                    nthr = max(blas)
+            except Exception:
+                pass
             out["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, nthr)
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         print(json.dumps(out), flush=True)
     eng.close()
     comm.close()
