@@ -92,34 +92,41 @@ const char* mitdvp_last_error(const mitdvp_engine* h) { return h ? h->err.c_str(
 #define ENG_CALL(h, body)                                   \
   if (!(h) || !(h)->e) { g_err = "null handle"; return MITDVP_EINVAL; } \
   return guard((h), [&] { body; })
+// argument pointers that must not be NULL (reported as MITDVP_EINVAL instead of a crash)
+#define NEED(...)                                                       \
+  do {                                                                  \
+    const void* ptrs_[] = {__VA_ARGS__};                                \
+    for (const void* q_ : ptrs_)                                        \
+      if (!q_) throw mitdvp::ArgError("null pointer argument");         \
+  } while (0)
 
 int mitdvp_set_site(mitdvp_engine* h, int isite, const double* reim, int l, int n, int r, int gauge) {
-  ENG_CALL(h, h->e->set_site(isite, reim, l, n, r, gauge));
+  ENG_CALL(h, { NEED(reim); h->e->set_site(isite, reim, l, n, r, gauge); });
 }
 int mitdvp_get_site_shape(mitdvp_engine* h, int isite, int* l, int* n, int* r, int* gauge) {
-  ENG_CALL(h, h->e->get_site_shape(isite, l, n, r, gauge));
+  ENG_CALL(h, { NEED(l, n, r, gauge); h->e->get_site_shape(isite, l, n, r, gauge); });
 }
-int mitdvp_get_site(mitdvp_engine* h, int isite, double* out) { ENG_CALL(h, h->e->get_site(isite, out)); }
+int mitdvp_get_site(mitdvp_engine* h, int isite, double* out) { ENG_CALL(h, { NEED(out); h->e->get_site(isite, out); }); }
 int mitdvp_init_random(mitdvp_engine* h, const int* dims, int bond_dim, uint64_t seed) {
-  ENG_CALL(h, h->e->init_random(dims, bond_dim, seed));
+  ENG_CALL(h, { NEED(dims); h->e->init_random(dims, bond_dim, seed); });
 }
 int mitdvp_canonicalize(mitdvp_engine* h, double scale) { ENG_CALL(h, h->e->canonicalize(scale)); }
 int mitdvp_set_mpo_core(mitdvp_engine* h, int op_id, int isite, const double* reim, int ml, int d_out, int d_in,
                         int mr) {
-  ENG_CALL(h, h->e->set_mpo_core(op_id, isite, reim, ml, d_out, d_in, mr));
+  ENG_CALL(h, { NEED(reim); h->e->set_mpo_core(op_id, isite, reim, ml, d_out, d_in, mr); });
 }
 int mitdvp_set_shift(mitdvp_engine* h, int op_id, double re, double im) { ENG_CALL(h, h->e->set_shift(op_id, re, im)); }
 int mitdvp_step(mitdvp_engine* h, double dt) { ENG_CALL(h, h->e->step(dt)); }
 int mitdvp_sweep(mitdvp_engine* h, double dt, int forward) { ENG_CALL(h, h->e->sweep(dt, forward != 0)); }
 int mitdvp_invalidate_env(mitdvp_engine* h) { ENG_CALL(h, h->e->invalidate_env()); }
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]) {
-  ENG_CALL(h, { auto v = h->e->expect(op_id); out[0] = v.real(); out[1] = v.imag(); });
+  ENG_CALL(h, { NEED(out); auto v = h->e->expect(op_id); out[0] = v.real(); out[1] = v.imag(); });
 }
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]) {
-  ENG_CALL(h, { auto v = h->e->autocorr(); out[0] = v.real(); out[1] = v.imag(); });
+  ENG_CALL(h, { NEED(out); auto v = h->e->autocorr(); out[0] = v.real(); out[1] = v.imag(); });
 }
-int mitdvp_norm(mitdvp_engine* h, double* out) { ENG_CALL(h, *out = h->e->norm()); }
-int mitdvp_site_rdm(mitdvp_engine* h, int isite, double* out) { ENG_CALL(h, h->e->site_rdm(isite, out)); }
+int mitdvp_norm(mitdvp_engine* h, double* out) { ENG_CALL(h, { NEED(out); *out = h->e->norm(); }); }
+int mitdvp_site_rdm(mitdvp_engine* h, int isite, double* out) { ENG_CALL(h, { NEED(out); h->e->site_rdm(isite, out); }); }
 int mitdvp_reduced_density(mitdvp_engine* h, const int* remain_nleg, int nlen, double* out, size_t* n_out) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] {

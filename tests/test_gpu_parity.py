@@ -200,6 +200,19 @@ def test_bad_arguments_raise():
     eng.set_site(2, np.ones((2, 2, 1)), "B")
     with pytest.raises(ValueError, match="mismatch"):
         eng.expectation()
+    # NULL pointers at the C boundary are argument errors, not crashes
+    import ctypes as C
+
+    from pytdscf_amd import _lib
+
+    lib = _lib.load()
+    assert lib.mitdvp_norm(eng._h, None) == _lib.EINVAL
+    assert lib.mitdvp_get_site(eng._h, 0, None) == _lib.EINVAL
+    assert lib.mitdvp_set_site(eng._h, 0, None, 1, 2, 2, 0) == _lib.EINVAL
+    assert lib.mitdvp_expect(eng._h, 0, None) == _lib.EINVAL
+    assert lib.mitdvp_norm(None, C.byref(C.c_double())) == _lib.EINVAL
+    assert b"null" in lib.mitdvp_last_error(eng._h)
+    eng.close()
 
 
 def test_oracle_parity_liouvillian_arnoldi():
