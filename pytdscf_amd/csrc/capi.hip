@@ -175,15 +175,15 @@ int mitdvp_apply_kraus(mitdvp_engine* h) {
   return guard(h, [&] { h->e->apply_kraus(); });
 }
 int mitdvp_rccl_unique_id(char out[128]) {
-  return guard(nullptr, [&] { mitdvp::Engine::rccl_unique_id(out); });
+  return guard(nullptr, [&] { NEED(out); mitdvp::Engine::rccl_unique_id(out); });
 }
 int mitdvp_set_parallel_rccl(mitdvp_engine* h, int nranks, int rank, const char id[128]) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
-  return guard(h, [&] { h->e->set_parallel_rccl(nranks, rank, id); });
+  return guard(h, [&] { NEED(id); h->e->set_parallel_rccl(nranks, rank, id); });
 }
 int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
-  return guard(h, [&] { *mismatches = h->e->rccl_selftest(); });
+  return guard(h, [&] { NEED(mismatches); *mismatches = h->e->rccl_selftest(); });
 }
 int mitdvp_save_reference(mitdvp_engine* h) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
@@ -192,6 +192,7 @@ int mitdvp_save_reference(mitdvp_engine* h) {
 int mitdvp_overlap_reference(mitdvp_engine* h, double out[2]) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] {
+    NEED(out);
     const mitdvp::hzc v = h->e->overlap_reference();
     out[0] = v.real(); out[1] = v.imag();
   });
@@ -242,11 +243,12 @@ int mitdvp_svd(int device, const double* A, int r, int c, double* U, double* S, 
   });
 }
 int mitdvp_set_trace_op_core(mitdvp_engine* h, int op_id, int isite, const double* reim, int ml, int n, int mr) {
-  ENG_CALL(h, h->e->set_trace_op_core(op_id, isite, reim, ml, n, mr));
+  ENG_CALL(h, { NEED(reim); h->e->set_trace_op_core(op_id, isite, reim, ml, n, mr); });
 }
 int mitdvp_expect_trace(mitdvp_engine* h, int op_id, double out[2]) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] {
+    NEED(out);
     const auto v = h->e->expect_trace(op_id);
     out[0] = v.real();
     out[1] = v.imag();
@@ -278,8 +280,8 @@ int mitdvp_partial_trace(mitdvp_engine* h, const int* remain_nleg, int nlen, dou
     *n_out = v.size();
   });
 }
-int mitdvp_krylov_stats(mitdvp_engine* h, int* per_site) { ENG_CALL(h, h->e->krylov_stats(per_site)); }
-int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out) { ENG_CALL(h, h->e->counters_get(out)); }
+int mitdvp_krylov_stats(mitdvp_engine* h, int* per_site) { ENG_CALL(h, { NEED(per_site); h->e->krylov_stats(per_site); }); }
+int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out) { ENG_CALL(h, { NEED(out); h->e->counters_get(out); }); }
 int mitdvp_counters_reset(mitdvp_engine* h) { ENG_CALL(h, h->e->counters_reset()); }
 int mitdvp_set_profiling(mitdvp_engine* h, int on) { ENG_CALL(h, h->e->set_profiling(on != 0)); }
 int mitdvp_set_parallel(mitdvp_engine* h, int nranks, int rank, mitdvp_collective_fn fn, void* user) {
