@@ -10,6 +10,11 @@ Parity status: PINNED.  Every function below is checked in
 running the reference itself (``/root/reference``, PyTDSCF v1.3.3, NumPy
 backend) in the development container with ``tests/golden/make_golden.py``.
 
+Beyond the sweep itself (rows a1-a11) the module restates, each pinned the same way: SVD bond
+truncation, Liouville-space traces, adaptive bond dimension (a1TDVP), one-site gates and Kraus
+maps between the half-sweeps, ``Simulator.operate``.  ``tests/golden/crosscheck_reference.py``
+additionally runs reference and oracle side by side on combinations of these features.
+
 All ``file:line`` citations are relative to ``/root/reference/pytdscf``.
 
 Conventions:
