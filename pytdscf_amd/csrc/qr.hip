@@ -223,30 +223,42 @@ __global__ __launch_bounds__(256) void k_qr_extract_v(const zc* __restrict__ A, 
   }
 }
 
-// zlarft (forward, columnwise) from G = V^H V and tau; one workgroup
+// zlarft (forward, columnwise) from G = V^H V and tau; one workgroup.  G and tau are staged in
+// LDS once (a global load inside the 32-step recurrence costs ~1 us per step); the 8 adjacent
+// lanes (t, 0..7) share row t's triangular inner product and add their parts by cross-lane moves.
 __global__ __launch_bounds__(256) void k_qr_build_t(const zc* __restrict__ G, const zc* __restrict__ tau, int nbp,
                                                     zc* __restrict__ T) {
   __shared__ zc Ts[QR_NB][QR_NB + 1];
-  __shared__ zc zs[QR_NB];
-  const int t = threadIdx.x;
-  for (int e = t; e < QR_NB * QR_NB; e += 256) Ts[e / QR_NB][e % QR_NB] = make_double2(0.0, 0.0);
+  __shared__ zc Gs[QR_NB][QR_NB + 1];
+  __shared__ zc taus[QR_NB];
+  const int t = threadIdx.x >> 3, part = threadIdx.x & 7;
+  for (int e = threadIdx.x; e < QR_NB * QR_NB; e += 256) {
+    const int r = e / QR_NB, c = e % QR_NB;
+    Ts[r][c] = make_double2(0.0, 0.0);
+    Gs[r][c] = (r < nbp && c < nbp) ? G[(long)r * nbp + c] : make_double2(0.0, 0.0);
+  }
+  if (threadIdx.x < QR_NB) taus[threadIdx.x] = threadIdx.x < nbp ? tau[threadIdx.x] : make_double2(0.0, 0.0);
   __syncthreads();
   for (int i = 0; i < nbp; ++i) {
-    const zc ti = tau[i];
+    const zc ti = taus[i];
+    zc acc = make_double2(0.0, 0.0);
     if (t < i) {
-      const zc g = G[(long)t * nbp + i];
-      zs[t] = make_double2(-(ti.x * g.x - ti.y * g.y), -(ti.x * g.y + ti.y * g.x));
+      for (int sI = t + part; sI < i; sI += 8) {  // z_s = -tau_i G[s][i]
+        const zc g = Gs[sI][i];
+        const zc z = make_double2(-(ti.x * g.x - ti.y * g.y), -(ti.x * g.y + ti.y * g.x));
+        acc = zadd(acc, zmul(Ts[t][sI], z));
+      }
     }
-    __syncthreads();
-    if (t < i) {
-      zc acc = make_double2(0.0, 0.0);
-      for (int s = t; s < i; ++s) acc = zadd(acc, zmul(Ts[t][s], zs[s]));
-      Ts[t][i] = acc;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      acc.x += __shfl_xor(acc.x, o, 64);
+      acc.y += __shfl_xor(acc.y, o, 64);
     }
-    if (t == 0) Ts[i][i] = ti;
+    if (part == 0 && t < i) Ts[t][i] = acc;  // column i is only read from the next iteration on
+    if (threadIdx.x == 0) Ts[i][i] = ti;
     __syncthreads();
   }
-  for (int e = t; e < nbp * nbp; e += 256) T[e] = Ts[e / nbp][e % nbp];
+  for (int e = threadIdx.x; e < nbp * nbp; e += 256) T[e] = Ts[e / nbp][e % nbp];
 }
 
 __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, long lda, int n, zc* __restrict__ R) {
