@@ -272,7 +272,10 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 // ---------------------------------------------------------------------------
 // rows per workgroup in the panel kernels: enough workgroups to spread a column
 // step over the chip, few enough that summing their partials stays cheap
-static int qr_rows_for(int m) { return m <= 8192 ? 32 : (m <= 65536 ? 128 : 256); }
+// (measured: 32 rows per workgroup win up to the C4 shape 16384 x 1024 -- 61 vs 66 ms for the seven QRs of a
+// D = 1024 chain -- once the partial sums are loaded eight at a time; beyond that every workgroup would read
+// megabytes of partials per column)
+static int qr_rows_for(int m) { return m <= 16384 ? 32 : (m <= 131072 ? 128 : 256); }
 
 size_t qr_work_elems(int m, int n, int next) {
   const int nblk = (m + 31) / 32;  // upper bound over all row-block sizes

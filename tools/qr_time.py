@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytdscf_amd import TDVPEngine
 
-shapes = [("C5", 4, 512, 12), ("C3", 32, 128, 6), ("C2", 10, 32, 10), ("C4", 16, 1024, 5), ("mid", 8, 256, 10)]
+shapes = [("C4i", 16, 1024, 8), ("C5", 4, 512, 12), ("C3", 32, 128, 6), ("C2", 10, 32, 10), ("C4", 16, 1024, 5), ("mid", 8, 256, 10)]
 for name, d, D, L in shapes:
     eng = TDVPEngine(L)
     eng.init_random([d] * L, D, seed=1)   # warm-up (allocations)
