@@ -827,6 +827,205 @@ def overlap(bra: list[np.ndarray], ket: list[np.ndarray], conj_bra: bool = True)
 
 
 # --------------------------------------------------------------------------
+# several electronic states: one MPS per state, Hamiltonian blocks H[i][j]
+# --------------------------------------------------------------------------
+@dataclass
+class OracleMultiMPS:
+    """MPS-SM with ``nstate > 1``: ``cores[i]`` is the site-0-centred MPS of state i,
+    ``mpo[i][j]`` the full-chain MPO between bra state i and ket state j (or None),
+    ``coupleJ[i][j]`` the scalar term (it multiplies the bra/ket overlap blocks,
+    _contraction.py:1200-1216; for i == j those are the identity).
+
+    The local problems act on the states' centre tensors stacked into one vector
+    (SplitStack.stack/split, _contraction.py:479-608): sigma_i = sum_j H_eff[i][j] psi_j
+    with the blocks of the state pair (i, j) (multiplyH_MPS_direct_MPO.dot,
+    _contraction.py:1182-1243; operators_for_superH, _mps_mpo.py:698-858).  Environment
+    blocks are kept per state pair (renormalize_op_psite, _mps_mpo.py:421-696), the gauge
+    move is a separate QR per state (trans_next_psite_AsigmaB, _mps_cls.py:1798-1850) and
+    ``kprev`` is shared by all states (one Krylov solve per site).
+    """
+
+    cores: list[list[np.ndarray]]
+    mpo: list[list[list[np.ndarray] | None]]
+    coupleJ: list[list[complex]]
+    integrator: str = "lanczos"
+    thresh: float = 1e-9
+    conserve_norm: bool = True
+    relax: bool | str = False
+    kprev: dict = field(default_factory=dict)
+    center: int = 0
+
+    def __post_init__(self):
+        self.cores = [[np.array(c, dtype=np.complex128) for c in st] for st in self.cores]
+        self.nstate = len(self.cores)
+        self.nsite = len(self.cores[0])
+        self.mpo = [
+            [None if m is None else [np.array(w, dtype=np.complex128) for w in m] for m in row] for row in self.mpo
+        ]
+        self.pairs = [(i, j) for i in range(self.nstate) for j in range(self.nstate)]
+        one = np.ones((1, 1, 1), dtype=np.complex128)
+        # per pair: operator blocks ("op") and overlap blocks ("ov", i != j with a scalar term)
+        self.left = {(k, ij): {0: one} for k in ("op", "ov") for ij in self.pairs}
+        self.right = {(k, ij): {self.nsite - 1: one} for k in ("op", "ov") for ij in self.pairs}
+        self._built = False
+
+    def _chains(self, mpo=None, coupleJ=None):
+        """(kind, (i, j), cores, factor) for every chain that enters H."""
+        mpo = self.mpo if mpo is None else mpo
+        cj = self.coupleJ if coupleJ is None else coupleJ
+        out = []
+        for i, j in self.pairs:
+            if mpo[i][j] is not None:
+                out.append(("op", (i, j), mpo[i][j], 1.0))
+            if i != j and cj[i][j] != 0.0:
+                d = [c.shape[1] for c in self.cores[j]]
+                out.append(("ov", (i, j), [np.eye(n, dtype=np.complex128)[None, :, :, None] for n in d], cj[i][j]))
+        return out
+
+    def build_right_envs(self):
+        for kind, (i, j), w, _ in self._chains():
+            R = self.right[(kind, (i, j))]
+            for p in range(self.nsite - 1, 0, -1):
+                R[p - 1] = env_update_right(R[p], self.cores[j][p], w[p], bra=self.cores[i][p])
+        self._built = True
+
+    # ---- stacked vectors ---------------------------------------------------
+    @staticmethod
+    def _stack(xs):
+        return np.concatenate([x.reshape(-1) for x in xs])
+
+    @staticmethod
+    def _split(v, shapes):
+        out, o = [], 0
+        for sh in shapes:
+            n = int(np.prod(sh))
+            out.append(v[o : o + n].reshape(sh))
+            o += n
+        return out
+
+    def _heff(self, p, shapes):
+        chains = self._chains()
+
+        def mv(v):
+            xs = self._split(v, shapes)
+            ys = [np.zeros(sh, dtype=np.complex128) for sh in shapes]
+            for i in range(self.nstate):
+                if self.coupleJ[i][i] != 0.0:
+                    ys[i] = ys[i] + self.coupleJ[i][i] * xs[i]
+            for kind, (i, j), w, f in chains:
+                ys[i] = ys[i] + f * heff_apply(self.left[(kind, (i, j))][p], w[p], self.right[(kind, (i, j))][p], xs[j])
+            return self._stack(ys)
+
+        return mv
+
+    def _keff(self, pl, pr, shapes):
+        chains = self._chains()
+
+        def mv(v):
+            xs = self._split(v, shapes)
+            ys = [np.zeros(sh, dtype=np.complex128) for sh in shapes]
+            for i in range(self.nstate):
+                if self.coupleJ[i][i] != 0.0:
+                    ys[i] = ys[i] + self.coupleJ[i][i] * xs[i]
+            for kind, (i, j), _, f in chains:
+                ys[i] = ys[i] + f * keff_apply(self.left[(kind, (i, j))][pl], self.right[(kind, (i, j))][pr], xs[j])
+            return self._stack(ys)
+
+        return mv
+
+    def _exp(self, scale, matvec, xs, site):
+        shapes = [x.shape for x in xs]
+        fn = sil_lanczos if self.integrator == "lanczos" else sil_arnoldi
+        # _iter_info sizes the Krylov space by the LARGEST state tensor, not the stack (_integrator.py:178-186)
+        size = max(x.size for x in xs)
+        out, k = fn(scale, matvec, self._stack(xs), self.thresh, self.kprev.get(site, 0), self.conserve_norm, size)
+        self.kprev[site] = k
+        return self._split(out, shapes)
+
+    def sweep(self, dt: float, forward: bool):
+        n, S = self.nsite, self.nstate
+        end = n - 1 if forward else 0
+        zs = -1.0 if self.relax else -1.0j
+        for p in range(0, n) if forward else range(n - 1, -1, -1):
+            xs = [self.cores[s][p] for s in range(S)]
+            shapes = [x.shape for x in xs]
+            if self.relax == "improved":
+                new, k = lanczos_ground_state(self._heff(p, shapes), self._stack(xs), self.thresh)
+                self.kprev[p] = k
+                new = self._split(new / np.linalg.norm(new), shapes)
+            else:
+                new = self._exp(zs * dt / 2, self._heff(p, shapes), xs, p)
+            for s in range(S):
+                self.cores[s][p] = new[s]
+            if p == end:
+                break
+            svals = []
+            for s in range(S):
+                if forward:
+                    A, sv = qr_psi2Asigma(self.cores[s][p])
+                    self.cores[s][p] = A
+                else:
+                    sv, B = qr_psi2sigmaB(self.cores[s][p])
+                    self.cores[s][p] = np.ascontiguousarray(B)
+                svals.append(sv)
+            for kind, (i, j), w, _ in self._chains():
+                if forward:
+                    self.left[(kind, (i, j))][p + 1] = env_update_left(
+                        self.left[(kind, (i, j))][p], self.cores[j][p], w[p], bra=self.cores[i][p]
+                    )
+                else:
+                    self.right[(kind, (i, j))][p - 1] = env_update_right(
+                        self.right[(kind, (i, j))][p], self.cores[j][p], w[p], bra=self.cores[i][p]
+                    )
+            if self.relax != "improved":
+                shp = [x.shape for x in svals]
+                mk = self._keff(p + 1, p, shp) if forward else self._keff(p, p - 1, shp)
+                svals = self._exp(-zs * dt / 2, mk, svals, p)
+            for s in range(S):
+                if forward:
+                    self.cores[s][p + 1] = np.tensordot(svals[s], self.cores[s][p + 1], axes=(1, 0))
+                else:
+                    self.cores[s][p - 1] = np.tensordot(self.cores[s][p - 1], svals[s], axes=(2, 0))
+        self.center = end
+
+    def propagate(self, dt: float):
+        if not self._built:
+            self.build_right_envs()
+        self.sweep(dt, True)
+        self.sweep(dt, False)
+
+    # ---- observables (site-0 centred) ----------------------------------------
+    def pop_states(self) -> list[float]:
+        """pop_states (_mps_cls.py:682-703)."""
+        return [float(np.linalg.norm(st[0]) ** 2) for st in self.cores]
+
+    def norm(self) -> float:
+        return math.sqrt(sum(self.pop_states()))
+
+    def expectation(self, mpo=None, coupleJ=None) -> complex:
+        """sum_ij <Psi_i|O_ij|Psi_j> with fresh right blocks (MPSCoef.expectation, _mps_cls.py:540-612)."""
+        cj = self.coupleJ if coupleJ is None else coupleJ
+        if mpo is not None and coupleJ is None:
+            cj = [[0.0] * self.nstate for _ in range(self.nstate)]
+        tot = 0.0 + 0.0j
+        for i in range(self.nstate):
+            if cj[i][i] != 0.0:
+                tot += cj[i][i] * np.vdot(self.cores[i][0], self.cores[i][0])
+        one = np.ones((1, 1, 1), dtype=np.complex128)
+        for _, (i, j), w, f in self._chains(mpo, cj):
+            R = one
+            for p in range(self.nsite - 1, 0, -1):
+                R = env_update_right(R, self.cores[j][p], w[p], bra=self.cores[i][p])
+            sig = heff_apply(one, w[0], R, self.cores[j][0])
+            tot += f * np.vdot(self.cores[i][0].reshape(-1), sig.reshape(-1))
+        return complex(tot)
+
+    def autocorr(self) -> complex:
+        """sum_i <Psi_i^*|Psi_i> (only the diagonal pairs carry an "auto" block, _mps_mpo.py:386-395)."""
+        return sum(overlap(st, st, conj_bra=False) for st in self.cores)
+
+
+# --------------------------------------------------------------------------
 # Simulator.operate: variational application of an MPO to the state
 # --------------------------------------------------------------------------
 def operate(cores0: list[np.ndarray], mpo: list[np.ndarray], maxstep: int = 10, conv_tol: float = 1.0e-8, shift: complex = 0.0):

@@ -789,6 +789,81 @@ def main():
     save("adaptive_chain_shift.npz", dt_au=np.array(0.05 / au_in_fs), nsite=np.array(La), bond_dim0=np.array(Da0),
          Dmax=np.array(7), dD=np.array(1), p_proj=np.array(1.0e-8), coupleJ=np.array(0.7), **o)
 
+    # (x) several electronic states (MPS-SM, nstate = 2): one MPS per state, Hamiltonian blocks
+    # H[i][j] (TensorHamiltonian(potential=[[..]]), hamiltonian_cls.py:628-752), the centre tensors
+    # of all states stacked for the local solves.  NOTE the reference's NumPy backend caches its
+    # contraction expressions by OPERATOR KEY only (_contraction.py:1050-1055, :1165-1172), so two
+    # state pairs that use the same key (or both carry a "summed" / non-identity "ovlp" block) share
+    # the first pair's blocks -- its JAX path has no such cache.  The fixture therefore gives every
+    # pair a distinct full-chain key (mixing 4-leg and diagonal 3-leg cores) and keeps the
+    # off-diagonal scalar terms zero, which makes the NumPy path exact.
+    rng_m = np.random.default_rng(70707)
+
+    def crandn_m(*shape):
+        return rng_m.standard_normal(shape) + 1j * rng_m.standard_normal(shape)
+
+    Lm, dm, Mm, Dm = 5, 3, 4, 5
+    eye_m = np.eye(dm)
+    adj = lambda w: np.ascontiguousarray(np.conj(w.transpose(0, 2, 1, 3)))  # noqa: E731
+    full = lambda w: np.einsum("cit,ij->cijt", w, eye_m)  # noqa: E731
+    h00 = orc.synthetic_mpo(Lm, dm, Mm, seed=31)
+    d11 = [np.ascontiguousarray(np.einsum("ciit->cit", w).real) + 0j for w in orc.synthetic_mpo(Lm, dm, Mm, seed=32)]
+    # coupling block: sites 0-2 four-leg, sites 3-4 diagonal; its adjoint is written with site 3 as a 4-leg core
+    bm = [1, 3, 3, 2, 2, 1]
+    h01 = [0.12 * crandn_m(bm[i], dm, dm, bm[i + 1]) for i in range(3)] + [0.5 * crandn_m(bm[3], dm, bm[4]), 0.5 * crandn_m(bm[4], dm, bm[5])]
+    h10 = [adj(w) for w in h01[:3]] + [adj(full(h01[3])), np.conj(h01[4])]
+    keys = {
+        (0, 0): (tuple((i, i) for i in range(Lm)), None),
+        (1, 1): (tuple(range(Lm)), tuple(range(Lm))),
+        (0, 1): (((0, 0), (1, 1), (2, 2), 3, 4), (0, 0, 1, 1, 2, 2, 3, 4)),
+        (1, 0): (((0, 0), (1, 1), (2, 2), (3, 3), 4), (0, 0, 1, 1, 2, 2, 3, 3, 4)),
+    }
+    blocks = {(0, 0): h00, (1, 1): d11, (0, 1): h01, (1, 0): h10}
+    cj_m = [[0.0, 0.0], [0.0, 0.05]]
+
+    def ham_m():
+        pot = [[None, None], [None, None]]
+        for (i_, j_), cores_ in blocks.items():
+            key_, legs_ = keys[(i_, j_)]
+            pot[i_][j_] = {key_: TensorOperator(mpo=[w.copy() for w in cores_], legs=legs_)}
+            if cj_m[i_][j_] != 0.0:
+                pot[i_][j_][()] = cj_m[i_][j_]
+        return TensorHamiltonian(Lm, potential=pot, kinetic=None, backend="numpy")
+
+    basis_m = [[Exciton(nstate=dm) for _ in range(Lm)] for _ in range(2)]
+    bd_m = orc.bond_dims([dm] * Lm, Dm)
+    init_m = [[crandn_m(a, dm, b) for a, b in bd_m] for _ in range(2)]
+    weights_m = [0.8, 0.6]
+    o = {"coupleJ": np.array(cj_m), "weights": np.array(weights_m)}
+    for (i_, j_), cores_ in blocks.items():  # stored as full-chain 4-leg cores
+        for p_, w in enumerate(cores_):
+            o[f"mpo{i_}{j_}_{p_}"] = w if w.ndim == 4 else full(w)
+    for s_ in range(2):
+        o.update({f"init{s_}_{p_}": c for p_, c in enumerate(init_m[s_])})
+    for tag, kw in (("", {}), ("relax_", {"relax": True})):
+        for n in (1, 3):
+            model_m = Model(basis_m, operators={"hamiltonian": ham_m()}, bond_dim=Dm)
+            model_m.init_HartreeProduct = [[np.array(c) for c in st_] for st_ in init_m]
+            model_m.init_weight_ESTATE = list(weights_m)
+            helper._Debug.niter_krylov.clear()
+            sim = Simulator("gold_multistate", model_m, backend="numpy", verbose=0)
+            if kw:
+                ener, wf = sim.relax(stepsize=0.2, maxstep=n, improved=False)
+            else:
+                ener, wf = sim.propagate(stepsize=0.05, maxstep=n)
+            pre = f"{tag}n{n}"
+            o[f"{pre}_energy_last"] = np.array(ener)
+            o[f"{pre}_energy_final"] = np.array(wf.expectation(model_m.hamiltonian))
+            o[f"{pre}_pops"] = np.array(wf.pop_states())
+            o[f"{pre}_norm"] = np.array(wf.norm())
+            o[f"{pre}_autocorr"] = np.array(wf._ints_wf_ovlp_mpssm(wf.ci_coef, conj=False))
+            o[f"{pre}_krylov"] = np.array([helper._Debug.niter_krylov[i] for i in range(Lm)])
+            for s_ in range(2):
+                for p_, c in enumerate(wf.ci_coef.superblock_states[s_]):
+                    o[f"{pre}_final{s_}_{p_}"] = np.array(c.data)
+    save("multistate_chain.npz", dt_au=np.array(0.05 / au_in_fs), dt_relax_au=np.array(0.2 / au_in_fs),
+         nsite=np.array(Lm), nstate=np.array(2), bond_dim=np.array(Dm), **o)
+
 
 if __name__ == "__main__":
     main()

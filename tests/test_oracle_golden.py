@@ -299,3 +299,41 @@ def test_operate_variational_application(golden):
         np.testing.assert_allclose(nrm, float(g[f"n{ns}_norm"]), rtol=1e-12)
         for i in range(n):
             np.testing.assert_allclose(bra[i], g[f"n{ns}_final{i}"], atol=1e-11)
+
+
+def load_multistate(g):
+    """(initial states, blocks mpo[i][j], coupleJ) of tests/golden/multistate_chain.npz."""
+    n, S = int(g["nsite"]), int(g["nstate"])
+    mpo = [[[g[f"mpo{i}{j}_{p}"] for p in range(n)] for j in range(S)] for i in range(S)]
+    w = g["weights"] / g["weights"].sum()  # _get_initial_condition, _mps_cls.py:152-155
+    init = [
+        orc.canonicalize_site0([g[f"init{s}_{p}"] for p in range(n)], float(np.sqrt(w[s])))  # _mps_mpo.py:88-94
+        for s in range(S)
+    ]
+    return init, mpo, [[complex(c) for c in row] for row in g["coupleJ"]]
+
+
+@pytest.mark.parametrize("mode", ["propagate", "relax"])
+def test_multistate_chain(golden, mode):
+    """nstate = 2: one MPS per electronic state, stacked local solves, blocks per state pair."""
+    g = golden("multistate_chain.npz")
+    init, mpo, cj = load_multistate(g)
+    n, S = int(g["nsite"]), int(g["nstate"])
+    relax = mode == "relax"
+    dt = float(g["dt_relax_au"] if relax else g["dt_au"])
+    pre = "relax_" if relax else ""
+    for steps in (1, 3):
+        st = orc.OracleMultiMPS(init, mpo, cj, relax=relax)
+        for _ in range(steps):
+            e_last = st.expectation()
+            st.propagate(dt)
+        k = f"{pre}n{steps}"
+        assert [st.kprev[p] for p in range(n)] == list(g[f"{k}_krylov"])
+        np.testing.assert_allclose(e_last.real, g[f"{k}_energy_last"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(st.expectation().real, g[f"{k}_energy_final"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(st.pop_states(), g[f"{k}_pops"], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(st.norm(), g[f"{k}_norm"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(st.autocorr(), complex(g[f"{k}_autocorr"]), rtol=0, atol=1e-11)
+        for s in range(S):
+            for p in range(n):
+                np.testing.assert_allclose(st.cores[s][p], g[f"{k}_final{s}_{p}"], rtol=0, atol=1e-10)
