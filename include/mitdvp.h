@@ -128,6 +128,33 @@ int mitdvp_rccl_unique_id(char out[128]);
 int mitdvp_set_parallel_rccl(mitdvp_engine* h, int nranks, int rank, const char id[128]);
 int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches);
 
+/* -- several electronic states (MPS-SM, nstate > 1) -------------------------
+ * The reference keeps one MPS per electronic state (superblock_states[istate][isite],
+ * _mps_cls.py:84-118; the SURVEY's istate / ibra / iket arguments) and one MPO block plus one
+ * scalar per (bra, ket) state pair (TensorHamiltonian.mpo[i][j], .coupleJ[i][j],
+ * hamiltonian_cls.py:618-752).  The local solves act on all states' centre tensors stacked into
+ * one Krylov vector (SplitStack, _contraction.py:479-608; multiplyH_MPS_direct_MPO.dot, :1182-1243),
+ * environment blocks are kept per state pair (renormalize_op_psite, _mps_mpo.py:421-696) and the
+ * gauge move is one QR per state (_mps_cls.py:1798-1850).  mitdvp_ms_configure switches a handle
+ * to this mode; states share the physical dimensions, bond dimensions may differ per state;
+ * every MPO block spans all sites (4-leg cores).  mitdvp_krylov_stats and mitdvp_counters apply
+ * unchanged.  Not available in this mode: adaptive bonds, gates, Kraus maps, improved relaxation,
+ * bond sharding. */
+int mitdvp_ms_configure(mitdvp_engine* h, int nstate);
+int mitdvp_ms_set_site(mitdvp_engine* h, int istate, int isite, const double* reim, int l, int n, int r, int gauge);
+int mitdvp_ms_get_site_shape(mitdvp_engine* h, int istate, int isite, int* l, int* n, int* r, int* gauge);
+int mitdvp_ms_get_site(mitdvp_engine* h, int istate, int isite, double* out);
+/* right-to-left QR of one state, site 0 scaled to `scale` = sqrt(weight of the state) >= 0
+ * (alloc_superblock_random, _mps_cls.py:2684-2699; _mps_mpo.py:88-94) */
+int mitdvp_ms_canonicalize(mitdvp_engine* h, int istate, double scale);
+int mitdvp_ms_set_mpo_core(mitdvp_engine* h, int op_id, int ibra, int iket, int isite, const double* reim, int ml, int d_out,
+                           int d_in, int mr);
+int mitdvp_ms_set_coupleJ(mitdvp_engine* h, int op_id, int ibra, int iket, double re, double im);
+int mitdvp_ms_step(mitdvp_engine* h, double dt_au);                   /* MPSCoef.propagate, _mps_cls.py:452-503 */
+int mitdvp_ms_expect(mitdvp_engine* h, int op_id, double out[2]);     /* sum over state pairs, _mps_cls.py:540-612 */
+int mitdvp_ms_autocorr(mitdvp_engine* h, double out[2]);              /* sum over states, wavefunction.py:226-257 */
+int mitdvp_ms_pops(mitdvp_engine* h, double* out /* [nstate] */);      /* pop_states, _mps_cls.py:682-703 */
+
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */

@@ -3,10 +3,10 @@
 from . import units  # noqa: F401
 from .api import BasInfo, Model, Simulator, TensorHamiltonian, TensorOperator, WFunc  # noqa: F401
 from .basis import Boson, Exciton, HarmonicOscillator  # noqa: F401
-from .engine import TDVPEngine  # noqa: F401
+from .engine import MultiStateEngine, TDVPEngine  # noqa: F401
 from . import dvr_operator_cls  # noqa: F401,E402
 
 __all__ = [
-    "TDVPEngine", "Simulator", "Model", "BasInfo", "TensorHamiltonian", "TensorOperator", "WFunc",
+    "TDVPEngine", "MultiStateEngine", "Simulator", "Model", "BasInfo", "TensorHamiltonian", "TensorOperator", "WFunc",
     "Exciton", "Boson", "HarmonicOscillator", "units",
 ]

@@ -124,6 +124,17 @@ def load() -> C.CDLL:
         "mitdvp_set_parallel_rccl": (i, [vp, i, i, C.c_char_p]),
         "mitdvp_rccl_selftest": (i, [vp, ip]),
         "mitdvp_operate": (i, [vp, i, i, d, dp, ip]),
+        "mitdvp_ms_configure": (i, [vp, i]),
+        "mitdvp_ms_set_site": (i, [vp, i, i, dp, i, i, i, i]),
+        "mitdvp_ms_get_site_shape": (i, [vp, i, i, ip, ip, ip, ip]),
+        "mitdvp_ms_get_site": (i, [vp, i, i, dp]),
+        "mitdvp_ms_canonicalize": (i, [vp, i, d]),
+        "mitdvp_ms_set_mpo_core": (i, [vp, i, i, i, i, dp, i, i, i, i]),
+        "mitdvp_ms_set_coupleJ": (i, [vp, i, i, i, d, d]),
+        "mitdvp_ms_step": (i, [vp, d]),
+        "mitdvp_ms_expect": (i, [vp, i, dp]),
+        "mitdvp_ms_autocorr": (i, [vp, dp]),
+        "mitdvp_ms_pops": (i, [vp, dp]),
         "mitdvp_set_kraus": (i, [vp, i, i, dp, i, i]),
         "mitdvp_apply_kraus": (i, [vp]),
         "mitdvp_clock_probe": (i, [i, C.c_long, dp]),

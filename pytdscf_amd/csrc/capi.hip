@@ -204,6 +204,34 @@ int mitdvp_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, do
     if (norm_out) *norm_out = n;
   });
 }
+// ---- several electronic states (engine_multi.hip) ---------------------------------------------
+int mitdvp_ms_configure(mitdvp_engine* h, int nstate) { ENG_CALL(h, { h->e->ms_configure(nstate); }); }
+int mitdvp_ms_set_site(mitdvp_engine* h, int istate, int isite, const double* reim, int l, int n, int r, int gauge) {
+  ENG_CALL(h, { NEED(reim); h->e->ms_set_site(istate, isite, reim, l, n, r, gauge); });
+}
+int mitdvp_ms_get_site_shape(mitdvp_engine* h, int istate, int isite, int* l, int* n, int* r, int* gauge) {
+  ENG_CALL(h, { NEED(l, n, r, gauge); h->e->ms_get_site_shape(istate, isite, l, n, r, gauge); });
+}
+int mitdvp_ms_get_site(mitdvp_engine* h, int istate, int isite, double* out) {
+  ENG_CALL(h, { NEED(out); h->e->ms_get_site(istate, isite, out); });
+}
+int mitdvp_ms_canonicalize(mitdvp_engine* h, int istate, double scale) { ENG_CALL(h, { h->e->ms_canonicalize(istate, scale); }); }
+int mitdvp_ms_set_mpo_core(mitdvp_engine* h, int op_id, int ibra, int iket, int isite, const double* reim, int ml, int d_out,
+                           int d_in, int mr) {
+  ENG_CALL(h, { NEED(reim); h->e->ms_set_mpo_core(op_id, ibra, iket, isite, reim, ml, d_out, d_in, mr); });
+}
+int mitdvp_ms_set_coupleJ(mitdvp_engine* h, int op_id, int ibra, int iket, double re, double im) {
+  ENG_CALL(h, { h->e->ms_set_couplej(op_id, ibra, iket, re, im); });
+}
+int mitdvp_ms_step(mitdvp_engine* h, double dt_au) { ENG_CALL(h, { h->e->ms_step(dt_au); }); }
+int mitdvp_ms_expect(mitdvp_engine* h, int op_id, double out[2]) {
+  ENG_CALL(h, { NEED(out); auto v = h->e->ms_expect(op_id); out[0] = v.real(); out[1] = v.imag(); });
+}
+int mitdvp_ms_autocorr(mitdvp_engine* h, double out[2]) {
+  ENG_CALL(h, { NEED(out); auto v = h->e->ms_autocorr(); out[0] = v.real(); out[1] = v.imag(); });
+}
+int mitdvp_ms_pops(mitdvp_engine* h, double* out) { ENG_CALL(h, { NEED(out); h->e->ms_pops(out); }); }
+
 int mitdvp_set_adaptive(mitdvp_engine* h, int enable, int dmax, int dd, double p_proj) {
   if (!h || !h->e) { g_err = "null handle"; return MITDVP_EINVAL; }
   return guard(h, [&] { h->e->set_adaptive(enable != 0, dmax, dd, p_proj); });

@@ -158,6 +158,20 @@ class Engine {
   void set_adaptive(bool on, int dmax, int dd, double p_proj);
   void thin_to_full_A(const zc* A, int l, int c, int r, int e, zc* out);
   void thin_to_full_B(const zc* B, int l, int c, int r, int e, zc* out);
+  // several electronic states: one MPS per state, Hamiltonian blocks per (bra, ket) state pair,
+  // the states' centre tensors stacked for the local solves (SplitStack, _contraction.py:479-608)
+  void ms_configure(int nstate);
+  int ms_nstate() const;
+  void ms_set_site(int istate, int isite, const double* reim, int l, int n, int r, int gauge);
+  void ms_get_site_shape(int istate, int isite, int* l, int* n, int* r, int* gauge);
+  void ms_get_site(int istate, int isite, double* out);
+  void ms_canonicalize(int istate, double scale);
+  void ms_set_mpo_core(int op_id, int ibra, int iket, int isite, const double* reim, int ml, int dout, int din, int mr);
+  void ms_set_couplej(int op_id, int ibra, int iket, double re, double im);
+  void ms_step(double dt);
+  hzc ms_expect(int op_id);
+  hzc ms_autocorr();
+  void ms_pops(double* out);
   hipStream_t stream() const { return st_; }
   const MpoSite& mpo(int op_id, int isite);
   mitdvp_config cfg;
@@ -225,6 +239,17 @@ class Engine {
   int cur_timer_ = -1;
 
   Operator& op(int id);
+  void upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, int din, int mr);
+
+  // several electronic states (MPS-SM, nstate > 1): engine_multi.hip
+  struct Multi;
+  std::shared_ptr<Multi> ms_;
+  Multi& ms();
+  void ms_require_ready();
+  void ms_build_chains();
+  void ms_build_right_envs();
+  void ms_sweep(double dt, bool forward);
+  void ms_site_exp(int p, double dt);
   void size_workspaces();
   void build_right_envs();
   void local_site_exp(int p, double dt);

@@ -164,8 +164,7 @@ const MpoSite& Engine::mpo(int op_id, int isite) {
   return it->second.sites[isite];
 }
 
-void Engine::set_mpo_core(int op_id, int isite, const double* reim, int ml, int dout, int din, int mr) {
-  if (isite < 0 || isite >= L_) throw ArgError("set_mpo_core: bad site index");
+void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, int din, int mr) {
   if (ml < 1 || mr < 1 || dout < 1 || dout != din) throw ArgError("set_mpo_core: need a square 4-leg core");
   const int d = dout;
   const hzc* W = reinterpret_cast<const hzc*>(reim);
@@ -178,7 +177,6 @@ void Engine::set_mpo_core(int op_id, int isite, const double* reim, int ml, int 
           w2l[((size_t)i * mr + t) * ((size_t)ml * d) + (size_t)c * d + j] = v;
           w2r[((size_t)i * ml + c) * ((size_t)mr * d) + (size_t)t * d + j] = v;
         }
-  MpoSite& s = op(op_id).sites[isite];
   s.ml = ml; s.d = d; s.mr = mr;
   s.w2l.reserve(w2l.size());
   s.w2r.reserve(w2r.size());
@@ -186,6 +184,11 @@ void Engine::set_mpo_core(int op_id, int isite, const double* reim, int ml, int 
   HIP_CHECK(hipMemcpyAsync(s.w2r.p, w2r.data(), w2r.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
   HIP_CHECK(hipStreamSynchronize(st_));
   s.set = true;
+}
+
+void Engine::set_mpo_core(int op_id, int isite, const double* reim, int ml, int dout, int din, int mr) {
+  if (isite < 0 || isite >= L_) throw ArgError("set_mpo_core: bad site index");
+  upload_mpo_core(op(op_id).sites[isite], reim, ml, dout, din, mr);
   if (op_id == 0) invalidate_env();
 }
 void Engine::set_shift(int op_id, double re, double im) { op(op_id).shift = hzc(re, im); }

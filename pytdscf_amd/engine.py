@@ -283,6 +283,90 @@ class TDVPEngine:
         self._ck(self._lib.mitdvp_set_profiling(self._h, int(on)))
 
 
+class MultiStateEngine(TDVPEngine):
+    """Several electronic states (MPS-SM, ``nstate > 1``): one MPS per state, one MPO block and
+    one scalar ``coupleJ`` per (bra, ket) state pair; the local solves act on the states' centre
+    tensors stacked into one vector (reference: ``superblock_states[istate][isite]``,
+    ``TensorHamiltonian.mpo[i][j]``, ``multiplyH_MPS_direct_MPO.dot``)."""
+
+    def __init__(self, nsite: int, nstate: int, **kw):
+        super().__init__(nsite, **kw)
+        self.nstate = nstate
+        self._ck(self._lib.mitdvp_ms_configure(self._h, nstate))
+
+    def set_state(self, istate: int, cores, canonicalize: bool = False, scale: float = 1.0):
+        """Site-0-centred cores of one state (gauges Psi,B,...,B), or arbitrary cores with
+        ``canonicalize=True`` once ALL states are set (``canonicalize_states``)."""
+        for p, c in enumerate(cores):
+            a = _c128(c)
+            if a.ndim != 3:
+                raise ValueError("site tensor must be (D_l, d, D_r)")
+            g = _lib.GAUGE_C if canonicalize else (_lib.GAUGE_PSI if p == 0 else _lib.GAUGE_B)
+            self._ck(self._lib.mitdvp_ms_set_site(self._h, istate, p, _dp(a), a.shape[0], a.shape[1], a.shape[2], g))
+
+    def set_states(self, states, weights=None):
+        """states[istate] = arbitrary cores; QR sweep per state and site 0 scaled to
+        sqrt(weight / sum(weights)) (alloc_superblock_random with init_weight_ESTATE)."""
+        if len(states) != self.nstate:
+            raise ValueError("one list of cores per state")
+        for s, cores in enumerate(states):
+            self.set_state(s, cores, canonicalize=weights is not None)
+        if weights is not None:
+            w = np.asarray(weights, dtype=float)
+            if len(w) != self.nstate or w.min() < 0 or w.sum() <= 0:
+                raise ValueError("weights must be non-negative, one per state")
+            w = w / w.sum()
+            for s in range(self.nstate):
+                self._ck(self._lib.mitdvp_ms_canonicalize(self._h, s, float(np.sqrt(w[s]))))
+
+    def get_state_site(self, istate: int, isite: int) -> np.ndarray:
+        l, n, r, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._lib.mitdvp_ms_get_site_shape(self._h, istate, isite, C.byref(l), C.byref(n), C.byref(r), C.byref(g)))
+        out = np.empty((l.value, n.value, r.value), dtype=np.complex128)
+        self._ck(self._lib.mitdvp_ms_get_site(self._h, istate, isite, _dp(out)))
+        return out
+
+    def get_states(self):
+        return [[self.get_state_site(s, p) for p in range(self.nsite)] for s in range(self.nstate)]
+
+    def set_block(self, ibra: int, iket: int, cores, op_id: int = 0):
+        for p, w in enumerate(cores):
+            a = _c128(w)
+            if a.ndim != 4:
+                raise ValueError("MPO core must be (M_l, d, d, M_r)")
+            self._ck(self._lib.mitdvp_ms_set_mpo_core(self._h, op_id, ibra, iket, p, _dp(a), *a.shape))
+
+    def set_hamiltonian(self, blocks, coupleJ=None, op_id: int = 0):
+        """blocks[i][j] = full-chain MPO cores or None; coupleJ[i][j] scalars."""
+        for i in range(self.nstate):
+            for j in range(self.nstate):
+                if blocks[i][j] is not None:
+                    self.set_block(i, j, blocks[i][j], op_id)
+                c = 0.0 if coupleJ is None else complex(coupleJ[i][j])
+                self._ck(self._lib.mitdvp_ms_set_coupleJ(self._h, op_id, i, j, complex(c).real, complex(c).imag))
+
+    def propagate(self, dt_au: float):
+        self._ck(self._lib.mitdvp_ms_step(self._h, dt_au))
+
+    def expectation(self, op_id: int = 0) -> complex:
+        out = np.zeros(2)
+        self._ck(self._lib.mitdvp_ms_expect(self._h, op_id, _dp(out)))
+        return complex(out[0], out[1])
+
+    def autocorr(self) -> complex:
+        out = np.zeros(2)
+        self._ck(self._lib.mitdvp_ms_autocorr(self._h, _dp(out)))
+        return complex(out[0], out[1])
+
+    def pop_states(self) -> list[float]:
+        out = np.zeros(self.nstate)
+        self._ck(self._lib.mitdvp_ms_pops(self._h, _dp(out)))
+        return [float(x) for x in out]
+
+    def norm(self) -> float:
+        return float(np.sqrt(sum(self.pop_states())))
+
+
 # ---- unit-level seam (SURVEY 8b "internal seam 1") ---------------------------
 def heff_apply(L, W, R, psi, device=0, reps=0):
     L, W, R, psi = map(_c128, (L, W, R, psi))
