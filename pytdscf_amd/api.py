@@ -17,7 +17,7 @@ import warnings
 import numpy as np
 
 from . import units
-from .engine import TDVPEngine
+from .engine import MultiStateEngine, TDVPEngine
 from .mps import product_state_cores
 from .operators import compress_mpo, merge_operator_terms
 
@@ -123,44 +123,75 @@ class TensorOperator:
         return out.reshape(out.shape[1:-1])
 
 
-def _as_term_dict(x):
+def _as_term_blocks(x, nstate=None):
+    """potential / kinetic -> [istate][jstate] -> dict (hamiltonian_cls.py:663-669)."""
     if x is None:
-        return {}
+        return None
     if isinstance(x, dict):
-        return x
-    if isinstance(x, list):  # [[{...}]] : [istate][jstate]
-        if len(x) != 1 or len(x[0]) != 1:
-            raise NotImplementedError("direct-product multi-state MPS: encode electronic states as an Exciton site")
-        return x[0][0] or {}
+        return [[x]]
+    if isinstance(x, list):  # [[{...}, ...], ...] : [istate][jstate]
+        n = len(x)
+        if any(not isinstance(row, list) or len(row) != n for row in x):
+            raise ValueError("potential/kinetic must be a square [istate][jstate] list of dicts")
+        return [[(b or {}) for b in row] for row in x]
     raise TypeError("potential/kinetic must be a dict or [[dict]]")
 
 
 class TensorHamiltonian:
     """``TensorHamiltonian(ndof, potential, name, kinetic, ..., backend)`` --
-    hamiltonian_cls.py:628-752.  Holds the operator dictionary; ``as_mpo(dims)``
-    reduces it to the single direct-sum MPO the engine contracts."""
+    hamiltonian_cls.py:628-752.  Holds the operator dictionaries per (bra, ket) state pair
+    (``potential=[[d00, d01], [d10, d11]]``; a plain dict is one state), the scalar terms
+    ``coupleJ[i][j]`` (key ``()``, :672-678); ``as_mpo(dims)`` / ``block_mpo(i, j, dims)``
+    reduce a pair's dictionary to the single direct-sum MPO the engine contracts."""
 
     def __init__(self, ndof, potential, name="hamiltonian", kinetic=None, decompose_type="QRD", rate=None,
                  bond_dimension=None, backend="hip"):
         self.ndof = int(ndof)
         self.name = name
-        self.nstate = 1
         self.backend = backend
-        self.terms = {}
-        self.terms.update(_as_term_dict(potential))
-        for k, v in _as_term_dict(kinetic).items():
-            if k in self.terms:
-                raise ValueError(f"operator key {k} given twice")
-            self.terms[k] = v
-        for op in self.terms.values():  # dense grid tensors -> MPO cores (hamiltonian_cls.py:705-722)
-            if not hasattr(op, "tensor_decomposed"):
-                op.decompose(bond_dimension=bond_dimension, decompose_type=decompose_type, rate=rate)
-        self.coupleJ = [[0.0]]  # hamiltonian_cls.py:337-358 scalar couplings
+        pot = _as_term_blocks(potential)
+        kin = _as_term_blocks(kinetic)
+        if pot is None:  # kinetic-only operators
+            n_ = len(kin) if kin is not None else 1
+            pot = [[{} for _ in range(n_)] for _ in range(n_)]
+        self.nstate = len(pot)
+        if kin is not None and len(kin) != self.nstate:
+            raise ValueError("kinetic and potential must have the same number of states")
+        self.coupleJ = [[0.0] * self.nstate for _ in range(self.nstate)]  # hamiltonian_cls.py:337-358
+        self.terms_ij = [[{} for _ in range(self.nstate)] for _ in range(self.nstate)]
+        for i in range(self.nstate):
+            for j in range(self.nstate):
+                t = self.terms_ij[i][j]
+                for k, v in pot[i][j].items():
+                    if k == ():
+                        if not isinstance(v, (float, complex, int)):
+                            raise ValueError(f"scalar term must be scalar but {v} is {type(v)}")
+                        self.coupleJ[i][j] = v
+                        continue
+                    t[k] = v
+                for k, v in (kin[i][j] if kin is not None else {}).items():
+                    if k in t:
+                        raise ValueError(f"key {k} is already set in potential. Concatenate KEO and PEO or set KEO as SOP")
+                    t[k] = v
+                for op in t.values():  # dense grid tensors -> MPO cores (hamiltonian_cls.py:705-722)
+                    if not hasattr(op, "tensor_decomposed"):
+                        op.decompose(bond_dimension=bond_dimension, decompose_type=decompose_type, rate=rate)
+        self.terms = self.terms_ij[0][0]
+
+    def block_mpo(self, i, j, dims, compress=True):
+        """Full-chain 4-leg MPO of the (bra i, ket j) block, or None when the pair has no operator."""
+        t = self.terms_ij[i][j]
+        if not t:
+            return None
+        mpo = merge_operator_terms([(op.tensor_decomposed, op.sites) for op in t.values()], dims)
+        return compress_mpo(mpo) if compress and len(mpo) > 1 else mpo
 
     def as_mpo(self, dims, compress=True):
         """One full-chain 4-leg MPO: exact direct sum of the operator terms, then a lossless
         rounding (``compress_mpo``, singular values below 1e-13 relative dropped) that removes
         the linear dependencies the direct sum introduces."""
+        if self.nstate != 1:
+            raise ValueError("as_mpo is the single-state form; use block_mpo(i, j, dims)")
         mpo = merge_operator_terms([(op.tensor_decomposed, op.sites) for op in self.terms.values()], dims)
         return compress_mpo(mpo) if compress and len(mpo) > 1 else mpo
 
@@ -193,9 +224,9 @@ class BasInfo:
     def __init__(self, prim_info, spf_info=None, ndof_per_sites=None):
         if not isinstance(prim_info[0], (list, tuple)):
             prim_info = [prim_info]
-        if len(prim_info) != 1:
-            raise NotImplementedError("direct-product multi-state MPS: encode electronic states as an Exciton site")
         self.prim_info = [list(p) for p in prim_info]
+        if any(len(p) != len(self.prim_info[0]) for p in self.prim_info):
+            raise ValueError("every electronic state needs the same number of degrees of freedom")
         self.is_DVR = True
         self.is_standard_method = True
 
@@ -237,6 +268,12 @@ class Model:
         self.space = space.lower()
         ops = {"hamiltonian": operators} if isinstance(operators, (TensorHamiltonian, list)) else dict(operators)
         self.dims = [self.basinfo.get_nprim(0, i) for i in range(self.basinfo.get_ndof())]
+        self.nstate = self.basinfo.get_nstate()
+        for s_ in range(1, self.nstate):
+            if [self.basinfo.get_nprim(s_, i) for i in range(len(self.dims))] != self.dims:
+                raise NotImplementedError("electronic states with different primitive-basis sizes per site")
+        if self.nstate > 1 and (space.lower() != "hilbert" or one_gate_to_apply is not None or kraus_op is not None):
+            raise NotImplementedError("several electronic states: Hilbert space without gates / Kraus maps only")
         out = {}
         if "potential" in ops:
             if "hamiltonian" in ops:
@@ -256,29 +293,48 @@ class Model:
                 raise TypeError(f"Operator {name} must be HamiltonianMixin or list of arrays.")
         self.hamiltonian = out.pop("hamiltonian")
         self.observables = out
-        self.nstate = 1
+        for name, op in dict(out, hamiltonian=self.hamiltonian).items():
+            if op.nstate != self.nstate:
+                raise ValueError(f"operator {name} has {op.nstate} electronic state(s), the basis {self.nstate}")
         self.m_aux_max = bond_dim
         self.use_mpo = True
         self.init_HartreeProduct = None
         self.init_weight_VIBSTATE = None
+        self.init_weight_ESTATE = None  # _get_initial_condition, _mps_cls.py:150-167
 
     def get_nstate(self):
-        return 1
+        return self.nstate
+
+    def estate_weights(self):
+        """Normalised weights of the electronic states (_mps_cls.py:150-167); default: all in state 0."""
+        if self.init_weight_ESTATE is None:
+            return [1.0] + [0.0] * (self.nstate - 1)
+        w = np.asarray(self.init_weight_ESTATE, dtype=float)
+        if len(w) != self.nstate:
+            raise ValueError("The length of weight_estate must be equal to nstate.")
+        w = w / w.sum()
+        if w.min() < 0.0:
+            raise ValueError("The elements of weight_estate must be positive.")
+        return [float(x) for x in w]
 
     def get_ndof(self):
         return len(self.dims)
 
-    def initial_cores(self):
+    def initial_cores(self, istate=0):
         D = self.m_aux_max if self.m_aux_max is not None else 1
         if self.init_HartreeProduct is not None:
-            return product_state_cores(self.init_HartreeProduct[0], D, space=self.space)
+            if len(self.init_HartreeProduct) != self.nstate:
+                raise ValueError("init_HartreeProduct needs one list of site weights / cores per electronic state")
+            return product_state_cores(self.init_HartreeProduct[istate], D, space=self.space)
         if self.init_weight_VIBSTATE is not None:
-            w = self.init_weight_VIBSTATE[0]
+            if len(self.init_weight_VIBSTATE) != self.nstate:
+                raise ValueError("The length of weight_vib must be equal to nstate.")
+            w = self.init_weight_VIBSTATE[istate]
         else:
             w = [[1.0] + [0.0] * (d - 1) for d in self.dims]
         cores = product_state_cores(w, D)
         rot = []
-        for c, b in zip(cores, self.basinfo.prim_info[0]):
+        for c, b in zip(cores, self.basinfo.prim_info[istate]):
             rot.append(np.einsum("abc,bd->adc", c, b.get_unitary()) if hasattr(b, "get_unitary") else c)
         return rot
 
@@ -296,6 +352,8 @@ class WFunc:
         return self.engine.norm()
 
     def pop_states(self):
+        if hasattr(self.engine, "pop_states"):  # several electronic states
+            return self.engine.pop_states()
         return [self.engine.norm() ** 2]
 
     def autocorr(self):
@@ -344,6 +402,8 @@ class WFunc:
         return getattr(matOp, "name", "hamiltonian")
 
     def get_mps(self):
+        if hasattr(self.engine, "get_states"):  # [istate][isite], superblock_states
+            return self.engine.get_states()
         return self.engine.get_mps()
 
 
@@ -373,6 +433,12 @@ class Simulator:
 
     def save_wavefunction(self, wf, ext=""):
         eng = wf.engine
+        if self.model.nstate > 1:
+            st = eng.get_states()
+            np.savez(self._wf_path(ext), nsite=np.array(eng.nsite), nstate=np.array(eng.nstate),
+                     space=np.array(self.model.space),
+                     **{f"site{s_}_{i}": c for s_, cs in enumerate(st) for i, c in enumerate(cs)})
+            return
         gauges = np.array([eng.get_site_shape(i)[3] for i in range(eng.nsite)])
         np.savez(self._wf_path(ext), nsite=np.array(eng.nsite), gauges=gauges, space=np.array(self.model.space),
                  **{f"site{i}": c for i, c in enumerate(eng.get_mps())})
@@ -388,8 +454,35 @@ class Simulator:
         names = {0: "Psi", 1: "A", 2: "B", -1: "C"}
         return [z[f"site{i}"] for i in range(n)], [names[int(g)] for g in z["gauges"]]
 
+    def _engine_multistate(self, integrator, conserve_norm, thresh, relax=False, restart_ext=None):
+        """nstate > 1: one MPS per electronic state, Hamiltonian / observable blocks per state pair."""
+        m = self.model
+        if relax == "improved":
+            raise NotImplementedError("improved relaxation with several electronic states: pass improved=False")
+        eng = MultiStateEngine(len(m.dims), m.nstate, integrator=integrator, conserve_norm=conserve_norm, thresh=thresh,
+                               relax=relax)
+        ids = {}
+        for k, (name, op) in enumerate([("hamiltonian", m.hamiltonian)] + list(m.observables.items())):
+            blocks = [[op.block_mpo(i, j, m.dims) for j in range(m.nstate)] for i in range(m.nstate)]
+            eng.set_hamiltonian(blocks, op.coupleJ, op_id=k)
+            ids[name] = k
+        if restart_ext is None:
+            eng.set_states([m.initial_cores(s_) for s_ in range(m.nstate)], weights=m.estate_weights())
+        else:
+            path = self._wf_path(restart_ext)
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"restart=True but {path} does not exist")
+            z = np.load(path)
+            if int(z["nsite"]) != len(m.dims) or "nstate" not in z or int(z["nstate"]) != m.nstate:
+                raise ValueError(f"{path} does not match the model's sites / states")
+            for s_ in range(m.nstate):  # saved in the site-0-centred canonical form
+                eng.set_state(s_, [z[f"site{s_}_{i}"] for i in range(len(m.dims))])
+        return eng, ids
+
     def _engine(self, integrator, conserve_norm, thresh, relax=False, restart_ext=None):
         m = self.model
+        if m.nstate > 1:
+            return self._engine_multistate(integrator, conserve_norm, thresh, relax, restart_ext)
         liou = m.space == "liouville"
         eng = TDVPEngine(len(m.dims), integrator=integrator, conserve_norm=conserve_norm, thresh=thresh, relax=relax)
         ids = {"hamiltonian": 0}
@@ -441,6 +534,9 @@ class Simulator:
             if autocorr:
                 autocorr = False
         eng, ids = self._engine(integrator, conserve_norm, thresh_sil, restart_ext=loadfile_ext if restart else None)
+        multi = self.model.nstate > 1
+        if multi and (adaptive or reduced_density is not None or not self.t2_trick):
+            raise NotImplementedError("several electronic states: adaptive bonds, reduced densities and t2_trick=False are not implemented")
         if adaptive:  # const.adaptive / Dmax / dD / p_proj (_const_cls.py:212-216); p_svd is unused there too (:968-983)
             eng.set_adaptive(True, Dmax=adaptive_Dmax, dD=adaptive_dD, p_proj=adaptive_p_proj)
         wf = self._wfunc(eng, ids)
@@ -462,9 +558,10 @@ class Simulator:
                         files["autocorr"].write(f"# time [{display_time_unit}]\t auto-correlation\n")
                     files["autocorr"].write(f"{(2 * t if self.t2_trick else t):6.9f}\t{a.real: 6.9f}{a.imag:+6.9f}j\n")
                 if populations and istep % populations_per_step == 0:
+                    pops = eng.pop_states() if multi else [eng.norm() ** 2]
                     if istep == 0:
-                        files["populations"].write(f"# time [{display_time_unit}]\tpop_0      \n")
-                    files["populations"].write(f"{t:6.9f}\t{eng.norm() ** 2:6.9f}\t\n")
+                        files["populations"].write(f"# time [{display_time_unit}]\t" + "".join(f"pop_{i_:<7}" for i_ in range(len(pops))) + "\n")
+                    files["populations"].write(f"{t:6.9f}\t" + "".join(f"{p_:6.9f}\t" for p_ in pops) + "\n")
                 row = {}
                 if energy and istep % energy_per_step == 0:
                     ener = eng.expectation(0).real
@@ -531,6 +628,8 @@ class Simulator:
         "hamiltonian" entry (e.g. a dipole operator) to the wavefunction variationally
         (``WFunc.apply_dipole``, at most ``maxstep`` double sweeps, converged when
         |1 - |<phi_i|phi_(i-1)>|| < 1e-8); returns (norm of O|Psi>, WFunc) and saves the state."""
+        if self.model.nstate > 1:
+            raise NotImplementedError("Simulator.operate with several electronic states")
         eng, ids = self._engine("lanczos", True, 1.0e-9, restart_ext=loadfile_ext if restart else None)
         norm, iters = eng.operate(0, maxstep)
         if iters >= maxstep:

@@ -373,3 +373,88 @@ def test_henon_heiles_reference_script_unchanged(tmp_path, monkeypatch):
     simulator = Simulator(jobname="henon_heiles", model=model, backend=backend)
     ener_calc, wf = simulator.propagate(maxstep=3, stepsize=Δt)
     assert pytest.approx(ener_calc) == 0.018225341011652626
+
+
+def _multistate_model(g):
+    """The two-state model of tests/golden/multistate_chain.npz typed the way the generating
+    script typed it for the reference: TensorHamiltonian(potential=[[..], [..]]) with one
+    operator dictionary per (bra, ket) state pair, basis = one list per electronic state."""
+    from pytdscf_amd import Exciton, Model, TensorHamiltonian, TensorOperator
+
+    n, S = int(g["nsite"]), int(g["nstate"])
+    d = g["init0_0"].shape[1]
+    blk = {(i, j): [g[f"mpo{i}{j}_{p}"] for p in range(n)] for i in range(S) for j in range(S)}
+    diag = lambda w: np.ascontiguousarray(np.einsum("ciit->cit", w))  # noqa: E731
+    pot = [[None] * S for _ in range(S)]
+    pot[0][0] = {tuple((p, p) for p in range(n)): TensorOperator(mpo=blk[(0, 0)])}
+    pot[1][1] = {tuple(range(n)): TensorOperator(mpo=[diag(w) for w in blk[(1, 1)]], legs=tuple(range(n))),
+                 (): float(g["coupleJ"][1, 1].real)}
+    pot[0][1] = {((0, 0), (1, 1), (2, 2), 3, 4): TensorOperator(
+        mpo=blk[(0, 1)][:3] + [diag(w) for w in blk[(0, 1)][3:]], legs=(0, 0, 1, 1, 2, 2, 3, 4))}
+    pot[1][0] = {((0, 0), (1, 1), (2, 2), (3, 3), 4): TensorOperator(
+        mpo=blk[(1, 0)][:4] + [diag(blk[(1, 0)][4])], legs=(0, 0, 1, 1, 2, 2, 3, 3, 4))}
+    ham = TensorHamiltonian(n, potential=pot, kinetic=None, backend="hip")
+    basis = [[Exciton(nstate=d) for _ in range(n)] for _ in range(S)]
+    model = Model(basis, operators={"hamiltonian": ham}, bond_dim=int(g["bond_dim"]))
+    model.init_HartreeProduct = [[g[f"init{s}_{p}"] for p in range(n)] for s in range(S)]
+    model.init_weight_ESTATE = list(g["weights"])
+    return model
+
+
+def test_multistate_model_validation():
+    from pytdscf_amd import Exciton, Model, TensorHamiltonian, TensorOperator
+
+    core = np.zeros((1, 2, 2, 1))
+    one = TensorHamiltonian(1, potential={((0, 0),): TensorOperator(mpo=[core])})
+    assert one.nstate == 1 and one.coupleJ == [[0.0]]
+    two = TensorHamiltonian(1, potential=[[{((0, 0),): TensorOperator(mpo=[core])}, {(): 0.2}], [{(): 0.2}, {(): 0.1}]])
+    assert two.nstate == 2 and two.coupleJ == [[0.0, 0.2], [0.2, 0.1]]
+    assert two.block_mpo(0, 1, [2]) is None and two.block_mpo(0, 0, [2])[0].shape == (1, 2, 2, 1)
+    with pytest.raises(ValueError, match="square"):
+        TensorHamiltonian(1, potential=[[{}, {}]])
+    with pytest.raises(ValueError, match="electronic state"):
+        Model([[Exciton(2)], [Exciton(2)]], {"hamiltonian": one}, bond_dim=2)
+    with pytest.raises(NotImplementedError):
+        Model([[Exciton(2)], [Exciton(3)]], {"hamiltonian": two}, bond_dim=2)
+    m = Model([[Exciton(2)], [Exciton(2)]], {"hamiltonian": two}, bond_dim=2)
+    assert m.get_nstate() == 2 and m.estate_weights() == [1.0, 0.0]
+    m.init_weight_ESTATE = [1.0, 3.0]
+    assert m.estate_weights() == [0.25, 0.75]
+
+
+@pytest.mark.gpu
+def test_multistate_script_on_gpu(golden, tmp_path, monkeypatch):
+    """Two electronic states through the shell: energies, populations.dat, restart."""
+    from pytdscf_amd import Simulator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("multistate_chain.npz")
+    sim = Simulator("ms", _multistate_model(g), backend="hip")
+    ener, wf = sim.propagate(stepsize=0.05, maxstep=3)
+    assert ener == pytest.approx(float(g["n3_energy_last"]), abs=1e-10)
+    np.testing.assert_allclose(wf.pop_states(), g["n3_pops"], atol=1e-10)
+    assert wf.norm() == pytest.approx(1.0, abs=1e-12)
+    assert abs(wf.autocorr() - complex(g["n3_autocorr"])) < 1e-10
+    assert wf.expectation("hamiltonian") == pytest.approx(float(g["n3_energy_final"]), abs=1e-10)
+    rows = np.loadtxt(tmp_path / "ms_prop" / "populations.dat")
+    assert rows.shape == (3, 3)
+    np.testing.assert_allclose(rows[0, 1:], g["weights"] / g["weights"].sum(), atol=1e-9)
+    np.testing.assert_allclose(rows[1, 1:], g["n1_pops"], atol=1e-9)
+    fin = wf.get_mps()
+    for s in range(2):
+        for p in range(int(g["nsite"])):
+            np.testing.assert_allclose(fin[s][p], g[f"n3_final{s}_{p}"], atol=1e-9)
+    # restart: 1 + 2 steps equal 3 steps
+    sim2 = Simulator("ms2", _multistate_model(g), backend="hip")
+    sim2.propagate(stepsize=0.05, maxstep=1, savefile_ext="_a")
+    e2, wf2 = sim2.propagate(stepsize=0.05, maxstep=2, restart=True, loadfile_ext="_a")
+    assert e2 == pytest.approx(float(g["n3_energy_last"]), abs=1e-10)
+    np.testing.assert_allclose(wf2.pop_states(), g["n3_pops"], atol=1e-10)
+    # imaginary time
+    e_r, wf_r = Simulator("ms3", _multistate_model(g), backend="hip").relax(stepsize=0.2, maxstep=3, improved=False)
+    assert e_r == pytest.approx(float(g["relax_n3_energy_last"]), abs=1e-10)
+    np.testing.assert_allclose(wf_r.pop_states(), g["relax_n3_pops"], atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        Simulator("ms4", _multistate_model(g), backend="hip").relax(maxstep=1)  # improved=True
+    with pytest.raises(NotImplementedError):
+        Simulator("ms5", _multistate_model(g), backend="hip").propagate(maxstep=1, adaptive=True)
