@@ -150,6 +150,47 @@ def main():
     assert [s.data.shape[2] for s in wf.ci_coef.superblock_states[0][:-1]] == [c.shape[2] for c in st.cores[:-1]]
     pt_ref = np.array(wf.get_reduced_densities((0, 0, 2))[0])
     report("Liouville + adaptive: norm, partial trace", abs(wf.norm() - st.norm()), np.abs(pt_ref - orc.liouville_partial_trace(st.cores, (0, 0, 2))).max())
+
+    # several electronic states with SHARED operator keys and off-diagonal scalar terms.  The
+    # reference's NumPy backend caches its contraction expressions by operator key only
+    # (_contraction.py:1050-1055, :1165-1172; multiplyK likewise), so state pairs that share a key,
+    # a "summed" block or a non-identity "ovlp" block reuse the first pair's constants -- its JAX
+    # path contracts without that cache.  DIAGNOSTIC: the two cached wrappers are called with
+    # key=None here (the un-cached branch of the same functions) to compare the intended
+    # arithmetic; the committed fixture (multistate_chain.npz) needs no such step.
+    import math
+
+    from pytdscf import _contraction as C_
+
+    gm = gold("multistate_chain.npz")
+    nm, dm = int(gm["nsite"]), 3
+    blk = {(i, j): [gm[f"mpo{i}{j}_{p}"] for p in range(nm)] for i in range(2) for j in range(2)}
+    raw = [[gm[f"init{s_}_{p}"] for p in range(nm)] for s_ in range(2)]
+    cjm = [[0.02, 0.1 - 0.03j], [0.1 + 0.03j, 0.05]]
+    key4 = tuple((i, i) for i in range(nm))
+    pot = [[{key4: TensorOperator(mpo=[w.copy() for w in blk[(i, j)]]), (): cjm[i][j]} for j in range(2)] for i in range(2)]
+    h2 = TensorHamiltonian(nm, potential=pot, kinetic=None, backend="numpy")
+    m = Model([[Exciton(nstate=dm) for _ in range(nm)] for _ in range(2)], operators={"hamiltonian": h2}, bond_dim=int(gm["bond_dim"]))
+    m.init_HartreeProduct = [[np.array(c) for c in st_] for st_ in raw]
+    m.init_weight_ESTATE = [0.8, 0.6]
+    h_, k_ = C_.multiplyH_MPS_direct_MPO._op_lcr_dot, C_.multiplyK_MPS_direct_MPO._op_lr_dot
+    C_.multiplyH_MPS_direct_MPO._op_lcr_dot = lambda self, a, b, c, t, key=None: h_(self, a, b, c, t, key=None)
+    C_.multiplyK_MPS_direct_MPO._op_lr_dot = lambda self, a, b, t, key=None: k_(self, a, b, t, key=None)
+    try:
+        helper._Debug.niter_krylov.clear()
+        ener, wf = Simulator("x", m, backend="numpy", verbose=0).propagate(stepsize=0.05, maxstep=3)
+    finally:
+        C_.multiplyH_MPS_direct_MPO._op_lcr_dot, C_.multiplyK_MPS_direct_MPO._op_lr_dot = h_, k_
+    w_ = np.array([0.8, 0.6]) / 1.4
+    st = orc.OracleMultiMPS([orc.canonicalize_site0(raw[s_], math.sqrt(w_[s_])) for s_ in range(2)],
+                            [[blk[(0, 0)], blk[(0, 1)]], [blk[(1, 0)], blk[(1, 1)]]], cjm)
+    for _ in range(3):
+        e = st.expectation()
+        st.propagate(float(gm["dt_au"]))
+    fin = [[np.array(c.data) for c in s_] for s_ in wf.ci_coef.superblock_states]
+    report("two states, shared keys + off-diagonal coupleJ (cache off): energy, pops, tensors", abs(ener - e.real),
+           np.abs(np.array(wf.pop_states()) - np.array(st.pop_states())).max(),
+           max(np.abs(a - b).max() for x, y in zip(fin, st.cores) for a, b in zip(x, y)))
     print("all differences should be at rounding level (<= 1e-12)")
 
 
