@@ -12,7 +12,8 @@ backend) in the development container with ``tests/golden/make_golden.py``.
 
 Beyond the sweep itself (rows a1-a11) the module restates, each pinned the same way: SVD bond
 truncation, Liouville-space traces, adaptive bond dimension (a1TDVP), one-site gates and Kraus
-maps between the half-sweeps, ``Simulator.operate``.  ``tests/golden/crosscheck_reference.py``
+maps between the half-sweeps, ``Simulator.operate``, several electronic states
+(:class:`OracleMultiMPS`).  ``tests/golden/crosscheck_reference.py``
 additionally runs reference and oracle side by side on combinations of these features.
 
 All ``file:line`` citations are relative to ``/root/reference/pytdscf``.
@@ -22,7 +23,7 @@ Conventions:
     left env     L[a, c, b]       (bra D_l, MPO bond M_l, ket D_l)
     right env    R[r, t, s]       (bra D_r, MPO bond M_r, ket D_r)
     MPO core     W[c, i, j, t]    (M_l, d_out(bra), d_in(ket), M_r)
-The oracle only knows ONE full-chain 4-leg MPO; the shell in
+The oracle only knows ONE full-chain 4-leg MPO (per pair of electronic states); the shell in
 ``pytdscf_amd.operators`` reduces the reference's operator dictionaries
 (several keys, diagonal 3-leg cores, identity fill-ins, coupleJ) to that form
 by an exact MPO direct sum, see DESIGN.md.

@@ -443,6 +443,7 @@ void Engine::ms_step(double dt) {
   ms_build_chains();
   if (L_ == 1) {
     if (m.center != 0) throw ArgError("no centre site");
+    ms_site_exp(0, dt);  // the forward and the backward half-sweep each propagate the only site
     ms_site_exp(0, dt);
     return;
   }

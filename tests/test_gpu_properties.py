@@ -139,3 +139,64 @@ def test_random_small_chains_against_oracle(L, d, D, M, integ, cn, shift, dt, se
     a_o, a_e = st_.autocorr(), eng.autocorr()
     assert abs(a_o - a_e) < 1e-8 * max(abs(a_o), 1e-12)
     eng.close()
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+@given(st.integers(1, 4), st.integers(2, 3), st.integers(1, 3), st.lists(st.integers(1, 5), min_size=3, max_size=3),
+       st.sampled_from(["lanczos", "arnoldi"]), st.booleans(), st.booleans(), st.sampled_from([0.05, 0.3]),
+       st.integers(0, 2**31 - 1))
+def test_random_multistate_chains_against_oracle(L, d, S, Ds, integ, cn, couple, dt, seed):
+    """Whole time steps with several electronic states: random numbers of states, bond dimensions
+    per state, present / absent off-diagonal blocks and scalar terms, both integrators."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import MultiStateEngine
+
+    rng = np.random.default_rng(seed)
+    herm = integ == "lanczos"
+    mpo = [[None] * S for _ in range(S)]
+    cj = [[0.0] * S for _ in range(S)]
+    bonds = lambda M: list(zip([1] + [M] * (L - 1), [M] * (L - 1) + [1]))  # noqa: E731
+    adj = lambda ws: [np.ascontiguousarray(np.conj(w.transpose(0, 2, 1, 3))) for w in ws]  # noqa: E731
+    for i in range(S):
+        if L > 1 and herm:
+            mpo[i][i] = orc.synthetic_mpo(L, d, 3, seed=(seed + i) % 1000)
+        else:
+            w = [0.3 * _crandn(rng, a, d, d, b) for a, b in bonds(2)]
+            if herm:  # one site: a Hermitian matrix
+                w = [0.5 * (w[0] + w[0].conj().transpose(0, 2, 1, 3))]
+            mpo[i][i] = w
+        cj[i][i] = float(rng.normal()) * 0.1 if couple else 0.0
+        for j in range(i + 1, S):
+            if rng.random() < 0.6:
+                w = [0.2 * _crandn(rng, a, d, d, b) for a, b in bonds(2)]
+                mpo[i][j] = w
+                mpo[j][i] = adj(w) if herm else [0.2 * _crandn(rng, a, d, d, b) for a, b in bonds(2)]
+            if couple and rng.random() < 0.6:
+                c = complex(rng.normal(), rng.normal()) * 0.1
+                cj[i][j], cj[j][i] = c, (c.conjugate() if herm else complex(rng.normal(), 0.0) * 0.1)
+    raw = [[_crandn(rng, a, d, b) for a, b in orc.bond_dims([d] * L, Ds[s])] for s in range(S)]
+    weights = rng.random(S) + 0.05
+    w = weights / weights.sum()
+    init = [orc.canonicalize_site0(raw[s], float(np.sqrt(w[s]))) for s in range(S)]
+    st_ = orc.OracleMultiMPS(init, mpo, cj, integrator=integ, conserve_norm=cn)
+    eng = MultiStateEngine(L, S, integrator=integ, conserve_norm=cn)
+    eng.set_hamiltonian(mpo, cj)
+    eng.set_states(raw, weights=list(weights))
+    try:
+        for _ in range(2):
+            st_.propagate(dt)
+    except ValueError:
+        with pytest.raises(ValueError):
+            for _ in range(2):
+                eng.propagate(dt)
+        eng.close()
+        return
+    for _ in range(2):
+        eng.propagate(dt)
+    assert eng.krylov_stats() == [st_.kprev[i] for i in range(L)]
+    np.testing.assert_allclose(eng.pop_states(), st_.pop_states(), rtol=1e-9, atol=1e-12)
+    e_o, e_e = st_.expectation(), eng.expectation()
+    assert abs(e_o - e_e) < 1e-8 * max(abs(e_o), 1e-10)
+    a_o, a_e = st_.autocorr(), eng.autocorr()
+    assert abs(a_o - a_e) < 1e-8 * max(abs(a_o), 1e-10)
+    eng.close()
