@@ -138,8 +138,8 @@ int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches);
  * gauge move is one QR per state (_mps_cls.py:1798-1850).  mitdvp_ms_configure switches a handle
  * to this mode; states share the physical dimensions, bond dimensions may differ per state;
  * every MPO block spans all sites (4-leg cores).  mitdvp_krylov_stats and mitdvp_counters apply
- * unchanged.  Not available in this mode: adaptive bonds, gates, Kraus maps, improved relaxation,
- * bond sharding. */
+ * unchanged.  Not available in this mode: adaptive bonds, gates, Kraus maps (single-state only in
+ * the reference too), operate, bond sharding. */
 int mitdvp_ms_configure(mitdvp_engine* h, int nstate);
 int mitdvp_ms_set_site(mitdvp_engine* h, int istate, int isite, const double* reim, int l, int n, int r, int gauge);
 int mitdvp_ms_get_site_shape(mitdvp_engine* h, int istate, int isite, int* l, int* n, int* r, int* gauge);

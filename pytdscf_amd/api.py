@@ -457,8 +457,6 @@ class Simulator:
     def _engine_multistate(self, integrator, conserve_norm, thresh, relax=False, restart_ext=None):
         """nstate > 1: one MPS per electronic state, Hamiltonian / observable blocks per state pair."""
         m = self.model
-        if relax == "improved":
-            raise NotImplementedError("improved relaxation with several electronic states: pass improved=False")
         eng = MultiStateEngine(len(m.dims), m.nstate, integrator=integrator, conserve_norm=conserve_norm, thresh=thresh,
                                relax=relax)
         ids = {}

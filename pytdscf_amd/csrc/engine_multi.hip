@@ -320,7 +320,10 @@ void Engine::ms_site_exp(int p, double dt) {
       if (!started[i]) HIP_CHECK(hipMemsetAsync(out + m.off[i], 0, (m.off[i + 1] - m.off[i]) * sizeof(zc), st_));
   };
   // _iter_info sizes the Krylov space by the largest state tensor, not by the stack (_integrator.py:178-186)
-  kprev_[p] = krylov_exp(scale_site(dt), mv, m.stack.p, m.off[m.S], kprev_[p], nmax);
+  if (cfg.relax == 2)  // improved relaxation: lowest eigenvector of the stacked H_eff (_mps_cls.py:1078-1084;
+    kprev_[p] = krylov_diag(mv, m.stack.p, m.off[m.S]);  // ndim = size of the stack, _integrator.py:98)
+  else
+    kprev_[p] = krylov_exp(scale_site(dt), mv, m.stack.p, m.off[m.S], kprev_[p], nmax);
   for (int s = 0; s < m.S; ++s)
     HIP_CHECK(hipMemcpyAsync(m.site[s][p].p, m.stack.p + m.off[s], (m.off[s + 1] - m.off[s]) * sizeof(zc),
                              hipMemcpyDeviceToDevice, st_));
@@ -411,8 +414,10 @@ void Engine::ms_sweep(double dt, bool forward) {
       for (int i = 0; i < m.S; ++i)
         if (!started[i]) HIP_CHECK(hipMemsetAsync(out + so[i], 0, (so[i + 1] - so[i]) * sizeof(zc), st_));
     };
-    kprev_[p] = krylov_exp(scale_bond(dt), mk, m.sigstack.p, so[m.S], kprev_[p], smax);
-    cnt_.n_exp_bond += 1;
+    if (cfg.relax != 2) {  // improved relaxation leaves the bond matrices alone (_mps_cls.py:1159-1160)
+      kprev_[p] = krylov_exp(scale_bond(dt), mk, m.sigstack.p, so[m.S], kprev_[p], smax);
+      cnt_.n_exp_bond += 1;
+    }
     // the block on the other side of the bond is stale now; absorb the bond matrices
     for (auto& c : m.chains) {
       if (forward) { c.Rok[p + 1] = 0; pool_put(std::move(c.R[p + 1])); }
@@ -437,7 +442,6 @@ void Engine::ms_sweep(double dt, bool forward) {
 
 void Engine::ms_step(double dt) {
   Multi& m = ms();
-  if (cfg.relax == 2) throw ArgError("improved relaxation is not implemented for several electronic states");
   if (adaptive_) throw ArgError("adaptive bond dimension is not implemented for several electronic states");
   ms_require_ready();
   ms_build_chains();

@@ -840,7 +840,7 @@ def main():
             o[f"mpo{i_}{j_}_{p_}"] = w if w.ndim == 4 else full(w)
     for s_ in range(2):
         o.update({f"init{s_}_{p_}": c for p_, c in enumerate(init_m[s_])})
-    for tag, kw in (("", {}), ("relax_", {"relax": True})):
+    for tag, kw in (("", {}), ("relax_", {"relax": True}), ("improved_", {"relax": "improved"})):
         for n in (1, 3):
             model_m = Model(basis_m, operators={"hamiltonian": ham_m()}, bond_dim=Dm)
             model_m.init_HartreeProduct = [[np.array(c) for c in st_] for st_ in init_m]
@@ -848,7 +848,7 @@ def main():
             helper._Debug.niter_krylov.clear()
             sim = Simulator("gold_multistate", model_m, backend="numpy", verbose=0)
             if kw:
-                ener, wf = sim.relax(stepsize=0.2, maxstep=n, improved=False)
+                ener, wf = sim.relax(stepsize=0.2, maxstep=n, improved=kw["relax"] == "improved")
             else:
                 ener, wf = sim.propagate(stepsize=0.05, maxstep=n)
             pre = f"{tag}n{n}"

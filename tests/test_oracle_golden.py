@@ -337,3 +337,22 @@ def test_multistate_chain(golden, mode):
         for s in range(S):
             for p in range(n):
                 np.testing.assert_allclose(st.cores[s][p], g[f"{k}_final{s}_{p}"], rtol=0, atol=1e-10)
+
+
+def test_multistate_improved_relaxation(golden):
+    """nstate = 2, doRelax="improved": Lanczos ground state of the stacked H_eff per site."""
+    g = golden("multistate_chain.npz")
+    init, mpo, cj = load_multistate(g)
+    S = int(g["nstate"])
+    for steps in (1, 3):
+        st = orc.OracleMultiMPS(init, mpo, cj, relax="improved")
+        for _ in range(steps):
+            e_last = st.expectation()
+            st.propagate(0.0)
+        k = f"improved_n{steps}"
+        np.testing.assert_allclose(e_last.real, g[f"{k}_energy_last"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(st.expectation().real, g[f"{k}_energy_final"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(st.pop_states(), g[f"{k}_pops"], rtol=0, atol=1e-8)
+        ref = [[g[f"{k}_final{s}_{p}"] for p in range(int(g["nsite"]))] for s in range(S)]
+        ov = sum(orc.overlap(ref[s], st.cores[s]) for s in range(S))  # one global phase for all states
+        assert abs(abs(ov) - 1) < 1e-8

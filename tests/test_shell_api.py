@@ -454,7 +454,7 @@ def test_multistate_script_on_gpu(golden, tmp_path, monkeypatch):
     e_r, wf_r = Simulator("ms3", _multistate_model(g), backend="hip").relax(stepsize=0.2, maxstep=3, improved=False)
     assert e_r == pytest.approx(float(g["relax_n3_energy_last"]), abs=1e-10)
     np.testing.assert_allclose(wf_r.pop_states(), g["relax_n3_pops"], atol=1e-10)
-    with pytest.raises(NotImplementedError):
-        Simulator("ms4", _multistate_model(g), backend="hip").relax(maxstep=1)  # improved=True
+    e_i, _ = Simulator("ms4", _multistate_model(g), backend="hip").relax(maxstep=3)  # improved=True
+    assert e_i == pytest.approx(float(g["improved_n3_energy_last"]), abs=1e-9)
     with pytest.raises(NotImplementedError):
         Simulator("ms5", _multistate_model(g), backend="hip").propagate(maxstep=1, adaptive=True)
