@@ -139,7 +139,7 @@ int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches);
  * to this mode; states share the physical dimensions, bond dimensions may differ per state;
  * every MPO block spans all sites (4-leg cores).  mitdvp_krylov_stats and mitdvp_counters apply
  * unchanged.  Not available in this mode: adaptive bonds, gates, Kraus maps (single-state only in
- * the reference too), operate, bond sharding. */
+ * the reference too), bond sharding. */
 int mitdvp_ms_configure(mitdvp_engine* h, int nstate);
 int mitdvp_ms_set_site(mitdvp_engine* h, int istate, int isite, const double* reim, int l, int n, int r, int gauge);
 int mitdvp_ms_get_site_shape(mitdvp_engine* h, int istate, int isite, int* l, int* n, int* r, int* gauge);
@@ -153,6 +153,9 @@ int mitdvp_ms_set_coupleJ(mitdvp_engine* h, int op_id, int ibra, int iket, doubl
 int mitdvp_ms_step(mitdvp_engine* h, double dt_au);                   /* MPSCoef.propagate, _mps_cls.py:452-503 */
 int mitdvp_ms_expect(mitdvp_engine* h, int op_id, double out[2]);     /* sum over state pairs, _mps_cls.py:540-612 */
 int mitdvp_ms_autocorr(mitdvp_engine* h, double out[2]);              /* sum over states, wavefunction.py:226-257 */
+/* Simulator.operate with several states (apply_dipole_along_sweep, _mps_cls.py:718-796): every state must
+ * be fed by at least one block or scalar term (the reference fails otherwise, _contraction.py:555) */
+int mitdvp_ms_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, double* norm_out, int* iters_out);
 int mitdvp_ms_pops(mitdvp_engine* h, double* out /* [nstate] */);      /* pop_states, _mps_cls.py:682-703 */
 
 /* -- observables -------------------------------------------------------- */

@@ -1089,6 +1089,73 @@ def operate(cores0: list[np.ndarray], mpo: list[np.ndarray], maxstep: int = 10, 
     return norm, bra, it
 
 
+def operate_multi(states0, mpo, coupleJ, maxstep: int = 10, conv_tol: float = 1.0e-8):
+    """:func:`operate` for several electronic states: ``states0[i]`` the site-0-centred MPS of
+    state i, ``mpo[i][j]`` / ``coupleJ[i][j]`` the operator blocks.  All states' site tensors are
+    replaced together, sigma_i = sum_j O_ij psi0_j with the blocks of (bra = phi_i, ket = psi0_j),
+    and normalised by the norm of the stack (apply_superOp_direct, _mps_cls.py:2733-2778); the
+    scalar terms go through the overlap blocks of the pair, which are not identities here even
+    for i == j.  Returns (norm, states of phi, iterations)."""
+    S, n = len(states0), len(states0[0])
+    ket = [[np.array(c, dtype=np.complex128) for c in st] for st in states0]
+    bra = [[c.copy() for c in st] for st in ket]
+    chains = []  # (i, j, cores, factor)
+    for i in range(S):
+        for j in range(S):
+            if mpo[i][j] is not None:
+                chains.append((i, j, [np.asarray(w, dtype=np.complex128) for w in mpo[i][j]], 1.0))
+            if coupleJ[i][j] != 0.0:
+                chains.append((i, j, [np.eye(c.shape[1], dtype=np.complex128)[None, :, :, None] for c in ket[j]], coupleJ[i][j]))
+    one = np.ones((1, 1, 1), dtype=np.complex128)
+    right = [{n - 1: one} for _ in chains]
+    left = [{0: one} for _ in chains]
+    for k, (i, j, w, _) in enumerate(chains):
+        for p in range(n - 1, 0, -1):
+            right[k][p - 1] = env_update_right(right[k][p], ket[j][p], w[p], bra=bra[i][p])
+    norm = 0.0
+
+    def site(p):
+        nonlocal norm
+        ys = [None] * S
+        for k, (i, j, w, f) in enumerate(chains):
+            y = f * heff_apply(left[k][p], w[p], right[k][p], ket[j][p])
+            ys[i] = y if ys[i] is None else ys[i] + y
+        if any(y is None for y in ys):  # the reference fails on a state no block feeds (_contraction.py:555)
+            raise ValueError("operate: every state needs at least one operator block or scalar term acting into it")
+        norm = math.sqrt(sum(float(np.linalg.norm(y)) ** 2 for y in ys))
+        for i in range(S):
+            bra[i][p] = ys[i] / norm
+
+    it = 0
+    for it in range(1, maxstep + 1):
+        prev = [[c.copy() for c in st] for st in bra]
+        for p in range(n):  # ->
+            site(p)
+            if p == n - 1:
+                break
+            for st in (bra, ket):
+                for s in range(S):
+                    st[s][p], sv = qr_psi2Asigma(st[s][p])
+                    st[s][p + 1] = np.tensordot(sv, st[s][p + 1], axes=(1, 0))
+            for k, (i, j, w, _) in enumerate(chains):
+                left[k][p + 1] = env_update_left(left[k][p], ket[j][p], w[p], bra=bra[i][p])
+        for p in range(n - 1, -1, -1):  # <-
+            site(p)
+            if p == 0:
+                break
+            for st in (bra, ket):
+                for s in range(S):
+                    sv, B = qr_psi2sigmaB(st[s][p])
+                    st[s][p] = np.ascontiguousarray(B)
+                    st[s][p - 1] = np.tensordot(st[s][p - 1], sv, axes=(2, 0))
+            for k, (i, j, w, _) in enumerate(chains):
+                right[k][p - 1] = env_update_right(right[k][p], ket[j][p], w[p], bra=bra[i][p])
+        ov = sum(overlap(bra[s], prev[s]) for s in range(S))  # _ints_wf_ovlp_mpssm, wavefunction.py:226-257
+        if abs(1 - abs(ov)) < conv_tol:
+            break
+    return norm, bra, it
+
+
 def site_rdm(cores: list[np.ndarray], site: int) -> np.ndarray:
     """One-site reduced density matrix rho[j,j'] of a site-0-centred MPS
     (what ``get_reduced_densities`` returns for key (site, site),

@@ -135,6 +135,7 @@ def load() -> C.CDLL:
         "mitdvp_ms_expect": (i, [vp, i, dp]),
         "mitdvp_ms_autocorr": (i, [vp, dp]),
         "mitdvp_ms_pops": (i, [vp, dp]),
+        "mitdvp_ms_operate": (i, [vp, i, i, d, dp, ip]),
         "mitdvp_set_kraus": (i, [vp, i, i, dp, i, i]),
         "mitdvp_apply_kraus": (i, [vp]),
         "mitdvp_clock_probe": (i, [i, C.c_long, dp]),

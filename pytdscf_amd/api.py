@@ -626,8 +626,6 @@ class Simulator:
         "hamiltonian" entry (e.g. a dipole operator) to the wavefunction variationally
         (``WFunc.apply_dipole``, at most ``maxstep`` double sweeps, converged when
         |1 - |<phi_i|phi_(i-1)>|| < 1e-8); returns (norm of O|Psi>, WFunc) and saves the state."""
-        if self.model.nstate > 1:
-            raise NotImplementedError("Simulator.operate with several electronic states")
         eng, ids = self._engine("lanczos", True, 1.0e-9, restart_ext=loadfile_ext if restart else None)
         norm, iters = eng.operate(0, maxstep)
         if iters >= maxstep:

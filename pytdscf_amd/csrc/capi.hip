@@ -230,6 +230,12 @@ int mitdvp_ms_expect(mitdvp_engine* h, int op_id, double out[2]) {
 int mitdvp_ms_autocorr(mitdvp_engine* h, double out[2]) {
   ENG_CALL(h, { NEED(out); auto v = h->e->ms_autocorr(); out[0] = v.real(); out[1] = v.imag(); });
 }
+int mitdvp_ms_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, double* norm_out, int* iters_out) {
+  ENG_CALL(h, {
+    const double n = h->e->ms_operate(op_id, maxstep, conv_tol, iters_out);
+    if (norm_out) *norm_out = n;
+  });
+}
 int mitdvp_ms_pops(mitdvp_engine* h, double* out) { ENG_CALL(h, { NEED(out); h->e->ms_pops(out); }); }
 
 int mitdvp_set_adaptive(mitdvp_engine* h, int enable, int dmax, int dd, double p_proj) {

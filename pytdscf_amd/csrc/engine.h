@@ -170,6 +170,7 @@ class Engine {
   void ms_set_couplej(int op_id, int ibra, int iket, double re, double im);
   void ms_step(double dt);
   hzc ms_expect(int op_id);
+  double ms_operate(int op_id, int maxstep, double conv_tol, int* iters_out);
   hzc ms_autocorr();
   void ms_pops(double* out);
   hipStream_t stream() const { return st_; }

@@ -455,6 +455,206 @@ void Engine::ms_step(double dt) {
   ms_sweep(dt, false);
 }
 
+// Simulator.operate for several states (WFunc.apply_dipole, wavefunction.py:303-351;
+// apply_dipole_along_sweep, _mps_cls.py:718-796; apply_superOp_direct, :2733-2778): fit
+// phi ~ O|psi_0> / ||O|psi_0>|| in the bond dimensions of psi_0.  Every sweep replaces all states'
+// site tensors by sigma_i = sum_j O_ij psi0_j with blocks of the pair (bra = phi_i, ket = psi0_j) and
+// normalises by the norm of the stack; scalar terms run through overlap chains for every pair,
+// i == j included (phi_i != psi0_i).
+double Engine::ms_operate(int op_id, int maxstep, double conv_tol, int* iters_out) {
+  Multi& m = ms();
+  ms_require_ready();
+  if (m.center != 0) throw ArgError("operate needs the centre at site 0");
+  if (maxstep < 1) throw ArgError("operate: maxstep must be >= 1");
+  auto it_op = m.ops.find(op_id);
+  if (it_op == m.ops.end()) throw ArgError("operator not set");
+  Multi::OpMs& o = it_op->second;
+  const int S = m.S;
+  struct Ch { int i, j; hzc f; const std::vector<MpoSite>* w; std::vector<DevBuf> L, R; };
+  std::vector<Ch> ch;
+  std::vector<char> fed(S, 0);
+  for (int i = 0; i < S; ++i)
+    for (int j = 0; j < S; ++j) {
+      const size_t ij = (size_t)i * S + j;
+      if (o.has[ij]) {
+        for (int p = 0; p < L_; ++p)
+          if (!o.blk[ij][p].set || o.blk[ij][p].d != m.d[p]) throw ArgError("an MPO block is missing cores or has the wrong physical dimension");
+        ch.push_back(Ch{i, j, hzc(1, 0), &o.blk[ij], {}, {}});
+        fed[i] = 1;
+      }
+      if (o.cj[ij] != hzc(0, 0)) {
+        for (int p = 0; p < L_; ++p) {
+          if (m.ident[p].set && m.ident[p].d == m.d[p]) continue;
+          const int d = m.d[p];
+          std::vector<hzc> eye((size_t)d * d, hzc(0, 0));
+          for (int a = 0; a < d; ++a) eye[(size_t)a * d + a] = hzc(1, 0);
+          upload_mpo_core(m.ident[p], reinterpret_cast<const double*>(eye.data()), 1, d, d, 1);
+        }
+        ch.push_back(Ch{i, j, o.cj[ij], &m.ident, {}, {}});
+        fed[i] = 1;
+      }
+    }
+  for (int i = 0; i < S; ++i)
+    if (!fed[i]) throw ArgError("operate: every state needs at least one operator block or scalar term acting into it");
+  const size_t cap = m.spare.n;
+  std::vector<std::vector<DevBuf>> ket(S), prev(S);
+  std::vector<DevBuf> kt(S);
+  for (int s = 0; s < S; ++s) {
+    ket[s].resize(L_); prev[s].resize(L_);
+    kt[s] = pool_get(cap);
+    for (int p = 0; p < L_; ++p) {
+      const size_t e = (size_t)m.dl[s][p] * m.d[p] * m.dr[s][p];
+      ket[s][p] = pool_get(cap);
+      prev[s][p] = pool_get(e);
+      HIP_CHECK(hipMemcpyAsync(ket[s][p].p, m.site[s][p].p, e * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+    }
+  }
+  auto envsz = [&](const Ch& c, int b) {  // block on bond b (left of site b)
+    const int mb = b == 0 ? 1 : (*c.w)[b - 1].mr;
+    const int di = b == 0 ? 1 : m.dr[c.i][b - 1], dj = b == 0 ? 1 : m.dr[c.j][b - 1];
+    return (size_t)di * mb * dj;
+  };
+  // right blocks of the initial bra / ket pair (bra = ket = psi_0 at this point)
+  for (auto& c : ch) { c.L.resize(L_ + 1); c.R.resize(L_ + 1); }
+  for (int p = L_ - 1; p >= 1; --p) {
+    for (int s = 0; s < S; ++s) transpose_rev3(st_, ket[s][p].p, kt[s].p, m.dl[s][p], m.d[p], m.dr[s][p]);
+    for (auto& c : ch) {
+      const MpoSite& w = (*c.w)[p];
+      const zc* in = p + 1 == L_ ? m.one.p : c.R[p + 1].p;
+      c.R[p] = pool_get(envsz(c, p));
+      env_update_rect(in, kt[c.j].p, kt[c.i].p, w.w2r.p, c.R[p].p, m.dr[c.i][p], m.dr[c.j][p], w.mr, m.d[p], m.dl[c.i][p],
+                      m.dl[c.j][p], w.ml);
+    }
+  }
+  double nrm = 0.0;
+  auto apply_site = [&](int p) {  // apply_superOp_direct
+    std::vector<char> started(S, 0);
+    for (auto& c : ch) {
+      const MpoSite& w = (*c.w)[p];
+      const zc* Lb = p == 0 ? m.one.p : c.L[p].p;
+      const zc* Rb = p + 1 == L_ ? m.one.p : c.R[p + 1].p;
+      const long e = (long)m.dl[c.i][p] * m.d[p] * m.dr[c.i][p];
+      const bool direct = !started[c.i] && c.f == hzc(1.0, 0.0);
+      zc* dst = direct ? m.site[c.i][p].p : m.acc.p;
+      heff_apply_rect(Lb, w, Rb, ket[c.j][p].p, dst, m.dl[c.i][p], m.dl[c.j][p], m.d[p], m.dr[c.i][p], m.dr[c.j][p]);
+      if (!direct) {
+        if (!started[c.i]) {
+          HIP_CHECK(hipMemcpyAsync(m.site[c.i][p].p, m.acc.p, e * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+          vec_scale(st_, m.site[c.i][p].p, e, make_double2(c.f.real(), c.f.imag()));
+        } else {
+          vec_axpby(st_, m.site[c.i][p].p, m.acc.p, e, make_double2(c.f.real(), c.f.imag()), make_double2(1.0, 0.0));
+        }
+      }
+      started[c.i] = 1;
+    }
+    double s2 = 0;
+    for (int s = 0; s < S; ++s) {
+      const long e = (long)m.dl[s][p] * m.d[p] * m.dr[s][p];
+      vec_sumsq(st_, m.site[s][p].p, e, reinterpret_cast<double*>(red_.p + RED_MISC));
+      read_partials(RED_MISC, NPART / 2);
+      const double* hp = reinterpret_cast<const double*>(h_red_ + RED_MISC);
+      for (int k = 0; k < NPART; ++k) s2 += hp[k];
+    }
+    nrm = std::sqrt(s2);
+    if (!(nrm > 0.0)) throw ArgError("operate: the operator annihilates the state");
+    for (int s = 0; s < S; ++s) {
+      vec_scale(st_, m.site[s][p].p, (long)m.dl[s][p] * m.d[p] * m.dr[s][p], make_double2(1.0 / nrm, 0.0));
+      m.gauge[s][p] = MITDVP_GAUGE_PSI;
+    }
+  };
+  const zc one = make_double2(1.0, 0.0);
+  int it = 0;
+  for (it = 1; it <= maxstep; ++it) {
+    for (int s = 0; s < S; ++s)
+      for (int p = 0; p < L_; ++p)
+        HIP_CHECK(hipMemcpyAsync(prev[s][p].p, m.site[s][p].p, (size_t)m.dl[s][p] * m.d[p] * m.dr[s][p] * sizeof(zc),
+                                 hipMemcpyDeviceToDevice, st_));
+    for (int p = 0; p < L_; ++p) {  // ->
+      apply_site(p);
+      if (p == L_ - 1) break;
+      const int d = m.d[p];
+      for (int s = 0; s < S; ++s) {
+        const int l = m.dl[s][p], r = m.dr[s][p];
+        gauge_qr_left(m.site[s][p].p, l, d, r, m.spare.p, sig_.p);  // phi: Psi -> A (sigma goes into a tensor replaced next)
+        std::swap(m.site[s][p], m.spare);
+        m.gauge[s][p] = MITDVP_GAUGE_A;
+        gauge_qr_left(ket[s][p].p, l, d, r, m.spare.p, sig_.p);  // psi_0: Psi -> A sigma, sigma into the next site
+        std::swap(ket[s][p], m.spare);
+        ZgemmDesc g = zgemm_desc(sig_.p, ket[s][p + 1].p, m.spare.p, r, m.d[p + 1] * m.dr[s][p + 1], r);
+        zgemm(st_, g);
+        std::swap(ket[s][p + 1], m.spare);
+      }
+      for (auto& c : ch) {
+        const MpoSite& w = (*c.w)[p];
+        const zc* in = p == 0 ? m.one.p : c.L[p].p;
+        pool_put(std::move(c.L[p + 1]));
+        c.L[p + 1] = pool_get(envsz(c, p + 1));
+        env_update_rect(in, ket[c.j][p].p, m.site[c.i][p].p, w.w2l.p, c.L[p + 1].p, m.dl[c.i][p], m.dl[c.j][p], w.ml, d,
+                        m.dr[c.i][p], m.dr[c.j][p], w.mr);
+      }
+    }
+    for (int p = L_ - 1; p >= 0; --p) {  // <-
+      apply_site(p);
+      if (p == 0) break;
+      const int d = m.d[p];
+      for (int s = 0; s < S; ++s) {
+        const int l = m.dl[s][p], r = m.dr[s][p];
+        gauge_qr_right(m.site[s][p].p, l, d, r, m.spare.p, m.bt[s].p, sig_.p);
+        std::swap(m.site[s][p], m.spare);
+        m.gauge[s][p] = MITDVP_GAUGE_B;
+        gauge_qr_right(ket[s][p].p, l, d, r, m.spare.p, kt[s].p, sig_.p);
+        std::swap(ket[s][p], m.spare);
+        ZgemmDesc g = zgemm_desc(ket[s][p - 1].p, sig_.p, m.spare.p, m.dl[s][p - 1] * m.d[p - 1], l, l);
+        zgemm(st_, g);
+        std::swap(ket[s][p - 1], m.spare);
+      }
+      for (auto& c : ch) {
+        const MpoSite& w = (*c.w)[p];
+        const zc* in = p + 1 == L_ ? m.one.p : c.R[p + 1].p;
+        pool_put(std::move(c.R[p]));
+        c.R[p] = pool_get(envsz(c, p));
+        env_update_rect(in, kt[c.j].p, m.bt[c.i].p, w.w2r.p, c.R[p].p, m.dr[c.i][p], m.dr[c.j][p], w.mr, d, m.dl[c.i][p],
+                        m.dl[c.j][p], w.ml);
+      }
+    }
+    // _is_converged (wavefunction.py:285-301): |1 - |sum_s <phi_s(i) | phi_s(i-1)>|| < conv_tol
+    hzc ov(0, 0);
+    for (int s = 0; s < S; ++s) {
+      HIP_CHECK(hipMemcpyAsync(sig_.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
+      zc* T = sig_.p;
+      zc* Tn = sig2_.p;
+      for (int p = 0; p < L_; ++p) {
+        const int dl = m.dl[s][p], d = m.d[p], dr = m.dr[s][p];
+        ZgemmDesc u = zgemm_desc(T, prev[s][p].p, tmp1_.p, dl, d * dr, dl);
+        zgemm(st_, u);
+        ZgemmDesc t = zgemm_desc(m.site[s][p].p, tmp1_.p, Tn, dr, dr, dl * d);
+        t.transA = 1; t.conjA = 1; t.lda = dr;
+        zgemm(st_, t);
+        std::swap(T, Tn);
+      }
+      hzc v;
+      HIP_CHECK(hipMemcpyAsync(&v, T, sizeof(zc), hipMemcpyDeviceToHost, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));
+      ov += v;
+    }
+    if (std::fabs(1.0 - std::abs(ov)) < conv_tol) break;
+    if (it == maxstep) break;
+  }
+  m.center = 0;
+  m.chains_ok = false;  // the state changed: the Hamiltonian's blocks are rebuilt by the next step
+  for (auto& c : ch) {
+    for (auto& b : c.L) pool_put(std::move(b));
+    for (auto& b : c.R) pool_put(std::move(b));
+  }
+  for (int s = 0; s < S; ++s) {
+    for (auto& b : ket[s]) pool_put(std::move(b));
+    for (auto& b : prev[s]) pool_put(std::move(b));
+    pool_put(std::move(kt[s]));
+  }
+  if (iters_out) *iters_out = std::min(it, maxstep);
+  return nrm;
+}
+
 // pop_states (_mps_cls.py:682-703): ||Psi_i(site 0)||^2
 void Engine::ms_pops(double* out) {
   Multi& m = ms();

@@ -358,6 +358,11 @@ class MultiStateEngine(TDVPEngine):
         self._ck(self._lib.mitdvp_ms_autocorr(self._h, _dp(out)))
         return complex(out[0], out[1])
 
+    def operate(self, op_id: int = 0, maxstep: int = 10, conv_tol: float = 1.0e-8):
+        nrm, it = C.c_double(), C.c_int()
+        self._ck(self._lib.mitdvp_ms_operate(self._h, op_id, maxstep, conv_tol, C.byref(nrm), C.byref(it)))
+        return nrm.value, it.value
+
     def pop_states(self) -> list[float]:
         out = np.zeros(self.nstate)
         self._ck(self._lib.mitdvp_ms_pops(self._h, _dp(out)))

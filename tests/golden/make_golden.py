@@ -861,6 +861,18 @@ def main():
             for s_ in range(2):
                 for p_, c in enumerate(wf.ci_coef.superblock_states[s_]):
                     o[f"{pre}_final{s_}_{p_}"] = np.array(c.data)
+    # Simulator.operate with two states (same blocks used as the "dipole")
+    for n in (1, 10):
+        model_m = Model(basis_m, operators={"hamiltonian": ham_m()}, bond_dim=Dm)
+        model_m.init_HartreeProduct = [[np.array(c) for c in st_] for st_ in init_m]
+        model_m.init_weight_ESTATE = list(weights_m)
+        sim = Simulator("gold_multistate_op", model_m, backend="numpy", verbose=0)
+        nrm, wf = sim.operate(maxstep=n)
+        o[f"operate_n{n}_norm"] = np.array(nrm)
+        o[f"operate_n{n}_pops"] = np.array(wf.pop_states())
+        for s_ in range(2):
+            for p_, c in enumerate(wf.ci_coef.superblock_states[s_]):
+                o[f"operate_n{n}_final{s_}_{p_}"] = np.array(c.data)
     save("multistate_chain.npz", dt_au=np.array(0.05 / au_in_fs), dt_relax_au=np.array(0.2 / au_in_fs),
          nsite=np.array(Lm), nstate=np.array(2), bond_dim=np.array(Dm), **o)
 

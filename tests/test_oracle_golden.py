@@ -356,3 +356,17 @@ def test_multistate_improved_relaxation(golden):
         ref = [[g[f"{k}_final{s}_{p}"] for p in range(int(g["nsite"]))] for s in range(S)]
         ov = sum(orc.overlap(ref[s], st.cores[s]) for s in range(S))  # one global phase for all states
         assert abs(abs(ov) - 1) < 1e-8
+
+
+def test_multistate_operate(golden):
+    """Simulator.operate with two electronic states (all states' site tensors replaced together)."""
+    g = golden("multistate_chain.npz")
+    init, mpo, cj = load_multistate(g)
+    for n in (1, 10):
+        nrm, bra, it = orc.operate_multi(init, mpo, cj, maxstep=n)
+        assert it == n
+        np.testing.assert_allclose(nrm, float(g[f"operate_n{n}_norm"]), rtol=1e-12)
+        np.testing.assert_allclose([np.linalg.norm(st[0]) ** 2 for st in bra], g[f"operate_n{n}_pops"], atol=1e-12)
+        for s in range(2):
+            for p in range(int(g["nsite"])):
+                np.testing.assert_allclose(bra[s][p], g[f"operate_n{n}_final{s}_{p}"], rtol=0, atol=1e-11)

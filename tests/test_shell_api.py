@@ -458,3 +458,12 @@ def test_multistate_script_on_gpu(golden, tmp_path, monkeypatch):
     assert e_i == pytest.approx(float(g["improved_n3_energy_last"]), abs=1e-9)
     with pytest.raises(NotImplementedError):
         Simulator("ms5", _multistate_model(g), backend="hip").propagate(maxstep=1, adaptive=True)
+    # relax -> operate -> propagate through the checkpoint files, like the single-state workflow
+    sim6 = Simulator("ms6", _multistate_model(g), backend="hip")
+    nrm, wf_o = sim6.operate(maxstep=10)
+    assert nrm == pytest.approx(float(g["operate_n10_norm"]), rel=1e-10)
+    np.testing.assert_allclose(wf_o.pop_states(), g["operate_n10_pops"], atol=1e-10)
+    assert (tmp_path / "wf_ms6_operate.npz").exists()
+    e6, wf6 = sim6.propagate(stepsize=0.05, maxstep=2, restart=True)  # loadfile_ext="_operate"
+    assert wf6.norm() == pytest.approx(1.0, abs=1e-12)
+    np.testing.assert_allclose(sum(wf6.pop_states()), 1.0, atol=1e-12)
