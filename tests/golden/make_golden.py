@@ -876,6 +876,27 @@ def main():
     save("multistate_chain.npz", dt_au=np.array(0.05 / au_in_fs), dt_relax_au=np.array(0.2 / au_in_fs),
          nsite=np.array(Lm), nstate=np.array(2), bond_dim=np.array(Dm), **o)
 
+    # (xi) the built-in equidistant-grid DVR bases (pytdscf/basis/sin.py, exponential.py): grids,
+    # transformation and derivative matrices -- setup-side data of the user surface
+    from pytdscf.basis import Exponential as RefExp, Sine as RefSine
+
+    o = {}
+    for tag, b in (("sine_t", RefSine(7, 3.0, x0=0.5, units="angstrom", include_terminal=True)),
+                   ("sine_n", RefSine(6, 4.0, x0=-1.0, units="bohr", include_terminal=False)),
+                   ("exp", RefExp(7, 2.0 * np.pi, x0=0.1))):
+        o[f"{tag}_grids"] = np.array(b.get_grids())
+        o[f"{tag}_unitary"] = np.array(b.get_unitary())
+        o[f"{tag}_sqrt_weights"] = np.array(b.get_sqrt_weights())
+        o[f"{tag}_d1_dvr"] = np.array(b.get_1st_derivative_matrix_dvr())
+        o[f"{tag}_d2_dvr"] = np.array(b.get_2nd_derivative_matrix_dvr())
+        o[f"{tag}_d1_fbr"] = np.array(b.get_1st_derivative_matrix_fbr())
+        o[f"{tag}_d2_fbr"] = np.array(b.get_2nd_derivative_matrix_fbr())
+        o[f"{tag}_fbr2_at_grid"] = np.array([b.fbr_func(2, x) for x in b.get_grids()])
+        o[f"{tag}_dvr3_at_grid"] = np.array([b.dvr_func(3, x) for x in b.get_grids()])
+        if tag != "exp":
+            o[f"{tag}_pos"] = np.array(b.get_pos_rep_matrix())
+    save("basis_dvr.npz", **o)
+
 
 if __name__ == "__main__":
     main()

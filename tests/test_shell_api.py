@@ -467,3 +467,35 @@ def test_multistate_script_on_gpu(golden, tmp_path, monkeypatch):
     e6, wf6 = sim6.propagate(stepsize=0.05, maxstep=2, restart=True)  # loadfile_ext="_operate"
     assert wf6.norm() == pytest.approx(1.0, abs=1e-12)
     np.testing.assert_allclose(sum(wf6.pop_states()), 1.0, atol=1e-12)
+
+
+def test_grid_dvr_bases_match_reference(golden):
+    """Sine / Exponential DVR primitives (pytdscf/basis/sin.py, exponential.py) against vectors
+    produced by the reference's classes."""
+    from pytdscf_amd import Exponential, Sine
+
+    g = golden("basis_dvr.npz")
+    cases = {"sine_t": Sine(7, 3.0, x0=0.5, units="angstrom", include_terminal=True),
+             "sine_n": Sine(6, 4.0, x0=-1.0, units="bohr", include_terminal=False),
+             "exp": Exponential(7, 2.0 * np.pi, x0=0.1)}
+    for tag, b in cases.items():
+        assert len(b) == b.nprim == len(g[f"{tag}_grids"])
+        np.testing.assert_allclose(b.get_grids(), g[f"{tag}_grids"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(list(b), g[f"{tag}_grids"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(b.get_unitary(), g[f"{tag}_unitary"], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(b.get_sqrt_weights(), g[f"{tag}_sqrt_weights"], rtol=1e-13)
+        for name, fn in (("d1_dvr", b.get_1st_derivative_matrix_dvr), ("d2_dvr", b.get_2nd_derivative_matrix_dvr),
+                         ("d1_fbr", b.get_1st_derivative_matrix_fbr), ("d2_fbr", b.get_2nd_derivative_matrix_fbr)):
+            ref = g[f"{tag}_{name}"]
+            np.testing.assert_allclose(fn(), ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max()), err_msg=f"{tag} {name}")
+        np.testing.assert_allclose([b.fbr_func(2, x) for x in b.get_grids()], g[f"{tag}_fbr2_at_grid"], rtol=0, atol=1e-13)
+        np.testing.assert_allclose([b.dvr_func(3, x) for x in b.get_grids()], g[f"{tag}_dvr3_at_grid"], rtol=0, atol=1e-12)
+        if tag != "exp":
+            np.testing.assert_allclose(b.get_pos_rep_matrix(), g[f"{tag}_pos"], rtol=0, atol=1e-15)
+    with pytest.raises(ValueError):
+        Exponential(6, 1.0)
+    # the kinetic-energy builders take these bases like the harmonic-oscillator DVR
+    from pytdscf_amd.dvr_operator_cls import construct_kinetic_mpo
+
+    kin = construct_kinetic_mpo([cases["sine_n"], cases["sine_t"]])
+    assert len(kin) == 2
