@@ -4,9 +4,19 @@ from . import units  # noqa: F401
 from .api import BasInfo, Model, Simulator, TensorHamiltonian, TensorOperator, WFunc  # noqa: F401
 from .basis import Boson, Exciton, Exponential, HarmonicOscillator, Sine  # noqa: F401
 from .engine import MultiStateEngine, TDVPEngine  # noqa: F401
-from . import dvr_operator_cls  # noqa: F401,E402
+from . import dvr_operator_cls, kraus, spectra  # noqa: F401,E402
+from .dvr_operator_cls import (  # noqa: F401,E402
+    construct_fulldimensional,
+    construct_kinetic_mpo,
+    construct_kinetic_operator,
+    construct_nMR_recursive,
+)
+
+__version__ = "0.1.0"
 
 __all__ = [
     "TDVPEngine", "MultiStateEngine", "Simulator", "Model", "BasInfo", "TensorHamiltonian", "TensorOperator", "WFunc",
-    "Exciton", "Boson", "HarmonicOscillator", "Sine", "Exponential", "units",
+    "Exciton", "Boson", "HarmonicOscillator", "Sine", "Exponential", "units", "dvr_operator_cls", "kraus", "spectra",
+    "construct_fulldimensional", "construct_kinetic_mpo", "construct_kinetic_operator", "construct_nMR_recursive",
+    "__version__",
 ]
