@@ -81,6 +81,19 @@ def test_exciton_script_on_gpu(golden, tmp_path, monkeypatch):
     z = np.load(tmp_path / "LVC_Exciton_test_prop" / "reduced_density.npz")
     assert z["time"].shape == (20,) and z["rho_(3, 3)"].shape == (20, 2, 2)
     np.testing.assert_allclose(z["rho_(3, 3)"][-1], g["ref_pin_rdm33"], atol=1e-9)
+    # the analysis-side reader of the reference (util/read_nc.py), also when asked for the .nc name
+    from pytdscf_amd.util import read_nc
+
+    data = read_nc(str(tmp_path / "LVC_Exciton_test_prop" / "reduced_density.nc"), [(3, 3)])
+    assert data["time"].shape == (20,)
+    np.testing.assert_allclose(data[(3, 3)][-1], g["ref_pin_rdm33"], atol=1e-9)
+    # and the spectrum chain on the auto-correlation file just written
+    from pytdscf_amd import spectra
+
+    t_fs, ac = spectra.load_autocorr(str(tmp_path / "LVC_Exciton_test_prop" / "autocorr.dat"))
+    assert t_fs[1] == pytest.approx(0.2) and len(ac) == 20  # t/2 trick: the file's time axis is 2 t
+    freq, inten = spectra.ifft_autocorr(t_fs, ac)
+    assert len(freq) == len(inten) > 0
 
 
 @pytest.mark.gpu
