@@ -65,9 +65,11 @@ def construct_kinetic_operator(dvr_prims, coefs=None, forms="mpo"):
     raise ValueError("forms must be 'sop' or 'mpo'")
 
 
-def _tt_round_diag(cores, rate, cap=None):
+def _tt_round_diag(cores, rate, cap=None, power=2):
     """Tensor-train rounding of a chain of diagonal (r, n, r') cores: right-to-left QR sweep, then
-    left-to-right SVDs that keep the leading singular values whose squared sum reaches ``rate``."""
+    left-to-right SVDs that keep the leading singular values whose squared sum (``power=2``) or
+    plain sum (``power=1``, what the reference's final sweep_compress_twodot measures,
+    _mpo_cls.py:764) reaches ``rate``."""
     cores = [np.array(c) for c in cores]
     for i in range(len(cores) - 1, 0, -1):
         r, n, rr = cores[i].shape
@@ -77,11 +79,14 @@ def _tt_round_diag(cores, rate, cap=None):
     for i in range(len(cores) - 1):
         r, n, rr = cores[i].shape
         u, sv, vh = np.linalg.svd(cores[i].reshape(r * n, rr), full_matrices=False)
-        w = sv**2
-        tot, cum, k = w.sum(), 0.0, 0
-        while k < len(sv) and (tot == 0.0 or cum / tot < rate):
-            cum += w[k]
-            k += 1
+        if rate >= 1.0:  # lossless: only numerically zero directions go
+            k = int(np.count_nonzero(sv > 1.0e-13 * sv[0])) if sv[0] > 0 else 1
+        else:
+            w = sv**power
+            tot, cum, k = w.sum(), 0.0, 0
+            while k < len(sv) and (tot == 0.0 or cum / tot < rate):
+                cum += w[k]
+                k += 1
         k = max(min(k, cap) if cap else k, 1)
         cores[i] = u[:, :k].reshape(r, n, k)
         cores[i + 1] = np.tensordot(sv[:k, None] * vh[:k], cores[i + 1], axes=(1, 0))
@@ -127,5 +132,43 @@ def construct_nMR_recursive(dvr_prims, nMR=3, ndof=None, func=None, db=None, df=
     full = merge_operator_terms(terms, dims)  # 4-leg cores of a diagonal operator
     diag = [np.real_if_close(np.einsum("aiib->aib", w)) for w in full]
     if rate < 1.0 or (k and max(c.shape[2] for c in diag) > k):
-        diag = _tt_round_diag(diag, min(rate, 1.0), cap=k)
+        diag = _tt_round_diag(diag, min(rate, 1.0), cap=k, power=1)  # the criterion of the final sweep_compress_twodot
+    return diag
+
+
+def tensor_dict_to_mpo(tensor_dict, rate: float = 1.0, nsweep: int = 1):
+    """n-mode-representation grid tensors ``{(i,): v_i[q_i], (i, j): v_ij[q_i, q_j], ...}`` -> one
+    full-chain DIAGONAL MPO (3-leg cores (M_l, n, M_r)) whose value at a grid point is the sum of
+    the tensors' values there (dvr_operator_cls.py:1012-1048; reference test
+    tests/test_compress_mpo.py).  The scalar entry ``tensor_dict[()]`` is not part of the MPO.
+    Every term is tensor-train decomposed exactly, the terms are summed as a direct sum with
+    identity fill-ins and the chain is rounded to the contribution ``rate``."""
+    from .api import TensorOperator
+    from .operators import merge_operator_terms
+
+    if not (0.0 < rate <= 1.0):
+        raise ValueError("rate must be 0.0 < rate <= 1.0")
+    dims = []
+    while (len(dims),) in tensor_dict:
+        dims.append(int(np.asarray(tensor_dict[(len(dims),)]).shape[0]))
+    if not dims:
+        raise ValueError("tensor_dict needs the one-mode terms (0,), (1,), ... to size the sites")
+    terms = []
+    for key, t in tensor_dict.items():
+        if key == ():
+            continue
+        t = np.asarray(t)
+        if t.shape != tuple(dims[i] for i in key):
+            raise ValueError(f"tensor of key {key} has shape {t.shape}, the grids {tuple(dims[i] for i in key)}")
+        if list(key) != sorted(set(key)):
+            raise ValueError(f"key {key} must list distinct sites in ascending order")
+        op = TensorOperator(tensor=t, legs=tuple(key), only_diag=True)
+        op.decompose()
+        terms.append((op.tensor_decomposed, op.sites))
+    full = merge_operator_terms(terms, dims)
+    diag = [np.ascontiguousarray(np.einsum("ajjb->ajb", w)) for w in full]
+    for _ in range(max(1, int(nsweep))):
+        diag = _tt_round_diag(diag, rate, power=1)
+    if all(np.abs(w.imag).max() == 0.0 for w in diag):
+        diag = [np.ascontiguousarray(w.real) for w in diag]
     return diag

@@ -576,3 +576,37 @@ def test_lindblad_to_kraus_same_channel_as_reference(golden):
     ch = lambda Bs: sum(np.kron(b, b.conj()) for b in Bs)  # noqa: E731
     assert B.shape == g["B"].shape
     np.testing.assert_allclose(ch(B), ch(g["B"]), atol=1e-12)
+
+
+@pytest.mark.parametrize("rate,J", [(1.0, [2, 2, 2, 2, 2, 2]), (0.999999999999, [1, 2, 3, 1, 2, 3])])
+def test_tensor_dict_to_mpo_reference_test(rate, J):
+    """tests/test_compress_mpo.py of the reference on its own data file (H2CO grid tensors up to
+    two-mode terms): the value of the MPO at a grid point equals the sum of the tensors there."""
+    import os
+    import pickle
+
+    from pytdscf_amd.dvr_operator_cls import tensor_dict_to_mpo
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h2co.tensor"), "rb") as f:
+        tensor_dict = pickle.load(f)
+    J = np.array(J)
+    mpo = tensor_dict_to_mpo(tensor_dict, rate=rate)
+    val_tensor = sum(t[tuple(J[np.ix_(k)])] for k, t in tensor_dict.items() if k != ())
+    r = mpo[0][0, J[0], :]
+    for i, W in enumerate(mpo[1:], 1):
+        r = r @ W[:, J[i], :]
+    assert abs(val_tensor - r[0].real) < 1.0e-10
+    assert [w.ndim for w in mpo] == [3] * 6 and max(w.shape[-1] for w in mpo) <= 14
+    # every grid point, and a visibly lossy rate still returns a valid chain
+    full = np.zeros((5,) * 6)
+    for k, t in tensor_dict.items():
+        if k != ():
+            full = full + t.reshape([5 if i in k else 1 for i in range(6)])
+    dense = mpo[0]
+    for w in mpo[1:]:
+        dense = np.tensordot(dense, w, axes=(dense.ndim - 1, 0))
+    np.testing.assert_allclose(dense.reshape((5,) * 6), full, atol=1e-9)
+    lossy = tensor_dict_to_mpo(tensor_dict, rate=0.99)
+    assert max(w.shape[-1] for w in lossy) < max(w.shape[-1] for w in mpo)
+    with pytest.raises(ValueError):
+        tensor_dict_to_mpo(tensor_dict, rate=1.5)
