@@ -189,6 +189,7 @@ class Engine {
   std::vector<DevBuf> envL_, envR_;
   std::vector<char> envL_ok_, envR_ok_;
   std::vector<DevBuf> pool_;
+  size_t pool_cap_ = 48;  // buffers kept for reuse (raised when many environment chains are alive)
   DevBuf pool_get(size_t elems);
   void pool_put(DevBuf&& b);
 

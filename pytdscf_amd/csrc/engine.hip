@@ -71,7 +71,7 @@ DevBuf Engine::pool_get(size_t elems) {
 }
 void Engine::pool_put(DevBuf&& b) {
   if (b.p) pool_.push_back(std::move(b));
-  if (pool_.size() > 48) pool_.erase(pool_.begin());  // adaptive ranks: block sizes drift, drop the oldest
+  if (pool_.size() > pool_cap_) pool_.erase(pool_.begin());  // adaptive ranks: block sizes drift, drop the oldest
 }
 
 void Engine::timer_begin(int kind) {

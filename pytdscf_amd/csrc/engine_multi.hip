@@ -250,6 +250,8 @@ void Engine::ms_build_chains() {
         add(i, j, o.cj[ij], &m.ident);
       }
     }
+  // every chain parks one block per bond in the pool between the half-sweeps
+  pool_cap_ = std::max<size_t>(pool_cap_, 2 * m.chains.size() * (size_t)(L_ + 1) + 16);
   m.chains_ok = true;
 }
 
