@@ -249,6 +249,7 @@ class Engine {
   Multi& ms();
   void ms_require_ready();
   void ms_build_chains();
+  void ms_ident_cores();
   void ms_build_right_envs();
   void ms_sweep(double dt, bool forward);
   void ms_site_exp(int p, double dt);

@@ -211,6 +211,18 @@ void Engine::ms_require_ready() {
   }
 }
 
+// identity cores (M = 1) of the overlap chains that carry the scalar terms
+void Engine::ms_ident_cores() {
+  Multi& m = ms();
+  for (int p = 0; p < L_; ++p) {
+    if (m.ident[p].set && m.ident[p].d == m.d[p]) continue;
+    const int d = m.d[p];
+    std::vector<hzc> eye((size_t)d * d, hzc(0, 0));
+    for (int a = 0; a < d; ++a) eye[(size_t)a * d + a] = hzc(1, 0);
+    upload_mpo_core(m.ident[p], reinterpret_cast<const double*>(eye.data()), 1, d, d, 1);
+  }
+}
+
 // the chains that enter operator 0: MPO blocks, and overlap chains for i != j with a scalar term
 void Engine::ms_build_chains() {
   Multi& m = ms();
@@ -240,13 +252,7 @@ void Engine::ms_build_chains() {
         add(i, j, hzc(1.0, 0.0), &o.blk[ij]);
       }
       if (i != j && o.cj[ij] != hzc(0, 0)) {
-        for (int p = 0; p < L_; ++p) {
-          if (m.ident[p].set && m.ident[p].d == m.d[p]) continue;
-          const int d = m.d[p];
-          std::vector<hzc> eye((size_t)d * d, hzc(0, 0));
-          for (int a = 0; a < d; ++a) eye[(size_t)a * d + a] = hzc(1, 0);
-          upload_mpo_core(m.ident[p], reinterpret_cast<const double*>(eye.data()), 1, d, d, 1);
-        }
+        ms_ident_cores();
         add(i, j, o.cj[ij], &m.ident);
       }
     }
@@ -485,13 +491,7 @@ double Engine::ms_operate(int op_id, int maxstep, double conv_tol, int* iters_ou
         fed[i] = 1;
       }
       if (o.cj[ij] != hzc(0, 0)) {
-        for (int p = 0; p < L_; ++p) {
-          if (m.ident[p].set && m.ident[p].d == m.d[p]) continue;
-          const int d = m.d[p];
-          std::vector<hzc> eye((size_t)d * d, hzc(0, 0));
-          for (int a = 0; a < d; ++a) eye[(size_t)a * d + a] = hzc(1, 0);
-          upload_mpo_core(m.ident[p], reinterpret_cast<const double*>(eye.data()), 1, d, d, 1);
-        }
+        ms_ident_cores();
         ch.push_back(Ch{i, j, o.cj[ij], &m.ident, {}, {}});
         fed[i] = 1;
       }
@@ -729,13 +729,7 @@ hzc Engine::ms_expect(int op_id) {
         chain(i, j, hzc(1, 0), o.blk[ij]);
       }
       if (i != j && o.cj[ij] != hzc(0, 0)) {
-        for (int p = 0; p < L_; ++p) {
-          if (m.ident[p].set && m.ident[p].d == m.d[p]) continue;
-          const int d = m.d[p];
-          std::vector<hzc> eye((size_t)d * d, hzc(0, 0));
-          for (int a = 0; a < d; ++a) eye[(size_t)a * d + a] = hzc(1, 0);
-          upload_mpo_core(m.ident[p], reinterpret_cast<const double*>(eye.data()), 1, d, d, 1);
-        }
+        ms_ident_cores();
         chain(i, j, o.cj[ij], m.ident);
       }
     }

@@ -99,3 +99,32 @@ def test_adaptive_growth_properties_large():
     print("energy", e0, e1)
     assert abs(e1.imag) < 1e-10 * abs(e1) and abs(e1 - e0) < 2e-3  # |H| = O(1) for this chain
     eng.close()
+
+
+def test_multistate_conservation_at_moderate_size():
+    """Two coupled electronic states, L=8 d=8 D=64: energy and norm are conserved, the populations
+    move and sum to one (size-independent properties; no oracle at this size)."""
+    from oracle import tdvp_oracle as orc  # synthetic input builders only
+    from pytdscf_amd import MultiStateEngine
+
+    L, d, D, M, S = 8, 8, 64, 8, 2
+    rng = np.random.default_rng(3)
+    crandn = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)  # noqa: E731
+    raw = [[crandn(a, d, b) for a, b in orc.bond_dims([d] * L, D)] for _ in range(S)]
+    mpo = [[orc.synthetic_mpo(L, d, M, seed=0), None], [None, orc.synthetic_mpo(L, d, M, seed=1)]]
+    w = [0.05 * crandn(a, d, d, b) for a, b in zip([1] + [3] * (L - 1), [3] * (L - 1) + [1])]
+    mpo[0][1] = w
+    mpo[1][0] = [np.ascontiguousarray(np.conj(c.transpose(0, 2, 1, 3))) for c in w]
+    eng = MultiStateEngine(L, S)
+    eng.set_hamiltonian(mpo, [[0.0, 0.01 + 0.02j], [0.01 - 0.02j, 0.3]])
+    eng.set_states(raw, weights=[0.9, 0.1])
+    e0, p0 = eng.expectation(), eng.pop_states()
+    assert abs(e0.imag) < 1e-12
+    for _ in range(3):
+        eng.propagate(0.3)
+    e1, p1 = eng.expectation(), eng.pop_states()
+    assert abs(e1 - e0) < 1e-8 * max(1.0, abs(e0))
+    assert abs(eng.norm() - 1.0) < 1e-12 and abs(sum(p1) - 1.0) < 1e-12
+    assert abs(p1[0] - p0[0]) > 1e-6
+    assert max(eng.krylov_stats()) <= 20
+    eng.close()
