@@ -139,7 +139,7 @@ int mitdvp_rccl_selftest(mitdvp_engine* h, int* mismatches);
  * to this mode; states share the physical dimensions, bond dimensions may differ per state;
  * every MPO block spans all sites (4-leg cores).  mitdvp_krylov_stats and mitdvp_counters apply
  * unchanged.  Not available in this mode: adaptive bonds, gates, Kraus maps (single-state only in
- * the reference too), bond sharding. */
+ * the reference too).  mitdvp_set_parallel* shards this mode like the single-state one. */
 int mitdvp_ms_configure(mitdvp_engine* h, int nstate);
 int mitdvp_ms_set_site(mitdvp_engine* h, int istate, int isite, const double* reim, int l, int n, int r, int gauge);
 int mitdvp_ms_get_site_shape(mitdvp_engine* h, int istate, int isite, int* l, int* n, int* r, int* gauge);

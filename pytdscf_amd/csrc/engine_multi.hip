@@ -55,7 +55,6 @@ int Engine::ms_nstate() const { return ms_ ? ms_->S : 0; }
 
 void Engine::ms_configure(int nstate) {
   if (nstate < 1 || nstate > 64) throw ArgError("ms_configure: nstate must be in [1, 64]");
-  if (nranks_ > 1) throw ArgError("multi-state mode is not bond-sharded");
   ms_ = std::make_shared<Multi>();
   Multi& m = *ms_;
   m.S = nstate;

@@ -169,3 +169,66 @@ def test_native_rccl_collectives_world1(tmp_path):
     """))
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout + p.stderr
+
+
+WORKER_MS = """
+import sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from pytdscf_amd import MultiStateEngine
+from pytdscf_amd.dist import Comm, attach_parallel
+comm = Comm()
+L, d, M, S = 6, 4, 4, 2
+rng = np.random.default_rng(7)
+crandn = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+Ds = [32, 16]                      # both shard over 2 ranks in the middle of the chain
+raw = [[crandn(a, d, b) for a, b in orc.bond_dims([d] * L, D)] for D in Ds]
+mpo = [[orc.synthetic_mpo(L, d, M, seed=1), None], [None, orc.synthetic_mpo(L, d, M, seed=2)]]
+w = [0.1 * crandn(a, d, d, b) for a, b in zip([1] + [2] * (L - 1), [2] * (L - 1) + [1])]
+mpo[0][1] = w
+mpo[1][0] = [np.ascontiguousarray(np.conj(c.transpose(0, 2, 1, 3))) for c in w]
+eng = MultiStateEngine(L, S, device=0)
+eng.set_hamiltonian(mpo, [[0.0, 0.05j], [-0.05j, 0.1]])
+eng.set_states(raw, weights=[0.7, 0.3])
+attach_parallel(eng, comm)
+e0 = eng.expectation()
+for _ in range(2):
+    eng.propagate(0.3)
+out = dict(rank=comm.rank, e0=[e0.real, e0.imag], e=[eng.expectation().real, eng.expectation().imag],
+           norm=eng.norm(), pops=eng.pop_states(), k=eng.krylov_stats(), ncoll=eng.counters()["n_collectives"])
+np.save({out!r} + f".rank{{comm.rank}}.npy", np.concatenate([c.reshape(-1) for st in eng.get_states() for c in st]))
+print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+comm.close()
+"""
+
+
+def test_multistate_bond_sharded_matches_single_rank(tmp_path):
+    """Several electronic states under bond sharding: the per-pair applies / environment updates
+    shard over the bra-side bond like the single-state ones (2 ranks sharing the GPU over gloo)."""
+    import json
+
+    def run(world):
+        script = tmp_path / f"ms{world}.py"
+        out = str(tmp_path / f"ms_w{world}")
+        script.write_text(textwrap.dedent(WORKER_MS.format(root=ROOT, out=out)))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+                   MITDVP_DIST_BACKEND="gloo")
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
+        return res, [np.load(out + f".rank{r}.npy") for r in range(world)]
+
+    ref, vref = run(1)
+    res, vecs = run(2)
+    assert ref[0]["ncoll"] == 0 and all(r["ncoll"] > 0 for r in res)
+    for r, v in zip(res, vecs):
+        assert r["k"] == ref[0]["k"]
+        np.testing.assert_allclose(r["e"], ref[0]["e"], atol=1e-10)
+        np.testing.assert_allclose(r["pops"], ref[0]["pops"], atol=1e-10)
+        assert abs(r["norm"] - 1) < 1e-12
+        np.testing.assert_allclose(v, vref[0], atol=1e-9)
+    assert np.array_equal(vecs[0], vecs[1])  # the replicated state is bit-identical across ranks
