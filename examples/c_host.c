@@ -51,6 +51,56 @@ static void fill_core(double* w, int ml, int d, int mr, int first, int last, uns
   free(A); free(B);
 }
 
+/* Two electronic states (mitdvp_ms_*): the same chain on both states, shifted by a scalar on the
+ * second one and coupled by a scalar term; host-side random tensors, canonicalised on the device. */
+static int two_states(void) {
+  enum { L = 6, D = 8, PHYS = 3, M = 3, S = 2 };
+  mitdvp_engine* eng = NULL;
+  mitdvp_config cfg = {0};
+  cfg.nsite = L; cfg.device = 0; cfg.integrator = MITDVP_LANCZOS; cfg.conserve_norm = 1; cfg.thresh = 1e-9; cfg.max_krylov = 20;
+  CHECK(mitdvp_create(&cfg, &eng));
+  CHECK(mitdvp_ms_configure(eng, S));
+  unsigned seed = 11;
+  for (int p = 0; p < L; ++p) {
+    const int ml = p == 0 ? 1 : M, mr = p == L - 1 ? 1 : M;
+    double* w = malloc(sizeof(double) * 2 * ml * PHYS * PHYS * mr);
+    fill_core(w, ml, PHYS, mr, p == 0, p == L - 1, &seed);
+    for (int s = 0; s < S; ++s) CHECK(mitdvp_ms_set_mpo_core(eng, 0, s, s, p, w, ml, PHYS, PHYS, mr));
+    free(w);
+  }
+  CHECK(mitdvp_ms_set_coupleJ(eng, 0, 1, 1, 0.2, 0.0));   /* energy offset of state 1 */
+  CHECK(mitdvp_ms_set_coupleJ(eng, 0, 0, 1, 0.05, 0.02)); /* Hermitian scalar coupling */
+  CHECK(mitdvp_ms_set_coupleJ(eng, 0, 1, 0, 0.05, -0.02));
+  int bl[L + 1];
+  bl[0] = 1; bl[L] = 1;
+  for (int p = 1; p < L; ++p) {  /* min(D, d^p, d^(L-p)) */
+    long a = 1, b = 1;
+    for (int q = 0; q < p && a <= D; ++q) a *= PHYS;
+    for (int q = p; q < L && b <= D; ++q) b *= PHYS;
+    bl[p] = (int)(a < b ? (a < D ? a : D) : (b < D ? b : D));
+  }
+  for (int s = 0; s < S; ++s)
+    for (int p = 0; p < L; ++p) {
+      const long n = 2L * bl[p] * PHYS * bl[p + 1];
+      double* t = malloc(sizeof(double) * n);
+      for (long i = 0; i < n; ++i) t[i] = (double)rand_r(&seed) / RAND_MAX - 0.5;
+      CHECK(mitdvp_ms_set_site(eng, s, p, t, bl[p], PHYS, bl[p + 1], MITDVP_GAUGE_C));
+      free(t);
+    }
+  CHECK(mitdvp_ms_canonicalize(eng, 0, sqrt(0.8)));
+  CHECK(mitdvp_ms_canonicalize(eng, 1, sqrt(0.2)));
+  double e0[2], e1[2], pops0[S], pops[S];
+  CHECK(mitdvp_ms_expect(eng, 0, e0));
+  CHECK(mitdvp_ms_pops(eng, pops0));
+  for (int k = 0; k < 4; ++k) CHECK(mitdvp_ms_step(eng, 0.5));
+  CHECK(mitdvp_ms_expect(eng, 0, e1));
+  CHECK(mitdvp_ms_pops(eng, pops));
+  printf("two states: populations %.6f %.6f -> %.6f %.6f, energy %.12f -> %.12f\n", pops0[0], pops0[1], pops[0], pops[1], e0[0], e1[0]);
+  const int ok = fabs(pops[0] + pops[1] - 1.0) < 1e-12 && fabs(e1[0] - e0[0]) < 1e-8 && fabs(pops[0] - pops0[0]) > 1e-6;
+  mitdvp_destroy(eng);
+  return ok ? 0 : 1;
+}
+
 int main(void) {
   enum { L = 8, D = 16, PHYS = 4, M = 3 };
   mitdvp_engine* eng = NULL;
@@ -81,7 +131,8 @@ int main(void) {
   printf("energy before %.12f  after 5 steps %.12f (imag %.1e)\n", e0[0], e1[0], e1[1]);
   printf("norm %.15f  autocorr %.9f%+.9fi  krylov[0] %d\n", nrm, ac[0], ac[1], k[0]);
   const int ok = fabs(nrm - 1.0) < 1e-12 && fabs(e1[0] - e0[0]) < 1e-8 * fmax(1.0, fabs(e0[0])) && fabs(e1[1]) < 1e-12;
-  printf("%s\n", ok ? "C-HOST OK" : "C-HOST FAILED");
   mitdvp_destroy(eng);
-  return ok ? 0 : 1;
+  const int ok2 = two_states() == 0;
+  printf("%s\n", ok && ok2 ? "C-HOST OK" : "C-HOST FAILED");
+  return ok && ok2 ? 0 : 1;
 }
