@@ -236,6 +236,9 @@ class BasInfo:
     def get_ndof(self):
         return len(self.prim_info[0])
 
+    def get_primbas(self, istate, idof):
+        return self.prim_info[istate][idof]
+
     def get_nprim(self, istate, idof):
         b = self.prim_info[istate][idof]
         return b.nprim if hasattr(b, "nprim") else len(b)
@@ -266,7 +269,7 @@ class Model:
             raise TypeError("one_gate_to_apply must be a TensorHamiltonian of one-site operators")
         self.one_gate_to_apply = one_gate_to_apply
         self.space = space.lower()
-        ops = {"hamiltonian": operators} if isinstance(operators, (TensorHamiltonian, list)) else dict(operators)
+        ops = {"hamiltonian": operators} if isinstance(operators, (TensorHamiltonian, list)) or hasattr(operators, "to_tensor_hamiltonian") else dict(operators)
         self.dims = [self.basinfo.get_nprim(0, i) for i in range(self.basinfo.get_ndof())]
         self.nstate = self.basinfo.get_nstate()
         for s_ in range(1, self.nstate):
@@ -283,6 +286,8 @@ class Model:
                 len(self.dims), {"potential": TensorOperator(mpo=pot)},
                 kinetic=None if kin is None else {"kinetic": TensorOperator(mpo=kin)})
         for name, op in ops.items():
+            if hasattr(op, "to_tensor_hamiltonian"):  # PolynomialHamiltonian: exact MPO of the sum of products
+                op = op.to_tensor_hamiltonian(self.basinfo)
             if isinstance(op, TensorHamiltonian):
                 out[name] = op
             elif isinstance(op, list):
@@ -321,7 +326,7 @@ class Model:
         return len(self.dims)
 
     def initial_cores(self, istate=0):
-        D = self.m_aux_max if self.m_aux_max is not None else 1
+        D = self.m_aux_max if self.m_aux_max is not None else 10**9  # _get_initial_condition, _mps_cls.py:147-148
         if self.init_HartreeProduct is not None:
             if len(self.init_HartreeProduct) != self.nstate:
                 raise ValueError("init_HartreeProduct needs one list of site weights / cores per electronic state")
@@ -414,7 +419,7 @@ class Simulator:
     returned energy is the one of the last loop iteration (Appendix B.1)."""
 
     def __init__(self, jobname, model, ci_type="MPS", backend="hip", proj_gs=False, t2_trick=True, verbose=2):
-        if ci_type.lower() not in ("mps", "mps-sm"):
+        if ci_type.lower() not in ("mps", "mps-sm", "standard-method"):
             raise NotImplementedError("only the MPS standard method (MPO Hamiltonian) is on the accelerated path")
         if backend.lower() not in ("hip", "numpy", "jax"):
             raise ValueError(f"unknown backend {backend}")

@@ -295,3 +295,57 @@ class Exponential(_GridDVR):
     def get_2nd_derivative_matrix_fbr(self) -> np.ndarray:
         u = self.get_unitary()
         return u @ self.get_2nd_derivative_matrix_dvr() @ u.T
+
+
+class PrimBas_HO:
+    """Harmonic-oscillator EIGENFUNCTION primitive basis (FBR) in mass-weighted coordinates,
+    ``PrimBas_HO(origin, freq_cm1, nprim, origin_is_dimless=True)`` (pytdscf/basis/ho.py:255-315):
+    chi_n(q) = HO eigenfunction n of frequency omega centred at ``origin_mwc``.  The operator
+    matrices are the exact integrals <chi_m| q^k |chi_n>, <chi_m| d^k/dq^k |chi_n> (not powers of
+    a truncated matrix): ladder operators in a basis enlarged by k, then cut back."""
+
+    def __init__(self, origin: float, freq_cm1: float, nprim: int, origin_is_dimless: bool = True):
+        self.freq_cm1 = freq_cm1
+        self.nprim = int(nprim)
+        self.freq_au = freq_cm1 / _units.au_in_cm1
+        if origin_is_dimless:
+            self.origin_mwc = origin / math.sqrt(self.freq_au)
+            self.origin = origin
+        else:
+            self.origin_mwc = origin
+            self.origin = origin * math.sqrt(self.freq_au)
+
+    def __len__(self) -> int:
+        return self.nprim
+
+    def _ladder(self, extra: int):
+        n = self.nprim + extra
+        a = np.diag(np.sqrt(np.arange(1, n)), 1)  # annihilation operator
+        return a, a.T
+
+    def q_matrix(self, order: int = 1) -> np.ndarray:
+        """<m| q^order |n> with q the absolute mass-weighted coordinate (basis centred at origin_mwc)."""
+        a, ad = self._ladder(order)
+        q = self.origin_mwc * np.eye(a.shape[0]) + (a + ad) / math.sqrt(2.0 * self.freq_au)
+        return np.linalg.matrix_power(q, order)[: self.nprim, : self.nprim]
+
+    def d_matrix(self, order: int = 1) -> np.ndarray:
+        """<m| d^order/dq^order |n>; d/dq = sqrt(omega / 2) (a - a^+)."""
+        a, ad = self._ladder(order)
+        d = math.sqrt(self.freq_au / 2.0) * (a - ad)
+        return np.linalg.matrix_power(d, order)[: self.nprim, : self.nprim]
+
+    def op_matrix(self, key: str) -> np.ndarray:
+        """Site matrix of an operator key of the polynomial Hamiltonians: "ovlp", "q^k" ("q" = "q^1"),
+        "d^k", "ham1" (= -d^2/2 + omega^2 (q - q0)^2 / 2, diagonal omega (n + 1/2))."""
+        if key == "ovlp":
+            return np.eye(self.nprim)
+        if key == "ham1":
+            return np.diag(self.freq_au * (np.arange(self.nprim) + 0.5))
+        name, _, power = key.partition("^")
+        k = int(power) if power else 1
+        if name == "q":
+            return self.q_matrix(k)
+        if name == "d":
+            return self.d_matrix(k)
+        raise ValueError(f"unknown operator key {key!r}")

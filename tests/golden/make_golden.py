@@ -897,6 +897,50 @@ def main():
             o[f"{tag}_pos"] = np.array(b.get_pos_rep_matrix())
     save("basis_dvr.npz", **o)
 
+    # (xii) polynomial (sum-of-products) Hamiltonians with the MPS standard method: BASELINE
+    # configs[0] (tests/test_harmonic_fbr_sm_propagate_numpy.py) and the anharmonic H2O force
+    # field (tests/test_anharmonic_fbr_mpssm_propagate_np.py).  The reference runs them through its
+    # SoP contractions (MPSCoefSoP); the engine runs the exact MPO of the same operator.
+    import math as _math
+
+    from pytdscf.basis._primints_cls import PrimBas_HO as RefPrimHO
+    from pytdscf.hamiltonian_cls import PolynomialHamiltonian as RefPoly, read_potential_nMR as ref_read_nMR
+    from pytdscf.model_cls import BasInfo as RefBasInfo
+    from pytdscf.potentials.h2o_potential import k_orig as h2o_k
+
+    o = {}
+    prim_h = [[RefPrimHO(0.0, 1500, 8), RefPrimHO(0.0, 2000, 8)]]
+    bi = RefBasInfo(prim_h)
+    ham_h = RefPoly(ndof=2)
+    ham_h.set_HO_potential(bi)
+    ener, _ = Simulator("harmonic_fbr_sm", Model(bi, {"hamiltonian": ham_h}), ci_type="standard-method",
+                        backend="numpy", verbose=0).propagate(maxstep=1)
+    assert abs(ener - 0.007973586692598029) < 1e-12  # the reference's own pin
+    o["harmonic_energy"] = np.array(ener)
+    keys = sorted(k for k in h2o_k.keys())
+    o["h2o_keys"] = np.array([list(k) + [0] * (4 - len(k)) for k in keys])  # zero padded mode labels
+    o["h2o_vals"] = np.array([h2o_k[k] for k in keys])
+
+    def h2o_model(nprim, bond_dim):
+        prim = [[RefPrimHO(0.0, _math.sqrt(h2o_k[(i, i)]) * units.au_in_cm1, nprim) for i in (1, 2, 3)]]
+        return Model(RefBasInfo(prim), {"hamiltonian": ref_read_nMR(h2o_k)}, bond_dim=bond_dim)
+
+    ener, _ = Simulator("anharmonic_fbr_propagate_sm", h2o_model(6, 4), backend="numpy", verbose=0).propagate(maxstep=2)
+    assert abs(ener - 0.021360262338234466) < 1e-12  # the reference's own pin
+    o["h2o_energy_pin"] = np.array(ener)
+    for n in (1, 5):  # dynamics from |000> and from a vibrationally excited product state
+        for tag, wts in (("gs", None), ("ex", [[[0.0, 1.0, 0.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0, 0.0, 0.0], [0.6, 0.8, 0.0, 0.0, 0.0, 0.0]]])):
+            m_ = h2o_model(6, 4)
+            if wts is not None:
+                m_.init_weight_VIBSTATE = wts
+            ener, wf = Simulator("h2o_dyn", m_, backend="numpy", verbose=0).propagate(stepsize=0.2, maxstep=n)
+            o[f"h2o_{tag}_n{n}_energy_last"] = np.array(ener)
+            o[f"h2o_{tag}_n{n}_autocorr"] = np.array(wf.autocorr())
+            o[f"h2o_{tag}_n{n}_norm"] = np.array(wf.norm())
+            for p_, c in enumerate(wf.ci_coef.superblock_states[0]):
+                o[f"h2o_{tag}_n{n}_final{p_}"] = np.array(c.data)
+    save("polynomial_sm.npz", dt_au=np.array(0.2 / au_in_fs), **o)
+
 
 if __name__ == "__main__":
     main()

@@ -610,3 +610,88 @@ def test_tensor_dict_to_mpo_reference_test(rate, J):
     assert max(w.shape[-1] for w in lossy) < max(w.shape[-1] for w in mpo)
     with pytest.raises(ValueError):
         tensor_dict_to_mpo(tensor_dict, rate=1.5)
+
+
+def _h2o_model(g, nprim=6, bond_dim=4, weights=None):
+    """tests/test_anharmonic_fbr_mpssm_propagate_np.py of the reference: force constants of its
+    H2O potential (stored in the fixture), HO-eigenfunction primitives, polynomial Hamiltonian."""
+    import math
+
+    from pytdscf_amd import BasInfo, Model, PrimBas_HO, read_potential_nMR, units
+
+    k_orig = {tuple(int(x) for x in key if x): float(v) for key, v in zip(g["h2o_keys"], g["h2o_vals"])}
+    prim = [[PrimBas_HO(0.0, math.sqrt(k_orig[(i, i)]) * units.au_in_cm1, nprim) for i in (1, 2, 3)]]
+    model = Model(BasInfo(prim), {"hamiltonian": read_potential_nMR(k_orig)}, bond_dim=bond_dim)
+    if weights is not None:
+        model.init_weight_VIBSTATE = weights
+    return model
+
+
+EXCITED = [[[0.0, 1.0, 0.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0, 0.0, 0.0], [0.6, 0.8, 0.0, 0.0, 0.0, 0.0]]]
+
+
+def test_polynomial_hamiltonian_as_mpo_cpu(golden):
+    """Sum-of-products Hamiltonians of the MPS standard method become exact MPOs.  The fixture holds
+    the reference's SoP runs (its MPSCoefSoP contractions).  Energies agree to 1e-12 (both reference
+    pins included); the dynamics agree to ~1e-7: the reference's own SoP and MPO sweeps differ from
+    each other by that much on the same operator (infidelity 4e-9 after one step at D = 4, checked in
+    the development container; its MPO sweep on the converted operator equals the oracle to 2e-16 and
+    is the one closer to the exact propagation)."""
+    from pytdscf_amd import BasInfo, Model, PolynomialHamiltonian, PrimBas_HO
+    from pytdscf_amd.operators import mpo_to_dense
+
+    g = golden("polynomial_sm.npz")
+    # BASELINE configs[0]: two harmonic modes in their own eigenbasis
+    bi = BasInfo([[PrimBas_HO(0.0, 1500, 8), PrimBas_HO(0.0, 2000, 8)]])
+    ham = PolynomialHamiltonian(ndof=2)
+    ham.set_HO_potential(bi)
+    m = Model(bi, {"hamiltonian": ham})
+    dense = mpo_to_dense(m.hamiltonian.as_mpo(m.dims))
+    np.testing.assert_allclose(dense, np.diag(np.diag(dense)), atol=1e-15)
+    assert dense[0, 0].real == pytest.approx(float(g["harmonic_energy"]), abs=1e-15)
+    assert float(g["harmonic_energy"]) == pytest.approx(0.007973586692598029)
+    # anharmonic H2O
+    for tag, wts in (("gs", None), ("ex", EXCITED)):
+        for n in (1, 5):
+            model = _h2o_model(g, weights=wts)
+            st = orc.OracleMPS(orc.canonicalize_site0(model.initial_cores()), model.hamiltonian.as_mpo(model.dims),
+                               shift=model.hamiltonian.coupleJ[0][0])
+            for _ in range(n):
+                e = st.expectation()
+                st.propagate(float(g["dt_au"]))
+            k = f"h2o_{tag}_n{n}"
+            assert e.real == pytest.approx(float(g[f"{k}_energy_last"]), abs=1e-12)
+            assert abs(st.autocorr() - complex(g[f"{k}_autocorr"])) < 2e-6
+            assert abs(abs(orc.overlap([g[f"{k}_final{p}"] for p in range(3)], st.cores)) - 1) < 1e-6
+    st = orc.OracleMPS(orc.canonicalize_site0(_h2o_model(g).initial_cores()), _h2o_model(g).hamiltonian.as_mpo([6, 6, 6]))
+    assert st.expectation().real == pytest.approx(0.021360262338234466, abs=1e-12)  # the reference test's pin
+
+
+@pytest.mark.gpu
+def test_polynomial_scripts_on_gpu(golden, tmp_path, monkeypatch):
+    """The two reference tests with polynomial Hamiltonians, typed against the shell."""
+    from pytdscf_amd import BasInfo, Model, PolynomialHamiltonian, PrimBas_HO, Simulator
+
+    monkeypatch.chdir(tmp_path)
+    g = golden("polynomial_sm.npz")
+    basinfo = BasInfo([[PrimBas_HO(0.0, 1500, 8), PrimBas_HO(0.0, 2000, 8)]])
+    hamiltonian = PolynomialHamiltonian(ndof=2)
+    hamiltonian.set_HO_potential(basinfo)
+    simulator = Simulator("harmonic_fbr_sm", Model(basinfo, {"hamiltonian": hamiltonian}), ci_type="standard-method", backend="numpy")
+    ener_calc, wf = simulator.propagate(maxstep=1)
+    assert pytest.approx(ener_calc) == 0.007973586692598029
+    simulator = Simulator("anharmonic_fbr_propagate_sm", _h2o_model(g), backend="numpy")
+    ener_calc, wf = simulator.propagate(maxstep=2)
+    assert pytest.approx(ener_calc) == 0.021360262338234466
+    ener, wf = Simulator("h2o_dyn", _h2o_model(g, weights=EXCITED), backend="hip").propagate(stepsize=0.2, maxstep=5)
+    assert ener == pytest.approx(float(g["h2o_ex_n5_energy_last"]), abs=1e-11)
+    assert abs(wf.autocorr() - complex(g["h2o_ex_n5_autocorr"])) < 2e-6  # SoP vs MPO sweep of the reference, see the CPU test
+    assert abs(abs(orc.overlap([g[f"h2o_ex_n5_final{p}"] for p in range(3)], wf.get_mps())) - 1) < 1e-6
+    assert abs(wf.norm() - 1) < 1e-12
+    # against the oracle (= the reference's MPO sweep) on the same converted operator: the usual bar
+    model = _h2o_model(g, weights=EXCITED)
+    st = orc.OracleMPS(orc.canonicalize_site0(model.initial_cores()), model.hamiltonian.as_mpo(model.dims))
+    for _ in range(5):
+        st.propagate(float(g["dt_au"]))
+    assert abs(wf.autocorr() - st.autocorr()) < 1e-10
+    assert abs(abs(orc.overlap(st.cores, wf.get_mps())) - 1) < 1e-10
