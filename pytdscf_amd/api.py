@@ -411,6 +411,32 @@ class WFunc:
             return self.engine.get_states()
         return self.engine.get_mps()
 
+    @property
+    def ci_coef(self):
+        """``wf.ci_coef.<method>`` of reference scripts: the MPS coefficients live in this handle."""
+        return self
+
+    def get_CI_coef_state(self, J=None, trans_arrays=None, istate: int = 0):
+        """Coefficient <j_1 j_2 ... j_f|Psi> of one basis configuration ``J``, or the contraction of
+        every physical leg with a vector (``trans_arrays``, e.g. coherent-state overlaps)
+        (MPSCoef.get_CI_coef_state, _mps_cls.py:1680-1736)."""
+        mps = self.get_mps()
+        cores = mps[istate] if hasattr(self.engine, "get_states") else mps
+        if trans_arrays is None:
+            if J is None:
+                raise ValueError("Either `J` or `trans_arrays` must be set.")
+            trans_arrays = []
+            for c, j in zip(cores, J):
+                v = np.zeros(c.shape[1], dtype=complex)
+                v[j] = 1.0
+                trans_arrays.append(v)
+        elif len(trans_arrays) != len(cores):
+            raise ValueError("The length of `trans_arrays` must be equal to the number of DOFs.")
+        row = np.ones((1,), dtype=complex)
+        for c, t in zip(cores, trans_arrays):
+            row = row @ np.tensordot(c, np.asarray(t), axes=(1, 0))
+        return complex(row[0])
+
 
 class Simulator:
     """``Simulator(jobname, model, ci_type="MPS", backend="hip", ...)`` --

@@ -695,3 +695,34 @@ def test_polynomial_scripts_on_gpu(golden, tmp_path, monkeypatch):
         st.propagate(float(g["dt_au"]))
     assert abs(wf.autocorr() - st.autocorr()) < 1e-10
     assert abs(abs(orc.overlap(st.cores, wf.get_mps())) - 1) < 1e-10
+
+
+@pytest.mark.gpu
+def test_dipole_operate_script_on_gpu(tmp_path, monkeypatch):
+    """tests/test_sample_CS_ovlp_np.py of the reference up to the coherent-state sampling: a dipole
+    from ``read_potential_nMR(dipole_emu=...)`` applied to the HO ground state (its norm is the
+    reference's known answer), then configuration coefficients of the result."""
+    from pytdscf_amd import BasInfo, Model, PrimBas_HO, Simulator
+    from pytdscf_amd.hamiltonian_cls import read_potential_nMR
+
+    monkeypatch.chdir(tmp_path)
+    prim_info = [[PrimBas_HO(0.0, 1500, 5), PrimBas_HO(0.0, 2000, 5), PrimBas_HO(0.0, 2500, 5)]]
+    basinfo = BasInfo(prim_info)
+    mu = {(0,): [1 / 30, 1 / 30, 1 / 30], (1,): [1 / 30, 1 / 30, 1 / 30], (2,): [1 / 30, 1 / 30, 1 / 30]}
+    dipole = read_potential_nMR(potential_emu=None, dipole_emu=mu)
+    model = Model(basinfo, {"hamiltonian": dipole})
+    model.m_aux_max = 4
+    simulator = Simulator("coherent_sample_FBR", model, backend="numpy")
+    norm, wf = simulator.operate(maxstep=10, restart=False)
+    assert pytest.approx(norm) == 1.3111895155460684
+    # mu|000> = 0.1 sum_i q_i |000>: one quantum in one mode, amplitudes 0.1 / sqrt(2 w_i) / norm
+    w = [p.freq_au for p in prim_info[0]]
+    amps = [abs(wf.ci_coef.get_CI_coef_state(J=tuple(1 if k == i else 0 for k in range(3)))) for i in range(3)]
+    np.testing.assert_allclose(amps, [0.1 / np.sqrt(2 * x) / norm for x in w], rtol=1e-9)
+    assert abs(wf.ci_coef.get_CI_coef_state(J=(0, 0, 0))) < 1e-12
+    dense = wf.get_mps()[0]
+    for c in wf.get_mps()[1:]:
+        dense = np.tensordot(dense, c, axes=(dense.ndim - 1, 0))
+    t = [np.arange(1, 6) * (0.3 + 0.1j * k) for k in range(3)]
+    ref = np.einsum("ijk,i,j,k->", dense.reshape(5, 5, 5), *t)
+    assert abs(wf.ci_coef.get_CI_coef_state(trans_arrays=t) - ref) < 1e-12
