@@ -726,3 +726,53 @@ def test_dipole_operate_script_on_gpu(tmp_path, monkeypatch):
     t = [np.arange(1, 6) * (0.3 + 0.1j * k) for k in range(3)]
     ref = np.einsum("ijk,i,j,k->", dense.reshape(5, 5, 5), *t)
     assert abs(wf.ci_coef.get_CI_coef_state(trans_arrays=t) - ref) < 1e-12
+
+
+@pytest.mark.gpu
+def test_lvc_polynomial_two_states_on_gpu(tmp_path, monkeypatch):
+    """Linear vibronic coupling typed like tests/test_LVC_propagate_np.py (PolynomialHamiltonian.set_LVC,
+    coupleJ matrix, init_weight_ESTATE) but with the MPS standard method and one primitive basis for
+    both states: the sum of products becomes per-pair MPO blocks of the multi-state engine.  Checked
+    against the multi-state oracle on the same blocks and against exact propagation."""
+    import scipy.linalg
+
+    from pytdscf_amd import BasInfo, Model, PolynomialHamiltonian, PrimBas_HO, Simulator, units
+    from pytdscf_amd.operators import mpo_to_dense
+
+    monkeypatch.chdir(tmp_path)
+    freqs = [1000, 2000, 3000]
+    s0 = [PrimBas_HO(0.0, f, 5) for f in freqs]
+    basinfo = BasInfo([s0, s0])
+    ham = PolynomialHamiltonian(basinfo.get_ndof(), basinfo.get_nstate())
+    ham.coupleJ = [[0, -0.004], [-0.004, 0.007]]
+    lam = {(0, 1): {0: 0.002, 1: 0.002, 2: 0.002}, (1, 0): {0: 0.002, 1: 0.002, 2: 0.002}}
+    ham.set_LVC(basinfo, lam)
+    model = Model(basinfo, {"hamiltonian": ham}, bond_dim=5)
+    model.init_weight_ESTATE = [1.0, 0.0]
+    assert model.hamiltonian.nstate == 2 and model.hamiltonian.coupleJ[1][1] == pytest.approx(0.007)
+    ener, wf = Simulator("LVC_sm", model, backend="hip").propagate(maxstep=3, stepsize=0.05)
+    assert ener == pytest.approx(0.5 * sum(freqs) / units.au_in_cm1, abs=1e-12)  # <H> of |S0, 000>: the zero-point energy
+    assert ener == pytest.approx(0.013669005758738601, rel=1e-9)  # = the value tests/test_LVC_propagate_np.py pins
+    # multi-state oracle on the same blocks
+    blocks = [[model.hamiltonian.block_mpo(i, j, model.dims) for j in range(2)] for i in range(2)]
+    raw = [model.initial_cores(s) for s in range(2)]
+    z = orc.canonicalize_site0(raw[1], 1.0)
+    z[0] = z[0] * 0.0
+    st = orc.OracleMultiMPS([orc.canonicalize_site0(raw[0], 1.0), z], blocks, model.hamiltonian.coupleJ)
+    for _ in range(3):
+        st.propagate(0.05 / units.au_in_fs)
+    np.testing.assert_allclose(wf.pop_states(), st.pop_states(), atol=1e-10)
+    assert abs(wf.autocorr() - st.autocorr()) < 1e-10
+    # exact propagation in the 2 x 125-dimensional product basis (bond dimension 5 is the full rank here)
+    n = 125
+    H = np.zeros((2 * n, 2 * n), dtype=complex)
+    for i in range(2):
+        for j in range(2):
+            blk = mpo_to_dense(blocks[i][j]) if blocks[i][j] is not None else 0.0
+            H[i * n:(i + 1) * n, j * n:(j + 1) * n] = blk + complex(model.hamiltonian.coupleJ[i][j]) * np.eye(n)
+    assert np.abs(H - H.conj().T).max() < 1e-15
+    v0 = np.zeros(2 * n, dtype=complex)
+    v0[0] = 1.0
+    vt = scipy.linalg.expm(-1j * H * 3 * 0.05 / units.au_in_fs) @ v0
+    np.testing.assert_allclose(wf.pop_states(), [np.linalg.norm(vt[:n]) ** 2, np.linalg.norm(vt[n:]) ** 2], atol=1e-7)
+    assert wf.pop_states()[1] > 1e-6
