@@ -4,7 +4,11 @@ tests, re-typed against ``pytdscf_amd`` (same class names / kwargs)."""
 import numpy as np
 import pytest
 
+import os
+
 from oracle import tdvp_oracle as orc
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _exciton_model(g):
@@ -776,3 +780,74 @@ def test_lvc_polynomial_two_states_on_gpu(tmp_path, monkeypatch):
     vt = scipy.linalg.expm(-1j * H * 3 * 0.05 / units.au_in_fs) @ v0
     np.testing.assert_allclose(wf.pop_states(), [np.linalg.norm(vt[:n]) ** 2, np.linalg.norm(vt[n:]) ** 2], atol=1e-7)
     assert wf.pop_states()[1] > 1e-6
+
+
+def test_compat_aliases_resolve_reference_import_paths():
+    """``pytdscf_amd.compat.install()``: the import lines of scripts written for the reference
+    resolve to this package (no GPU needed to import)."""
+    import subprocess
+    import sys as _sys
+
+    code = """
+import sys
+sys.path.insert(0, %r)
+import pytdscf_amd.compat as c
+names = c.install()
+import pytdscf
+from pytdscf import BasInfo, Model, Simulator, units, Exciton, Boson, TensorHamiltonian, TensorOperator, construct_kinetic_mpo
+from pytdscf.basis import PrimBas_HO, Sine, Exponential, HarmonicOscillator
+from pytdscf.basis._primints_cls import PrimBas_HO as P2
+from pytdscf.hamiltonian_cls import PolynomialHamiltonian, TensorHamiltonian as T2, read_potential_nMR
+from pytdscf.model_cls import BasInfo as B2, Model as M2
+from pytdscf.simulator_cls import Simulator as S2
+from pytdscf.dvr_operator_cls import TensorOperator as TO2, construct_nMR_recursive, construct_kinetic_operator, construct_fulldimensional
+from pytdscf.kraus import lindblad_to_kraus
+from pytdscf.util import read_nc
+from pytdscf.wavefunction import WFunc
+import pytdscf.spectra
+from discvar import HarmonicOscillator as HO
+import pytdscf_amd
+assert Model is pytdscf_amd.Model is M2 and Simulator is S2 and P2 is PrimBas_HO and HO is pytdscf_amd.HarmonicOscillator
+assert pytdscf.spectra.ifft_autocorr is pytdscf_amd.spectra.ifft_autocorr and pytdscf.__version__
+c.uninstall()
+assert "pytdscf" not in sys.modules and "discvar" not in sys.modules
+print("ALIASES OK", len(names))
+""" % ROOT_DIR
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ALIASES OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_compat_runs_a_reference_style_script(tmp_path):
+    """A script with the reference's import lines (``import pytdscf``, ``from discvar import ...``,
+    ``backend="numpy"``) runs unedited through ``python -m pytdscf_amd.compat`` and reproduces the
+    Hénon–Heiles pin of the reference's test."""
+    import subprocess
+    import sys as _sys
+
+    script = tmp_path / "hh_reference_style.py"
+    script.write_text('''
+from discvar import HarmonicOscillator as HO
+from pytdscf import units
+from pytdscf.dvr_operator_cls import construct_kinetic_mpo, construct_nMR_recursive
+from pytdscf.model_cls import Model
+from pytdscf.simulator_cls import Simulator
+
+w, lam, f, N, m, dt = 2000, 1.0e-03, 2, 5, 4, 0.001
+dvr_prims = [HO(N, w) for _ in range(f)]
+w_au = w / units.au_in_cm1
+func = {(0,): lambda Q1: pow(w_au, 2) / 2 * Q1**2,
+        (0, 1): lambda Q1, Q2: lam * pow(w_au, 3 / 2) * (Q1**2 * Q2),
+        (1,): lambda Qf: pow(w_au, 2) / 2 * Qf**2 - lam * pow(w_au, 3 / 2) / 3 * Qf**3}
+operators = {"potential": construct_nMR_recursive(dvr_prims, nMR=2, func=func, rate=0.99999999999),
+             "kinetic": construct_kinetic_mpo(dvr_prims)}
+model = Model(dvr_prims, operators=operators, bond_dim=m)
+model.init_weight_VIBSTATE = [[[0.0, 1.0] + [0.0] * (N - 2)] + [[1.0] + [0.0] * (N - 1)] * (f - 1)]
+ener, wf = Simulator(jobname="henon_heiles", model=model, backend="numpy").propagate(maxstep=3, stepsize=dt)
+print(f"ENERGY {ener:.15f}")
+''')
+    r = subprocess.run([_sys.executable, "-m", "pytdscf_amd.compat", str(script)], capture_output=True, text=True, timeout=300,
+                       cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=ROOT_DIR + os.pathsep + os.environ.get("PYTHONPATH", "")))
+    assert r.returncode == 0, r.stdout + r.stderr
+    ener = float([l for l in r.stdout.splitlines() if l.startswith("ENERGY")][0].split()[1])
+    assert ener == pytest.approx(0.018225341011652626)
