@@ -232,3 +232,64 @@ def test_multistate_bond_sharded_matches_single_rank(tmp_path):
         assert abs(r["norm"] - 1) < 1e-12
         np.testing.assert_allclose(v, vref[0], atol=1e-9)
     assert np.array_equal(vecs[0], vecs[1])  # the replicated state is bit-identical across ranks
+
+
+WORKER_OPS = """
+import sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from pytdscf_amd import TDVPEngine
+from pytdscf_amd.dist import Comm, attach_parallel
+comm = Comm()
+L, d, M, D = 8, 4, 5, 32
+mpo = orc.synthetic_mpo(L, d, M, seed=3)
+dip = orc.synthetic_mpo(L, d, 3, seed=9)
+mps = orc.synthetic_mps([d] * L, D, seed=4)
+rng = np.random.default_rng(2)
+q, _ = np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))
+eng = TDVPEngine(L, device=0)
+eng.set_mpo(mpo, shift=0.2)
+eng.set_mpo(dip, op_id=1, shift=0.1)
+eng.set_mps(mps)
+attach_parallel(eng, comm)
+eng.set_gates({{2: q, 5: np.exp(1j * np.arange(d))}})          # applied between the half-sweeps
+eng.propagate(0.3)
+nrm, it = eng.operate(1, maxstep=3)                          # mixed bra / ket blocks, shift through overlap chains
+eng.propagate(0.3)
+out = dict(rank=comm.rank, nrm=nrm, it=it, e=[eng.expectation().real, eng.expectation().imag], norm=eng.norm(),
+           k=eng.krylov_stats(), ncoll=eng.counters()["n_collectives"])
+np.save({out!r} + f".rank{{comm.rank}}.npy", np.concatenate([c.reshape(-1) for c in eng.get_mps()]))
+print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+comm.close()
+"""
+
+
+def test_bond_sharded_gates_and_operate(tmp_path):
+    """One-site gates between the half-sweeps and Simulator.operate (mixed bra/ket blocks and the
+    scalar term's overlap chain) under bond sharding."""
+    import json
+
+    def run(world):
+        script = tmp_path / f"ops{world}.py"
+        out = str(tmp_path / f"ops_w{world}")
+        script.write_text(textwrap.dedent(WORKER_OPS.format(root=ROOT, out=out)))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+                   MITDVP_DIST_BACKEND="gloo")
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
+        return res, [np.load(out + f".rank{r}.npy") for r in range(world)]
+
+    ref, vref = run(1)
+    res, vecs = run(2)
+    assert all(r["ncoll"] > 0 for r in res)
+    for r, v in zip(res, vecs):
+        assert r["k"] == ref[0]["k"] and r["it"] == ref[0]["it"]
+        assert abs(r["nrm"] - ref[0]["nrm"]) < 1e-10 * ref[0]["nrm"]
+        np.testing.assert_allclose(r["e"], ref[0]["e"], atol=1e-10)
+        assert v.shape == vref[0].shape and np.abs(v - vref[0]).max() < 1e-8
+    assert np.array_equal(vecs[0], vecs[1])
