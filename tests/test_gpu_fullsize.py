@@ -128,3 +128,16 @@ def test_multistate_conservation_at_moderate_size():
     assert abs(p1[0] - p0[0]) > 1e-6
     assert max(eng.krylov_stats()) <= 20
     eng.close()
+
+
+def test_heff_throughput_floor_at_c4_shape():
+    """Regression guard for the dominant kernel: three H_eff applies at the C4 interior shape
+    (D=1024, d=16, M=32; 1.1e13 flop each) run at 81 TFLOP/s algorithmic on an MI355X
+    (profiles/r01_bench_C4.json); fail when a change drops it below 60."""
+    from pytdscf_amd import engine as E
+
+    dl, d, dr, m = 1024, 16, 1024, 32
+    ms = E.bench_heff(dl, d, dr, m, m, reps=3, warmup=1)
+    flops = 8.0 * (dl * dl * m * d * dr + dl * dr * m * m * d * d + dl * dr * dr * m * d)
+    tflops = flops / (ms * 1e-3) / 1e12
+    assert tflops > 60.0, f"H_eff apply at the C4 shape: {tflops:.1f} TFLOP/s ({ms:.1f} ms)"
