@@ -130,6 +130,20 @@ def heff_traffic(d, D, M):
     return None
 
 
+def small_regime_traffic(L, d, D, M):
+    """Fabric-side bytes per H_eff apply in the small-bond regime from the committed PMC passes over
+    tools/small_trace.py (profiles/r01_c2_traffic.json: FETCH doubled + WRITE of the NN / NT GEMM
+    launches, divided by the applies -- an upper bound, those launches also serve the environment
+    updates); None for shapes that were not measured."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_c2_traffic.json")))
+    except OSError:
+        return None
+    if (L, d, D, M) == (10, 10, 32, 6):
+        return t["zgemm_NN_NT_bytes_per_heff_apply_upper_bound"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,7 +164,7 @@ def main():
             sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
 
-    from oracle import tdvp_oracle as orc  # synthetic inputs + cpu_baseline leg only
+    from pytdscf_amd import synthetic as syn  # synthetic inputs; oracle/ is imported by the cpu_baseline leg only
     from pytdscf_amd import TDVPEngine
     from pytdscf_amd.engine import get_gemm_mode
 
@@ -163,7 +177,7 @@ def main():
 
     liouville = integ == "arnoldi"
     eng = TDVPEngine(L, device=local_rank, integrator=integ, conserve_norm=not liouville)
-    eng.set_mpo(orc.synthetic_liouvillian_mpo(L, M, seed=0, gamma=0.002) if liouville else orc.synthetic_mpo(L, d, M, seed=0))
+    eng.set_mpo(syn.synthetic_liouvillian_mpo(L, M, seed=0, gamma=0.002) if liouville else syn.synthetic_mpo(L, d, M, seed=0))
     mode = args.parallel
     if mode == "auto":
         mode = "tp" if (world > 1 and D % world == 0 and D >= 8 * world) else "replicas"
@@ -284,7 +298,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": small_regime_traffic(L, d, D, M),
                 "bytes_per_apply": bytes_apply,
                 "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
                 "n_apply": cnt["n_heff"],

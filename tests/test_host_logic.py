@@ -111,3 +111,15 @@ def test_henon_heiles_pin_through_merged_mpo(golden):
     ref = [g["n3_final0"], g["n3_final1"]]
     fid = abs(orc.overlap(ref, st.cores))
     assert abs(fid - 1) < 1e-9
+
+
+def test_product_side_synthetic_inputs_equal_the_oracles():
+    """bench.py / tools build their inputs with pytdscf_amd.synthetic (so that oracle/ is only
+    imported by the CPU-baseline leg); the two sets of builders must stay identical."""
+    from pytdscf_amd import synthetic as syn
+
+    for L, d, M in ((6, 3, 4), (3, 2, 3), (1, 2, 3)):
+        assert all(np.array_equal(a, b) for a, b in zip(orc.synthetic_mpo(L, d, M, seed=5), syn.synthetic_mpo(L, d, M, seed=5)))
+    assert all(np.array_equal(a, b) for a, b in zip(orc.synthetic_liouvillian_mpo(5, 8, seed=2), syn.synthetic_liouvillian_mpo(5, 8, seed=2)))
+    assert syn.bond_dims([3] * 5, 4) == orc.bond_dims([3] * 5, 4)
+    assert [c.shape for c in syn.random_mps_cores([3] * 5, 4)] == [(a, 3, b) for a, b in orc.bond_dims([3] * 5, 4)]

@@ -12,13 +12,12 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-from oracle import tdvp_oracle as orc
-from pytdscf_amd import TDVPEngine
+from pytdscf_amd import TDVPEngine, synthetic
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 L, d, M, D0, Dmax, dD, steps = (int(x) for x in args) if len(args) == 7 else (16, 8, 16, 32, 256, 32, 4)
 dt, p = 0.5, 1e-10
-mpo = orc.synthetic_mpo(L, d, M, seed=0)
+mpo = synthetic.synthetic_mpo(L, d, M, seed=0)
 eng = TDVPEngine(L)
 eng.set_mpo(mpo)
 eng.init_random([d] * L, D0, seed=1)
@@ -35,7 +34,9 @@ for s in range(steps):
 c = eng.counters()
 out["gpu_counters"] = {k: c[k] for k in ("n_heff", "n_env", "n_qr", "n_launch") if k in c}
 out["bond_dims_gpu"] = eng.bond_dims()
-if "--cpu" in sys.argv:
+if "--cpu" in sys.argv:  # CPU baseline leg: the only place this tool touches oracle/
+    from oracle import tdvp_oracle as orc
+
     st = orc.OracleMPS([x.copy() for x in init], mpo, adaptive=True, Dmax=Dmax, dD=dD, p_proj=p)
     for s in range(steps):
         t0 = time.perf_counter()

@@ -2,7 +2,7 @@
 share the GPU -- aggregate throughput of an ensemble of trajectories vs a single one."""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import tdvp_oracle as orc
+from pytdscf_amd import synthetic as orc  # product-side synthetic inputs (oracle/ is test infrastructure)
 from pytdscf_amd import TDVPEngine
 
 L, d, D, M = 10, 10, 32, 6

@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from oracle import tdvp_oracle as orc  # only the synthetic input builders  # noqa: E402
+from pytdscf_amd import synthetic as orc  # product-side synthetic inputs  # noqa: E402
 from pytdscf_amd import MultiStateEngine, TDVPEngine  # noqa: E402
 
 

@@ -1,7 +1,7 @@
 """Small-bond regime (C2-like) timing with and without per-phase HIP-event profiling."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import tdvp_oracle as orc
+from pytdscf_amd import synthetic as orc  # product-side synthetic inputs (oracle/ is test infrastructure)
 from pytdscf_amd import TDVPEngine
 
 L, d, D, M = (int(x) for x in sys.argv[1:5]) if len(sys.argv) > 4 else (10, 10, 32, 6)

@@ -1,7 +1,7 @@
 """C2-like run for rocprofv3 --kernel-trace: wall time of N steps next to the kernel-time sum."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import tdvp_oracle as orc
+from pytdscf_amd import synthetic as orc  # product-side synthetic inputs (oracle/ is test infrastructure)
 from pytdscf_amd import TDVPEngine
 L, d, D, M = 10, 10, 32, 6
 eng = TDVPEngine(L)

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from oracle import tdvp_oracle as orc
+from pytdscf_amd import synthetic as orc  # product-side synthetic inputs (oracle/ is test infrastructure)
 from pytdscf_amd import TDVPEngine
 
 L, d, M = 12, 6, 5
