@@ -19,6 +19,9 @@ class Comm:
         self.dist = None
         self.device = None
         if self.world > 1:
+            # dmabuf IPC is the only form this driver stack supports; without it RCCL's cross-process
+            # buffer sharing fails (hipIpcGetMemHandle: invalid argument).  Normally exported already.
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             import torch
             import torch.distributed as dist
 
