@@ -69,6 +69,12 @@ int mitdvp_create(const mitdvp_config* cfg, mitdvp_engine** out);
 void mitdvp_destroy(mitdvp_engine* h);
 const char* mitdvp_last_error(const mitdvp_engine* h); /* h may be NULL */
 const char* mitdvp_version(void);
+/* Number of HIP devices visible to this process (0 without a GPU; no engine needed).  Lets a launcher map
+ * ranks to devices (rank % count) without importing a second GPU runtime. */
+int mitdvp_device_count(int* count);
+/* hipDeviceSynchronize on `device`: the fence bench.py puts on both sides of its timed region (the engine's
+ * stream is private, so a foreign runtime's "current stream" synchronise would not see its work). */
+int mitdvp_device_sync(int device);
 
 /* -- state: superblock_states[0][isite] (SiteCoef), _site_cls.py:27-60 --- */
 int mitdvp_set_site(mitdvp_engine* h, int isite, const double* reim, int l, int n, int r, int gauge);

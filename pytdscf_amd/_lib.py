@@ -99,6 +99,8 @@ def load() -> C.CDLL:
         "mitdvp_destroy": (None, [vp]),
         "mitdvp_last_error": (C.c_char_p, [vp]),
         "mitdvp_version": (C.c_char_p, []),
+        "mitdvp_device_count": (i, [ip]),
+        "mitdvp_device_sync": (i, [i]),
         "mitdvp_set_site": (i, [vp, i, dp, i, i, i, i]),
         "mitdvp_get_site_shape": (i, [vp, i, ip, ip, ip, ip]),
         "mitdvp_get_site": (i, [vp, i, dp]),

@@ -70,7 +70,23 @@ void to_host(hipStream_t st, double* dst, const mitdvp::zc* src, size_t elems) {
 
 extern "C" {
 
-const char* mitdvp_version(void) { return "mitdvp 0.1 (gfx950)"; }
+const char* mitdvp_version(void) { return "mitdvp 0.2 (gfx950)"; }
+
+int mitdvp_device_count(int* count) {
+  if (!count) { g_err = "null argument"; return MITDVP_EINVAL; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;  // no driver / no GPU: 0 devices, not an error
+  (void)hipGetLastError();
+  *count = n;
+  return MITDVP_OK;
+}
+
+int mitdvp_device_sync(int device) {
+  return guard(nullptr, [&] {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
 
 int mitdvp_create(const mitdvp_config* cfg, mitdvp_engine** out) {
   if (!cfg || !out) { g_err = "null argument"; return MITDVP_EINVAL; }

@@ -12,39 +12,67 @@ import os
 
 
 class Comm:
-    def __init__(self):
+    """Rendezvous from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.  At world size 1 nothing but the
+    HIP library is touched (no torch import); with several ranks ``torch.distributed`` carries the
+    barrier and the scalar reductions.  ``device`` is the HIP ordinal the engine runs on:
+    LOCAL_RANK modulo the number of visible devices, so several ranks can share one GPU in tests."""
+
+    def __init__(self, n_devices: int | None = None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = None
+        self.backend = None
+        torch = None
         if self.world > 1:
             # dmabuf IPC is the only form this driver stack supports; without it RCCL's cross-process
             # buffer sharing fails (hipIpcGetMemHandle: invalid argument).  Normally exported already.
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # torch brings its own HIP runtime: it must initialise BEFORE libmitdvp.so pulls in the
+            # system one (the other order leaves torch with "No HIP GPUs are available")
             import torch
+
+            if n_devices is None:
+                n_devices = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_devices is None:
+            try:
+                from .engine import device_count
+
+                n_devices = device_count()
+            except Exception:  # library not built: CPU-only plumbing tests
+                n_devices = 0
+        self.n_devices = n_devices
+        self.gpu = self.local_rank % n_devices if n_devices > 0 else None
+        self.shared_gpu = self.world > 1 and n_devices > 0 and self.world > n_devices
+        if self.world > 1:
             import torch.distributed as dist
 
-            backend = os.environ.get("MITDVP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            if torch.cuda.is_available():
-                torch.cuda.set_device(self.local_rank)
+            # RCCL refuses two ranks on one device: ranks sharing a GPU (rehearsals, tests) use gloo
+            backend = os.environ.get("MITDVP_DIST_BACKEND") or ("nccl" if n_devices > 0 and not self.shared_gpu else "gloo")
+            if n_devices > 0:
+                torch.cuda.set_device(self.gpu)
             if backend == "nccl":
-                self.device = torch.device("cuda", self.local_rank)
+                self.device = torch.device("cuda", self.gpu)
                 dist.init_process_group("nccl", device_id=self.device)
             else:  # gloo: CPU-only hosts, or several test ranks sharing one GPU
                 self.device = torch.device("cpu")
                 dist.init_process_group("gloo")
             self.dist = dist
+            self.backend = backend
+
+    def device_sync(self):
+        if self.gpu is not None:
+            from .engine import device_sync
+
+            device_sync(self.gpu)
 
     def barrier(self):
-        import torch
-
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        """device synchronise, barrier over the ranks, device synchronise."""
+        self.device_sync()
         if self.dist is not None:
             self.dist.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+            self.device_sync()
 
     def max_over_ranks(self, x: float) -> float:
         if self.dist is None:

@@ -498,6 +498,17 @@ def set_gemm_mode(mode: str):
     _lib.load().mitdvp_set_gemm_mode({"4m": 0, "3m": 1}[mode.lower()])
 
 
+def device_count() -> int:
+    """HIP devices visible to this process (0 on a CPU-only box); does not create a context."""
+    n = C.c_int()
+    _lib.check(_lib.load().mitdvp_device_count(C.byref(n)))
+    return n.value
+
+
+def device_sync(device: int = 0) -> None:
+    _lib.check(_lib.load().mitdvp_device_sync(device))
+
+
 def get_gemm_mode() -> str:
     return "3m" if _lib.load().mitdvp_get_gemm_mode() else "4m"
 

@@ -7,6 +7,8 @@ import subprocess
 import sys
 import textwrap
 
+from helpers.ranks import run_ranks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -41,11 +43,7 @@ def test_two_rank_replica_aggregation(tmp_path):
         )
     )
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", CUDA_VISIBLE_DEVICES="")
-    procs = [
-        subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        for r in range(2)
-    ]
-    outs = [p.communicate(timeout=120)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    rcs, outs = run_ranks([[sys.executable, str(script)]] * 2, [dict(env, RANK=str(r), LOCAL_RANK=str(r)) for r in range(2)],
+                          timeout=120)
+    assert rcs == [0, 0], outs
     assert "OK 4.0" in outs[0]

@@ -1,17 +1,24 @@
 """GPU: the bench.py contract the driver depends on -- one JSON line on stdout with the metric,
-the roofline and cpu_baseline objects -- on the small workload, at N=1 and as two bond-sharded
-ranks sharing the test GPU (gloo-staged collectives)."""
+the roofline and cpu_baseline objects.  Covered: the small workload at N=1; the driver's EXACT
+command line (default workload C4, --steps 20 --warmup 5) under a small wall budget; the plain
+`python bench.py --gpus 2` form, which starts its own ranks (two bond-sharded ranks sharing the
+test GPU, gloo-staged collectives); and the same two ranks started by a launcher."""
 
 import json
 import os
 import socket
 import subprocess
 import sys
+import time
 
 import pytest
 
+from helpers.ranks import run_ranks
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline")
 
 
 def _line(out):
@@ -20,23 +27,62 @@ def _line(out):
     return json.loads(lines[0])
 
 
+def _check_common(o):
+    for k in KEYS:
+        assert k in o, k
+    assert o["metric"] == "tdvp_sweeps_per_sec" and o["unit"] == "sweeps/s"
+    assert o["higher_is_better"] is True and o["vs_baseline"] is None and o["data"] == "synthetic" and o["dtype"] == "c128"
+    assert "workload" in o["config"] and "model" not in o["config"]
+    units = o["n_gpus"] if o["scaling"] == "weak" else 1  # replicas: every rank runs its own sweeps
+    assert abs(o["value"] - units * 1e3 / o["ms_per_step"]) < 1e-6 * o["value"]
+    r = o["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0 < r["frac"] <= 1.0, r  # a utilisation: executed work over the peak, never above 1
+    assert 1 <= o["steps"] <= o["steps_requested"] and 1 <= o["warmup"]
+
+
 def test_bench_single_gpu_contract():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C2", "--steps", "4", "--warmup", "1"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     o = _line(p.stdout)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in o, k
-    assert o["metric"] == "tdvp_sweeps_per_sec" and o["unit"] == "sweeps/s" and o["n_gpus"] == 1 and o["steps"] == 4
-    assert o["higher_is_better"] is True and o["vs_baseline"] is None and o["data"] == "synthetic" and o["dtype"] == "c128"
-    assert "workload" in o["config"] and "model" not in o["config"]
-    assert abs(o["value"] - 1e3 / o["ms_per_step"]) < 1e-6 * o["value"]
-    r = o["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    _check_common(o)
+    assert o["n_gpus"] == 1 and o["steps"] == 4 and o["warmup"] == 1
     c = o["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "sweeps/s" and c["sample"]
     assert abs(o["config"]["norm_after"] - 1) < 1e-10
+
+
+def test_bench_driver_command_line_fits_its_wall_budget():
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5` is what the driver runs (600 s limit).  On
+    the default workload (C4: about a minute per sweep) 25 sweeps do not fit: the run must cut
+    them to the wall budget, say so, and still print the full line.  The budget is set low here
+    (one warm-up + one timed sweep + the CPU sample) to keep the test short."""
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=560, cwd=ROOT, env=dict(os.environ, MITDVP_BENCH_BUDGET="150"))
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = _line(p.stdout)
+    _check_common(o)
+    assert o["config"]["workload"].startswith("C4") and o["config"]["D"] == 1024 and o["config"]["L"] == 64
+    assert o["steps_requested"] == 20 and o["warmup_requested"] == 5 and o["steps"] < 20
+    assert o["roofline"]["bound"] == "mfma" and o["roofline"]["unit"] == "TFLOP/s"
+    assert o["roofline"]["algorithmic_tflops"] >= o["roofline"]["achieved"]
+    assert o["cpu_baseline"]["value"] > 0
+    assert abs(o["config"]["norm_after"] - 1) < 1e-10
+    assert wall < 420, wall  # budget 150 s + at most one sweep + the CPU sample
+
+
+def test_bench_plain_multi_gpu_command_launches_its_own_ranks():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _line(p.stdout)
+    _check_common(o)
+    assert o["n_gpus"] == 2 and o["scaling"] == "strong" and o["config"]["collectives"] > 0, p.stderr[-3000:]
+    assert "bond-sharded" in o["config"]["parallelism"] and abs(o["config"]["norm_after"] - 1) < 1e-10
 
 
 def test_bench_two_ranks_bond_sharded():
@@ -47,10 +93,9 @@ def test_bench_two_ranks_bond_sharded():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", MITDVP_DIST_BACKEND="gloo")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline"]
-    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                              text=True, cwd=ROOT) for r in range(2)]
-    outs = [p.communicate(timeout=600) for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
+    rcs, outs = run_ranks([cmd] * 2, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(2)], timeout=600, cwd=ROOT,
+                          split_stderr=True)
+    assert rcs == [0, 0], "\n".join(o[1][-1500:] for o in outs)
     o = _line(outs[0][0])
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]  # only rank 0 prints
     assert o["n_gpus"] == 2 and o["scaling"] == "strong" and o["config"]["collectives"] > 0

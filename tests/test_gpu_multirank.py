@@ -11,6 +11,8 @@ import textwrap
 import numpy as np
 import pytest
 
+from helpers.ranks import run_ranks
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -63,13 +65,9 @@ def _run(world, tmp_path, integ="lanczos", cn=True, backend_env=None, D=48, adap
                MITDVP_DIST_BACKEND="gloo")
     if backend_env:
         env.update(backend_env)
-    procs = [
-        subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        for r in range(world)
-    ]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
+                          timeout=300)
+    assert rcs == [0] * world, "\n".join(outs)
     res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
     vecs = [np.load(out + f".rank{r}.npy") for r in range(world)]
     return res, vecs
@@ -215,10 +213,9 @@ def test_multistate_bond_sharded_matches_single_rank(tmp_path):
         script.write_text(textwrap.dedent(WORKER_MS.format(root=ROOT, out=out)))
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                    MITDVP_DIST_BACKEND="gloo")
-        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-        outs = [p.communicate(timeout=300)[0] for p in procs]
-        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        rcs, outs = run_ranks([[sys.executable, str(script)]] * world,
+                              [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)], timeout=300)
+        assert rcs == [0] * world, "\n".join(outs)
         res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
         return res, [np.load(out + f".rank{r}.npy") for r in range(world)]
 
@@ -277,10 +274,9 @@ def test_bond_sharded_gates_and_operate(tmp_path):
         script.write_text(textwrap.dedent(WORKER_OPS.format(root=ROOT, out=out)))
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                    MITDVP_DIST_BACKEND="gloo")
-        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-        outs = [p.communicate(timeout=300)[0] for p in procs]
-        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        rcs, outs = run_ranks([[sys.executable, str(script)]] * world,
+                              [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)], timeout=300)
+        assert rcs == [0] * world, "\n".join(outs)
         res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
         return res, [np.load(out + f".rank{r}.npy") for r in range(world)]
 
