@@ -8,6 +8,7 @@
 #include "../../include/mitdvp.h"
 #include "common.h"
 #include "qr.h"
+#include "small_site.h"
 #include "svd.h"
 #include "vecops.h"
 
@@ -56,6 +57,8 @@ struct MpoSite {
   int ml = 0, d = 0, mr = 0;
   DevBuf w2l;  // W2L[(i,t)][(c,j)] = W[c,i,j,t]   (d*mr) x (ml*d)
   DevBuf w2r;  // W2R[(i,c)][(t,j)] = W[c,i,j,t]   (d*ml) x (mr*d)
+  DevBuf w2el;  // small-site environment update, -> direction: [(t,j)][(i,c)] = W[c,i,j,t]
+  DevBuf w2er;  // small-site environment update, <- direction: [(c,j)][(i,t)] = W[c,i,j,t]
   DevBuf wtr;  // Liouville trace operator: O2[f][(a,c,d)] = O[a,d,c,f], n = sqrt(site dim)
   int ntr = 0, mltr = 0, mrtr = 0;
   bool set = false;
@@ -109,7 +112,7 @@ class Engine {
   void set_trace_op_core(int op_id, int isite, const double* reim, int ml, int n, int mr);
   hzc expect_trace(int op_id);
   void partial_trace(const int* legs, int nlen, std::vector<hzc>& out);
-  void krylov_stats(int* per_site) const;
+  void krylov_stats(int* per_site);
 
   void counters_get(mitdvp_counters* out);
   void counters_reset();
@@ -134,8 +137,9 @@ class Engine {
                        int min_, int d, int dbo, int dko, int mout);
   // generic environment update: env_in (din, min, din), T (din, d, dout),
   // W2 ((d*mout) x (min*d)) -> env_out (dout, mout, dout)
+  // w2e: the small-site form of the same core (MpoSite::w2el / w2er), nullptr = general path only
   void env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
-                  int mout);
+                  int mout, const zc* w2e = nullptr);
   // x <- exp(scale * Op) x ; returns Krylov dimension used
   template <class MV>
   int krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev, long nsize = -1);
@@ -209,6 +213,23 @@ class Engine {
   void collective(int op, zc* p, size_t elems);
 
   bool small_kernels_ = true;  // MITDVP_SMALL_KERNELS=0: always the general multi-launch kernels (A/B testing)
+  // small-bond kernel family (small_site.hip): one launch per apply / environment update / local exponential
+  SmallSync ss_;
+  DevBuf ss_part_;               // chunk partials
+  int n_cu_ = 0;
+  bool ss_dirty_ = false;        // small-site launches issued since the last error check
+  std::vector<char> exp_small_;  // per site: its local exponentials (site and bonds) run in one launch each
+  std::vector<int> ss_shape_key_;
+  bool small_ok() const;
+  bool chain_heff(SmallChain& c, const zc* L, const MpoSite& w, const zc* R, int dl, int d, int dr, bool exp_mode) const;
+  bool chain_keff(SmallChain& c, const zc* L, const zc* R, int d1, int d2, int m, bool exp_mode) const;
+  bool chain_env(SmallChain& c, const zc* T, const zc* w2e, int din, int min_, int d, int dout, int mout) const;
+  zc* ss_partials(const SmallChain& c);
+  void ss_refresh_plan();
+  void ss_check();               // raises what the small-site kernels recorded (not converged / timed out)
+  void ss_pull_kprev();
+  bool small_site_exp(int p, double dt);
+  bool small_bond_exp(int p, const zc* Lb, const zc* Rb, int dim, int m, double dt);
   struct Gate { DevBuf u; int d = 0; };
   std::map<int, Gate> gates_;
   std::vector<DevBuf> ref_;

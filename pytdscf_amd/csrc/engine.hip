@@ -30,6 +30,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
   if (c.device < 0 || c.device >= ndev) throw ArgError("bad device ordinal");
   HIP_CHECK(hipSetDevice(c.device));
+  HIP_CHECK(hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, c.device));
   HIP_CHECK(hipStreamCreate(&st_));
   dl_.assign(L_, 0); dd_.assign(L_, 0); dr_.assign(L_, 0); gauge_.assign(L_, -1);
   site_.resize(L_);
@@ -50,6 +51,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
 
 Engine::~Engine() {
   if (st_) (void)hipStreamSynchronize(st_);
+  small_sync_free(ss_);
   if (rccl_comm_) (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(rccl_comm_));
   for (auto& t : pending_) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& e : evpool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -111,10 +113,14 @@ void Engine::resolve_timers() {
   pending_.clear();
 }
 void Engine::counters_get(mitdvp_counters* out) {
+  ss_dirty_ = ss_dirty_ || ss_.words != nullptr;
+  ss_check();  // merges the apply counts kept on the device
   resolve_timers();
   *out = cnt_;
 }
 void Engine::counters_reset() {
+  ss_dirty_ = ss_dirty_ || ss_.words != nullptr;
+  ss_check();
   resolve_timers();
   std::memset(&cnt_, 0, sizeof(cnt_));
 }
@@ -169,6 +175,7 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
   const int d = dout;
   const hzc* W = reinterpret_cast<const hzc*>(reim);
   std::vector<hzc> w2l((size_t)d * mr * ml * d), w2r((size_t)d * ml * mr * d);
+  std::vector<hzc> w2el(w2l.size()), w2er(w2r.size());
   for (int c = 0; c < ml; ++c)
     for (int i = 0; i < d; ++i)
       for (int j = 0; j < d; ++j)
@@ -176,12 +183,18 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
           const hzc v = W[(((size_t)c * d + i) * d + j) * mr + t];
           w2l[((size_t)i * mr + t) * ((size_t)ml * d) + (size_t)c * d + j] = v;
           w2r[((size_t)i * ml + c) * ((size_t)mr * d) + (size_t)t * d + j] = v;
+          w2el[((size_t)t * d + j) * ((size_t)d * ml) + (size_t)i * ml + c] = v;
+          w2er[((size_t)c * d + j) * ((size_t)d * mr) + (size_t)i * mr + t] = v;
         }
   s.ml = ml; s.d = d; s.mr = mr;
   s.w2l.reserve(w2l.size());
   s.w2r.reserve(w2r.size());
   HIP_CHECK(hipMemcpyAsync(s.w2l.p, w2l.data(), w2l.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
   HIP_CHECK(hipMemcpyAsync(s.w2r.p, w2r.data(), w2r.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  s.w2el.reserve(w2el.size());
+  s.w2er.reserve(w2er.size());
+  HIP_CHECK(hipMemcpyAsync(s.w2el.p, w2el.data(), w2el.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipMemcpyAsync(s.w2er.p, w2er.data(), w2er.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
   HIP_CHECK(hipStreamSynchronize(st_));
   s.set = true;
 }
@@ -244,6 +257,7 @@ void Engine::require_ready() {
   }
   if (dl_[0] != 1 || dr_[L_ - 1] != 1) throw ArgError("open boundary bonds must be 1");
   size_workspaces();
+  ss_refresh_plan();
 }
 
 // ---------------------------------------------------------------------------
@@ -384,6 +398,16 @@ void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const z
 
 void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
                         hzc shift) {
+  SmallChain sc;
+  if (small_ok() && chain_heff(sc, L, w, R, dl, d, dr, false)) {  // one launch, X / Y in LDS
+    timer_begin(10);
+    small_apply(st_, ss_, sc, psi, out, ss_partials(sc), make_double2(shift.real(), shift.imag()), shift != hzc(0.0, 0.0));
+    timer_end();
+    cnt_.n_launch += 1;
+    cnt_.n_heff += 1;
+    cnt_.heff_flops += 8.0 * ((double)dl * dl * w.ml * d * dr + (double)dl * dr * w.ml * w.mr * d * d + (double)dl * dr * dr * w.mr * d);
+    return;
+  }
   heff_apply_rect(L, w, R, psi, out, dl, dl, d, dr, dr);
   if (shift != hzc(0.0, 0.0))
     vec_axpby(st_, out, psi, (long)dl * d * dr, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
@@ -413,6 +437,16 @@ void Engine::keff_apply_rect(const zc* L, const zc* R, const zc* sig, zc* out, i
 }
 
 void Engine::keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift) {
+  SmallChain sc;
+  if (small_ok() && chain_keff(sc, L, R, d1, d2, m, false)) {
+    timer_begin(2);
+    small_apply(st_, ss_, sc, sig, out, ss_partials(sc), make_double2(shift.real(), shift.imag()), shift != hzc(0.0, 0.0));
+    timer_end();
+    cnt_.n_launch += 1;
+    cnt_.n_keff += 1;
+    cnt_.keff_flops += 8.0 * ((double)d1 * d1 * m * d2 + (double)d1 * d2 * d2 * m);
+    return;
+  }
   keff_apply_rect(L, R, sig, out, d1, d1, d2, d2, m);
   if (shift != hzc(0.0, 0.0))
     vec_axpby(st_, out, sig, (long)d1 * d2, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
@@ -450,7 +484,18 @@ void Engine::env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const
 }
 
 void Engine::env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
-                        int mout) {
+                        int mout, const zc* w2e) {
+  SmallChain sc;
+  if (w2e && small_ok() && chain_env(sc, T, w2e, din, min_, d, dout, mout)) {
+    timer_begin(1);
+    small_apply(st_, ss_, sc, env_in, env_out, ss_partials(sc), make_double2(0.0, 0.0), false);
+    timer_end();
+    cnt_.n_launch += 1;
+    cnt_.n_env += 1;
+    cnt_.env_flops += 8.0 * ((double)din * din * min_ * d * dout + (double)din * dout * min_ * mout * d * d +
+                             (double)din * dout * dout * mout * d);
+    return;
+  }
   env_update_rect(env_in, T, T, w2, env_out, din, din, min_, d, dout, dout, mout);
 }
 
@@ -577,7 +622,7 @@ void Engine::build_right_envs() {
     const MpoSite& w = mpo(0, p);
     transpose_rev3(st_, site_[p].p, tmp1_.p, dl_[p], dd_[p], dr_[p]);
     envR_[p] = pool_get((size_t)dl_[p] * w.ml * dl_[p]);
-    env_update(envR_[p + 1].p, tmp1_.p, w.w2r.p, envR_[p].p, dr_[p], w.mr, dd_[p], dl_[p], w.ml);
+    env_update(envR_[p + 1].p, tmp1_.p, w.w2r.p, envR_[p].p, dr_[p], w.mr, dd_[p], dl_[p], w.ml, w.w2er.p);
     envR_ok_[p] = 1;
   }
 }
@@ -592,7 +637,7 @@ void Engine::build_left_envs() {
     const MpoSite& w = mpo(0, p);
     pool_put(std::move(envL_[p + 1]));
     envL_[p + 1] = pool_get((size_t)dr_[p] * w.mr * dr_[p]);
-    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl_[p], w.ml, dd_[p], dr_[p], w.mr);
+    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl_[p], w.ml, dd_[p], dr_[p], w.mr, w.w2el.p);
     envL_ok_[p + 1] = 1;
   }
 }
@@ -600,6 +645,7 @@ void Engine::build_left_envs() {
 void Engine::local_site_exp(int p, double dt) {
   const MpoSite& w = mpo(0, p);
   if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
+  if (small_site_exp(p, dt)) return;  // one launch, no host round trip
   const int dl = dl_[p], d = dd_[p], dr = dr_[p];
   const zc* Lb = envL_[p].p;
   const zc* Rb = envR_[p + 1].p;
@@ -617,6 +663,7 @@ void Engine::sweep(double dt, bool forward) {
   if (L_ == 1) {
     if (center_ != 0) throw ArgError("no centre site");
     local_site_exp(0, dt);
+    ss_check();
     return;
   }
   const int begin = forward ? 0 : L_ - 1, end = forward ? L_ - 1 : 0;
@@ -648,14 +695,14 @@ void Engine::sweep(double dt, bool forward) {
       gauge_[p] = MITDVP_GAUGE_A;
       // renormalize_op_psite: L_{p+1}
       envL_[p + 1] = pool_get((size_t)dr * w.mr * dr);
-      env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr);
+      env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr, w.w2el.p);
       envL_ok_[p + 1] = 1;
       // exp(+i K dt/2) on the bond matrix
       const zc* Lb = envL_[p + 1].p;
       const zc* Rb = envR_[p + 1].p;
       const int m = w.mr;
       auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dr, dr, m, shift); };
-      if (cfg.relax != 2) {  // improved relaxation leaves the bond matrix alone (_mps_cls.py:1159-1160)
+      if (cfg.relax != 2 && !small_bond_exp(p, Lb, Rb, dr, m, dt)) {  // improved relaxation leaves the bond matrix alone (_mps_cls.py:1159-1160)
         kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dr * dr, kprev_[p]);
         cnt_.n_exp_bond += 1;
       }
@@ -674,13 +721,13 @@ void Engine::sweep(double dt, bool forward) {
       std::swap(site_[p], spare);
       gauge_[p] = MITDVP_GAUGE_B;
       envR_[p] = pool_get((size_t)dl * w.ml * dl);
-      env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml);
+      env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml, w.w2er.p);
       envR_ok_[p] = 1;
       const zc* Lb = envL_[p].p;
       const zc* Rb = envR_[p].p;
       const int m = w.ml;
       auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dl, dl, m, shift); };
-      if (cfg.relax != 2) {
+      if (cfg.relax != 2 && !small_bond_exp(p, Lb, Rb, dl, m, dt)) {
         kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dl * dl, kprev_[p]);
         cnt_.n_exp_bond += 1;
       }
@@ -696,6 +743,7 @@ void Engine::sweep(double dt, bool forward) {
     }
   }
   pool_put(std::move(spare));
+  ss_check();  // the one host synchronisation of a small-bond sweep: errors raised on the device
 }
 
 void Engine::step(double dt) {

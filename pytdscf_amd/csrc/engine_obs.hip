@@ -437,7 +437,8 @@ void Engine::partial_trace(const int* legs, int nlen, std::vector<hzc>& out) {
   pool_put(std::move(left)); pool_put(std::move(right)); pool_put(std::move(rnext)); pool_put(std::move(tq));
 }
 
-void Engine::krylov_stats(int* per_site) const {
+void Engine::krylov_stats(int* per_site) {
+  ss_pull_kprev();
   for (int i = 0; i < L_; ++i) per_site[i] = kprev_[i];
 }
 

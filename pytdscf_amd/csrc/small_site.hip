@@ -1,0 +1,784 @@
+// small_site.hip -- the small-bond kernel family (SURVEY 8d "C2 and small-D": a site is a few hundred KB,
+// every step of the reference is latency bound; north_star: "SIL local propagator fused into one kernel
+// launch per site").
+//
+// Reference functions replaced (paths relative to /root/reference/pytdscf):
+//   multiplyH_MPS_direct_MPO._op_lcr_dot / .dot     _contraction.py:1038-1243   (H_eff apply)
+//   multiplyK_MPS_direct_MPO._op_lr_dot / .dot      _contraction.py:1297-1407   (K_eff apply)
+//   contract_with_site_mpo                          _contraction.py:148-397     (environment update)
+//   short_iterative_lanczos / short_iterative_arnoldi  _integrator.py:453-655, :287-432
+//     incl. the host work the reference does per iteration: two device->host syncs (:553-554),
+//     eigh_tridiagonal / eig + solve of the projected matrix (:590, :618, :402-408), vstack (:568).
+//
+// ONE kernel, k_small_site:
+//   * a workgroup owns (slab a, chunk sc of the contracted right index s); the three stages of the
+//     contraction chain run out of LDS (operands A_a, W2, R staged once per launch, X and Y never leave
+//     LDS); the chunk partials of a slab are summed in a fixed order by the owners of the output range;
+//   * EXP mode wraps the Krylov loop around it: per iteration TWO grid-wide exchanges of a few doubles
+//     per workgroup (the projections <v_j|H v_l>, which are linear in the chunk partials and therefore
+//     travel with them; then the norm of the new vector), the k x k exponential (scaling and squaring,
+//     degree-20 Taylor: the algorithm of small_linalg.h::expm_col0) evaluated redundantly by every
+//     workgroup, the reference's convergence test and the final linear combination -- no host involvement.
+//     The basis is kept unnormalised (u_j) with the factors 1/beta_j applied on the fly: v_j = u_j * invb_j
+//     is the same floating-point number wherever it is formed, so results equal the multi-launch path's.
+//
+// Inter-workgroup protocol (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility", valid forms, row 1):
+// every byte another workgroup reads is stored with an agent-scope (sc1) store and read with an agent-scope
+// (sc1) load; every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the
+// ONE arrival atomic per workgroup; one lane polls the counter and the other waves proceed behind a
+// workgroup barrier.  The grid never exceeds the CU count and a workgroup takes more than half a CU's LDS,
+// so all workgroups are resident; every poll loop is bounded (2 s) and raises a sticky error instead of
+// hanging.  Reductions are summed in a fixed order: all workgroups obtain bit-identical scalars and take
+// identical branches.
+#include "small_site.h"
+
+#include <algorithm>
+#include <mutex>
+
+#include "../../include/mitdvp.h"
+
+namespace mitdvp {
+namespace {
+
+constexpr int SS_THREADS = 256;
+constexpr int SS_PAYMAX = 2 * MAXK + 2;  // doubles one workgroup contributes to an exchange
+constexpr int SS_MAXG = 256;
+constexpr double SS_EPS = 1e-12;  // _integrator.py:22
+
+#define SS_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ double ld_sh(const double* p) { return __hip_atomic_load(p, SS_RLX); }
+__device__ __forceinline__ void st_sh(double* p, double v) { __hip_atomic_store(p, v, SS_RLX); }
+__device__ __forceinline__ zc ldz_sh(const zc* p) {
+  const double* q = reinterpret_cast<const double*>(p);
+  return make_double2(ld_sh(q), ld_sh(q + 1));
+}
+__device__ __forceinline__ void stz_sh(zc* p, zc v) {
+  double* q = reinterpret_cast<double*>(p);
+  st_sh(q, v.x);
+  st_sh(q + 1, v.y);
+}
+
+struct SsArgs {
+  SmallChain c;
+  int mode;
+  const zc* v;  // APPLY: input vector
+  zc* out;      // APPLY: output (contiguous (na, ni, nr))
+  zc* x;        // EXP: in/out vector
+  zc* U;        // EXP: unnormalised Krylov vectors, U[j] at j*N (j >= 1; vector 0 is x)
+  zc* P;        // chunk partials [nsc][N]
+  zc shift;
+  int add_shift;
+  SmallExp e;
+  unsigned* ctr;
+  unsigned* ctr_other;
+  unsigned* abort_w;
+  unsigned* err_w;
+  double* slots;
+  long long* stats;
+  int* kprev;
+};
+
+struct Sync {
+  unsigned* ctr;
+  unsigned* abort_w;
+  double* slots;
+  int G, wg;
+  unsigned epoch;
+};
+
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Grid-wide exchange: every workgroup contributes pay[0..npay) (LDS), every workgroup receives the
+// element-wise sums over all workgroups in red[0..npay) (LDS), summed in the same order everywhere.
+// Also orders all sc1 stores issued before it against all sc1 loads issued after it, grid-wide.
+// Returns false (uniformly) when the wait timed out or another workgroup raised the abort flag.
+__device__ bool ss_exchange(Sync& s, const double* pay, int npay, double* red, double* wsh /*[4*SS_PAYMAX]*/, int* flag) {
+  s.epoch += 1;
+  const int tid = threadIdx.x;
+  double* mine = s.slots + ((size_t)(s.epoch & 1) * SS_MAXG + s.wg) * SS_PAYMAX;
+  if (tid < npay) st_sh(mine + tid, pay[tid]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its sc1 stores (payload and vector data) are out
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(s.ctr, 1u, SS_RLX);
+    const unsigned target = s.epoch * (unsigned)s.G;
+    int ok = 1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    unsigned spins = 0;
+    while (__hip_atomic_load(s.ctr, SS_RLX) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0) {
+        if (__hip_atomic_load(s.abort_w, SS_RLX) != 0u) { ok = 0; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: a workgroup is not resident
+          __hip_atomic_store(s.abort_w, 1u, SS_RLX);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    *flag = ok;
+  }
+  __syncthreads();
+  if (!*flag) return false;
+  if (npay > 0) {
+    const double* base = s.slots + (size_t)(s.epoch & 1) * SS_MAXG * SS_PAYMAX;
+    const int lane = tid & 63, w = tid >> 6;
+    for (int c = 0; c < npay; ++c) {
+      double v = tid < s.G ? ld_sh(base + (size_t)tid * SS_PAYMAX + c) : 0.0;
+      v = wave_sum64(v);
+      if (lane == 0) wsh[c * 4 + w] = v;
+    }
+    __syncthreads();
+    if (tid < npay) red[tid] = (wsh[tid * 4 + 0] + wsh[tid * 4 + 1]) + (wsh[tid * 4 + 2] + wsh[tid * 4 + 3]);
+    __syncthreads();
+  }
+  return true;
+}
+
+// C(M x N) = A(M x K) * B(K x N), all row-major in LDS; each thread owns TM x TN outputs, rows / columns
+// interleaved over the threads so that neighbouring lanes read neighbouring LDS words.
+template <int TM, int TN, class Epi>
+__device__ __forceinline__ void lds_gemm(const zc* __restrict__ A, int lda, const zc* __restrict__ B, int ldb, int M, int N,
+                                         int K, Epi epi) {
+  const int mt = (M + TM - 1) / TM, nt = (N + TN - 1) / TN;
+  for (int t = threadIdx.x; t < mt * nt; t += SS_THREADS) {
+    const int mi = t / nt, ni = t - mi * nt;
+    int row[TM], col[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) row[i] = min(mi + i * mt, M - 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) col[j] = min(ni + j * nt, N - 1);
+    double cr[TM][TN], ci[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { cr[i][j] = 0.0; ci[i][j] = 0.0; }
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      zc a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = A[row[i] * lda + k];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = B[k * ldb + col[j]];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          cr[i][j] = fma(a[i].x, b[j].x, cr[i][j]);
+          cr[i][j] = fma(-a[i].y, b[j].y, cr[i][j]);
+          ci[i][j] = fma(a[i].x, b[j].y, ci[i][j]);
+          ci[i][j] = fma(a[i].y, b[j].x, ci[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (mi + i * mt < M && ni + j * nt < N) epi(mi + i * mt, ni + j * nt, make_double2(cr[i][j], ci[i][j]));
+  }
+}
+
+template <class Epi>
+__device__ __forceinline__ void lds_gemm_auto(const zc* A, int lda, const zc* B, int ldb, int M, int N, int K, Epi epi) {
+  const int mn = M * N;
+  if (mn <= SS_THREADS) lds_gemm<1, 1>(A, lda, B, ldb, M, N, K, epi);
+  else if (mn <= 2 * SS_THREADS) { if (N >= M) lds_gemm<1, 2>(A, lda, B, ldb, M, N, K, epi); else lds_gemm<2, 1>(A, lda, B, ldb, M, N, K, epi); }
+  else if (mn <= 4 * SS_THREADS || M < 4 || N < 4) lds_gemm<2, 2>(A, lda, B, ldb, M, N, K, epi);
+  else if (mn <= 8 * SS_THREADS) { if (N >= M) lds_gemm<2, 4>(A, lda, B, ldb, M, N, K, epi); else lds_gemm<4, 2>(A, lda, B, ldb, M, N, K, epi); }
+  else lds_gemm<4, 4>(A, lda, B, ldb, M, N, K, epi);
+}
+
+// first column of exp(T) for the k x k matrix T (LDS, row-major, ld = k), by the whole workgroup:
+// scaling and squaring around a degree-20 Taylor polynomial (small_linalg.h::expm_col0).
+// Tm is destroyed; Pm, Em, Qm are k x k scratch.  Result in coef[0..k).
+__device__ void ss_expm_col0(zc* Tm, zc* Pm, zc* Em, zc* Qm, int k, zc* coef, double* wsh) {
+  const int tid = threadIdx.x, kk = k * k;
+  if (k == 1) {
+    if (tid == 0) {
+      const zc z = Tm[0];
+      const double e = exp(z.x);
+      coef[0] = make_double2(e * cos(z.y), e * sin(z.y));
+    }
+    __syncthreads();
+    return;
+  }
+  // 1-norm: max column sum
+  if (tid < k) {
+    double s = 0.0;
+    for (int i = 0; i < k; ++i) { const zc z = Tm[i * k + tid]; s += sqrt(z.x * z.x + z.y * z.y); }
+    wsh[tid] = s;
+  }
+  __syncthreads();
+  double nrm = 0.0;
+  for (int j = 0; j < k; ++j) nrm = fmax(nrm, wsh[j]);
+  int sq = 0;
+  while (nrm > 0.5 && sq < 60) { nrm *= 0.5; ++sq; }
+  const double sc = ldexp(1.0, -sq);
+  for (int t = tid; t < kk; t += SS_THREADS) {
+    zc z = Tm[t];
+    z.x *= sc; z.y *= sc;
+    Tm[t] = z;
+    const double one = (t / k == t % k) ? 1.0 : 0.0;
+    Pm[t] = make_double2(one, 0.0);
+    Em[t] = make_double2(one, 0.0);
+  }
+  __syncthreads();
+  for (int deg = 1; deg <= 20; ++deg) {  // P <- P T / deg ; E += P
+    const double inv = 1.0 / deg;
+    for (int t = tid; t < kk; t += SS_THREADS) {
+      const int i = t / k, j = t - i * k;
+      double re = 0.0, im = 0.0;
+      for (int l = 0; l < k; ++l) {
+        const zc x = Pm[i * k + l], y = Tm[l * k + j];
+        re = fma(x.x, y.x, re); re = fma(-x.y, y.y, re);
+        im = fma(x.x, y.y, im); im = fma(x.y, y.x, im);
+      }
+      Qm[t] = make_double2(re * inv, im * inv);
+    }
+    __syncthreads();
+    for (int t = tid; t < kk; t += SS_THREADS) {
+      const zc q = Qm[t];
+      Pm[t] = q;
+      zc e = Em[t];
+      e.x += q.x; e.y += q.y;
+      Em[t] = e;
+    }
+    __syncthreads();
+  }
+  for (int s = 0; s < sq; ++s) {  // E <- E E
+    for (int t = tid; t < kk; t += SS_THREADS) {
+      const int i = t / k, j = t - i * k;
+      double re = 0.0, im = 0.0;
+      for (int l = 0; l < k; ++l) {
+        const zc x = Em[i * k + l], y = Em[l * k + j];
+        re = fma(x.x, y.x, re); re = fma(-x.y, y.y, re);
+        im = fma(x.x, y.y, im); im = fma(x.y, y.x, im);
+      }
+      Qm[t] = make_double2(re, im);
+    }
+    __syncthreads();
+    for (int t = tid; t < kk; t += SS_THREADS) Em[t] = Qm[t];
+    __syncthreads();
+  }
+  if (tid < k) coef[tid] = Em[tid * k];
+  __syncthreads();
+}
+
+// LDS carve (units: zc unless noted); the same arithmetic runs on the host in small_chain_lds
+struct Carve {
+  size_t As, Rs, Ws, Bs, Xs, Ys, Sg, misc, total;  // offsets in zc
+};
+__host__ __device__ inline Carve ss_carve(const SmallChain& c, bool exp_mode) {
+  Carve k{};
+  size_t o = 0;
+  k.As = o; o += (size_t)c.nc * c.nb;
+  k.Rs = o; o += (size_t)c.nt * c.cs * c.nr;
+  k.Ws = o; o += c.W2 ? (size_t)c.ni * c.nt * c.nc * c.nj : 0;
+  k.Bs = o;
+  size_t bs = (size_t)c.nb * c.nj * c.cs;
+  if (exp_mode) bs = bs > (size_t)4 * MAXK * MAXK ? bs : (size_t)4 * MAXK * MAXK;  // also the k x k exponential's scratch
+  o += bs;
+  k.Xs = o; o += (size_t)c.nc * c.nj * c.cs;
+  k.Ys = o; o += c.W2 ? (size_t)c.ni * c.nt * c.cs : 0;
+  k.Sg = o; o += (size_t)c.ni * c.nr;  // this chunk's partial of the output slab
+  k.misc = o;
+  // misc: pay[SS_PAYMAX] red[SS_PAYMAX] wsh[4*SS_PAYMAX] (doubles) + alpha[MAXK] coef[MAXK] cprev[MAXK] (zc)
+  //       + hess[(MAXK+1)*MAXK] (zc) + beta[MAXK] invb[MAXK+1] (doubles) + ints
+  o += (size_t)(6 * SS_PAYMAX + 1) / 2 + 3 * MAXK + (size_t)(MAXK + 1) * MAXK + (2 * MAXK + 2) / 2 + 8;
+  k.total = o;
+  return k;
+}
+
+__global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  zc* sm = reinterpret_cast<zc*>(smem);
+  const SmallChain& c = g.c;
+  const bool exp_mode = g.mode == SS_MODE_EXP;
+  const Carve cv = ss_carve(c, exp_mode);
+  zc* As = sm + cv.As;
+  zc* Rs = sm + cv.Rs;
+  zc* Ws = sm + cv.Ws;
+  zc* Bs = sm + cv.Bs;
+  zc* Xs = sm + cv.Xs;
+  zc* Ys = c.W2 ? sm + cv.Ys : Xs;
+  zc* Sg = sm + cv.Sg;
+  double* pay = reinterpret_cast<double*>(sm + cv.misc);
+  double* red = pay + SS_PAYMAX;
+  double* wsh = red + SS_PAYMAX;
+  zc* alpha = reinterpret_cast<zc*>(wsh + 4 * SS_PAYMAX + (SS_PAYMAX & 1));
+  zc* coef = alpha + MAXK;
+  zc* cprev = coef + MAXK;
+  zc* hess = cprev + MAXK;  // (MAXK+1) x MAXK, row-major, ld = MAXK
+  double* beta = reinterpret_cast<double*>(hess + (MAXK + 1) * MAXK);
+  double* invb = beta + MAXK;
+  int* ctl = reinterpret_cast<int*>(invb + MAXK + 1);  // [0] exchange verdict, [1] action, [2] kdim, [3] next_unread
+
+  const int tid = threadIdx.x;
+  const int nsc = c.nsc, cs = c.cs;
+  const int a = blockIdx.x / nsc, sc = blockIdx.x - a * nsc;
+  const int s0 = sc * cs;
+  const int csl = min(cs, c.ns - s0);  // >= 1 by construction of the plan
+  const int slab = c.ni * c.nr;
+  const long N = (long)c.na * slab;
+  const int rg = (slab + nsc - 1) / nsc;
+  const long e0 = (long)a * slab + min(sc * rg, slab);
+  const long e1 = (long)a * slab + min((sc + 1) * rg, slab);
+
+  Sync sy{g.ctr, g.abort_w, g.slots, (int)gridDim.x, (int)blockIdx.x, 0u};
+  if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(g.ctr_other, 0u, SS_RLX);  // the next launch's counter
+
+  // ---- operands that do not change during the launch -> LDS -------------------------------
+  for (int t = tid; t < c.nc * c.nb; t += SS_THREADS) {
+    const int cc = t / c.nb, b = t - cc * c.nb;
+    zc z = c.A[(long)a * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
+    if (c.conjA) z.y = -z.y;
+    As[t] = z;
+  }
+  {
+    const int kk = c.nt * cs;  // rows of Rs: (t, sl)
+    for (int t = tid; t < kk * c.nr; t += SS_THREADS) {
+      // r fastest in LDS; pick the global order that keeps loads coalesced for the common layouts
+      const int k = t / c.nr, r = t - k * c.nr;
+      const int tt = k / cs, sl = k - tt * cs;
+      zc z = make_double2(0.0, 0.0);
+      if (sl < csl) z = c.R[(long)r * c.sRr + (long)tt * c.sRt + (long)(s0 + sl) * c.sRs];
+      Rs[t] = z;
+    }
+  }
+  if (c.W2)
+    for (int t = tid; t < c.ni * c.nt * c.nc * c.nj; t += SS_THREADS) Ws[t] = c.W2[t];
+
+  // stage-1 operand of this chunk: Bs[b][(j, sl)] = scale * vec(b, j, s0 + sl)
+  auto load_B = [&](const zc* vec, bool shared, double scl) {
+    const int ncol = c.nj * cs;
+    for (int t = tid; t < c.nb * ncol; t += SS_THREADS) {
+      const int b = t / ncol, q = t - b * ncol;
+      const int j = q / cs, sl = q - j * cs;
+      zc z = make_double2(0.0, 0.0);
+      if (sl < csl) {
+        const zc* p = vec + (long)b * c.sBb + (long)j * c.sBj + (long)(s0 + sl) * c.sBs;
+        z = shared ? ldz_sh(p) : *p;
+        z.x *= scl; z.y *= scl;
+      }
+      Bs[t] = z;
+    }
+  };
+
+  // the three stages; this chunk's partial of out[a][:][:] ends up in Sg (LDS)
+  auto chain = [&]() {
+    __syncthreads();
+    lds_gemm_auto(As, c.nb, Bs, c.nj * cs, c.nc, c.nj * cs, c.nb, [&](int m, int n, zc v) { Xs[m * (c.nj * cs) + n] = v; });
+    __syncthreads();
+    if (c.W2) {
+      lds_gemm_auto(Ws, c.nc * c.nj, Xs, cs, c.ni * c.nt, cs, c.nc * c.nj, [&](int m, int n, zc v) { Ys[m * cs + n] = v; });
+      __syncthreads();
+    }
+    lds_gemm_auto(Ys, c.nt * cs, Rs, c.nr, c.ni, c.nr, c.nt * cs, [&](int m, int n, zc v) { Sg[m * c.nr + n] = v; });
+    __syncthreads();
+  };
+
+  zc* Pmine = g.P + (size_t)sc * N + (size_t)a * slab;
+
+  if (!exp_mode) {
+    load_B(g.v, false, 1.0);
+    chain();
+    for (int q = tid; q < slab; q += SS_THREADS) {
+      zc v = Sg[q];
+      if (g.add_shift && sc == 0) {  // the scalar term (coupleJ * ovlp, _contraction.py:1200-1216) rides on chunk 0
+        const zc x = g.v[(long)a * slab + q];
+        v.x += g.shift.x * x.x - g.shift.y * x.y;
+        v.y += g.shift.x * x.y + g.shift.y * x.x;
+      }
+      stz_sh(Pmine + q, v);
+    }
+    if (!ss_exchange(sy, pay, 0, red, wsh, ctl)) {
+      if (blockIdx.x == 0 && tid == 0) atomicMax(g.err_w, (unsigned)SS_ETIMEOUT);
+      return;
+    }
+    for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+      zc s = make_double2(0.0, 0.0);
+      for (int q = 0; q < nsc; ++q) {
+        const zc p = ldz_sh(g.P + (size_t)q * N + e);
+        s.x += p.x; s.y += p.y;
+      }
+      g.out[e] = s;
+    }
+    return;
+  }
+
+  // =====================================================================================
+  // EXP mode: x <- exp(scale * Op) x   (short_iterative_lanczos / _arnoldi)
+  // =====================================================================================
+  const SmallExp& ex = g.e;
+  const bool lanczos = ex.integrator == MITDVP_LANCZOS;
+  const bool cn = ex.conserve_norm != 0;
+  const long nsize = N;
+  const int ndim = (int)min((long)ex.max_krylov, nsize);
+  const int k_prev = g.kprev[ex.site];
+  const int n_warm = (int)min(nsize, (long)min(max(0, k_prev - 2), 15));  // _iter_info, _integrator.py:178-186
+  const zc scale = make_double2(ex.scale_re, ex.scale_im);
+
+  // basis vector j at element e: v_j(e) = u_j(e) * invb[j], u_0 = x (input, plain loads)
+  auto basis = [&](int j, long e) -> zc {
+    zc z = j == 0 ? g.x[e] : ldz_sh(g.U + (size_t)j * N + e);
+    const double f = invb[j];
+    z.x *= f; z.y *= f;
+    return z;
+  };
+  auto fail = [&](int code) {
+    if (blockIdx.x == 0 && tid == 0) atomicMax(g.err_w, (unsigned)code);
+  };
+
+  // ---- _normalize (_integrator.py:189-203) ---------------------------------------------
+  double beta0 = 1.0;
+  if (!cn) {
+    double s = 0.0;
+    for (long e = e0 + tid; e < e1; e += SS_THREADS) { const zc z = g.x[e]; s += z.x * z.x + z.y * z.y; }
+    s = wave_sum64(s);
+    if ((tid & 63) == 0) wsh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+    __syncthreads();
+    if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+    beta0 = sqrt(red[0]);
+    if (beta0 == 0.0) { fail(SS_EZERO); return; }
+  }
+  if (tid == 0) {
+    invb[0] = 1.0 / beta0;
+    ctl[3] = 0;  // next_unread
+  }
+  __syncthreads();
+
+  bool have_prev = false;
+  int prev_len = 0;
+  int napply = 0;
+  for (int l = 0; l < ndim; ++l) {
+    // ---- sigma = Op v_l : chunk partials + the projections that are linear in them ----------
+    load_B(l == 0 ? g.x : g.U + (size_t)l * N, l != 0, invb[l]);
+    const int jlo = lanczos ? (ex.variant == 0 ? 0 : l) : 0;
+    const int jhi = lanczos ? jlo : l;
+    double dre[MAXK], dim_[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) { dre[j] = 0.0; dim_[j] = 0.0; }
+    chain();
+    for (int q = tid; q < slab; q += SS_THREADS) {
+      zc v = Sg[q];
+      const long e = (long)a * slab + q;
+      if (g.add_shift && sc == 0) {  // (H + shift) v_l: the projections below must see the scalar term too
+        const zc vl = basis(l, e);
+        v.x += g.shift.x * vl.x - g.shift.y * vl.y;
+        v.y += g.shift.x * vl.y + g.shift.y * vl.x;
+      }
+      stz_sh(Pmine + q, v);
+#pragma unroll
+      for (int j = 0; j < MAXK; ++j)
+        if (j <= jhi - jlo) {
+          const zc b = basis(jlo + j, e);  // conj(b) * v
+          dre[j] += b.x * v.x + b.y * v.y;
+          dim_[j] += b.x * v.y - b.y * v.x;
+        }
+    }
+    napply += 1;
+    {
+      const int nd = jhi - jlo + 1;
+      const int lane = tid & 63, w = tid >> 6;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < MAXK; ++j)
+        if (j < nd) {
+          const double r1 = wave_sum64(dre[j]), r2 = wave_sum64(dim_[j]);
+          if (lane == 0) { wsh[(2 * j) * 4 + w] = r1; wsh[(2 * j + 1) * 4 + w] = r2; }
+        }
+      __syncthreads();
+      if (tid < 2 * nd) pay[tid] = (wsh[tid * 4 + 0] + wsh[tid * 4 + 1]) + (wsh[tid * 4 + 2] + wsh[tid * 4 + 3]);
+      __syncthreads();
+      if (!ss_exchange(sy, pay, 2 * nd, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+      if (tid == 0) {
+        if (lanczos) alpha[l] = make_double2(red[0], red[1]);
+        else
+          for (int j = 0; j <= l; ++j) hess[j * MAXK + l] = make_double2(red[2 * j], red[2 * j + 1]);
+      }
+      __syncthreads();
+    }
+    // ---- own range: assemble sigma, orthogonalise, norm ---------------------------------------
+    {
+      double s = 0.0;
+      const double bprev = l > 0 ? beta[l - 1] : 0.0;
+      for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+        zc u = make_double2(0.0, 0.0);
+        for (int q = 0; q < nsc; ++q) {
+          const zc p = ldz_sh(g.P + (size_t)q * N + e);
+          u.x += p.x; u.y += p.y;
+        }
+        const zc vl = basis(l, e);
+        if (lanczos) {  // _integrator.py:556-562
+          const zc al = alpha[l];
+          u.x -= al.x * vl.x - al.y * vl.y;
+          u.y -= al.x * vl.y + al.y * vl.x;
+          if (l > 0) {
+            const zc vm = basis(l - 1, e);
+            u.x -= bprev * vm.x;
+            u.y -= bprev * vm.y;
+          }
+        } else {  // classical Gram-Schmidt against all vectors, _orth_step_np (:247-260)
+          for (int j = 0; j <= l; ++j) {
+            const zc h = hess[j * MAXK + l];
+            const zc vj = j == l ? vl : basis(j, e);
+            u.x -= h.x * vj.x - h.y * vj.y;
+            u.y -= h.x * vj.y + h.y * vj.x;
+          }
+        }
+        stz_sh(g.U + (size_t)(l + 1) * N + e, u);
+        s += u.x * u.x + u.y * u.y;
+      }
+      s = wave_sum64(s);
+      __syncthreads();
+      if ((tid & 63) == 0) wsh[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+      __syncthreads();
+      if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+    }
+    // ---- scalars; decide what this iteration inspects (_integrator.py:569-652, :392-430) --------
+    if (tid == 0) {
+      const double b = sqrt(red[0]);
+      beta[l] = b;
+      invb[l + 1] = b >= SS_EPS ? 1.0 / b : 1.0;  // exhausted Krylov space: the vector is left as it is
+      if (!lanczos && b > SS_EPS) hess[(l + 1) * MAXK + l] = make_double2(b, 0.0);
+      int act = 0, kd = 0;
+      const bool last_possible = (l + 1 == nsize);
+      if (!(l < n_warm && !last_possible && l + 1 < ndim)) {
+        int ld = l;
+        bool exhausted = false;
+        for (int q = ctl[3]; q <= l; ++q)
+          if (beta[q] < SS_EPS || q + 1 == nsize) { ld = q; exhausted = true; break; }
+        ctl[3] = l + 1;
+        if (!(ld < n_warm && !exhausted)) { kd = ld + 1; act = exhausted ? 2 : 1; }
+      }
+      ctl[1] = act;
+      ctl[2] = kd;
+    }
+    __syncthreads();
+    int act = ctl[1];
+    const int k = ctl[2];
+    if (act == 0) continue;
+
+    // ---- coef = exp(scale * T_k) e_0 ------------------------------------------------------------
+    {
+      zc* Tm = Bs;
+      zc* Pm = Tm + MAXK * MAXK;
+      zc* Em = Pm + MAXK * MAXK;
+      zc* Qm = Em + MAXK * MAXK;
+      for (int t = tid; t < k * k; t += SS_THREADS) {
+        const int i = t / k, j = t - i * k;
+        zc z = make_double2(0.0, 0.0);
+        if (lanczos) {
+          if (i == j) z = alpha[i];
+          else if (i == j + 1) z = make_double2(beta[j], 0.0);
+          else if (j == i + 1) z = make_double2(beta[i], 0.0);
+        } else {
+          if (i <= j + 1) z = hess[i * MAXK + j];
+        }
+        Tm[t] = make_double2(scale.x * z.x - scale.y * z.y, scale.x * z.y + scale.y * z.x);
+      }
+      __syncthreads();
+      ss_expm_col0(Tm, Pm, Em, Qm, k, coef, wsh);
+    }
+    if (act == 1) {
+      if (have_prev) {  // || psi_k - psi_{k-1} ||  (:644-652)
+        double s = 0.0;
+        for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+          double re = 0.0, im = 0.0;
+          for (int j = 0; j < k; ++j) {
+            zc d = coef[j];
+            if (j < prev_len) { d.x -= cprev[j].x; d.y -= cprev[j].y; }
+            const zc vj = basis(j, e);
+            re += d.x * vj.x - d.y * vj.y;
+            im += d.x * vj.y + d.y * vj.x;
+          }
+          s += re * re + im * im;
+        }
+        s = wave_sum64(s);
+        __syncthreads();
+        if ((tid & 63) == 0) wsh[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+        __syncthreads();
+        if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+        if (sqrt(red[0]) < ex.thresh) act = 2;
+      }
+      if (act == 1) {
+        __syncthreads();
+        if (tid < k) cprev[tid] = coef[tid];
+        __syncthreads();
+        have_prev = true;
+        prev_len = k;
+        continue;
+      }
+    }
+    // ---- act == 2: psi = sum_j c_j v_j, renormalised or rescaled (_rescale, :206-213) ------------
+    // x is read by OTHER workgroups only before this iteration's exchanges; from here on every
+    // workgroup touches its own range only.  With conserve_norm the new vector waits in the unused
+    // slot 0 of the basis buffer until its norm is known.
+    {
+      const double cs_ = cn ? 1.0 : beta0;
+      double s = 0.0;
+      for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+        double re = 0.0, im = 0.0;
+        for (int j = 0; j < k; ++j) {
+          const zc d = make_double2(coef[j].x * cs_, coef[j].y * cs_);
+          const zc vj = basis(j, e);
+          re += d.x * vj.x - d.y * vj.y;
+          im += d.x * vj.y + d.y * vj.x;
+        }
+        if (cn) g.U[e] = make_double2(re, im);
+        else g.x[e] = make_double2(re, im);
+        s += re * re + im * im;
+      }
+      if (cn) {
+        s = wave_sum64(s);
+        __syncthreads();
+        if ((tid & 63) == 0) wsh[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+        __syncthreads();
+        if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+        const double inv = 1.0 / sqrt(red[0]);
+        for (long e = e0 + tid; e < e1; e += SS_THREADS) {  // same thread wrote g.U[e] above
+          zc z = g.U[e];
+          z.x *= inv; z.y *= inv;
+          g.x[e] = z;
+        }
+      }
+      if (blockIdx.x == 0 && tid == 0) {
+        g.kprev[ex.site] = k;
+        atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + ex.stat_slot), (unsigned long long)napply);
+        atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2 + ex.stat_slot),
+                  (unsigned long long)napply * (unsigned long long)ex.flops_per_apply);
+      }
+      return;
+    }
+  }
+  fail(SS_ENOTCONV);  // "... is not converged in N basis. Try shorter time interval." (:430, :653)
+  if (blockIdx.x == 0 && tid == 0) {
+    g.kprev[ex.site] = ndim;
+    atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + ex.stat_slot), (unsigned long long)napply);
+    atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2 + ex.stat_slot),
+              (unsigned long long)napply * (unsigned long long)ex.flops_per_apply);
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+size_t small_chain_lds(const SmallChain& c, bool exp_mode) { return ss_carve(c, exp_mode).total * sizeof(zc); }
+
+bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
+  if (c.na < 1 || c.ns < 1 || c.nr < 1 || c.nb < 1) return false;
+  const int gmax = std::min(n_cu, SS_MAXG);
+  if (c.na > gmax) return false;
+  // as many chunks as the CU count allows, but keep chunks at least 4 wide (a chunk row is one 64-byte segment)
+  for (int nsc = 8; nsc >= 1; nsc >>= 1) {
+    if (c.na * nsc > gmax) continue;
+    const int cs = (c.ns + nsc - 1) / nsc;
+    if (nsc > 1 && cs < 4) continue;
+    if ((nsc - 1) * cs >= c.ns) continue;  // every chunk must be non-empty
+    c.nsc = nsc;
+    c.cs = cs;
+    const size_t lds = small_chain_lds(c, exp_mode);
+    // more than half of a CU's 160 KiB: one workgroup per CU, all resident, the protocol's measured regime;
+    // below that the launch pads its request
+    if (lds <= 150 * 1024) return true;
+  }
+  return false;
+}
+
+void small_sync_alloc(SmallSync& s, int nsite, hipStream_t st) {
+  if (s.words) return;
+  HIP_CHECK(hipMalloc(&s.words, 16 * sizeof(unsigned)));
+  HIP_CHECK(hipMalloc(&s.slots, (size_t)2 * SS_MAXG * SS_PAYMAX * sizeof(double)));
+  HIP_CHECK(hipMalloc(&s.stats, 4 * sizeof(long long)));
+  HIP_CHECK(hipMalloc(&s.kprev, (size_t)std::max(nsite, 1) * sizeof(int)));
+  HIP_CHECK(hipMemsetAsync(s.words, 0, 16 * sizeof(unsigned), st));
+  HIP_CHECK(hipMemsetAsync(s.slots, 0, (size_t)2 * SS_MAXG * SS_PAYMAX * sizeof(double), st));
+  HIP_CHECK(hipMemsetAsync(s.stats, 0, 4 * sizeof(long long), st));
+  HIP_CHECK(hipMemsetAsync(s.kprev, 0, (size_t)std::max(nsite, 1) * sizeof(int), st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  s.launches = 0;
+}
+
+void small_sync_free(SmallSync& s) {
+  if (s.words) (void)hipFree(s.words);
+  if (s.slots) (void)hipFree(s.slots);
+  if (s.stats) (void)hipFree(s.stats);
+  if (s.kprev) (void)hipFree(s.kprev);
+  s = SmallSync{};
+}
+
+static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
+  const SmallChain& c = g.c;
+  // validate what the kernel's indexing assumes before anything is launched
+  if (c.nsc < 1 || c.cs < 1 || (c.nsc - 1) * c.cs >= c.ns || c.nsc * c.cs < c.ns) throw ArgError("small_site: bad chunking");
+  if (c.na * c.nsc > SS_MAXG) throw ArgError("small_site: grid exceeds the resident-workgroup bound");
+  if (!c.W2 && (c.ni != 1 || c.nj != 1 || c.nt != c.nc)) throw ArgError("small_site: chain without W stage needs ni = nj = 1, nt = nc");
+  size_t lds = small_chain_lds(c, exp_mode);
+  if (lds > 160 * 1024) throw ArgError("small_site: chain does not fit LDS");
+  lds = std::max<size_t>(lds, 84 * 1024);  // > half a CU's LDS: at most one workgroup per CU
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  static bool attr_set[64] = {};  // the attribute is per device
+  static std::mutex attr_mu;
+  std::lock_guard<std::mutex> lk(attr_mu);
+  if (dev >= 64 || !attr_set[dev]) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_site), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+    if (dev < 64) attr_set[dev] = true;
+  }
+  g.ctr = sy.words + (sy.launches & 1u);
+  g.ctr_other = sy.words + ((sy.launches + 1u) & 1u);
+  g.abort_w = sy.words + 2;
+  g.err_w = sy.words + 3;
+  g.slots = sy.slots;
+  g.stats = sy.stats;
+  g.kprev = sy.kprev;
+  sy.launches += 1;
+  hipLaunchKernelGGL(k_small_site, dim3(c.na * c.nsc), dim3(SS_THREADS), lds, st, g);
+  HIP_CHECK(hipGetLastError());
+}
+
+void small_apply(hipStream_t st, SmallSync& sy, const SmallChain& c, const zc* v, zc* out, zc* partials, zc shift,
+                 bool add_shift) {
+  SsArgs g{};
+  g.c = c;
+  g.mode = SS_MODE_APPLY;
+  g.v = v;
+  g.out = out;
+  g.P = partials;
+  g.shift = shift;
+  g.add_shift = add_shift ? 1 : 0;
+  ss_launch(st, sy, g, false);
+}
+
+void small_exp(hipStream_t st, SmallSync& sy, const SmallChain& c, const SmallExp& e, zc* x, zc* basis, zc* partials,
+               zc shift) {
+  if ((long)c.na * c.ni * c.nr != (long)c.nb * c.nj * c.ns) throw ArgError("small_exp: the operator must be square");
+  SsArgs g{};
+  g.c = c;
+  g.mode = SS_MODE_EXP;
+  g.x = x;
+  g.U = basis;
+  g.P = partials;
+  g.shift = shift;
+  g.add_shift = (shift.x != 0.0 || shift.y != 0.0) ? 1 : 0;
+  g.e = e;
+  ss_launch(st, sy, g, true);
+}
+
+}  // namespace mitdvp
