@@ -122,7 +122,6 @@ void Engine::ss_check() {
   if (w[3] != 0 || w[2] != 0) {
     HIP_CHECK(hipMemsetAsync(ss_.words, 0, 4 * sizeof(unsigned), st_));  // counters, abort flag, error code
     HIP_CHECK(hipStreamSynchronize(st_));
-    ss_.launches = 0;
     if (w[3] == SS_ENOTCONV)
       throw NotConverged(std::string(cfg.integrator == MITDVP_LANCZOS ? "Short Iterative Lanczos" : "Short Iterative Arnoldi") +
                          " is not converged in " + std::to_string(cfg.max_krylov) + " basis. Try shorter time interval.");

@@ -29,11 +29,11 @@ enum { SS_OK = 0, SS_ENOTCONV = 1, SS_ETIMEOUT = 2, SS_EZERO = 3 };
 
 // device-resident state shared by all small-site launches of one engine
 struct SmallSync {
-  unsigned* words = nullptr;  // [0],[1]: alternating arrival counters; [2]: abort flag; [3]: sticky error code
-  double* slots = nullptr;    // payload exchange area [2][256][SS_PAYMAX]
+  unsigned* words = nullptr;  // [2]: abort flag; [3]: sticky error code
+  double* slots = nullptr;    // granule exchange area (two buffers)
   long long* stats = nullptr; // [0] applies inside site exponentials, [1] inside bond exponentials, [2], [3] their flops
   int* kprev = nullptr;       // per-site Krylov iteration memory (device copy)
-  unsigned launches = 0;      // parity of the counter in use
+  unsigned launches = 0;      // launch sequence number (exchange tags are unique per launch)
 };
 
 struct SmallExp {

@@ -33,6 +33,7 @@
 #include "small_site.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "../../include/mitdvp.h"
@@ -40,9 +41,11 @@
 namespace mitdvp {
 namespace {
 
-constexpr int SS_THREADS = 256;
+constexpr int SS_THREADS = 1024;  // 16 waves: four per SIMD hide the LDS / L2 latencies of the short dependent chains
+constexpr int SS_WAVES = SS_THREADS / 64;
 constexpr int SS_PAYMAX = 2 * MAXK + 2;  // doubles one workgroup contributes to an exchange
 constexpr int SS_MAXG = 256;
+constexpr int SS_NGR = 2 * SS_PAYMAX;  // granules per workgroup and exchange
 constexpr double SS_EPS = 1e-12;  // _integrator.py:22
 
 #define SS_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -70,22 +73,33 @@ struct SsArgs {
   zc shift;
   int add_shift;
   SmallExp e;
-  unsigned* ctr;
-  unsigned* ctr_other;
+  unsigned epoch0;  // tags of this launch's exchanges are epoch0 + 1, + 2, ...
   unsigned* abort_w;
   unsigned* err_w;
-  double* slots;
+  unsigned long long* gran;
   long long* stats;
   int* kprev;
+  long long* trace;  // debugging: workgroup 0 stamps s_memrealtime at its phase boundaries (nullptr = off)
 };
 
 struct Sync {
-  unsigned* ctr;
+  unsigned long long* gran;
   unsigned* abort_w;
-  double* slots;
   int G, wg;
   unsigned epoch;
 };
+
+// fixed-order sum of the SS_WAVES per-wave partials p[0..SS_WAVES)
+__device__ __forceinline__ double wtree(const double* p) {
+  double a[SS_WAVES];
+#pragma unroll
+  for (int i = 0; i < SS_WAVES; ++i) a[i] = p[i];
+#pragma unroll
+  for (int st = SS_WAVES / 2; st > 0; st >>= 1)
+#pragma unroll
+    for (int i = 0; i < st; ++i) a[i] += a[i + st];
+  return a[0];
+}
 
 __device__ __forceinline__ double wave_sum64(double v) {
 #pragma unroll
@@ -96,107 +110,142 @@ __device__ __forceinline__ double wave_sum64(double v) {
 // Grid-wide exchange: every workgroup contributes pay[0..npay) (LDS), every workgroup receives the
 // element-wise sums over all workgroups in red[0..npay) (LDS), summed in the same order everywhere.
 // Also orders all sc1 stores issued before it against all sc1 loads issued after it, grid-wide.
-// Returns false (uniformly) when the wait timed out or another workgroup raised the abort flag.
-__device__ bool ss_exchange(Sync& s, const double* pay, int npay, double* red, double* wsh /*[4*SS_PAYMAX]*/, int* flag) {
+//
+// The data is the flag (MI355X_MICROARCH.md price list, "allgather"; cdna_hip_programming.md Guideline 16 R2):
+// every double travels as two 8-byte granules {tag = epoch, 32 payload bits}, each written by ONE
+// agent-scope store; thread t reads the granules of workgroup t until all carry this epoch's tag.  No
+// counter, no separate flag: one store->load round trip.  Granules are laid out [index][workgroup] so a
+// wave's poll is one coalesced request; two buffers alternate (a writer can be at most one epoch ahead of
+// the slowest reader).  Returns false (uniformly) when a wait timed out or the abort flag was raised.
+__device__ bool ss_exchange(Sync& s, const double* pay, int npay, double* red, double* wsh /*[SS_WAVES*SS_PAYMAX]*/) {
   s.epoch += 1;
-  const int tid = threadIdx.x;
-  double* mine = s.slots + ((size_t)(s.epoch & 1) * SS_MAXG + s.wg) * SS_PAYMAX;
-  if (tid < npay) st_sh(mine + tid, pay[tid]);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its sc1 stores (payload and vector data) are out
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ng = npay > 0 ? 2 * npay : 1;
+  unsigned long long* base = s.gran + (size_t)(s.epoch & 1u) * SS_NGR * SS_MAXG;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its sc1 stores of vector data have landed
   __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(s.ctr, 1u, SS_RLX);
-    const unsigned target = s.epoch * (unsigned)s.G;
-    int ok = 1;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-    unsigned spins = 0;
-    while (__hip_atomic_load(s.ctr, SS_RLX) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 1023u) == 0) {
-        if (__hip_atomic_load(s.abort_w, SS_RLX) != 0u) { ok = 0; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: a workgroup is not resident
-          __hip_atomic_store(s.abort_w, 1u, SS_RLX);
-          ok = 0;
-          break;
+  if (tid < ng) {
+    unsigned half = 0u;
+    if (npay > 0) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(pay[tid >> 1]);
+      half = (tid & 1) ? (unsigned)(b >> 32) : (unsigned)b;
+    }
+    __hip_atomic_store(base + (size_t)tid * SS_MAXG + s.wg, ((unsigned long long)s.epoch << 32) | half, SS_RLX);
+  }
+  int ok = 1;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+  for (int g0 = 0; g0 < ng; g0 += 8) {
+    unsigned long long x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = 0ull;
+    if (tid < s.G && ok) {
+      unsigned spins = 0;
+      for (;;) {
+        bool ready = true;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (g0 + q < ng) {
+            x[q] = __hip_atomic_load(base + (size_t)(g0 + q) * SS_MAXG + tid, SS_RLX);
+            ready = ready && (unsigned)(x[q] >> 32) == s.epoch;
+          }
+        if (ready) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0u) {
+          if (__hip_atomic_load(s.abort_w, SS_RLX) != 0u) { ok = 0; break; }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: a workgroup is not resident
+            __hip_atomic_store(s.abort_w, 1u, SS_RLX);
+            ok = 0;
+            break;
+          }
         }
       }
     }
-    *flag = ok;
-  }
-  __syncthreads();
-  if (!*flag) return false;
-  if (npay > 0) {
-    const double* base = s.slots + (size_t)(s.epoch & 1) * SS_MAXG * SS_PAYMAX;
-    const int lane = tid & 63, w = tid >> 6;
-    for (int c = 0; c < npay; ++c) {
-      double v = tid < s.G ? ld_sh(base + (size_t)tid * SS_PAYMAX + c) : 0.0;
-      v = wave_sum64(v);
-      if (lane == 0) wsh[c * 4 + w] = v;
+    if (npay > 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (g0 + 2 * q < ng) {
+          double v = 0.0;
+          if (tid < s.G) v = __longlong_as_double((long long)((x[2 * q] & 0xffffffffull) | (x[2 * q + 1] << 32)));
+          v = wave_sum64(v);
+          if (lane == 0 && w < 4) wsh[(g0 / 2 + q) * 4 + w] = v;  // G <= 256: waves 0..3 hold the workgroups
+        }
     }
-    __syncthreads();
+  }
+  if (!__syncthreads_and(ok)) return false;
+  if (npay > 0) {
     if (tid < npay) red[tid] = (wsh[tid * 4 + 0] + wsh[tid * 4 + 1]) + (wsh[tid * 4 + 2] + wsh[tid * 4 + 3]);
     __syncthreads();
   }
   return true;
 }
 
-// C(M x N) = A(M x K) * B(K x N), all row-major in LDS; each thread owns TM x TN outputs, rows / columns
-// interleaved over the threads so that neighbouring lanes read neighbouring LDS words.
-template <int TM, int TN, class Epi>
-__device__ __forceinline__ void lds_gemm(const zc* __restrict__ A, int lda, const zc* __restrict__ B, int ldb, int M, int N,
-                                         int K, Epi epi) {
-  const int mt = (M + TM - 1) / TM, nt = (N + TN - 1) / TN;
-  for (int t = threadIdx.x; t < mt * nt; t += SS_THREADS) {
-    const int mi = t / nt, ni = t - mi * nt;
-    int row[TM], col[TN];
+// C(M x N) = A(M x K) * B(K x N), all row-major in LDS.  The operands are tiny (a few hundred outputs,
+// K of a few dozen): the time goes into the dependent chain of K multiply-adds behind LDS latency, so K is
+// split over KS adjacent lanes (KS = the largest power of two that still leaves every thread an output)
+// and the KS partial sums are combined with cross-lane adds in a fixed order.
+// all-reduce over groups of KS (<= 16) adjacent lanes with DPP moves (a cross-lane add costs one VALU
+// issue; the LDS-crossbar shuffle would cost a round trip per step); the pairing order is fixed
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ks_allreduce(double v, int KS) {
+  if (KS >= 2) v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  if (KS >= 4) v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  if (KS >= 8) v = dpp_add<0x141>(v);  // row_half_mirror: the other quad of the same 8 lanes
+  if (KS >= 16) v = dpp_add<0x140>(v); // row_mirror: the other half of the same 16 lanes
+  return v;
+}
+
+// C = scl * A B.
+__device__ __forceinline__ void lds_gemm(const zc* __restrict__ A, int lda, const zc* __restrict__ B, int ldb,
+                                         zc* __restrict__ C, int ldc, int M, int N, int K, double scl) {
+  const int mn = M * N;
+  int KS = 1, lg = 0;
+  while (KS < 16 && mn * KS * 2 <= SS_THREADS && KS * 2 <= K) { KS *= 2; ++lg; }
+  const int per = SS_THREADS >> lg;
+  const int ks = threadIdx.x & (KS - 1);
+  const int npass = (mn + per - 1) / per;
+  for (int ps = 0; ps < npass; ++ps) {
+    const int o = ps * per + (threadIdx.x >> lg);
+    const bool valid = o < mn;
+    const int oo = valid ? o : mn - 1;
+    const int m = oo / N, n = oo - m * N;
+    const zc* ap = A + m * lda;
+    const zc* bp = B + n;
+    // four k-steps per batch: all eight LDS reads are issued before the first multiply-add (hipcc otherwise
+    // waits for every pair), and the four products feed independent accumulators
+    double r0 = 0.0, r1 = 0.0, i0 = 0.0, i1 = 0.0;
+    int k = ks;
+    for (; k + 3 * KS < K; k += 4 * KS) {
+      zc av[4], bv[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) row[i] = min(mi + i * mt, M - 1);
+      for (int u = 0; u < 4; ++u) { av[u] = ap[k + u * KS]; bv[u] = bp[(k + u * KS) * ldb]; }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) col[j] = min(ni + j * nt, N - 1);
-    double cr[TM][TN], ci[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) { cr[i][j] = 0.0; ci[i][j] = 0.0; }
-#pragma unroll 4
-    for (int k = 0; k < K; ++k) {
-      zc a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = A[row[i] * lda + k];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = B[k * ldb + col[j]];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          cr[i][j] = fma(a[i].x, b[j].x, cr[i][j]);
-          cr[i][j] = fma(-a[i].y, b[j].y, cr[i][j]);
-          ci[i][j] = fma(a[i].x, b[j].y, ci[i][j]);
-          ci[i][j] = fma(a[i].y, b[j].x, ci[i][j]);
-        }
+      for (int u = 0; u < 4; ++u) {
+        r0 = fma(av[u].x, bv[u].x, r0); r1 = fma(-av[u].y, bv[u].y, r1);
+        i0 = fma(av[u].x, bv[u].y, i0); i1 = fma(av[u].y, bv[u].x, i1);
+      }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        if (mi + i * mt < M && ni + j * nt < N) epi(mi + i * mt, ni + j * nt, make_double2(cr[i][j], ci[i][j]));
+    for (; k < K; k += KS) {
+      const zc a = ap[k], b = bp[k * ldb];
+      r0 = fma(a.x, b.x, r0); r1 = fma(-a.y, b.y, r1);
+      i0 = fma(a.x, b.y, i0); i1 = fma(a.y, b.x, i1);
+    }
+    const double re = ks_allreduce(r0 + r1, KS), im = ks_allreduce(i0 + i1, KS);
+    if (valid && ks == 0) C[m * ldc + n] = make_double2(re * scl, im * scl);
   }
 }
 
-template <class Epi>
-__device__ __forceinline__ void lds_gemm_auto(const zc* A, int lda, const zc* B, int ldb, int M, int N, int K, Epi epi) {
-  const int mn = M * N;
-  if (mn <= SS_THREADS) lds_gemm<1, 1>(A, lda, B, ldb, M, N, K, epi);
-  else if (mn <= 2 * SS_THREADS) { if (N >= M) lds_gemm<1, 2>(A, lda, B, ldb, M, N, K, epi); else lds_gemm<2, 1>(A, lda, B, ldb, M, N, K, epi); }
-  else if (mn <= 4 * SS_THREADS || M < 4 || N < 4) lds_gemm<2, 2>(A, lda, B, ldb, M, N, K, epi);
-  else if (mn <= 8 * SS_THREADS) { if (N >= M) lds_gemm<2, 4>(A, lda, B, ldb, M, N, K, epi); else lds_gemm<4, 2>(A, lda, B, ldb, M, N, K, epi); }
-  else lds_gemm<4, 4>(A, lda, B, ldb, M, N, K, epi);
-}
-
 // first column of exp(T) for the k x k matrix T (LDS, row-major, ld = k), by the whole workgroup:
-// scaling and squaring around a degree-20 Taylor polynomial (small_linalg.h::expm_col0).
-// Tm is destroyed; Pm, Em, Qm are k x k scratch.  Result in coef[0..k).
-__device__ void ss_expm_col0(zc* Tm, zc* Pm, zc* Em, zc* Qm, int k, zc* coef, double* wsh) {
+// scaling and squaring (|T / 2^s|_1 <= 1/2) around the degree-16 Taylor polynomial, remainder
+// 0.5^17 / 17! = 2e-20 (small_linalg.h::expm_col0 is the host twin, summed to degree 20), evaluated in
+// Paterson-Stockmeyer form with the powers A^2, A^3, A^4:
+//   p(A) = B0 + A^4 (B1 + A^4 (B2 + A^4 (B3 + A^4 / 16!))),  Bi = sum_{r<4} A^r / (4i + r)!
+// = 3 + 4 products instead of 16.  Tm is destroyed; M2, M3, M4, Pm, Qm are k x k scratch.
+__device__ void ss_expm_col0(zc* Tm, zc* M2, zc* M3, zc* M4, zc* Pm, zc* Qm, int k, zc* coef, double* wsh) {
   const int tid = threadIdx.x, kk = k * k;
   if (k == 1) {
     if (tid == 0) {
@@ -207,8 +256,7 @@ __device__ void ss_expm_col0(zc* Tm, zc* Pm, zc* Em, zc* Qm, int k, zc* coef, do
     __syncthreads();
     return;
   }
-  // 1-norm: max column sum
-  if (tid < k) {
+  if (tid < k) {  // 1-norm: max column sum
     double s = 0.0;
     for (int i = 0; i < k; ++i) { const zc z = Tm[i * k + tid]; s += sqrt(z.x * z.x + z.y * z.y); }
     wsh[tid] = s;
@@ -219,53 +267,44 @@ __device__ void ss_expm_col0(zc* Tm, zc* Pm, zc* Em, zc* Qm, int k, zc* coef, do
   int sq = 0;
   while (nrm > 0.5 && sq < 60) { nrm *= 0.5; ++sq; }
   const double sc = ldexp(1.0, -sq);
-  for (int t = tid; t < kk; t += SS_THREADS) {
-    zc z = Tm[t];
-    z.x *= sc; z.y *= sc;
-    Tm[t] = z;
+  for (int t = tid; t < kk; t += SS_THREADS) { zc z = Tm[t]; z.x *= sc; z.y *= sc; Tm[t] = z; }
+  __syncthreads();
+  lds_gemm(Tm, k, Tm, k, M2, k, k, k, k, 1.0);
+  __syncthreads();
+  lds_gemm(M2, k, Tm, k, M3, k, k, k, k, 1.0);
+  lds_gemm(M2, k, M2, k, M4, k, k, k, k, 1.0);
+  __syncthreads();
+  // inverse factorials 1/n!, n = 0..16
+  constexpr double F[17] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                            1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+                            1.0 / 1307674368000.0, 1.0 / 20922789888000.0};
+  auto bcoef = [&](int i, int t) -> zc {  // element t of B_i
+    const zc a1 = Tm[t], a2 = M2[t], a3 = M3[t];
     const double one = (t / k == t % k) ? 1.0 : 0.0;
-    Pm[t] = make_double2(one, 0.0);
-    Em[t] = make_double2(one, 0.0);
+    return make_double2(F[4 * i] * one + F[4 * i + 1] * a1.x + F[4 * i + 2] * a2.x + F[4 * i + 3] * a3.x,
+                        F[4 * i + 1] * a1.y + F[4 * i + 2] * a2.y + F[4 * i + 3] * a3.y);
+  };
+  for (int t = tid; t < kk; t += SS_THREADS) {  // P = B3 + A^4 / 16!
+    const zc b = bcoef(3, t), a4 = M4[t];
+    Pm[t] = make_double2(b.x + F[16] * a4.x, b.y + F[16] * a4.y);
   }
   __syncthreads();
-  for (int deg = 1; deg <= 20; ++deg) {  // P <- P T / deg ; E += P
-    const double inv = 1.0 / deg;
-    for (int t = tid; t < kk; t += SS_THREADS) {
-      const int i = t / k, j = t - i * k;
-      double re = 0.0, im = 0.0;
-      for (int l = 0; l < k; ++l) {
-        const zc x = Pm[i * k + l], y = Tm[l * k + j];
-        re = fma(x.x, y.x, re); re = fma(-x.y, y.y, re);
-        im = fma(x.x, y.y, im); im = fma(x.y, y.x, im);
-      }
-      Qm[t] = make_double2(re * inv, im * inv);
-    }
+  for (int i = 2; i >= 0; --i) {  // P <- B_i + A^4 P
+    lds_gemm(M4, k, Pm, k, Qm, k, k, k, k, 1.0);
     __syncthreads();
     for (int t = tid; t < kk; t += SS_THREADS) {
-      const zc q = Qm[t];
-      Pm[t] = q;
-      zc e = Em[t];
-      e.x += q.x; e.y += q.y;
-      Em[t] = e;
+      const zc b = bcoef(i, t), q = Qm[t];
+      Pm[t] = make_double2(b.x + q.x, b.y + q.y);
     }
     __syncthreads();
   }
   for (int s = 0; s < sq; ++s) {  // E <- E E
-    for (int t = tid; t < kk; t += SS_THREADS) {
-      const int i = t / k, j = t - i * k;
-      double re = 0.0, im = 0.0;
-      for (int l = 0; l < k; ++l) {
-        const zc x = Em[i * k + l], y = Em[l * k + j];
-        re = fma(x.x, y.x, re); re = fma(-x.y, y.y, re);
-        im = fma(x.x, y.y, im); im = fma(x.y, y.x, im);
-      }
-      Qm[t] = make_double2(re, im);
-    }
+    lds_gemm(Pm, k, Pm, k, Qm, k, k, k, k, 1.0);
     __syncthreads();
-    for (int t = tid; t < kk; t += SS_THREADS) Em[t] = Qm[t];
+    for (int t = tid; t < kk; t += SS_THREADS) Pm[t] = Qm[t];
     __syncthreads();
   }
-  if (tid < k) coef[tid] = Em[tid * k];
+  if (tid < k) coef[tid] = Pm[tid * k];
   __syncthreads();
 }
 
@@ -281,15 +320,15 @@ __host__ __device__ inline Carve ss_carve(const SmallChain& c, bool exp_mode) {
   k.Ws = o; o += c.W2 ? (size_t)c.ni * c.nt * c.nc * c.nj : 0;
   k.Bs = o;
   size_t bs = (size_t)c.nb * c.nj * c.cs;
-  if (exp_mode) bs = bs > (size_t)4 * MAXK * MAXK ? bs : (size_t)4 * MAXK * MAXK;  // also the k x k exponential's scratch
+  if (exp_mode) bs = bs > (size_t)6 * MAXK * MAXK ? bs : (size_t)6 * MAXK * MAXK;  // also the k x k exponential's scratch
   o += bs;
   k.Xs = o; o += (size_t)c.nc * c.nj * c.cs;
   k.Ys = o; o += c.W2 ? (size_t)c.ni * c.nt * c.cs : 0;
   k.Sg = o; o += (size_t)c.ni * c.nr;  // this chunk's partial of the output slab
   k.misc = o;
-  // misc: pay[SS_PAYMAX] red[SS_PAYMAX] wsh[4*SS_PAYMAX] (doubles) + alpha[MAXK] coef[MAXK] cprev[MAXK] (zc)
+  // misc: pay[SS_PAYMAX] red[SS_PAYMAX] wsh[SS_WAVES*SS_PAYMAX] (doubles) + alpha[MAXK] coef[MAXK] cprev[MAXK] (zc)
   //       + hess[(MAXK+1)*MAXK] (zc) + beta[MAXK] invb[MAXK+1] (doubles) + ints
-  o += (size_t)(6 * SS_PAYMAX + 1) / 2 + 3 * MAXK + (size_t)(MAXK + 1) * MAXK + (2 * MAXK + 2) / 2 + 8;
+  o += (size_t)((2 + SS_WAVES) * SS_PAYMAX + 1) / 2 + 3 * MAXK + (size_t)(MAXK + 1) * MAXK + (2 * MAXK + 2) / 2 + 8;
   k.total = o;
   return k;
 }
@@ -310,7 +349,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
   double* pay = reinterpret_cast<double*>(sm + cv.misc);
   double* red = pay + SS_PAYMAX;
   double* wsh = red + SS_PAYMAX;
-  zc* alpha = reinterpret_cast<zc*>(wsh + 4 * SS_PAYMAX + (SS_PAYMAX & 1));
+  zc* alpha = reinterpret_cast<zc*>(wsh + SS_WAVES * SS_PAYMAX);
   zc* coef = alpha + MAXK;
   zc* cprev = coef + MAXK;
   zc* hess = cprev + MAXK;  // (MAXK+1) x MAXK, row-major, ld = MAXK
@@ -329,8 +368,18 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
   const long e0 = (long)a * slab + min(sc * rg, slab);
   const long e1 = (long)a * slab + min((sc + 1) * rg, slab);
 
-  Sync sy{g.ctr, g.abort_w, g.slots, (int)gridDim.x, (int)blockIdx.x, 0u};
-  if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(g.ctr_other, 0u, SS_RLX);  // the next launch's counter
+  Sync sy{g.gran, g.abort_w, (int)gridDim.x, (int)blockIdx.x, g.epoch0};
+  int ntr = 1;
+  auto stamp = [&](int label) {
+    if (g.trace && blockIdx.x == 0 && tid == 0 && ntr < 250) {
+      g.trace[2 * ntr] = (long long)__builtin_amdgcn_s_memrealtime();
+      g.trace[2 * ntr + 1] = label;
+      g.trace[512 + ntr] = (long long)__builtin_amdgcn_s_memtime();
+      ntr += 1;
+      g.trace[0] = ntr;
+    }
+  };
+  stamp(0);
 
   // ---- operands that do not change during the launch -> LDS -------------------------------
   for (int t = tid; t < c.nc * c.nb; t += SS_THREADS) {
@@ -355,38 +404,54 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
 
   // stage-1 operand of this chunk: Bs[b][(j, sl)] = scale * vec(b, j, s0 + sl)
   auto load_B = [&](const zc* vec, bool shared, double scl) {
-    const int ncol = c.nj * cs;
-    for (int t = tid; t < c.nb * ncol; t += SS_THREADS) {
-      const int b = t / ncol, q = t - b * ncol;
-      const int j = q / cs, sl = q - j * cs;
-      zc z = make_double2(0.0, 0.0);
-      if (sl < csl) {
-        const zc* p = vec + (long)b * c.sBb + (long)j * c.sBj + (long)(s0 + sl) * c.sBs;
-        z = shared ? ldz_sh(p) : *p;
-        z.x *= scl; z.y *= scl;
+    const int ncol = c.nj * cs, total = c.nb * ncol;
+    for (int t0 = 0; t0 < total; t0 += 4 * SS_THREADS) {  // all loads of a batch in flight before the first use
+      zc z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * SS_THREADS + tid;
+        z[u] = make_double2(0.0, 0.0);
+        if (t < total) {
+          const int b = t / ncol, q = t - b * ncol;
+          const int j = q / cs, sl = q - j * cs;
+          if (sl < csl) {
+            const zc* p = vec + (long)b * c.sBb + (long)j * c.sBj + (long)(s0 + sl) * c.sBs;
+            z[u] = shared ? ldz_sh(p) : *p;
+          }
+        }
       }
-      Bs[t] = z;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * SS_THREADS + tid;
+        if (t < total) Bs[t] = make_double2(z[u].x * scl, z[u].y * scl);
+      }
     }
   };
 
   // the three stages; this chunk's partial of out[a][:][:] ends up in Sg (LDS)
   auto chain = [&]() {
     __syncthreads();
-    lds_gemm_auto(As, c.nb, Bs, c.nj * cs, c.nc, c.nj * cs, c.nb, [&](int m, int n, zc v) { Xs[m * (c.nj * cs) + n] = v; });
+    stamp(20);
+    lds_gemm(As, c.nb, Bs, c.nj * cs, Xs, c.nj * cs, c.nc, c.nj * cs, c.nb, 1.0);
     __syncthreads();
+    stamp(21);
     if (c.W2) {
-      lds_gemm_auto(Ws, c.nc * c.nj, Xs, cs, c.ni * c.nt, cs, c.nc * c.nj, [&](int m, int n, zc v) { Ys[m * cs + n] = v; });
+      lds_gemm(Ws, c.nc * c.nj, Xs, cs, Ys, cs, c.ni * c.nt, cs, c.nc * c.nj, 1.0);
       __syncthreads();
     }
-    lds_gemm_auto(Ys, c.nt * cs, Rs, c.nr, c.ni, c.nr, c.nt * cs, [&](int m, int n, zc v) { Sg[m * c.nr + n] = v; });
+    stamp(22);
+    lds_gemm(Ys, c.nt * cs, Rs, c.nr, Sg, c.nr, c.ni, c.nr, c.nt * cs, 1.0);
     __syncthreads();
+    stamp(23);
   };
 
   zc* Pmine = g.P + (size_t)sc * N + (size_t)a * slab;
 
   if (!exp_mode) {
     load_B(g.v, false, 1.0);
+    stamp(1);
     chain();
+    stamp(2);
     for (int q = tid; q < slab; q += SS_THREADS) {
       zc v = Sg[q];
       if (g.add_shift && sc == 0) {  // the scalar term (coupleJ * ovlp, _contraction.py:1200-1216) rides on chunk 0
@@ -396,7 +461,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
       }
       stz_sh(Pmine + q, v);
     }
-    if (!ss_exchange(sy, pay, 0, red, wsh, ctl)) {
+    if (!ss_exchange(sy, pay, 0, red, wsh)) {
       if (blockIdx.x == 0 && tid == 0) atomicMax(g.err_w, (unsigned)SS_ETIMEOUT);
       return;
     }
@@ -442,9 +507,9 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     s = wave_sum64(s);
     if ((tid & 63) == 0) wsh[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+    if (tid == 0) pay[0] = wtree(wsh);
     __syncthreads();
-    if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+    if (!ss_exchange(sy, pay, 1, red, wsh)) { fail(SS_ETIMEOUT); return; }
     beta0 = sqrt(red[0]);
     if (beta0 == 0.0) { fail(SS_EZERO); return; }
   }
@@ -459,13 +524,14 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
   int napply = 0;
   for (int l = 0; l < ndim; ++l) {
     // ---- sigma = Op v_l : chunk partials + the projections that are linear in them ----------
+    stamp(10);
     load_B(l == 0 ? g.x : g.U + (size_t)l * N, l != 0, invb[l]);
+    stamp(11);
     const int jlo = lanczos ? (ex.variant == 0 ? 0 : l) : 0;
     const int jhi = lanczos ? jlo : l;
-    double dre[MAXK], dim_[MAXK];
-#pragma unroll
-    for (int j = 0; j < MAXK; ++j) { dre[j] = 0.0; dim_[j] = 0.0; }
     chain();
+    stamp(12);
+    // store this chunk's partial (with the scalar term on chunk 0) and keep the shifted values in Sg
     for (int q = tid; q < slab; q += SS_THREADS) {
       zc v = Sg[q];
       const long e = (long)a * slab + q;
@@ -473,31 +539,41 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         const zc vl = basis(l, e);
         v.x += g.shift.x * vl.x - g.shift.y * vl.y;
         v.y += g.shift.x * vl.y + g.shift.y * vl.x;
+        Sg[q] = v;
       }
       stz_sh(Pmine + q, v);
-#pragma unroll
-      for (int j = 0; j < MAXK; ++j)
-        if (j <= jhi - jlo) {
-          const zc b = basis(jlo + j, e);  // conj(b) * v
-          dre[j] += b.x * v.x + b.y * v.y;
-          dim_[j] += b.x * v.y - b.y * v.x;
-        }
     }
     napply += 1;
     {
       const int nd = jhi - jlo + 1;
       const int lane = tid & 63, w = tid >> 6;
-      __syncthreads();
+      // projections <v_j | partial>, four basis vectors per pass (registers: 1024-thread workgroups get 128)
+      for (int j0 = 0; j0 < nd; j0 += 4) {
+        double dre[4] = {0.0, 0.0, 0.0, 0.0}, dim_[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int q = tid; q < slab; q += SS_THREADS) {
+          const zc v = Sg[q];
+          const long e = (long)a * slab + q;
 #pragma unroll
-      for (int j = 0; j < MAXK; ++j)
-        if (j < nd) {
-          const double r1 = wave_sum64(dre[j]), r2 = wave_sum64(dim_[j]);
-          if (lane == 0) { wsh[(2 * j) * 4 + w] = r1; wsh[(2 * j + 1) * 4 + w] = r2; }
+          for (int j = 0; j < 4; ++j)
+            if (j0 + j < nd) {
+              const zc b = basis(jlo + j0 + j, e);  // conj(b) * v
+              dre[j] += b.x * v.x + b.y * v.y;
+              dim_[j] += b.x * v.y - b.y * v.x;
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j0 + j < nd) {
+            const double r1 = wave_sum64(dre[j]), r2 = wave_sum64(dim_[j]);
+            if (lane == 0) { wsh[(2 * (j0 + j)) * SS_WAVES + w] = r1; wsh[(2 * (j0 + j) + 1) * SS_WAVES + w] = r2; }
+          }
+      }
       __syncthreads();
-      if (tid < 2 * nd) pay[tid] = (wsh[tid * 4 + 0] + wsh[tid * 4 + 1]) + (wsh[tid * 4 + 2] + wsh[tid * 4 + 3]);
+      if (tid < 2 * nd) pay[tid] = wtree(wsh + tid * SS_WAVES);
       __syncthreads();
-      if (!ss_exchange(sy, pay, 2 * nd, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+      stamp(13);
+      if (!ss_exchange(sy, pay, 2 * nd, red, wsh)) { fail(SS_ETIMEOUT); return; }
+      stamp(14);
       if (tid == 0) {
         if (lanczos) alpha[l] = make_double2(red[0], red[1]);
         else
@@ -540,9 +616,11 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
       __syncthreads();
       if ((tid & 63) == 0) wsh[tid >> 6] = s;
       __syncthreads();
-      if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+      if (tid == 0) pay[0] = wtree(wsh);
       __syncthreads();
-      if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+      stamp(15);
+      if (!ss_exchange(sy, pay, 1, red, wsh)) { fail(SS_ETIMEOUT); return; }
+      stamp(16);
     }
     // ---- scalars; decide what this iteration inspects (_integrator.py:569-652, :392-430) --------
     if (tid == 0) {
@@ -571,9 +649,11 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     // ---- coef = exp(scale * T_k) e_0 ------------------------------------------------------------
     {
       zc* Tm = Bs;
-      zc* Pm = Tm + MAXK * MAXK;
-      zc* Em = Pm + MAXK * MAXK;
-      zc* Qm = Em + MAXK * MAXK;
+      zc* M2 = Tm + MAXK * MAXK;
+      zc* M3 = M2 + MAXK * MAXK;
+      zc* M4 = M3 + MAXK * MAXK;
+      zc* Pm = M4 + MAXK * MAXK;
+      zc* Qm = Pm + MAXK * MAXK;
       for (int t = tid; t < k * k; t += SS_THREADS) {
         const int i = t / k, j = t - i * k;
         zc z = make_double2(0.0, 0.0);
@@ -587,7 +667,9 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         Tm[t] = make_double2(scale.x * z.x - scale.y * z.y, scale.x * z.y + scale.y * z.x);
       }
       __syncthreads();
-      ss_expm_col0(Tm, Pm, Em, Qm, k, coef, wsh);
+      stamp(17);
+      ss_expm_col0(Tm, M2, M3, M4, Pm, Qm, k, coef, wsh);
+      stamp(18);
     }
     if (act == 1) {
       if (have_prev) {  // || psi_k - psi_{k-1} ||  (:644-652)
@@ -607,9 +689,9 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         __syncthreads();
         if ((tid & 63) == 0) wsh[tid >> 6] = s;
         __syncthreads();
-        if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+        if (tid == 0) pay[0] = wtree(wsh);
         __syncthreads();
-        if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+        if (!ss_exchange(sy, pay, 1, red, wsh)) { fail(SS_ETIMEOUT); return; }
         if (sqrt(red[0]) < ex.thresh) act = 2;
       }
       if (act == 1) {
@@ -645,9 +727,9 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         __syncthreads();
         if ((tid & 63) == 0) wsh[tid >> 6] = s;
         __syncthreads();
-        if (tid == 0) pay[0] = (wsh[0] + wsh[1]) + (wsh[2] + wsh[3]);
+        if (tid == 0) pay[0] = wtree(wsh);
         __syncthreads();
-        if (!ss_exchange(sy, pay, 1, red, wsh, ctl)) { fail(SS_ETIMEOUT); return; }
+        if (!ss_exchange(sy, pay, 1, red, wsh)) { fail(SS_ETIMEOUT); return; }
         const double inv = 1.0 / sqrt(red[0]);
         for (long e = e0 + tid; e < e1; e += SS_THREADS) {  // same thread wrote g.U[e] above
           zc z = g.U[e];
@@ -684,18 +766,20 @@ bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
   if (c.na < 1 || c.ns < 1 || c.nr < 1 || c.nb < 1) return false;
   const int gmax = std::min(n_cu, SS_MAXG);
   if (c.na > gmax) return false;
-  // as many chunks as the CU count allows, but keep chunks at least 4 wide (a chunk row is one 64-byte segment)
-  for (int nsc = 8; nsc >= 1; nsc >>= 1) {
-    if (c.na * nsc > gmax) continue;
+  // chunks over s: enough workgroups that one holds about 0.4 Mflop of the chain (beyond that the exchanges
+  // between workgroups, not the arithmetic, set the pace), at least 4 columns per chunk, LDS permitting
+  const double flops = 8.0 * c.na * ((double)c.nc * c.nb * c.nj * c.ns + (c.W2 ? (double)c.ni * c.nt * c.nc * c.nj * c.ns : 0.0) +
+                                     (double)c.ni * c.nt * c.ns * c.nr);
+  int want = 1;
+  while (want < 8 && flops / ((double)c.na * want) > 0.6e6) want *= 2;
+  for (int nsc = want; nsc <= 8; nsc *= 2) {
+    if (c.na * nsc > gmax) break;
     const int cs = (c.ns + nsc - 1) / nsc;
-    if (nsc > 1 && cs < 4) continue;
+    if (nsc > 1 && cs < 4) break;
     if ((nsc - 1) * cs >= c.ns) continue;  // every chunk must be non-empty
     c.nsc = nsc;
     c.cs = cs;
-    const size_t lds = small_chain_lds(c, exp_mode);
-    // more than half of a CU's 160 KiB: one workgroup per CU, all resident, the protocol's measured regime;
-    // below that the launch pads its request
-    if (lds <= 150 * 1024) return true;
+    if (small_chain_lds(c, exp_mode) <= 150 * 1024) return true;
   }
   return false;
 }
@@ -703,11 +787,11 @@ bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
 void small_sync_alloc(SmallSync& s, int nsite, hipStream_t st) {
   if (s.words) return;
   HIP_CHECK(hipMalloc(&s.words, 16 * sizeof(unsigned)));
-  HIP_CHECK(hipMalloc(&s.slots, (size_t)2 * SS_MAXG * SS_PAYMAX * sizeof(double)));
+  HIP_CHECK(hipMalloc(&s.slots, (size_t)2 * SS_MAXG * SS_NGR * sizeof(unsigned long long)));
   HIP_CHECK(hipMalloc(&s.stats, 4 * sizeof(long long)));
   HIP_CHECK(hipMalloc(&s.kprev, (size_t)std::max(nsite, 1) * sizeof(int)));
   HIP_CHECK(hipMemsetAsync(s.words, 0, 16 * sizeof(unsigned), st));
-  HIP_CHECK(hipMemsetAsync(s.slots, 0, (size_t)2 * SS_MAXG * SS_PAYMAX * sizeof(double), st));
+  HIP_CHECK(hipMemsetAsync(s.slots, 0, (size_t)2 * SS_MAXG * SS_NGR * sizeof(unsigned long long), st));
   HIP_CHECK(hipMemsetAsync(s.stats, 0, 4 * sizeof(long long), st));
   HIP_CHECK(hipMemsetAsync(s.kprev, 0, (size_t)std::max(nsite, 1) * sizeof(int), st));
   HIP_CHECK(hipStreamSynchronize(st));
@@ -729,7 +813,7 @@ static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
   if (c.na * c.nsc > SS_MAXG) throw ArgError("small_site: grid exceeds the resident-workgroup bound");
   if (!c.W2 && (c.ni != 1 || c.nj != 1 || c.nt != c.nc)) throw ArgError("small_site: chain without W stage needs ni = nj = 1, nt = nc");
   size_t lds = small_chain_lds(c, exp_mode);
-  if (lds > 160 * 1024) throw ArgError("small_site: chain does not fit LDS");
+  if (lds > 156 * 1024) throw ArgError("small_site: chain does not fit LDS");
   lds = std::max<size_t>(lds, 84 * 1024);  // > half a CU's LDS: at most one workgroup per CU
   int dev = 0;
   HIP_CHECK(hipGetDevice(&dev));
@@ -738,19 +822,41 @@ static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
   std::lock_guard<std::mutex> lk(attr_mu);
   if (dev >= 64 || !attr_set[dev]) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_site), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024));
+                                  156 * 1024));  // the kernel's few static LDS words come out of the same 160 KiB
     if (dev < 64) attr_set[dev] = true;
   }
-  g.ctr = sy.words + (sy.launches & 1u);
-  g.ctr_other = sy.words + ((sy.launches + 1u) & 1u);
+  // exchange tags are unique per launch: 4096 epochs each (a launch needs at most 4 * MAXK + 2)
+  sy.launches += 1;
+  if ((sy.launches & 0xFFFFFu) == 0u) {  // tag space wraps: forget the old granules
+    HIP_CHECK(hipMemsetAsync(sy.slots, 0, (size_t)2 * SS_MAXG * SS_NGR * sizeof(unsigned long long), st));
+    sy.launches += 1;
+  }
+  g.epoch0 = (sy.launches & 0xFFFFFu) << 12;
   g.abort_w = sy.words + 2;
   g.err_w = sy.words + 3;
-  g.slots = sy.slots;
+  g.gran = reinterpret_cast<unsigned long long*>(sy.slots);
   g.stats = sy.stats;
   g.kprev = sy.kprev;
-  sy.launches += 1;
+  static const bool tracing = std::getenv("MITDVP_SS_TRACE") != nullptr;
+  static long long* trace_buf = nullptr;
+  if (tracing && !trace_buf) {
+    HIP_CHECK(hipMalloc(&trace_buf, 1024 * sizeof(long long)));
+  }
+  g.trace = tracing ? trace_buf : nullptr;
+  if (tracing) HIP_CHECK(hipMemsetAsync(trace_buf, 0, 1024 * sizeof(long long), st));
   hipLaunchKernelGGL(k_small_site, dim3(c.na * c.nsc), dim3(SS_THREADS), lds, st, g);
   HIP_CHECK(hipGetLastError());
+  if (tracing) {  // debugging aid: phase timeline of workgroup 0, microseconds since its first stamp
+    long long h[1024];
+    HIP_CHECK(hipMemcpyAsync(h, trace_buf, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    fprintf(stderr, "[ss_trace] mode=%d G=%d (na=%d nsc=%d cs=%d) lds=%zu:", g.mode, c.na * c.nsc, c.na, c.nsc, c.cs, lds);
+    for (int i = 1; i < (int)h[0] && i < 250; ++i) fprintf(stderr, " %lld:%.2f", h[2 * i + 1], (double)(h[2 * i] - h[2]) * 0.01);
+    const int nn = (int)h[0];
+    if (nn > 2)
+      fprintf(stderr, " | shader clock %.0f MHz", (double)(h[512 + nn - 1] - h[512 + 1]) / ((double)(h[2 * (nn - 1)] - h[2]) * 0.01));
+    fprintf(stderr, "\n");
+  }
 }
 
 void small_apply(hipStream_t st, SmallSync& sy, const SmallChain& c, const zc* v, zc* out, zc* partials, zc shift,
