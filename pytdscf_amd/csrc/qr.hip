@@ -13,6 +13,7 @@
 // O(m n^2) goes through the MFMA zgemm kernel.
 #include "qr.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "vecops.h"
@@ -270,6 +271,150 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 }
 
 // ---------------------------------------------------------------------------
+// Small matrices (one panel, m <= 16 * RPT rows): the WHOLE factorisation in one launch of one workgroup --
+// zgeqr2, R, and zung2r (Q = H_0 ... H_{n-1} [I; 0]) -- with the matrix in registers.
+//
+// Thread (rg, c) = (tid / 32, tid % 32) owns column c of the rows i = rg + 16 q, q < RPT.  A column step needs
+// the products y_c = sum_i conj(A[i,j]) A[i,c] over all rows (see k_qr_col): every thread adds up its rows, the
+// two row groups of a wave are combined with one cross-lane add, the 8 waves through LDS; one workgroup
+// barrier for the sums.  A[i,j] for "my row" lives in other threads: the owners of column j stage it in LDS
+// (one more barrier; per-row cross-lane reads instead would go through the LDS crossbar 80 times per step
+// and wave, which made this kernel slower than the 45 launches it replaces).
+// Same arithmetic as the multi-launch panel (LAPACK's sign convention, beta real).
+// ---------------------------------------------------------------------------
+template <int RPT>
+__global__ __launch_bounds__(512) void k_qr_small(const zc* __restrict__ A, int m, int n, zc* __restrict__ Q,
+                                                   zc* __restrict__ R) {
+  constexpr int NRG = 16, NW = 8;  // 16 row groups x 32 columns = 512 threads: 256 registers per thread
+  __shared__ zc part[2][NW][32];
+  __shared__ zc rowj[2][32];
+  __shared__ zc xc[2][NRG * RPT];  // one column of the matrix (all rows): the reflector's source
+  __shared__ zc taus[32];
+  const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, w = tid >> 6, lane = tid & 63;
+  zc a[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int i = rg + NRG * q;
+    a[q] = (i < m && c < n) ? A[(long)i * n + c] : make_double2(0.0, 0.0);
+  }
+  // the owners of column jn put it into LDS (row index order)
+  auto stage_col = [&](int jn, int buf) {
+    if (c == jn) {
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) xc[buf][rg + NRG * q] = a[q];
+    }
+  };
+  // partial products y_c = sum_{i > jn} conj(A[i,jn]) A[i,c] over my rows, and row jn itself
+  auto publish = [&](int jn, int buf) {
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = rg + NRG * q;
+      const zc x = xc[buf][i];
+      if (i > jn && i < m && c >= jn && c < n) {
+        sr += x.x * a[q].x + x.y * a[q].y;
+        si += x.x * a[q].y - x.y * a[q].x;
+      }
+      if (i == jn) rowj[buf][c] = a[q];
+    }
+    sr += __shfl_xor(sr, 32, 64);
+    si += __shfl_xor(si, 32, 64);
+    if (lane < 32) part[buf][w][c] = make_double2(sr, si);
+  };
+  auto total = [&](int buf, int col) -> zc {
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int u = 0; u < NW; ++u) { const zc p = part[buf][u][col]; sr += p.x; si += p.y; }
+    return make_double2(sr, si);
+  };
+  stage_col(0, 0);
+  __syncthreads();
+  publish(0, 0);
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const int buf = j & 1;
+    const zc yj = total(buf, j), yc = total(buf, c);
+    const House h = zlarfg(rowj[buf][j], yj.x);
+    zc f = make_double2(0.0, 0.0);
+    const bool active = c > j && c < n;
+    if (active) f = zmul(zconj(h.tau), zadd(zmul(zconj(h.scale), yc), rowj[buf][c]));
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = rg + NRG * q;
+      if (i >= j && i < m) {
+        const zc v = (i == j) ? make_double2(1.0, 0.0) : zmul(xc[buf][i], h.scale);
+        if (active) a[q] = zsub(a[q], zmul(v, f));
+        else if (c == j) a[q] = (i == j) ? make_double2(h.beta, 0.0) : v;
+      }
+    }
+    if (tid == 0) taus[j] = h.tau;
+    if (j + 1 < n) {
+      stage_col(j + 1, buf ^ 1);
+      __syncthreads();
+      publish(j + 1, buf ^ 1);
+    }
+    __syncthreads();
+  }
+  // R: upper triangle of the first n rows
+  if (R) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = rg + NRG * q;
+      if (i < n && c < n) R[(long)i * n + c] = c >= i ? a[q] : make_double2(0.0, 0.0);
+    }
+  }
+  if (!Q) return;
+  // zung2r: Q = H_0 ... H_{n-1} [I; 0], reflectors applied last to first
+  zc qv[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) qv[q] = (rg + NRG * q == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+  for (int j = n - 1; j >= 0; --j) {
+    const int buf = j & 1;
+    if (c == j) {  // v_j: 1 on the diagonal, the stored reflector below it, 0 above
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const int i = rg + NRG * q;
+        xc[buf][i] = (i == j) ? make_double2(1.0, 0.0) : ((i > j && i < m) ? a[q] : make_double2(0.0, 0.0));
+      }
+    }
+    __syncthreads();
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const zc v = xc[buf][rg + NRG * q];
+      sr += v.x * qv[q].x + v.y * qv[q].y;  // conj(v) * q
+      si += v.x * qv[q].y - v.y * qv[q].x;
+    }
+    sr += __shfl_xor(sr, 32, 64);
+    si += __shfl_xor(si, 32, 64);
+    if (lane < 32) part[buf][w][c] = make_double2(sr, si);
+    __syncthreads();
+    const zc tw = zmul(taus[j], total(buf, c));
+    if (c >= j && c < n) {
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) qv[q] = zsub(qv[q], zmul(xc[buf][rg + NRG * q], tw));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int i = rg + NRG * q;
+    if (i < m && c < n) Q[(long)i * n + c] = qv[q];
+  }
+}
+
+static bool qr_small_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R) {
+  if (n > 32 || m > 320) return false;
+  const int rpt = (m + 15) / 16;
+  if (rpt <= 2) hipLaunchKernelGGL(k_qr_small<2>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
+  else if (rpt <= 4) hipLaunchKernelGGL(k_qr_small<4>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
+  else if (rpt <= 8) hipLaunchKernelGGL(k_qr_small<8>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
+  else if (rpt <= 12) hipLaunchKernelGGL(k_qr_small<12>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
+  else hipLaunchKernelGGL(k_qr_small<20>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// ---------------------------------------------------------------------------
 // rows per workgroup in the panel kernels: enough workgroups to spread a column
 // step over the chip, few enough that summing their partials stays cheap
 // (measured: 32 rows per workgroup win up to the C4 shape 16384 x 1024 -- 61 vs 66 ms for the seven QRs of a
@@ -295,6 +440,11 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
   if (next < 0 || n + next > m) throw ArgError("qr: more orthogonal-complement columns requested than exist");
   if (n <= 0) return;
+  static const bool small_on = !(std::getenv("MITDVP_SMALL_KERNELS") && std::atoi(std::getenv("MITDVP_SMALL_KERNELS")) == 0);
+  if (next == 0 && small_on && qr_small_launch(st, A, m, n, Q, R)) {  // one launch, matrix in registers
+    if (nlaunch) *nlaunch += 1;
+    return;
+  }
   const int nqt = n + next;  // columns of Q: the thin factor and `next` columns of LAPACK's full Q
   const long lda = n;
   const int rows = qr_rows_for(m);
