@@ -77,6 +77,7 @@ enum { COLL_ALLGATHER = 0, COLL_ALLREDUCE = 1 };
 struct PhaseTimer {
   hipEvent_t a, b;
   int kind;
+  bool closed;  // the end event was recorded (an exception between begin and end leaves it open)
 };
 
 class Engine {

@@ -82,12 +82,13 @@ void Engine::timer_begin(int kind) {
   if (!evpool_.empty()) { ev = evpool_.back(); evpool_.pop_back(); }
   else { HIP_CHECK(hipEventCreate(&ev.first)); HIP_CHECK(hipEventCreate(&ev.second)); }
   HIP_CHECK(hipEventRecord(ev.first, st_));
-  pending_.push_back(PhaseTimer{ev.first, ev.second, kind});
+  pending_.push_back(PhaseTimer{ev.first, ev.second, kind, false});
   cur_timer_ = (int)pending_.size() - 1;
 }
 void Engine::timer_end() {
   if (!profiling_ || cur_timer_ < 0) return;
   HIP_CHECK(hipEventRecord(pending_[cur_timer_].b, st_));
+  pending_[cur_timer_].closed = true;
   cur_timer_ = -1;
   if (pending_.size() > 8192) resolve_timers();
 }
@@ -96,6 +97,10 @@ void Engine::resolve_timers() {
   HIP_CHECK(hipStreamSynchronize(st_));
   for (auto& t : pending_) {
     float ms = 0;
+    if (!t.closed) {  // unwound between begin and end: nothing to read, the events go back to the pool
+      evpool_.emplace_back(t.a, t.b);
+      continue;
+    }
     HIP_CHECK(hipEventElapsedTime(&ms, t.a, t.b));
     switch (t.kind) {
       case 0: cnt_.heff_ms += ms; break;
@@ -111,6 +116,7 @@ void Engine::resolve_timers() {
     evpool_.emplace_back(t.a, t.b);
   }
   pending_.clear();
+  cur_timer_ = -1;
 }
 void Engine::counters_get(mitdvp_counters* out) {
   ss_dirty_ = ss_dirty_ || ss_.words != nullptr;

@@ -42,7 +42,14 @@ struct House {
   zc scale;
 };
 
-// LAPACK zlarfg without the safmin rescaling loop
+// LAPACK zlarfg.  The products that feed it are sums of SQUARES (xnorm2, |alpha|^2), so a column whose
+// entries are below sqrt(safmin) ~ 1.5e-154 underflows to xnorm2 = 0 and LAPACK's rescaling loop (which
+// works on the vector itself) cannot be reproduced from the scalars alone.  What can: when the squares
+// have underflowed into the subnormal range or to zero although alpha is not zero, the norm is formed
+// from the scaled quantities (alpha / s, xnorm2 / s^2) so that beta, tau and the scale factor keep full
+// relative accuracy for |x| down to ~1e-154; below that the column is treated as H = I like LAPACK does
+// for an exactly zero tail (tau = 0).  Zero-padded initial states (rank-deficient columns that are exactly
+// zero) take the tau = 0 branch.
 __device__ __forceinline__ House zlarfg(zc alpha, double xnorm2) {
   House h;
   if (xnorm2 == 0.0 && alpha.y == 0.0) {
@@ -51,13 +58,17 @@ __device__ __forceinline__ House zlarfg(zc alpha, double xnorm2) {
     h.scale = make_double2(0.0, 0.0);
     return h;
   }
-  const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2);
+  // scale so that the largest of |re alpha|, |im alpha|, sqrt(xnorm2) is O(1): no over-/underflow in the squares
+  const double big = fmax(fmax(fabs(alpha.x), fabs(alpha.y)), sqrt(xnorm2));
+  const double s = (big > 1e100 || big < 1e-100) && big > 0.0 ? big : 1.0;
+  const double ar = alpha.x / s, ai = alpha.y / s;
+  const double nrm = s * sqrt(ar * ar + ai * ai + (xnorm2 / s) / s);
   const double beta = alpha.x >= 0.0 ? -nrm : nrm;
   h.beta = beta;
   h.tau = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
-  const double dr = alpha.x - beta, di = alpha.y;
+  const double dr = (alpha.x - beta) / s, di = alpha.y / s;
   const double den = dr * dr + di * di;
-  h.scale = make_double2(dr / den, -di / den);
+  h.scale = make_double2(dr / den / s, -di / den / s);
   return h;
 }
 

@@ -38,8 +38,12 @@ __device__ __forceinline__ double svd_block_sum(double v, double* sh) {
 }
 
 // one tournament step: workgroup k rotates the row pair it is assigned in round r
+// tiny2: squared norm below which a row counts as numerically null (1e-28 x the largest squared row norm
+// of the input, i.e. a singular value 1e-14 below the largest): such rows carry rounding noise only, their
+// normalised inner products are O(1) for ever, so they neither rotate nor hold up the convergence test
+// (rank-deficient matrices: direct sums with repeated channels, zero-padded bond matrices).
 __global__ __launch_bounds__(256) void k_jacobi_step(zc* __restrict__ M, zc* __restrict__ W, int nrow, int ncol, int np,
-                                                     int round, unsigned long long* __restrict__ offmax) {
+                                                     int round, unsigned long long* __restrict__ offmax, double tiny2) {
   __shared__ double sh[5];
   // round-robin pairing of np (even) players; player np-1 is fixed
   const int k = blockIdx.x;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void k_jacobi_step(zc* __restrict__ M, zc* __r
   gr = svd_block_sum(gr, sh);
   gi = svd_block_sum(gi, sh);
   const double g2 = gr * gr + gi * gi;
-  if (!(g2 > 0.0) || !(a > 0.0) || !(b > 0.0)) return;
+  if (!(g2 > 0.0) || !(a > tiny2) || !(b > tiny2)) return;
   const double rel = g2 / (a * b);
   if (threadIdx.x == 0) atomicMax(offmax, (unsigned long long)__double_as_longlong(rel));
   if (rel <= 1e-32) return;
@@ -117,14 +121,22 @@ __global__ __launch_bounds__(256) void k_svd_gather(const zc* __restrict__ M, co
 
 // Orthogonalise the rows of M (nr x nc) in place by Jacobi rotations (optionally accumulating
 // them in W); returns the number of sweeps.  off_dev: one device word for the convergence flag.
-static int jacobi_rows(hipStream_t st, zc* M, zc* W, int nr, int nc, unsigned long long* off_dev) {
+static int jacobi_rows(hipStream_t st, zc* M, zc* W, int nr, int nc, unsigned long long* off_dev, double* s_dev) {
   const int np = nr + (nr & 1);
   int sweeps = 0;
   if (nr <= 1) return 0;
+  // scale of the input: the largest row norm (rotations only move norm between rows, they never create it)
+  hipLaunchKernelGGL(k_row_norms, dim3(nr), dim3(256), 0, st, M, nc, s_dev);
+  std::vector<double> s0(nr);
+  HIP_CHECK(hipMemcpyAsync(s0.data(), s_dev, nr * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  double smax = 0.0;
+  for (double v : s0) smax = std::max(smax, v);
+  const double tiny2 = 1e-28 * smax * smax;
   for (; sweeps < 60; ++sweeps) {
     HIP_CHECK(hipMemsetAsync(off_dev, 0, sizeof(unsigned long long), st));
     for (int round = 0; round < np - 1; ++round)
-      hipLaunchKernelGGL(k_jacobi_step, dim3(np / 2), dim3(256), 0, st, M, W, nr, nc, np, round, off_dev);
+      hipLaunchKernelGGL(k_jacobi_step, dim3(np / 2), dim3(256), 0, st, M, W, nr, nc, np, round, off_dev, tiny2);
     HIP_CHECK(hipGetLastError());
     unsigned long long bits = 0;
     HIP_CHECK(hipMemcpyAsync(&bits, off_dev, sizeof(bits), hipMemcpyDeviceToHost, st));
@@ -143,7 +155,7 @@ static int jacobi_rows(hipStream_t st, zc* M, zc* W, int nr, int nc, unsigned lo
 void svd_rows_us(hipStream_t st, zc* M, int nr, int nc, double* S_host, int* idx_dev, zc* work, int* sweeps_out) {
   double* s_dev = reinterpret_cast<double*>(work);
   unsigned long long* off_dev = reinterpret_cast<unsigned long long*>(work + (nr + 1) / 2 + 1);
-  const int sw = jacobi_rows(st, M, nullptr, nr, nc, off_dev);
+  const int sw = jacobi_rows(st, M, nullptr, nr, nc, off_dev, s_dev);
   hipLaunchKernelGGL(k_row_norms, dim3(nr), dim3(256), 0, st, M, nc, s_dev);
   std::vector<double> s(nr);
   HIP_CHECK(hipMemcpyAsync(s.data(), s_dev, nr * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -177,7 +189,7 @@ void svd_jacobi(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host
   if (tr) transpose_batched(st, A, M, r, c, c, r, 1, 0, 0);
   else HIP_CHECK(hipMemcpyAsync(M, A, (size_t)r * c * sizeof(zc), hipMemcpyDeviceToDevice, st));
   set_identity(st, W, nr, nr, nr);
-  const int sweeps = jacobi_rows(st, M, W, nr, nc, off_dev);
+  const int sweeps = jacobi_rows(st, M, W, nr, nc, off_dev, s_dev);
   hipLaunchKernelGGL(k_row_norms, dim3(nr), dim3(256), 0, st, M, nc, s_dev);
   std::vector<double> s(nr);
   HIP_CHECK(hipMemcpyAsync(s.data(), s_dev, nr * sizeof(double), hipMemcpyDeviceToHost, st));

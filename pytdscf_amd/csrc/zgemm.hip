@@ -443,11 +443,19 @@ static void launch_one(hipStream_t st, const ZgemmDesc& d, dim3 grid, int ntm, i
   constexpr int B_SZ = TB ? BN * (BK + 1) : BK * BN;
   constexpr size_t lds = 2 * (size_t)(A_SZ + B_SZ) * sizeof(zc);
   auto kern = zgemm_kernel<WM, WN, BK, TA, TB, M3>;
-  static std::once_flag attr_once;  // one flag per instantiation
-  std::call_once(attr_once, [&] {
-    if (lds > 65536)
+  if (lds > 65536) {
+    // the attribute is per DEVICE (a process may hold engines on several GPUs): one flag per
+    // instantiation and device ordinal
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  });
+      if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, ntm, ntn, g_cd_mode);
 }
 
@@ -542,6 +550,7 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.K < 0) throw ArgError("zgemm: negative K");
   if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
   {
+    // the accumulator lane map is a property of the gfx950 ISA, not of a device: once per process
     static std::once_flag probe_once;  // several engines may issue their first GEMM concurrently
     std::call_once(probe_once, [&] { if (g_cd_mode < 0) mfma_layout_probe(st, nullptr); });
   }
