@@ -513,7 +513,7 @@ void Engine::gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* 
   HIP_CHECK(hipMemcpyAsync(tmp1_.p, psi, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
   timer_begin(3);
   long nl = 0;
-  qr_householder(st_, tmp1_.p, dl * d, dr, A_out, sigma_out, qrwork_.p, &nl);
+  qr_householder(st_, tmp1_.p, dl * d, dr, A_out, sigma_out, qrwork_.p, &nl, 0, qr_sync());
   timer_end();
   cnt_.n_launch += nl;
   cnt_.n_qr += 1;
@@ -525,7 +525,7 @@ void Engine::gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc*
   timer_begin(3);
   long nl = 0;
   transpose_rev3(st_, psi, tmp1_.p, dl, d, dr);  // (dr, d, dl)
-  qr_householder(st_, tmp1_.p, dr * d, dl, Bt_out, sig2_.p, qrwork_.p, &nl);
+  qr_householder(st_, tmp1_.p, dr * d, dl, Bt_out, sig2_.p, qrwork_.p, &nl, 0, qr_sync());
   transpose_batched(st_, sig2_.p, sigma_out, dl, dl, dl, dl, 1, 0, 0);  // sigma = R^T
   if (B_out) transpose_rev3(st_, Bt_out, B_out, dr, d, dl);             // (dl, d, dr)
   timer_end();
@@ -693,7 +693,7 @@ void Engine::sweep(double dt, bool forward) {
       // Psi2Asigma: site[p] (destroyed) -> A in spare, sigma in sig_
       timer_begin(3);
       long nl = 0;
-      qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl);
+      qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync());
       timer_end();
       cnt_.n_launch += nl; cnt_.n_qr += 1;
       cnt_.qr_flops += 4.0 * (4.0 * (double)dl * d * dr * dr - 4.0 * (double)dr * dr * dr / 3.0);

@@ -54,6 +54,13 @@ zc* Engine::ss_partials(const SmallChain& c) {
   return ss_part_.p;
 }
 
+SmallSync* Engine::qr_sync() {
+  if (!small_kernels_ || n_cu_ <= 0) return nullptr;
+  small_sync_alloc(ss_, L_, st_);
+  ss_dirty_ = true;
+  return &ss_;
+}
+
 // which sites run their local exponentials in one launch; device <-> host Krylov memories are
 // reconciled whenever the answer changes (shapes change rarely: adaptive ranks, new tensors)
 void Engine::ss_refresh_plan() {

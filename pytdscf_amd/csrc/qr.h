@@ -1,6 +1,7 @@
 // qr.h -- GPU Householder QR (see qr.hip)
 #pragma once
 #include "common.h"
+#include "small_site.h"
 
 namespace mitdvp {
 
@@ -12,6 +13,9 @@ size_t qr_work_elems(int m, int n, int next = 0);
 // Q (m x (n+next), ld = n+next) and R (n x n, ld = n, zero below the diagonal; may be
 // null) are written.  next > 0 appends the first `next` columns of the orthogonal
 // complement exactly as LAPACK's full-mode Q orders them (H_1..H_n applied to e_{n+1}..).
-void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next = 0);
+// sy: the engine's exchange state (granule buffer, abort / error words); with it every 32-column panel is
+// factored by ONE persistent launch instead of 37 (nullptr: the per-column launches).
+void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next = 0,
+                    SmallSync* sy = nullptr);
 
 }  // namespace mitdvp

@@ -13,9 +13,13 @@
 // O(m n^2) goes through the MFMA zgemm kernel.
 #include "qr.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
+#include "grid_exchange.h"
+#include "small_site.h"
 #include "vecops.h"
 
 namespace mitdvp {
@@ -283,7 +287,9 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 
 // ---------------------------------------------------------------------------
 // Small matrices (one panel, m <= 16 * RPT rows): the WHOLE factorisation in one launch of one workgroup --
-// zgeqr2, R, and zung2r (Q = H_0 ... H_{n-1} [I; 0]) -- with the matrix in registers.
+// zgeqr2, R, zlarft's T (its inner products v_c^H v_j ride on the column products for free) and
+// W = T V1^H -- with the matrix in registers; Q = [I; 0] - V W then takes one row-parallel launch
+// (zung2r inside the one workgroup would double its time: one compute unit's FP64 rate is the limit).
 //
 // Thread (rg, c) = (tid / 32, tid % 32) owns column c of the rows i = rg + 16 q, q < RPT.  A column step needs
 // the products y_c = sum_i conj(A[i,j]) A[i,c] over all rows (see k_qr_col): every thread adds up its rows, the
@@ -294,12 +300,15 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 // Same arithmetic as the multi-launch panel (LAPACK's sign convention, beta real).
 // ---------------------------------------------------------------------------
 template <int RPT>
-__global__ __launch_bounds__(512) void k_qr_small(const zc* __restrict__ A, int m, int n, zc* __restrict__ Q,
-                                                   zc* __restrict__ R) {
+__global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int n, zc* __restrict__ R,
+                                                  zc* __restrict__ Wout) {
   constexpr int NRG = 16, NW = 8;  // 16 row groups x 32 columns = 512 threads: 256 registers per thread
   __shared__ zc part[2][NW][32];
   __shared__ zc rowj[2][32];
   __shared__ zc xc[2][NRG * RPT];  // one column of the matrix (all rows): the reflector's source
+  __shared__ zc Ts[32][33];        // strictly upper part: G = V^H V as the reflectors appear; then W = T V1^H
+  __shared__ zc V1[32][33];        // unit lower triangle of the top n x n block
+  __shared__ zc Ws[32][33];
   __shared__ zc taus[32];
   const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, w = tid >> 6, lane = tid & 63;
   zc a[RPT];
@@ -308,6 +317,7 @@ __global__ __launch_bounds__(512) void k_qr_small(const zc* __restrict__ A, int 
     const int i = rg + NRG * q;
     a[q] = (i < m && c < n) ? A[(long)i * n + c] : make_double2(0.0, 0.0);
   }
+  for (int e = tid; e < 32 * 33; e += 512) (&Ts[0][0])[e] = make_double2(0.0, 0.0);
   // the owners of column jn put it into LDS (row index order)
   auto stage_col = [&](int jn, int buf) {
     if (c == jn) {
@@ -315,14 +325,15 @@ __global__ __launch_bounds__(512) void k_qr_small(const zc* __restrict__ A, int 
       for (int q = 0; q < RPT; ++q) xc[buf][rg + NRG * q] = a[q];
     }
   };
-  // partial products y_c = sum_{i > jn} conj(A[i,jn]) A[i,c] over my rows, and row jn itself
+  // products sum_{i > jn} conj(A[i,jn]) A[i,c] over my rows, for EVERY column c: c >= jn feeds the
+  // reflector of column jn (k_qr_col), c < jn is v_c^H x_jn, what zlarft needs for T's column jn
   auto publish = [&](int jn, int buf) {
     double sr = 0.0, si = 0.0;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int i = rg + NRG * q;
       const zc x = xc[buf][i];
-      if (i > jn && i < m && c >= jn && c < n) {
+      if (i > jn && i < m && c < n) {
         sr += x.x * a[q].x + x.y * a[q].y;
         si += x.x * a[q].y - x.y * a[q].x;
       }
@@ -349,6 +360,9 @@ __global__ __launch_bounds__(512) void k_qr_small(const zc* __restrict__ A, int 
     zc f = make_double2(0.0, 0.0);
     const bool active = c > j && c < n;
     if (active) f = zmul(zconj(h.tau), zadd(zmul(zconj(h.scale), yc), rowj[buf][c]));
+    // G[c][j] = v_c^H v_j = conj(A[j,c]) + scale_j * conj(sum_{i>j} conj(x_i) v_c[i])   (c < j)
+    if (rg == 0 && c < j) Ts[c][j] = zadd(zconj(rowj[buf][c]), zmul(h.scale, zconj(yc)));
+    if (tid == 0) taus[j] = h.tau;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int i = rg + NRG * q;
@@ -358,71 +372,202 @@ __global__ __launch_bounds__(512) void k_qr_small(const zc* __restrict__ A, int 
         else if (c == j) a[q] = (i == j) ? make_double2(h.beta, 0.0) : v;
       }
     }
-    if (tid == 0) taus[j] = h.tau;
-    if (j + 1 < n) {
-      stage_col(j + 1, buf ^ 1);
-      __syncthreads();
-      publish(j + 1, buf ^ 1);
-    }
+    if (j + 1 < n) stage_col(j + 1, buf ^ 1);
+    __syncthreads();
+    if (j + 1 < n) publish(j + 1, buf ^ 1);
     __syncthreads();
   }
-  // R: upper triangle of the first n rows
-  if (R) {
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int i = rg + NRG * q;
-      if (i < n && c < n) R[(long)i * n + c] = c >= i ? a[q] : make_double2(0.0, 0.0);
-    }
-  }
-  if (!Q) return;
-  // zung2r: Q = H_0 ... H_{n-1} [I; 0], reflectors applied last to first
-  zc qv[RPT];
-#pragma unroll
-  for (int q = 0; q < RPT; ++q) qv[q] = (rg + NRG * q == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
-  for (int j = n - 1; j >= 0; --j) {
-    const int buf = j & 1;
-    if (c == j) {  // v_j: 1 on the diagonal, the stored reflector below it, 0 above
-#pragma unroll
-      for (int q = 0; q < RPT; ++q) {
-        const int i = rg + NRG * q;
-        xc[buf][i] = (i == j) ? make_double2(1.0, 0.0) : ((i > j && i < m) ? a[q] : make_double2(0.0, 0.0));
-      }
-    }
-    __syncthreads();
-    double sr = 0.0, si = 0.0;
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const zc v = xc[buf][rg + NRG * q];
-      sr += v.x * qv[q].x + v.y * qv[q].y;  // conj(v) * q
-      si += v.x * qv[q].y - v.y * qv[q].x;
-    }
-    sr += __shfl_xor(sr, 32, 64);
-    si += __shfl_xor(si, 32, 64);
-    if (lane < 32) part[buf][w][c] = make_double2(sr, si);
-    __syncthreads();
-    const zc tw = zmul(taus[j], total(buf, c));
-    if (c >= j && c < n) {
-#pragma unroll
-      for (int q = 0; q < RPT; ++q) qv[q] = zsub(qv[q], zmul(xc[buf][rg + NRG * q], tw));
-    }
-  }
+  // reflectors and R back to memory (A is overwritten like LAPACK's zgeqrf does); R: upper triangle
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const int i = rg + NRG * q;
-    if (i < m && c < n) Q[(long)i * n + c] = qv[q];
+    if (i < m && c < n) A[(long)i * n + c] = a[q];
+    if (R && i < n && c < n) R[(long)i * n + c] = c >= i ? a[q] : make_double2(0.0, 0.0);
+    if (i < 32) V1[i][c] = (i < n && c < n) ? ((i == c) ? make_double2(1.0, 0.0) : (i > c ? a[q] : make_double2(0.0, 0.0)))
+                                            : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  // W = T V1^H (n x n) without forming T: T^-1 = striu(V^H V) + diag(1 / tau) (the compact-WY identity
+  // T^-1 + T^-H = V^H V), so W solves the upper-triangular system T^-1 W = V1^H: one back substitution per
+  // column, all columns side by side (thread c owns column c of W).  A reflector with tau = 0 (H = I) has a
+  // zero row and column in T: its row of W is zero.
+  if (rg == 0 && c < n) {
+    for (int t = n - 1; t >= 0; --t) {
+      zc acc = zconj(V1[c][t]);  // (V1^H)[t][c]
+      for (int sI = t + 1; sI < n; ++sI) acc = zsub(acc, zmul(Ts[t][sI], Ws[sI][c]));
+      const zc tt = taus[t];
+      const zc wv = (tt.x == 0.0 && tt.y == 0.0) ? make_double2(0.0, 0.0) : zmul(tt, acc);
+      Ws[t][c] = wv;
+      Wout[(long)t * n + c] = wv;
+    }
   }
 }
 
-static bool qr_small_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R) {
-  if (n > 32 || m > 320) return false;
+// Q[i][c] = delta_ic - sum_s V[i][s] W[s][c], V = unit lower trapezoid stored in the factored A
+__global__ __launch_bounds__(256) void k_qr_small_q(const zc* __restrict__ A, int m, int n, const zc* __restrict__ W,
+                                                    zc* __restrict__ Q) {
+  __shared__ zc Ws[32][33];
+  __shared__ zc Vs[8][33];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int i = blockIdx.x * 8 + r;
+  for (int e = threadIdx.x; e < n * n; e += 256) Ws[e / n][e % n] = W[e];
+  if (i < m && c < n) Vs[r][c] = (i == c) ? make_double2(1.0, 0.0) : (i > c ? A[(long)i * n + c] : make_double2(0.0, 0.0));
+  __syncthreads();
+  if (i >= m || c >= n) return;
+  zc acc = make_double2(i == c ? 1.0 : 0.0, 0.0);
+  const int smax = min(i, n - 1);
+  for (int sI = 0; sI <= smax; ++sI) acc = zsub(acc, zmul(Vs[r][sI], Ws[sI][c]));
+  Q[(long)i * n + c] = acc;
+}
+
+// work: n x n complex (W).  Returns the number of launches, 0 when the shape does not qualify.
+static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work) {
+  if (n > 32 || m > 320) return 0;
   const int rpt = (m + 15) / 16;
-  if (rpt <= 2) hipLaunchKernelGGL(k_qr_small<2>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
-  else if (rpt <= 4) hipLaunchKernelGGL(k_qr_small<4>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
-  else if (rpt <= 8) hipLaunchKernelGGL(k_qr_small<8>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
-  else if (rpt <= 12) hipLaunchKernelGGL(k_qr_small<12>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
-  else hipLaunchKernelGGL(k_qr_small<20>, dim3(1), dim3(512), 0, st, A, m, n, Q, R);
+  if (rpt <= 2) hipLaunchKernelGGL(k_qr_small<2>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
+  else if (rpt <= 4) hipLaunchKernelGGL(k_qr_small<4>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
+  else if (rpt <= 8) hipLaunchKernelGGL(k_qr_small<8>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
+  else if (rpt <= 12) hipLaunchKernelGGL(k_qr_small<12>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
+  else hipLaunchKernelGGL(k_qr_small<20>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
+  if (Q) hipLaunchKernelGGL(k_qr_small_q, dim3((m + 7) / 8), dim3(256), 0, st, A, m, n, work, Q);
   HIP_CHECK(hipGetLastError());
-  return true;
+  return Q ? 2 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// Panel factorisation in ONE persistent launch (any m up to 64 x 256 rows below the panel's first row).
+//
+// The per-column launches above cost a kernel boundary each (~6 us begin-to-begin on this GPU whatever the
+// kernel does).  Here a workgroup keeps 256 rows of the panel in registers for all 32 column steps; per step
+// the workgroups exchange their 32 partial column products through grid_exchange.h (one store -> load round
+// trip, ~3 us) and read the current row from a small double-buffered agent-scope buffer.  The products with
+// the FINISHED columns (c < j) travel along and give V^H V, hence zlarft's T (T^-1 = striu(V^H V) +
+// diag(1 / tau)) without the Gram GEMM; the unit-lower-trapezoid copy of the panel that the trailing
+// GEMMs take is written by the same kernel.  One launch replaces 33 + 4.
+// ---------------------------------------------------------------------------
+struct QrPanelArgs {
+  zc* A; long lda; int m, j0, j1;
+  zc* Vp;      // (m - j0) x nbp, unit lower trapezoid
+  zc* T;       // nbp x nbp
+  zc* tau;     // tau + j0
+  zc* rowbuf;  // [2][32] agent-scope row exchange
+  unsigned long long* gran; unsigned* abort_w; unsigned* err_w; unsigned epoch0;
+};
+
+template <int RPT>
+__global__ __launch_bounds__(512) void k_qr_panel(QrPanelArgs g) {
+  constexpr int NRG = 16, NW = 8, RB = NRG * RPT;
+  __shared__ zc part[NW][32];
+  __shared__ zc rowj[32];
+  __shared__ zc xc[2][RB];
+  __shared__ zc Gs[32][33];
+  __shared__ zc Tt[32][33];
+  __shared__ zc taus[32];
+  __shared__ double pay[64], red[64];
+  extern __shared__ __attribute__((aligned(16))) char dyn[];  // exchange scratch: G * 64 doubles
+  double* val = reinterpret_cast<double*>(dyn);
+  const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, w = tid >> 6, lane = tid & 63;
+  const int nbp = g.j1 - g.j0, m = g.m;
+  const int r0 = g.j0 + blockIdx.x * RB;
+  GxSync sy{g.gran, g.abort_w, (int)gridDim.x, (int)blockIdx.x, g.epoch0};
+  zc a[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int i = r0 + rg + NRG * q;
+    a[q] = (i < m && c < nbp) ? g.A[(long)i * g.lda + g.j0 + c] : make_double2(0.0, 0.0);
+  }
+  for (int e = tid; e < 32 * 33; e += 512) (&Gs[0][0])[e] = make_double2(0.0, 0.0);
+  auto stage_col = [&](int jj, int buf) {
+    if (c == jj) {
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) xc[buf][rg + NRG * q] = a[q];
+    }
+  };
+  // partial products of column jj with every column over this workgroup's rows below row j0 + jj;
+  // the owner of that row exports it
+  auto publish = [&](int jj, int buf) {
+    const int jrow = g.j0 + jj;
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = r0 + rg + NRG * q;
+      const zc x = xc[buf][rg + NRG * q];
+      if (i > jrow && i < m && c < nbp) {
+        sr += x.x * a[q].x + x.y * a[q].y;
+        si += x.x * a[q].y - x.y * a[q].x;
+      }
+      if (i == jrow) gx_stz(g.rowbuf + (size_t)buf * 32 + c, a[q]);
+    }
+    sr += __shfl_xor(sr, 32, 64);
+    si += __shfl_xor(si, 32, 64);
+    if (lane < 32) part[w][c] = make_double2(sr, si);
+    __syncthreads();
+    if (tid < 64) {
+      const int cc = tid >> 1;
+      double t = 0.0;
+#pragma unroll
+      for (int u = 0; u < NW; ++u) t += (tid & 1) ? part[u][cc].y : part[u][cc].x;
+      pay[tid] = t;
+    }
+    __syncthreads();
+  };
+  stage_col(0, 0);
+  __syncthreads();
+  publish(0, 0);
+  for (int jj = 0; jj < nbp; ++jj) {
+    const int buf = jj & 1, jrow = g.j0 + jj;
+    if (!gx_exchange<512>(sy, pay, 64, red, val)) {
+      if (blockIdx.x == 0 && tid == 0) atomicMax(g.err_w, 2u);
+      return;
+    }
+    if (tid < 32) rowj[tid] = gx_ldz(g.rowbuf + (size_t)buf * 32 + tid);
+    __syncthreads();
+    const zc yj = make_double2(red[2 * jj], red[2 * jj + 1]), yc = make_double2(red[2 * c], red[2 * c + 1]);
+    const House h = zlarfg(rowj[jj], yj.x);
+    zc f = make_double2(0.0, 0.0);
+    const bool active = c > jj && c < nbp;
+    if (active) f = zmul(zconj(h.tau), zadd(zmul(zconj(h.scale), yc), rowj[c]));
+    if (rg == 0 && c < jj) Gs[c][jj] = zadd(zconj(rowj[c]), zmul(h.scale, zconj(yc)));
+    if (tid == 0) taus[jj] = h.tau;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = r0 + rg + NRG * q;
+      if (i >= jrow && i < m) {
+        const zc v = (i == jrow) ? make_double2(1.0, 0.0) : zmul(xc[buf][rg + NRG * q], h.scale);
+        if (active) a[q] = zsub(a[q], zmul(v, f));
+        else if (c == jj) a[q] = (i == jrow) ? make_double2(h.beta, 0.0) : v;
+      }
+    }
+    if (jj + 1 < nbp) {
+      stage_col(jj + 1, buf ^ 1);
+      __syncthreads();
+      publish(jj + 1, buf ^ 1);
+    }
+  }
+  // the factored panel, its unit lower trapezoid, tau
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int i = r0 + rg + NRG * q;
+    if (i < m && c < nbp) {
+      g.A[(long)i * g.lda + g.j0 + c] = a[q];
+      const int ic = i - g.j0;
+      g.Vp[(long)ic * nbp + c] = (ic == c) ? make_double2(1.0, 0.0) : (ic > c ? a[q] : make_double2(0.0, 0.0));
+    }
+  }
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  if (tid < nbp) g.tau[tid] = taus[tid];
+  // T = S^-1, S = striu(V^H V) + diag(1 / tau): column r by back substitution, the columns side by side
+  if (rg == 0 && c < nbp) {
+    for (int t = nbp - 1; t >= 0; --t) {
+      zc acc = make_double2(t == c ? 1.0 : 0.0, 0.0);
+      for (int sI = t + 1; sI <= c; ++sI) acc = zsub(acc, zmul(Gs[t][sI], Tt[sI][c]));
+      const zc tt = taus[t];
+      const zc v = (t > c || (tt.x == 0.0 && tt.y == 0.0)) ? make_double2(0.0, 0.0) : zmul(tt, acc);
+      Tt[t][c] = v;
+      g.T[(long)t * nbp + c] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -447,14 +592,37 @@ size_t qr_work_elems(int m, int n, int next) {
   return e;
 }
 
-void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next) {
+void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy) {
   if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
   if (next < 0 || n + next > m) throw ArgError("qr: more orthogonal-complement columns requested than exist");
   if (n <= 0) return;
   static const bool small_on = !(std::getenv("MITDVP_SMALL_KERNELS") && std::atoi(std::getenv("MITDVP_SMALL_KERNELS")) == 0);
-  if (next == 0 && small_on && qr_small_launch(st, A, m, n, Q, R)) {  // one launch, matrix in registers
-    if (nlaunch) *nlaunch += 1;
-    return;
+  // opt-in (MITDVP_QR_PANEL=1): measured SLOWER than the per-column launches it replaces -- C5 (2048 x 512): 578 ms
+  // of QR per sweep against 510 ms, C3 (4096 x 128): 4.6 against 3.8 ms, at 64 / 128 rows per workgroup; a kernel
+  // boundary (~1.5 us + the kernel's own ~3 us) is a cheaper grid-wide barrier on this GPU than an exchange of
+  // 64 doubles per workgroup through agent-scope memory (profiles/r02_qr_panel_ab.json).  It cuts the launches of a
+  // C5 sweep from 92 628 to 25 288, which is what it is kept for (launch-rate-limited hosts, graphs).
+  static const bool panel_on = small_on && std::getenv("MITDVP_QR_PANEL") && std::atoi(std::getenv("MITDVP_QR_PANEL")) != 0;
+  if (panel_on && sy) {  // the panel kernel's exchange scratch is dynamic LDS on top of ~48 KB static: lift the 64 KB default
+    static std::mutex mu;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qr_panel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qr_panel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qr_panel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qr_panel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+  }
+  if (next == 0 && small_on) {  // factorisation in one launch (matrix in registers), Q in a second
+    const int nls = qr_small_launch(st, A, m, n, Q, R, work);
+    if (nls) {
+      if (nlaunch) *nlaunch += nls;
+      return;
+    }
   }
   const int nqt = n + next;  // columns of Q: the thin factor and `next` columns of LAPACK's full Q
   const long lda = n;
@@ -492,21 +660,43 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
         ++nl;
       }
     };
-    if (rows == 32) panel(std::integral_constant<int, 32>{});
-    else if (rows == 128) panel(std::integral_constant<int, 128>{});
-    else panel(std::integral_constant<int, 256>{});
-    HIP_CHECK(hipGetLastError());
-    // compact WY: T from G = V^H V
-    extract_v(j0, nbp);
-    {
-      ZgemmDesc g = zgemm_desc(Vp, Vp, G, nbp, nbp, mp);
-      g.transA = 1; g.conjA = 1; g.lda = nbp; g.ldb = nbp; g.ldc = nbp;
-      zgemm(st, g);
+    zc* Tp = T + (size_t)ip * QR_NB * QR_NB;
+    // rows per workgroup: as few as the 64-workgroup exchange allows -- the column update of a step is spread
+    // over (rows / rb) compute units, and that, not the exchange, is what a step waits for when rb is large
+    int rb = 32;
+    while ((mp + rb - 1) / rb > GX_MAXG && rb < 256) rb *= 2;
+    if (const char* e = std::getenv("MITDVP_QR_RB")) rb = std::max(32, std::min(256, std::atoi(e)));
+    const int gpan = (mp + rb - 1) / rb;
+    if (panel_on && sy && sy->slots && gpan <= GX_MAXG) {
+      // one persistent launch: column steps, T and the unit-lower copy of the panel
+      sy->launches += 1;
+      if ((sy->launches & 0xFFFFFu) == 0u) sy->launches += 1;  // tag 0 is the cleared state
+      QrPanelArgs pa{A, lda, m, j0, j1, Vp, Tp, tau + j0, rowb[0],
+                     reinterpret_cast<unsigned long long*>(sy->slots), sy->words + 2, sy->words + 3,
+                     (sy->launches & 0xFFFFFu) << 12};
+      const size_t dyn = (size_t)gpan * 64 * sizeof(double);
+      if (rb == 32) hipLaunchKernelGGL(k_qr_panel<2>, dim3(gpan), dim3(512), dyn, st, pa);
+      else if (rb == 64) hipLaunchKernelGGL(k_qr_panel<4>, dim3(gpan), dim3(512), dyn, st, pa);
+      else if (rb == 128) hipLaunchKernelGGL(k_qr_panel<8>, dim3(gpan), dim3(512), dyn, st, pa);
+      else hipLaunchKernelGGL(k_qr_panel<16>, dim3(gpan), dim3(512), dyn, st, pa);
+      ++nl;
+      HIP_CHECK(hipGetLastError());
+    } else {
+      if (rows == 32) panel(std::integral_constant<int, 32>{});
+      else if (rows == 128) panel(std::integral_constant<int, 128>{});
+      else panel(std::integral_constant<int, 256>{});
+      HIP_CHECK(hipGetLastError());
+      // compact WY: T from G = V^H V
+      extract_v(j0, nbp);
+      {
+        ZgemmDesc g = zgemm_desc(Vp, Vp, G, nbp, nbp, mp);
+        g.transA = 1; g.conjA = 1; g.lda = nbp; g.ldb = nbp; g.ldc = nbp;
+        zgemm(st, g);
+        ++nl;
+      }
+      hipLaunchKernelGGL(k_qr_build_t, dim3(1), dim3(256), 0, st, G, tau + j0, nbp, Tp);
       ++nl;
     }
-    zc* Tp = T + (size_t)ip * QR_NB * QR_NB;
-    hipLaunchKernelGGL(k_qr_build_t, dim3(1), dim3(256), 0, st, G, tau + j0, nbp, Tp);
-    ++nl;
     const int n2 = n - j1;
     if (n2 > 0) {
       zc* A2 = A + (long)j0 * lda + j1;
