@@ -403,7 +403,7 @@ def main():
             },
             "roofline": ({
                 "bound": "hbm",
-                "kernel": "H_eff apply in the small-bond regime",
+                "kernel": "k_small_site (one launch per local exponential: H_eff applies, Krylov algebra, k x k exponential, convergence test)",
                 "achieved": ach_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -413,7 +413,8 @@ def main():
                 "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
                 "n_apply": cnt["n_heff"],
                 "tflops": alg,
-                "note": "latency bound: a site is a few hundred KB",
+                "note": ("latency bound: a site is a few hundred KB; achieved = algorithmic bytes B_H per H_eff apply x applies / HIP-event "
+                         "time of the site exponentials (which also holds their Krylov algebra and grid-wide exchanges)"),
             } if small else {
                 "bound": "mfma",
                 "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)" + (" -- per GPU, this rank's bond shard" if mode == "tp" else ""),

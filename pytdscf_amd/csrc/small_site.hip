@@ -324,7 +324,9 @@ __host__ __device__ inline Carve ss_carve(const SmallChain& c, bool exp_mode) {
   o += bs;
   k.Xs = o; o += (size_t)c.nc * c.nj * c.cs;
   k.Ys = o; o += c.W2 ? (size_t)c.ni * c.nt * c.cs : 0;
-  k.Sg = o; o += (size_t)c.ni * c.nr;  // this chunk's partial of the output slab
+  // this chunk's partial of the output slab; with a W stage it may reuse X's space (stage 3 reads Y and R only)
+  if (c.W2 && (size_t)c.ni * c.nr <= (size_t)c.nc * c.nj * c.cs) k.Sg = k.Xs;
+  else { k.Sg = o; o += (size_t)c.ni * c.nr; }
   k.misc = o;
   // misc: pay[SS_PAYMAX] red[SS_PAYMAX] wsh[SS_WAVES*SS_PAYMAX] (doubles) + alpha[MAXK] coef[MAXK] cprev[MAXK] (zc)
   //       + hess[(MAXK+1)*MAXK] (zc) + beta[MAXK] invb[MAXK+1] (doubles) + ints
@@ -779,7 +781,7 @@ bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
     if ((nsc - 1) * cs >= c.ns) continue;  // every chunk must be non-empty
     c.nsc = nsc;
     c.cs = cs;
-    if (small_chain_lds(c, exp_mode) <= 150 * 1024) return true;
+    if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
   }
   return false;
 }
