@@ -164,6 +164,31 @@ int mitdvp_ms_autocorr(mitdvp_engine* h, double out[2]);              /* sum ove
 int mitdvp_ms_operate(mitdvp_engine* h, int op_id, int maxstep, double conv_tol, double* norm_out, int* iters_out);
 int mitdvp_ms_pops(mitdvp_engine* h, double* out /* [nstate] */);      /* pop_states, _mps_cls.py:682-703 */
 
+/* -- one block of a site-range sharded chain ----------------------------------
+ * Real-space parallel one-site TDVP (MPSCoefParallel.propagate, _mps_parallel.py:106-268): every rank owns a
+ * contiguous range of sites as an engine whose outer bonds are wider than 1.  The environment blocks at its
+ * two ends come from the neighbours (send_op_block / recv_op_block, :1610-1635), and a half-sweep is driven
+ * through the pieces of propagate_along_sweep (_mps_cls.py:798-1014) so that the end site can be left to the
+ * joint update of two ranks (skip_end_site, :876-877; propagate_joint_two_sites, _mps_parallel.py:270-470).
+ * Host side: pytdscf_amd/parallel_sites.py.
+ *   side 0: block left of site 0, L[a][c][b] (d, m, d); side 1: block right of the last site, R[r][t][s]. */
+int mitdvp_set_boundary_env(mitdvp_engine* h, int side, const double* reim, int d, int m);
+/* new values for a site tensor of unchanged shape; the environment cache is kept (mitdvp_set_site drops it) */
+int mitdvp_replace_site(mitdvp_engine* h, int isite, const double* reim, int gauge);
+/* environment block left (side 0) / right (side 1) of bond `bond` (the bond left of site `bond`); reim_out may be
+ * NULL to query the shape (d, m, d) */
+int mitdvp_get_env(mitdvp_engine* h, int side, int bond, double* reim_out, int* d, int* m);
+/* construct_op_sites (_mps_cls.py:1738-1796): all blocks on one side of the centre (0: left, 1: right) */
+int mitdvp_build_envs(mitdvp_engine* h, int side);
+int mitdvp_site_exp(mitdvp_engine* h, double dt_au);      /* exp_superH_propagation_direct, _mps_cls.py:1016-1100 */
+/* trans_next_psite_AsigmaB (:1798-1850): centre -> A sigma (forward) or sigma B; the block through the site is built,
+ * sigma stays in the engine as the pending bond matrix */
+int mitdvp_split_center(mitdvp_engine* h, int forward);
+int mitdvp_bond_exp(mitdvp_engine* h, double dt_au);      /* exp_superK_propagation_direct, :1102-1170 */
+int mitdvp_absorb_bond(mitdvp_engine* h, int forward);    /* trans_next_psite_APsiB, :1172-1206 */
+int mitdvp_get_bond(mitdvp_engine* h, double* reim_out, int* dim);   /* the pending bond matrix (joint_sigvec) */
+int mitdvp_set_bond(mitdvp_engine* h, int bond, const double* reim, int dim);
+
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */

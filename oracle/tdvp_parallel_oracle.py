@@ -1,0 +1,253 @@
+"""CPU oracle of the SITE-RANGE SHARDED (real-space parallel) one-site TDVP -- test infrastructure.
+
+PARITY UNPINNED with respect to the reference: its implementation of this scheme
+(``/root/reference/pytdscf/_mps_parallel.py``, ``MPSCoefParallel.propagate`` :106-268,
+``propagate_joint_two_sites`` :270-470, ``distribute_superblock_states`` :1520-1607, split rule
+``_const_cls.py:236-250``) needs ``mpi4py`` and several ranks, neither of which exists in the development
+container, so no golden vectors could be produced from it.  This file restates the same algorithm
+(Secular, Gourianov, Lubasch, Dolgov, Clark, Jaksch, PRB 101, 235123: blocks Phi_r joined by inverse
+bond matrices, Psi = Phi_0 X_0^+ Phi_1 X_1^+ ...) from the operation sequence of those functions and is
+pinned instead by what can be checked: (a) with one rank it IS the serial oracle (``tdvp_oracle.OracleMPS``,
+itself pinned to the reference); (b) for Hamiltonians without terms across the junctions it equals the
+serial sweep to rounding; (c) its deviation from the serial sweep vanishes as dt -> 0 (second order per
+step).  The reference's extra regularisations of small singular values (SQRT_EPSRHO = 1e-4,
+``_site_cls.py:22, :207-246, :657-664``, the reason its own tests accept 1e-2 on the norm) are NOT
+reproduced: the pseudo-inverse uses RCOND = 1e-13 (``_site_cls.py:24, :734``) only.
+
+All ranks are simulated in one process, in the order the real ranks would act; what one rank reads
+from another is exactly what ``pytdscf_amd/parallel_sites.py`` sends over RCCL / gloo.
+
+Per time step (reference diagram, ``_mps_parallel.py:115-122``):
+  S0   even ranks [psi B .. B], odd ranks [A .. A psi]; junctions hold X_j
+  (a)  every rank sweeps its block (even ->, odd <-) with FROZEN boundary environments and leaves its
+       end site unpropagated (``skip_end_site``), except at the ends of the chain
+  (b)  joint update of every even|odd junction: psi_L X^+ psi_R -> A X' B (site L +dt/2, bond -dt/2,
+       site R +dt/2, bond -dt/2), new boundary environments for both neighbours
+  (c)  psi_L = A X', psi_R = X' B; sweeps in the opposite directions; joint update of the odd|even
+       junctions; absorb again.  Every site has had two half steps, every bond two backward half steps.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import tdvp_oracle as orc
+
+RCOND = 1e-13  # _site_cls.py:24
+
+
+def split_sites(nsite: int, nrank: int) -> list[tuple[int, int]]:
+    """Contiguous, near-equal site ranges [lo, hi) per rank (parallel_split_indices, _const_cls.py:236-250)."""
+    base, rem = divmod(nsite, nrank)
+    out, lo = [], 0
+    for r in range(nrank):
+        n = base + (1 if r < rem else 0)
+        out.append((lo, lo + n))
+        lo += n
+    return out
+
+
+@dataclass
+class Block:
+    """One rank's block Phi_r: its site tensors, MPO cores, environment cache and boundary blocks."""
+
+    cores: list
+    mpo: list
+    lo: int  # global index of the first site
+    left_b: np.ndarray  # environment left of the block (through the orthonormal blocks of the ranks to the left)
+    right_b: np.ndarray
+    integrator: str = "lanczos"
+    thresh: float = 1e-9
+    conserve_norm: bool = True
+    kprev: dict = field(default_factory=dict)
+    left: dict = field(default_factory=dict)  # left[i]: environment left of local site i
+    right: dict = field(default_factory=dict)  # right[i]: environment right of local site i
+
+    def __post_init__(self):
+        self.n = len(self.cores)
+        self.left = {0: self.left_b}
+        self.right = {self.n - 1: self.right_b}
+
+    def _exp(self, scale, mv, x, site):
+        fn = orc.sil_lanczos if self.integrator == "lanczos" else orc.sil_arnoldi
+        out, k = fn(scale, mv, x, self.thresh, self.kprev.get(site, 0), self.conserve_norm, None)
+        self.kprev[site] = k
+        return out
+
+    def build_right(self):
+        for p in range(self.n - 1, 0, -1):
+            self.right[p - 1] = orc.env_update_right(self.right[p], self.cores[p], self.mpo[p])
+
+    def build_left(self):
+        for p in range(0, self.n - 1):
+            self.left[p + 1] = orc.env_update_left(self.left[p], self.cores[p], self.mpo[p])
+
+    def sweep(self, dt, forward, skip_end):
+        """propagate_along_sweep (_mps_cls.py:798-1014) over the block; with skip_end the end site keeps
+        the centre but is not propagated (:876-877)."""
+        n = self.n
+        sites = range(0, n) if forward else range(n - 1, -1, -1)
+        end = n - 1 if forward else 0
+        for p in sites:
+            g = self.lo + p
+            if skip_end and p == end:
+                return
+            L, W, R = self.left[p], self.mpo[p], self.right[p]
+            self.cores[p] = self._exp(-0.5j * dt, lambda x: orc.heff_apply(L, W, R, x), self.cores[p], g)
+            if p == end:
+                return
+            if forward:
+                A, s = orc.qr_psi2Asigma(self.cores[p])
+                self.cores[p] = A
+                self.left[p + 1] = orc.env_update_left(self.left[p], A, W)
+                Ln, Rn = self.left[p + 1], self.right[p]
+                s = self._exp(+0.5j * dt, lambda x: orc.keff_apply(Ln, Rn, x), s, g)
+                self.cores[p + 1] = np.tensordot(s, self.cores[p + 1], axes=(1, 0))
+            else:
+                s, B = orc.qr_psi2sigmaB(self.cores[p])
+                self.cores[p] = np.ascontiguousarray(B)
+                self.right[p - 1] = orc.env_update_right(self.right[p], self.cores[p], W)
+                Ln, Rn = self.left[p], self.right[p - 1]
+                s = self._exp(+0.5j * dt, lambda x: orc.keff_apply(Ln, Rn, x), s, g)
+                self.cores[p - 1] = np.tensordot(self.cores[p - 1], s, axes=(2, 0))
+
+
+def joint_update(bl: Block, br: Block, X: np.ndarray, dt: float):
+    """propagate_joint_two_sites (_mps_parallel.py:270-470) for the junction between ``bl`` (centre on
+    its last site) and ``br`` (centre on its first site).  Returns the new X; both blocks end with
+    orthonormal junction sites (A | B) and refreshed boundary environments."""
+    pl, pr = bl.n - 1, 0
+    Wl, Wr = bl.mpo[pl], br.mpo[pr]
+    gl, gr = bl.lo + pl, br.lo + pr
+    Lenv = bl.left[pl]  # through the A sites of the left block
+    Renv = br.right[pr]  # through the B sites of the right block
+    # psi_L X^+ (multiply_sigvec_pinv, _site_cls.py:709-754), then centre on the left site
+    theta = np.tensordot(bl.cores[pl], np.linalg.pinv(X, rcond=RCOND), axes=(2, 0))
+    s, B = orc.qr_psi2sigmaB(br.cores[pr])
+    B = np.ascontiguousarray(B)
+    theta = np.tensordot(theta, s, axes=(2, 0))
+    R1 = orc.env_update_right(Renv, B, Wr)
+    theta = bl._exp(-0.5j * dt, lambda x: orc.heff_apply(Lenv, Wl, R1, x), theta, gl)
+    A, s = orc.qr_psi2Asigma(theta)
+    L1 = orc.env_update_left(Lenv, A, Wl)
+    s = bl._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R1, x), s, gl)
+    psi_r = np.tensordot(s, B, axes=(1, 0))
+    psi_r = br._exp(-0.5j * dt, lambda x: orc.heff_apply(L1, Wr, Renv, x), psi_r, gr)
+    s, B = orc.qr_psi2sigmaB(psi_r)
+    B = np.ascontiguousarray(B)
+    R2 = orc.env_update_right(Renv, B, Wr)
+    s = br._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R2, x), s, gr)
+    bl.cores[pl], br.cores[pr] = A, B
+    # what each side needs next: its own block's environment through the junction site, and the
+    # neighbour's as its new boundary block
+    bl.left[pl + 1] = L1  # (kept for completeness: left block's full left environment)
+    bl.right_b = R2
+    bl.right = {pl: R2}
+    br.left_b = L1
+    br.left = {0: L1}
+    br.right_after_first = R2
+    return s
+
+
+class ParallelOracle:
+    """N blocks in one process.  ``cores``: site-0-centred canonical MPS (Psi, B, ..., B)."""
+
+    def __init__(self, cores, mpo, nrank, integrator="lanczos", thresh=1e-9, conserve_norm=True):
+        self.nsite = len(cores)
+        self.nrank = nrank
+        self.ranges = split_sites(self.nsite, nrank)
+        if any(hi - lo < 2 for lo, hi in self.ranges) and nrank > 1:
+            raise ValueError("every rank needs at least two sites")
+        cores = [np.array(c, dtype=np.complex128) for c in cores]
+        mpo = [np.array(w, dtype=np.complex128) for w in mpo]
+        one = np.ones((1, 1, 1), dtype=np.complex128)
+        # B world: right environments through every site
+        Rb = {self.nsite - 1: one}
+        for p in range(self.nsite - 1, 0, -1):
+            Rb[p - 1] = orc.env_update_right(Rb[p], cores[p], mpo[p])
+        # A world built incrementally; X_j = centre matrix at junction j (distribute_superblock_states, :1520-1607)
+        A = [c.copy() for c in cores]
+        La = {0: one}
+        self.X = []
+        cuts = [hi for _, hi in self.ranges[:-1]]
+        xs = {}
+        for p in range(self.nsite - 1):
+            Q, s = orc.qr_psi2Asigma(A[p])
+            A[p] = Q
+            La[p + 1] = orc.env_update_left(La[p], Q, mpo[p])
+            if p + 1 in cuts:
+                xs[p + 1] = s
+            A[p + 1] = np.tensordot(s, A[p + 1], axes=(1, 0))
+        self.blocks = []
+        for r, (lo, hi) in enumerate(self.ranges):
+            if r % 2 == 0:  # [psi B .. B]: B-world slice, first site carries X of the junction to its left
+                cs = [cores[p].copy() for p in range(lo, hi)]
+                if r > 0:
+                    cs[0] = np.tensordot(xs[lo], cores[lo], axes=(1, 0))
+            else:  # [A .. A psi]: A-world slice, last site carries X of the junction to its right
+                cs = [A[p].copy() for p in range(lo, hi)]
+                if r < nrank - 1:
+                    cs[-1] = np.tensordot(A[hi - 1], xs[hi], axes=(2, 0))
+                # (the last rank's last site already is the A-world centre)
+            blk = Block(cs, mpo[lo:hi], lo, La[lo], Rb[hi - 1], integrator, thresh, conserve_norm)
+            self.blocks.append(blk)
+        self.X = [xs[c] for c in cuts]
+        for r, blk in enumerate(self.blocks):
+            if r % 2 == 0:
+                blk.build_right()
+            else:
+                blk.build_left()
+
+    def step(self, dt):
+        nr = self.nrank
+        if nr == 1:
+            b = self.blocks[0]
+            b.sweep(dt, True, False)
+            b.sweep(dt, False, False)
+            return
+        # (a) even ->, odd <-
+        for r, b in enumerate(self.blocks):
+            fwd = r % 2 == 0
+            at_chain_end = (fwd and r == nr - 1) or (not fwd and r == 0)
+            b.sweep(dt, fwd, skip_end=not at_chain_end)
+        # (b) even|odd junctions
+        self._junctions(dt, 0)
+        # (c) even <-, odd ->
+        for r, b in enumerate(self.blocks):
+            fwd = r % 2 == 1
+            at_chain_end = (fwd and r == nr - 1) or (not fwd and r == 0)
+            b.sweep(dt, fwd, skip_end=not at_chain_end)
+        self._junctions(dt, 1)
+
+    def _junctions(self, dt, parity):
+        for j in range(parity, self.nrank - 1, 2):
+            bl, br = self.blocks[j], self.blocks[j + 1]
+            Xn = joint_update(bl, br, self.X[j], dt)
+            self.X[j] = Xn
+            # A X' B -> psi x^+ psi: both neighbours take the weight (send_joint_sigvec_to_right, :541-597)
+            R2 = br.right_after_first
+            bl.cores[-1] = np.tensordot(bl.cores[-1], Xn, axes=(2, 0))
+            br.cores[0] = np.tensordot(Xn, br.cores[0], axes=(1, 0))
+            # the blocks' own caches: left block sweeps <- next (needs its left environments, which its
+            # -> sweep left behind), right block sweeps -> next
+            bl.right = {bl.n - 1: bl.right_b}
+            br.left = {0: br.left_b}
+            # the right block's remaining right environments are still valid (its <- sweep built them)
+            _ = R2
+
+    # ---- the whole state as one MPS (tests, observables) ---------------------------------------
+    def gather(self):
+        """Site tensors of Psi = Phi_0 X_0^+ Phi_1 ... as one chain (not canonical)."""
+        out = []
+        for r, b in enumerate(self.blocks):
+            cs = [c.copy() for c in b.cores]
+            if r < self.nrank - 1:
+                cs[-1] = np.tensordot(cs[-1], np.linalg.pinv(self.X[r], rcond=RCOND), axes=(2, 0))
+            out.extend(cs)
+        return out
+
+    def norm(self):
+        g = self.gather()
+        return float(np.sqrt(abs(orc.overlap(g, g))))

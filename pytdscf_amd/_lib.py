@@ -111,6 +111,16 @@ def load() -> C.CDLL:
         "mitdvp_step": (i, [vp, d]),
         "mitdvp_sweep": (i, [vp, d, i]),
         "mitdvp_invalidate_env": (i, [vp]),
+        "mitdvp_set_boundary_env": (i, [vp, i, dp, i, i]),
+        "mitdvp_replace_site": (i, [vp, i, dp, i]),
+        "mitdvp_get_env": (i, [vp, i, i, dp, ip, ip]),
+        "mitdvp_build_envs": (i, [vp, i]),
+        "mitdvp_site_exp": (i, [vp, d]),
+        "mitdvp_split_center": (i, [vp, i]),
+        "mitdvp_bond_exp": (i, [vp, d]),
+        "mitdvp_absorb_bond": (i, [vp, i]),
+        "mitdvp_get_bond": (i, [vp, dp, ip]),
+        "mitdvp_set_bond": (i, [vp, i, dp, i]),
         "mitdvp_expect": (i, [vp, i, dp]),
         "mitdvp_autocorr": (i, [vp, dp]),
         "mitdvp_norm": (i, [vp, dp]),

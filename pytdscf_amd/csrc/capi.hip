@@ -135,6 +135,24 @@ int mitdvp_set_shift(mitdvp_engine* h, int op_id, double re, double im) { ENG_CA
 int mitdvp_step(mitdvp_engine* h, double dt) { ENG_CALL(h, h->e->step(dt)); }
 int mitdvp_sweep(mitdvp_engine* h, double dt, int forward) { ENG_CALL(h, h->e->sweep(dt, forward != 0)); }
 int mitdvp_invalidate_env(mitdvp_engine* h) { ENG_CALL(h, h->e->invalidate_env()); }
+int mitdvp_replace_site(mitdvp_engine* h, int isite, const double* reim, int gauge) {
+  ENG_CALL(h, { NEED(reim); h->e->replace_site(isite, reim, gauge); });
+}
+int mitdvp_set_boundary_env(mitdvp_engine* h, int side, const double* reim, int d, int m) {
+  ENG_CALL(h, { NEED(reim); h->e->set_boundary_env(side, reim, d, m); });
+}
+int mitdvp_get_env(mitdvp_engine* h, int side, int bond, double* reim_out, int* d, int* m) {
+  ENG_CALL(h, { NEED(d, m); h->e->env_shape(side, bond, d, m); if (reim_out) h->e->get_env(side, bond, reim_out); });
+}
+int mitdvp_build_envs(mitdvp_engine* h, int side) { ENG_CALL(h, h->e->build_envs(side)); }
+int mitdvp_site_exp(mitdvp_engine* h, double dt) { ENG_CALL(h, h->e->site_exp(dt)); }
+int mitdvp_split_center(mitdvp_engine* h, int forward) { ENG_CALL(h, h->e->split_center(forward != 0)); }
+int mitdvp_bond_exp(mitdvp_engine* h, double dt) { ENG_CALL(h, h->e->bond_exp(dt)); }
+int mitdvp_absorb_bond(mitdvp_engine* h, int forward) { ENG_CALL(h, h->e->absorb_bond(forward != 0)); }
+int mitdvp_get_bond(mitdvp_engine* h, double* reim_out, int* dim) { ENG_CALL(h, { NEED(dim); h->e->get_bond(reim_out, dim); }); }
+int mitdvp_set_bond(mitdvp_engine* h, int bond, const double* reim, int dim) {
+  ENG_CALL(h, { NEED(reim); h->e->set_bond(bond, reim, dim); });
+}
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]) {
   ENG_CALL(h, { NEED(out); auto v = h->e->expect(op_id); out[0] = v.real(); out[1] = v.imag(); });
 }

@@ -178,6 +178,18 @@ class Engine {
   double ms_operate(int op_id, int maxstep, double conv_tol, int* iters_out);
   hzc ms_autocorr();
   void ms_pops(double* out);
+  // one block of a site-range sharded chain (engine_segment.hip)
+  void replace_site(int isite, const double* reim, int gauge);  // same shape, environment cache kept
+  void set_boundary_env(int side, const double* reim, int d, int m);
+  void env_shape(int side, int bond, int* d, int* m);
+  void get_env(int side, int bond, double* out);
+  void build_envs(int side);
+  void site_exp(double dt);
+  void split_center(bool forward);
+  void bond_exp(double dt);
+  void absorb_bond(bool forward);
+  void get_bond(double* out, int* dim);
+  void set_bond(int b, const double* reim, int dim);
   hipStream_t stream() const { return st_; }
   const MpoSite& mpo(int op_id, int isite);
   mitdvp_config cfg;
@@ -189,6 +201,10 @@ class Engine {
   std::vector<DevBuf> site_;
   std::map<int, Operator> ops_;
   int center_ = -1;
+  // segment mode: outer bonds wider than 1, boundary blocks supplied by the neighbours; pending bond matrix in sig_
+  bool segment_ = false;
+  int bnd_dl_ = 1, bnd_ml_ = 1, bnd_dr_ = 1, bnd_mr_ = 1;
+  int bond_ = -1, bond_dim_ = 0, bond_site_ = 0;
 
   // environment cache: bond b is left of site b, b = 0..L
   std::vector<DevBuf> envL_, envR_;

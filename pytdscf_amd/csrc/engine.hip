@@ -261,7 +261,11 @@ void Engine::require_ready() {
     if (!site_[p].p) throw ArgError("site tensor not set");
     if (p + 1 < L_ && dr_[p] != dl_[p + 1]) throw ArgError("bond dimension mismatch between neighbouring sites");
   }
-  if (dl_[0] != 1 || dr_[L_ - 1] != 1) throw ArgError("open boundary bonds must be 1");
+  if (!segment_) {
+    if (dl_[0] != 1 || dr_[L_ - 1] != 1) throw ArgError("open boundary bonds must be 1");
+  } else if ((envL_ok_[0] && bnd_dl_ != dl_[0]) || (envR_ok_[L_] && bnd_dr_ != dr_[L_ - 1])) {
+    throw ArgError("segment: the outer bonds differ from the boundary blocks' dimension");
+  }
   size_workspaces();
   ss_refresh_plan();
 }

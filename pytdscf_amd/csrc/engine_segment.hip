@@ -1,0 +1,194 @@
+// engine_segment.hip -- the engine as ONE BLOCK of a site-range sharded chain (row (e) of SURVEY 8:
+// real-space parallel one-site TDVP, /root/reference/pytdscf/_mps_parallel.py).
+//
+// A rank's block is an ordinary engine whose outer bonds are not 1: the environment blocks at its two
+// ends come from the neighbouring ranks (set_boundary_env), and the half-sweep is driven step by step
+// from the host side (pytdscf_amd/parallel_sites.py) through four primitives that are the pieces of
+// propagate_along_sweep (_mps_cls.py:798-1014):
+//   site_exp      exp(-i H_eff dt/2) on the centre tensor            exp_superH_propagation_direct :1016-1100
+//   split_center  Psi -> A sigma | sigma B (QR) + environment update trans_next_psite_AsigmaB :1798-1850
+//   bond_exp      exp(+i K_eff dt/2) on the bond matrix              exp_superK_propagation_direct :1102-1170
+//   absorb_bond   sigma into the neighbouring site                   trans_next_psite_APsiB :1172-1206
+// The joint update of two blocks' facing sites (propagate_joint_two_sites, _mps_parallel.py:270-470) is
+// the same four on a two-site engine whose boundary blocks are the two ranks' environments.
+#include "engine_internal.h"
+#include "engine_krylov.inc"
+
+namespace mitdvp {
+
+// new values for a site tensor of unchanged shape; unlike set_site the environment cache survives (the
+// caller knows which blocks the new tensor invalidates: none, when a junction site is replaced by its
+// re-gauged twin and the blocks through it are replaced as well)
+void Engine::replace_site(int i, const double* reim, int gauge) {
+  if (i < 0 || i >= L_ || !site_[i].p) throw ArgError("replace_site: bad or unset site");
+  const size_t e = (size_t)dl_[i] * dd_[i] * dr_[i];
+  HIP_CHECK(hipMemcpyAsync(site_[i].p, reim, e * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  gauge_[i] = gauge;
+  if (gauge == MITDVP_GAUGE_PSI) center_ = i;
+  else if (center_ == i) center_ = -1;
+}
+
+// side 0: block left of site 0, L[a][c][b] (d, m, d); side 1: block right of the last site, R[r][t][s]
+void Engine::set_boundary_env(int side, const double* reim, int d, int m) {
+  if (side != 0 && side != 1) throw ArgError("set_boundary_env: side must be 0 (left) or 1 (right)");
+  if (d < 1 || m < 1) throw ArgError("set_boundary_env: bad shape");
+  DevBuf& b = side == 0 ? envL_[0] : envR_[L_];
+  const size_t e = (size_t)d * m * d;
+  b.reserve(e);
+  HIP_CHECK(hipMemcpyAsync(b.p, reim, e * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  (side == 0 ? bnd_dl_ : bnd_dr_) = d;
+  (side == 0 ? bnd_ml_ : bnd_mr_) = m;
+  (side == 0 ? envL_ok_[0] : envR_ok_[L_]) = 1;
+  segment_ = true;
+}
+
+void Engine::env_shape(int side, int bond, int* d, int* m) {
+  if (bond < 0 || bond > L_) throw ArgError("env_shape: bad bond");
+  if (side == 0) {
+    if (bond == 0) { *d = segment_ ? bnd_dl_ : 1; *m = segment_ ? bnd_ml_ : 1; }
+    else { *d = dr_[bond - 1]; *m = mpo(0, bond - 1).mr; }
+  } else {
+    if (bond == L_) { *d = segment_ ? bnd_dr_ : 1; *m = segment_ ? bnd_mr_ : 1; }
+    else { *d = dl_[bond]; *m = mpo(0, bond).ml; }
+  }
+}
+
+void Engine::get_env(int side, int bond, double* out) {
+  int d = 0, m = 0;
+  env_shape(side, bond, &d, &m);
+  const bool ok = side == 0 ? envL_ok_[bond] : envR_ok_[bond];
+  const DevBuf& b = side == 0 ? envL_[bond] : envR_[bond];
+  if (!ok || !b.p) throw ArgError("get_env: this environment block is not built");
+  HIP_CHECK(hipMemcpyAsync(out, b.p, (size_t)d * m * d * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+// environment blocks of all sites on one side of the centre (construct_op_sites, _mps_cls.py:1738-1796)
+void Engine::build_envs(int side) {
+  require_ready();
+  if (side == 0) build_left_envs();
+  else build_right_envs();
+}
+
+void Engine::site_exp(double dt) {
+  require_ready();
+  if (center_ < 0) throw ArgError("site_exp: no centre site");
+  const int p = center_;
+  if (!envL_ok_[p] || !envR_ok_[p + 1]) throw ArgError("site_exp: the environment blocks around the centre are not built");
+  local_site_exp(p, dt);
+  ss_check();
+}
+
+// forward: site p <- A, sigma (dr x dr) kept, L_{p+1} built; backward: site p <- B, sigma (dl x dl), R_p built
+void Engine::split_center(bool forward) {
+  require_ready();
+  if (center_ < 0) throw ArgError("split_center: no centre site");
+  const int p = center_;
+  const MpoSite& w = mpo(0, p);
+  const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+  DevBuf spare = pool_get(V_.n / MAXK);
+  if (forward) {
+    if (!envL_ok_[p]) throw ArgError("split_center: left environment missing");
+    timer_begin(3);
+    long nl = 0;
+    qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync());
+    timer_end();
+    cnt_.n_launch += nl; cnt_.n_qr += 1;
+    std::swap(site_[p], spare);
+    gauge_[p] = MITDVP_GAUGE_A;
+    pool_put(std::move(envL_[p + 1]));
+    envL_[p + 1] = pool_get((size_t)dr * w.mr * dr);
+    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr, w.w2el.p);
+    envL_ok_[p + 1] = 1;
+    bond_ = p + 1; bond_dim_ = dr;
+  } else {
+    if (!envR_ok_[p + 1]) throw ArgError("split_center: right environment missing");
+    gauge_qr_right(site_[p].p, dl, d, dr, spare.p, tmp2_.p, sig_.p);
+    std::swap(site_[p], spare);
+    gauge_[p] = MITDVP_GAUGE_B;
+    pool_put(std::move(envR_[p]));
+    envR_[p] = pool_get((size_t)dl * w.ml * dl);
+    env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml, w.w2er.p);
+    envR_ok_[p] = 1;
+    bond_ = p; bond_dim_ = dl;
+  }
+  pool_put(std::move(spare));
+  center_ = -1;
+  bond_site_ = p;
+}
+
+// exp(+i K_eff dt/2) on the pending bond matrix; environments on both sides of that bond must exist
+void Engine::bond_exp(double dt) {
+  require_ready();
+  if (bond_ < 0) throw ArgError("bond_exp: no pending bond matrix (call split_center first)");
+  const int b = bond_;
+  if (!envL_ok_[b] || !envR_ok_[b]) throw ArgError("bond_exp: the environment blocks around the bond are not built");
+  int d = 0, m = 0;
+  env_shape(0, b, &d, &m);
+  if (d != bond_dim_) throw ArgError("bond_exp: environment and bond matrix disagree");
+  const zc* Lb = envL_[b].p;
+  const zc* Rb = envR_[b].p;
+  const hzc shift = op(0).shift;
+  const int p = bond_site_;  // Krylov memory of the site the bond matrix came from (_Debug.niter_krylov[site_now])
+  if (!small_bond_exp(p, Lb, Rb, d, m, dt)) {
+    auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, d, d, m, shift); };
+    kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)d * d, kprev_[p]);
+    cnt_.n_exp_bond += 1;
+  }
+  ss_check();
+}
+
+// the pending bond matrix goes into the site right (forward) or left (backward) of the bond
+void Engine::absorb_bond(bool forward) {
+  require_ready();  // sizes the workspaces the spare tensor comes from
+  if (bond_ < 0) throw ArgError("absorb_bond: no pending bond matrix");
+  const int b = bond_, D = bond_dim_;
+  DevBuf spare = pool_get(V_.n / MAXK);
+  if (forward) {
+    if (b >= L_) throw ArgError("absorb_bond: no site right of the last bond (take the matrix with get_bond)");
+    if (dl_[b] != D) throw ArgError("absorb_bond: bond dimension mismatch");
+    ZgemmDesc g = zgemm_desc(sig_.p, site_[b].p, spare.p, D, dd_[b] * dr_[b], D);
+    zgemm(st_, g);
+    std::swap(site_[b], spare);
+    gauge_[b] = MITDVP_GAUGE_PSI;
+    center_ = b;
+  } else {
+    if (b < 1) throw ArgError("absorb_bond: no site left of the first bond (take the matrix with get_bond)");
+    if (dr_[b - 1] != D) throw ArgError("absorb_bond: bond dimension mismatch");
+    ZgemmDesc g = zgemm_desc(site_[b - 1].p, sig_.p, spare.p, dl_[b - 1] * dd_[b - 1], D, D);
+    zgemm(st_, g);
+    std::swap(site_[b - 1], spare);
+    gauge_[b - 1] = MITDVP_GAUGE_PSI;
+    center_ = b - 1;
+  }
+  cnt_.n_launch += 1;
+  pool_put(std::move(spare));
+  bond_ = -1;
+}
+
+void Engine::get_bond(double* out, int* dim) {
+  if (bond_ < 0) throw ArgError("get_bond: no pending bond matrix");
+  *dim = bond_dim_;
+  if (out) {
+    HIP_CHECK(hipMemcpyAsync(out, sig_.p, (size_t)bond_dim_ * bond_dim_ * sizeof(zc), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+}
+
+// x (dim x dim) becomes the pending bond matrix of bond b (the bond left of site b)
+void Engine::set_bond(int b, const double* reim, int dim) {
+  if (b < 0 || b > L_) throw ArgError("set_bond: bad bond");
+  if (dim < 1) throw ArgError("set_bond: bad dimension");
+  require_ready();  // workspaces first: growing sig_ afterwards would drop the matrix
+  if (!((b < L_ && dl_[b] == dim) || (b > 0 && dr_[b - 1] == dim))) throw ArgError("set_bond: dimension matches neither neighbouring site");
+  sig_.reserve((size_t)dim * dim);
+  HIP_CHECK(hipMemcpyAsync(sig_.p, reim, (size_t)dim * dim * sizeof(zc), hipMemcpyHostToDevice, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  bond_ = b; bond_dim_ = dim;
+  bond_site_ = std::min(std::max(b - 1, 0), L_ - 1);
+  center_ = -1;
+}
+
+}  // namespace mitdvp

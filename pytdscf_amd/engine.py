@@ -105,6 +105,54 @@ class TDVPEngine:
             )
         self._ck(self._lib.mitdvp_set_shift(self._h, op_id, complex(shift).real, complex(shift).imag))
 
+    # ---- one block of a site-range sharded chain (include/mitdvp.h, "one block ...") ---------
+    _GAUGE = {"Psi": _lib.GAUGE_PSI, "A": _lib.GAUGE_A, "B": _lib.GAUGE_B, "C": _lib.GAUGE_C}
+
+    def replace_site(self, isite: int, data, gauge: str):
+        a = _c128(data)
+        self._ck(self._lib.mitdvp_replace_site(self._h, isite, _dp(a), self._GAUGE[gauge]))
+
+    def set_boundary_env(self, side: int, block):
+        a = _c128(block)
+        if a.ndim != 3 or a.shape[0] != a.shape[2]:
+            raise ValueError("boundary block must be (D, M, D)")
+        self._ck(self._lib.mitdvp_set_boundary_env(self._h, side, _dp(a), a.shape[0], a.shape[1]))
+
+    def get_env(self, side: int, bond: int) -> np.ndarray:
+        d, m = C.c_int(), C.c_int()
+        self._ck(self._lib.mitdvp_get_env(self._h, side, bond, None, C.byref(d), C.byref(m)))
+        out = np.empty((d.value, m.value, d.value), dtype=np.complex128)
+        self._ck(self._lib.mitdvp_get_env(self._h, side, bond, _dp(out), C.byref(d), C.byref(m)))
+        return out
+
+    def build_envs(self, side: int):
+        self._ck(self._lib.mitdvp_build_envs(self._h, side))
+
+    def site_exp(self, dt_au: float):
+        self._ck(self._lib.mitdvp_site_exp(self._h, dt_au))
+
+    def split_center(self, forward: bool):
+        self._ck(self._lib.mitdvp_split_center(self._h, int(forward)))
+
+    def bond_exp(self, dt_au: float):
+        self._ck(self._lib.mitdvp_bond_exp(self._h, dt_au))
+
+    def absorb_bond(self, forward: bool):
+        self._ck(self._lib.mitdvp_absorb_bond(self._h, int(forward)))
+
+    def get_bond(self) -> np.ndarray:
+        n = C.c_int()
+        self._ck(self._lib.mitdvp_get_bond(self._h, None, C.byref(n)))
+        out = np.empty((n.value, n.value), dtype=np.complex128)
+        self._ck(self._lib.mitdvp_get_bond(self._h, _dp(out), C.byref(n)))
+        return out
+
+    def set_bond(self, bond: int, x):
+        a = _c128(x)
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError("bond matrix must be square")
+        self._ck(self._lib.mitdvp_set_bond(self._h, bond, _dp(a), a.shape[0]))
+
     # ---- hot path ------------------------------------------------------
     def propagate(self, dt_au: float):
         self._ck(self._lib.mitdvp_step(self._h, dt_au))

@@ -1,0 +1,129 @@
+"""GPU: site-range sharding (pytdscf_amd/parallel_sites.py) with 2 and 3 ranks sharing the test GPU over
+gloo, against (a) the oracle of the same algorithm (oracle/tdvp_parallel_oracle.py) at 1e-8 and (b) the
+serial sweep at the looser bar SURVEY 8(e) sets for this approximate scheme (the reference accepts 1e-2
+on the norm and 1e-1 on energies; here infidelity < 1e-6, norm to 1e-4 at dt = 0.2).  Plus the CPU
+test of the neighbour link (world size 2, gloo)."""
+
+import json
+import os
+import socket
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from helpers.ranks import run_ranks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+LINK_WORKER = """
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import _Link, split_sites
+c = Comm(n_devices=0)
+link = _Link(c)
+rng = np.random.default_rng(5)
+a = rng.standard_normal((3, 4, 5)) + 1j * rng.standard_normal((3, 4, 5))
+if c.rank == 0:
+    link.send(a, 1)
+    b = link.recv((5, 2), 1)
+    assert np.array_equal(b, (a.reshape(-1)[:10] * 2).reshape(5, 2))
+else:
+    got = link.recv((3, 4, 5), 0)
+    assert np.array_equal(got, a)
+    link.send((got.reshape(-1)[:10] * 2).reshape(5, 2), 0)
+assert link.messages == 1 and split_sites(7, 2) == [(0, 4), (4, 7)]
+c.barrier()
+print("LINK OK", flush=True)
+c.close()
+"""
+
+
+def test_neighbour_link_two_ranks_gloo(tmp_path):
+    script = tmp_path / "link.py"
+    script.write_text(textwrap.dedent(LINK_WORKER.format(root=ROOT)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", CUDA_VISIBLE_DEVICES="",
+               MITDVP_DIST_BACKEND="gloo")
+    rcs, outs = run_ranks([[sys.executable, str(script)]] * 2, [dict(env, RANK=str(r), LOCAL_RANK=str(r)) for r in range(2)],
+                          timeout=120)
+    assert rcs == [0, 0] and all("LINK OK" in o for o in outs), outs
+
+
+WORKER = """
+import os, sys, json
+os.environ["MITDVP_SMALL_KERNELS"] = "0"   # several processes share one GPU here: no persistent kernels
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from oracle import tdvp_parallel_oracle as par
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+comm = Comm()
+L, d, M, D, dt, nstep = {L}, 3, 4, 8, 0.2, 2
+mpo = orc.synthetic_mpo(L, d, M, seed=0)
+mps = orc.synthetic_mps([d] * L, D, seed=1)
+eng = SiteShardedTDVP(comm, mpo, cores=mps, integrator={integ!r}, conserve_norm={cn})
+g0 = eng.gather()
+for _ in range(nstep):
+    eng.step(dt)
+g = eng.gather()
+if comm.rank == 0:
+    ref = par.ParallelOracle([c.copy() for c in mps], mpo, comm.world, integrator={integ!r}, conserve_norm={cn})
+    ser = orc.OracleMPS([c.copy() for c in mps], mpo, integrator={integ!r}, conserve_norm={cn})
+    ser.build_right_envs()
+    for _ in range(nstep):
+        ref.step(dt)
+        ser.propagate(dt)
+    go = ref.gather()
+    nrm = float(np.sqrt(abs(orc.overlap(g, g))))
+    out = dict(init=abs(abs(orc.overlap(g0, mps)) - 1),
+               vs_oracle=abs(abs(orc.overlap(go, g)) / (nrm * ref.norm()) - 1),
+               norm_gap=abs(nrm - ref.norm()),
+               vs_serial=abs(abs(orc.overlap(ser.cores, g)) / nrm - 1), norm=nrm,
+               bytes=eng.traffic()[0], messages=eng.traffic()[1])
+    print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+eng.close()
+comm.close()
+"""
+
+
+def _run(world, tmp_path, L=8, integ="lanczos", cn=True):
+    script = tmp_path / f"ss{world}.py"
+    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, L=L, integ=integ, cn=cn)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               MITDVP_DIST_BACKEND="gloo")
+    rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
+                          timeout=300)
+    assert rcs == [0] * world, "\n".join(outs)
+    return json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_site_sharded_matches_its_oracle_and_the_serial_sweep(world, tmp_path):
+    r = _run(world, tmp_path, L=9 if world == 3 else 8)
+    assert r["init"] < 1e-12                      # Phi_0 X_0^+ Phi_1 ... is the input state
+    assert r["vs_oracle"] < 1e-8 and r["norm_gap"] < 1e-8
+    assert r["vs_serial"] < (1e-12 if world == 1 else 1e-6)
+    assert abs(r["norm"] - 1) < (1e-12 if world == 1 else 1e-4)  # O(dt^2) per junction (oracle: 1.2e-5 at N=3, dt=0.2)
+    if world > 1:
+        assert r["messages"] > 0                  # neighbour traffic only: 5 messages per junction and half step (+ gather)
+
+
+@pytest.mark.gpu
+def test_site_sharded_arnoldi_without_renormalisation(tmp_path):
+    r = _run(2, tmp_path, integ="arnoldi", cn=False)
+    assert r["vs_oracle"] < 1e-8 and r["vs_serial"] < 1e-6
