@@ -23,7 +23,14 @@ N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE
 in the environment) or plainly as `python bench.py --gpus N`, in which case this
 process starts the N ranks itself (fresh children, before anything touches the
 GPU) and forwards rank 0's JSON line.  --parallel:
-  tp        (default when D % N == 0) ONE sweep shared by all GPUs, "scaling":
+  sites     (default when every rank gets >= 4 sites) contiguous site ranges per
+            rank, "scaling": "strong": all ranks sweep their blocks at once, the two
+            sites facing each other across a rank boundary are updated together
+            through the pseudo-inverse of the joint bond matrix; neighbour send /
+            recv of boundary tensors only (RCCL over xGMI), no collective.  The
+            reference's real-space parallel TDVP (_mps_parallel.py): approximate,
+            deviation from the serial sweep ~ dt^2 (pytdscf_amd/parallel_sites.py).
+  tp        (when D % N == 0) ONE sweep shared by all GPUs, "scaling":
             "strong": every H_eff / K_eff apply and environment update is sharded
             over the bra-side bond index (each rank contracts D/N rows of the
             environment block), combined by one RCCL all-gather / all-reduce per
@@ -226,7 +233,7 @@ def main():
     ap.add_argument("--max-seconds", type=float, default=float(os.environ.get("MITDVP_BENCH_BUDGET", "420")),
                     help="wall budget for the whole run; steps / warmup are cut to fit (0 = no limit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parallel", default=os.environ.get("MITDVP_PARALLEL", "auto"), choices=["auto", "tp", "replicas"])
+    ap.add_argument("--parallel", default=os.environ.get("MITDVP_PARALLEL", "auto"), choices=["auto", "sites", "tp", "replicas"])
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.gpus < 1:
         ap.error("need --steps >= 1, --warmup >= 0, --gpus >= 1")
@@ -265,16 +272,45 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')} +{elapsed():.0f}s] {msg}", file=sys.stderr, flush=True)
 
     liouville = integ == "arnoldi"
-    eng = TDVPEngine(L, device=comm.gpu, integrator=integ, conserve_norm=not liouville)
-    eng.set_mpo(syn.synthetic_liouvillian_mpo(L, M, seed=0, gamma=0.002) if liouville else syn.synthetic_mpo(L, d, M, seed=0))
+    mpo_cores = syn.synthetic_liouvillian_mpo(L, M, seed=0, gamma=0.002) if liouville else syn.synthetic_mpo(L, d, M, seed=0)
     mode = args.parallel
-    if mode == "auto":
-        mode = "tp" if (world > 1 and D % world == 0 and D >= 8 * world) else "replicas"
     if world == 1:
         mode = "single"
-    # tp: every rank holds the same replicated state (same seed); replicas: one trajectory per rank
-    eng.init_random([d] * L, D, seed=1 + (rank if mode == "replicas" else 0))
+    elif mode == "auto":
+        # site ranges (the partitioning north_star names; approximate like the reference's) when every rank
+        # gets at least four sites, else exact bond sharding, else independent replicas
+        if L >= 4 * world:
+            mode = "sites"
+        elif D % world == 0 and D >= 8 * world:
+            mode = "tp"
+        else:
+            mode = "replicas"
+    if comm.shared_gpu:  # several processes on one GPU (rehearsals): no persistent kernels, they need every CU
+        os.environ.setdefault("MITDVP_SMALL_KERNELS", "0")
+    ss = None
+    if mode == "sites":
+        from pytdscf_amd.parallel_sites import SiteShardedTDVP
+
+        ok = 1.0
+        try:
+            ss = SiteShardedTDVP(comm, mpo_cores, dims=[d] * L, bond_dim=D, seed=1, integrator=integ, conserve_norm=not liouville)
+        except Exception as e:  # noqa: BLE001 -- the verdict below is common to all ranks
+            note(f"site sharding unavailable ({type(e).__name__}: {e})")
+            ok = 0.0
+        if comm.min_over_ranks(ok) < 0.5:
+            if ss is not None:
+                ss.close()
+                ss = None
+            mode = "tp" if (D % world == 0 and D >= 8 * world) else "replicas"
+            note(f"falling back to --parallel {mode}")
+    eng = None
     collectives = None
+    e0 = None
+    if mode != "sites":
+        eng = TDVPEngine(L, device=comm.gpu, integrator=integ, conserve_norm=not liouville)
+        eng.set_mpo(mpo_cores)
+        # tp: every rank holds the same replicated state (same seed); replicas: one trajectory per rank
+        eng.init_random([d] * L, D, seed=1 + (rank if mode == "replicas" else 0))
     if mode == "tp":
         from pytdscf_amd.dist import attach_parallel, attach_parallel_native
 
@@ -299,65 +335,81 @@ def main():
             note(f"{e}; falling back to independent replicas")
             mode = "replicas"
             eng.init_random([d] * L, D, seed=1 + rank)
-    e0 = eng.expectation().real  # also builds nothing persistent; forces setup to finish
+    if eng is not None:
+        e0 = eng.expectation().real  # also builds nothing persistent; forces setup to finish
 
-    note(f"{args.workload} set up on device {comm.gpu} (L={L} d={d} D={D} M={M}), <H>={e0:.9f}")
+    # one "unit" of work: a half-sweep; the site-sharded step is two half-sweeps + the junction updates
+    unit = 2 if mode == "sites" else 1
+    state = {"forward": True}
+
+    def run_unit():
+        if mode == "sites":
+            ss.step(dt)
+        else:
+            eng.sweep(dt, state["forward"])
+            state["forward"] = not state["forward"]
+
+    def sync_norm():  # synchronises the engine's stream; the centre tensor's norm (= the state's, every block carries it)
+        return ss.block.norm() if mode == "sites" else eng.norm()
+
+    meas = ss.block if mode == "sites" else eng  # the engine whose counters feed the roofline (rank 0's block)
+
+    note(f"{args.workload} set up on device {comm.gpu} (L={L} d={d} D={D} M={M}), mode {mode}" + (f", <H>={e0:.9f}" if e0 is not None else ""))
 
     barrier = comm.barrier
     budget = args.max_seconds if args.max_seconds > 0 else float("inf")
     with_cpu = not args.no_cpu_baseline and world == 1
     reserve = (cpu_baseline_seconds_estimate(L, d, D, M) if with_cpu else 0.0) + 8.0
 
-    # ---- warm-up: at least one sweep, which also measures the sweep time ----
-    forward = True
-    warm_done, steps = 0, args.steps
-    warm_target = max(1, args.warmup)
+    # ---- warm-up: at least one unit, which also measures the sweep time ----
+    steps_req = max(unit, (args.steps // unit) * unit)
+    warm_done, steps = 0, steps_req
+    warm_target = max(unit, (args.warmup // unit) * unit)
     while warm_done < warm_target:
         t1 = time.perf_counter()
-        eng.sweep(dt, forward)
-        eng.norm()  # synchronises the engine's stream
-        t_sweep = comm.max_over_ranks(time.perf_counter() - t1)
-        forward = not forward
-        warm_done += 1
-        note(f"warm-up sweep {warm_done} done in {t_sweep:.2f}s")
-        more, steps = plan_sweeps(budget, comm.max_over_ranks(elapsed()), t_sweep, warm_done, warm_target, args.steps, reserve)
+        run_unit()
+        sync_norm()
+        t_sweep = comm.max_over_ranks(time.perf_counter() - t1) / unit
+        warm_done += unit
+        note(f"warm-up sweep {warm_done} done in {t_sweep:.2f}s per sweep")
+        more, steps = plan_sweeps(budget, comm.max_over_ranks(elapsed()), t_sweep, warm_done, warm_target, steps_req, reserve)
+        more, steps = (more // unit) * unit, max(unit, (steps // unit) * unit)
         warm_target = warm_done + more
     if steps != args.steps or warm_done != args.warmup:
         note(f"wall budget {budget:.0f}s: running {warm_done} warm-up + {steps} timed sweeps "
              f"(requested {args.warmup} + {args.steps})")
-    eng.norm()
-    eng.counters_reset()
+    sync_norm()
+    meas.counters_reset()
     # Per-phase HIP-event timing (roofline / breakdown) costs two event records per phase:
     # nothing at C4 (0.01 %), a third of the run in the launch-bound small-bond regime.  There
     # the timed region runs unprofiled and the same number of sweeps is repeated afterwards,
     # profiled, only for the breakdown.
     profile_in_timed = D >= 128
-    eng.set_profiling(profile_in_timed)
+    meas.set_profiling(profile_in_timed)
     barrier()
     t0 = time.perf_counter()
-    for i in range(steps):
-        eng.sweep(dt, forward)
-        forward = not forward
-        if steps > 1 and t_sweep > 5.0:
-            eng.norm()
-            note(f"timed sweep {i + 1}/{steps} done")
-    nrm = eng.norm()  # synchronises the engine's stream
+    for i in range(0, steps, unit):
+        run_unit()
+        if steps > unit and t_sweep > 5.0:
+            sync_norm()
+            note(f"timed sweep {i + unit}/{steps} done")
+    nrm = sync_norm()
     barrier()
     el_rank = time.perf_counter() - t0
-    if mode == "tp":  # one shared job: units are counted once
+    if mode in ("tp", "sites"):  # one shared job: units are counted once
         el = comm.max_over_ranks(el_rank)
         value = steps / el
     else:
         value, el = replica_throughput(comm, float(steps), el_rank)
     if not profile_in_timed:
-        eng.counters_reset()
-        eng.set_profiling(True)
-        for i in range(steps):
-            eng.sweep(dt, forward)
-            forward = not forward
-        eng.norm()
-    cnt = eng.counters()
-    eng.set_profiling(False)
+        meas.counters_reset()
+        meas.set_profiling(True)
+        for i in range(0, steps, unit):
+            run_unit()
+        sync_norm()
+    cnt = meas.counters()
+    meas.set_profiling(False)
+    halo = ss.traffic() if ss is not None else (0, 0)
 
     if rank == 0:
         kh = cnt["n_heff"] / max(cnt["n_exp_site"], 1)
@@ -382,7 +434,7 @@ def main():
             "warmup_requested": args.warmup,
             "ms_per_step": 1e3 * el / steps,
             "higher_is_better": True,
-            "scaling": "strong" if mode == "tp" else "weak",
+            "scaling": "strong" if mode in ("tp", "sites") else "weak",
             "vs_baseline": None,
             "dtype": "c128",
             "data": "synthetic",
@@ -396,7 +448,12 @@ def main():
                 "norm_after": nrm,
                 "energy_before": e0,
                 "parallelism": {"single": "single GPU", "replicas": f"{args.gpus} independent replicas",
-                                "tp": f"bond-sharded over {args.gpus} GPUs (all-gather / all-reduce via {collectives})"}[mode],
+                                "tp": f"bond-sharded over {args.gpus} GPUs (all-gather / all-reduce via {collectives})",
+                                "sites": f"site ranges over {args.gpus} GPUs (L/N sites per rank, neighbour send/recv of boundary "
+                                         f"tensors via torch.distributed/{comm.backend}, joint two-site update through pinv(X)); "
+                                         "roofline / breakdown are rank 0's block"}[mode],
+                "halo_GB": halo[0] / 1e9,
+                "halo_messages": halo[1],
                 "collectives": int(cnt["n_collectives"]),
                 "collective_GB": cnt["collective_bytes"] / 1e9,
                 "wall_budget_s": args.max_seconds,
@@ -460,7 +517,10 @@ def main():
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         out["wall_s"] = elapsed()
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
+    if ss is not None:
+        ss.close()
     comm.close()
 
 

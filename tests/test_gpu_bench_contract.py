@@ -76,7 +76,20 @@ def test_bench_driver_command_line_fits_its_wall_budget():
 
 
 def test_bench_plain_multi_gpu_command_launches_its_own_ranks():
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "1"]
+    """`python bench.py --gpus 2`: starts its own ranks; the default partitioning is by site ranges."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = _line(p.stdout)
+    _check_common(o)
+    assert o["n_gpus"] == 2 and o["scaling"] == "strong", p.stderr[-3000:]
+    assert "site ranges" in o["config"]["parallelism"] and o["config"]["halo_messages"] > 0
+    assert abs(o["config"]["norm_after"] - 1) < 1e-3  # the site-sharded scheme keeps the norm to O(dt^2)
+
+
+def test_bench_plain_multi_gpu_command_bond_sharded():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "1",
+           "--parallel", "tp"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     o = _line(p.stdout)
@@ -92,7 +105,7 @@ def test_bench_two_ranks_bond_sharded():
     s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", MITDVP_DIST_BACKEND="gloo")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--parallel", "tp"]
     rcs, outs = run_ranks([cmd] * 2, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(2)], timeout=600, cwd=ROOT,
                           split_stderr=True)
     assert rcs == [0, 0], "\n".join(o[1][-1500:] for o in outs)
