@@ -288,7 +288,8 @@ typedef struct {
   double heff_stage_ms[3]; /* L.psi, W., .R stages of the H_eff applies (profiling on) */
   double n_collectives;    /* collectives issued (bond-sharded mode)                   */
   double collective_bytes; /* sum of the collective buffer sizes                       */
-  double reserved[3];
+  double heff_flops_skipped; /* part of heff_flops NOT executed: zero blocks of W skipped by the block-sparse W stage */
+  double reserved[2];
 } mitdvp_counters;
 int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out);
 int mitdvp_counters_reset(mitdvp_engine* h);

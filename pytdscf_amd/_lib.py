@@ -60,7 +60,8 @@ class Counters(C.Structure):
         ("heff_stage_ms", C.c_double * 3),
         ("n_collectives", C.c_double),
         ("collective_bytes", C.c_double),
-        ("reserved", C.c_double * 3),
+        ("heff_flops_skipped", C.c_double),
+        ("reserved", C.c_double * 2),
     ]
 
     def as_dict(self):

@@ -59,6 +59,16 @@ struct ZgemmDesc {
   int tile_cfg;  // -1 auto; 0: 128x128 (4M) / 128x64 (3M), 1: 64x64, 2: 32x32
   int mode3m;    // -1 library default; 0: 4M product; 1: 3M (Karatsuba) product
   int ksplit;    // internal: K range per workgroup row in split-K launches (0 = off)
+  // block-sparse A (the W stage of an apply with a finite-state-machine MPO): for row tile tm of the 64-row
+  // tile grid, klist[tm * klist_stride] = number of K tiles (16 wide) holding a non-zero of A, followed by their
+  // indices; nullptr = dense.  Requires tile_cfg 1, no transposes, K % 16 == 0.
+  const int* klist;
+  int klist_stride;
+  // row address map of C: row r is stored at (r % rowmap_p) * rowmap_s1 + (r / rowmap_p) * rowmap_s2 instead of
+  // r * ldc (rowmap_p = 0: off) -- lets A's rows be ordered so that its zero blocks line up with the tile grid
+  int rowmap_p;
+  long rowmap_s1, rowmap_s2;
+  int rowmap_r0;  // added to the row index before the map (a GEMM over a row range of a larger mapped matrix)
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
 void zgemm(hipStream_t st, const ZgemmDesc& d);
@@ -70,6 +80,7 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.tile_cfg = -1;
   d.mode3m = -1;
   d.ksplit = 0;
+  d.klist = nullptr; d.klist_stride = 0; d.rowmap_p = 0; d.rowmap_s1 = 0; d.rowmap_s2 = 0; d.rowmap_r0 = 0;
   return d;
 }
 int zgemm_default_mode();

@@ -57,6 +57,17 @@ struct MpoSite {
   int ml = 0, d = 0, mr = 0;
   DevBuf w2l;  // W2L[(i,t)][(c,j)] = W[c,i,j,t]   (d*mr) x (ml*d)
   DevBuf w2r;  // W2R[(i,c)][(t,j)] = W[c,i,j,t]   (d*ml) x (mr*d)
+  // block-sparse W stage (finite-state-machine MPOs: most (c, t) blocks of W are zero): the same matrices with their
+  // rows ordered (t, i) / (c, i) so that zero blocks line up with the GEMM's 64 x 16 tile grid, and per row tile the
+  // list of K tiles that hold a non-zero (ZgemmDesc::klist); sp_frac = visited / all tiles (1 = dense, not used)
+  DevBuf w2lt, w2rt, kl_l, kl_r;
+  int kl_stride_l = 0, kl_stride_r = 0;
+  double sp_frac_l = 1.0, sp_frac_r = 1.0;
+  // row-tile ranges [t0, t1) of the 64-row grid, each either dense (most K tiles needed: the plain kernel on that row
+  // range) or sparse (the list kernel) -- mixing both kinds in one launch lets the few heavy tiles crawl among the many
+  // light ones (23 ms instead of 6 at the C4 shape)
+  struct SpSeg { int t0, t1; bool dense; };
+  std::vector<SpSeg> seg_l, seg_r;
   DevBuf w2el;  // small-site environment update, -> direction: [(t,j)][(i,c)] = W[c,i,j,t]
   DevBuf w2er;  // small-site environment update, <- direction: [(c,j)][(i,t)] = W[c,i,j,t]
   DevBuf wtr;  // Liouville trace operator: O2[f][(a,c,d)] = O[a,d,c,f], n = sqrt(site dim)
@@ -135,12 +146,12 @@ class Engine {
                        int dro, int dri);
   void keff_apply_rect(const zc* L, const zc* R, const zc* sig, zc* out, int dlo, int dli, int dro, int dri, int m);
   void env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const zc* w2, zc* env_out, int dbi, int dki,
-                       int min_, int d, int dbo, int dko, int mout);
+                       int min_, int d, int dbo, int dko, int mout, const MpoSite* sp = nullptr, int sp_side = 0);
   // generic environment update: env_in (din, min, din), T (din, d, dout),
   // W2 ((d*mout) x (min*d)) -> env_out (dout, mout, dout)
   // w2e: the small-site form of the same core (MpoSite::w2el / w2er), nullptr = general path only
   void env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
-                  int mout, const zc* w2e = nullptr);
+                  int mout, const zc* w2e = nullptr, const MpoSite* sp = nullptr, int sp_side = 0);
   // x <- exp(scale * Op) x ; returns Krylov dimension used
   template <class MV>
   int krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev, long nsize = -1);
@@ -229,6 +240,10 @@ class Engine {
   bool shard_range(int n, int& a0, int& a1) const;
   void collective(int op, zc* p, size_t elems);
 
+  bool sparse_w_ = true;       // MITDVP_SPARSE_W=0: always the dense W stage (A/B testing)
+  // the W stage of an apply / environment update: dense GEMM, or row ranges of dense / list kernels (returns the
+  // executed share of the dense flop count)
+  double w_stage(const MpoSite* sp, int side, const zc* w2, int d, int mout, int min_, int ncol, int nbatch);
   bool small_kernels_ = true;  // MITDVP_SMALL_KERNELS=0: always the general multi-launch kernels (A/B testing)
   // small-bond kernel family (small_site.hip): one launch per apply / environment update / local exponential
   SmallSync ss_;

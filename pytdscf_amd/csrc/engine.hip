@@ -25,6 +25,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (c.relax < 0 || c.relax > 2) throw ArgError("relax must be 0, 1 or 2");
   max_diag_krylov_ = c.max_diag_krylov > 0 ? c.max_diag_krylov : 64;
   if (const char* e = std::getenv("MITDVP_SMALL_KERNELS")) small_kernels_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MITDVP_SPARSE_W")) sparse_w_ = std::atoi(e) != 0;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -197,6 +198,51 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
   s.w2r.reserve(w2r.size());
   HIP_CHECK(hipMemcpyAsync(s.w2l.p, w2l.data(), w2l.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
   HIP_CHECK(hipMemcpyAsync(s.w2r.p, w2r.data(), w2r.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+  // block-sparse forms: rows (t, i) for W2L, (c, i) for W2R; K-tile lists on the 64 x 16 tile grid
+  auto sparse_form = [&](const std::vector<hzc>& w2, int mo, int mi, DevBuf& wt, DevBuf& kl, int& stride, double& frac,
+                         std::vector<MpoSite::SpSeg>& segs) {
+    // w2: rows (i, q) with q in [0, mo), cols (p, j) with p in [0, mi); permuted rows (q, i)
+    const int M = d * mo, K = mi * d;
+    frac = 1.0; stride = 0; segs.clear();
+    if (K % 16 != 0) return;
+    std::vector<hzc> p((size_t)M * K);
+    for (int i = 0; i < d; ++i)
+      for (int q = 0; q < mo; ++q)
+        std::memcpy(&p[((size_t)q * d + i) * K], &w2[((size_t)i * mo + q) * K], (size_t)K * sizeof(hzc));
+    const int ntm = (M + 63) / 64, nkt = K / 16;
+    stride = nkt + 1;
+    std::vector<int> list((size_t)ntm * stride, 0);
+    long visited = 0;
+    for (int tm = 0; tm < ntm; ++tm) {
+      int cnt = 0;
+      for (int kt = 0; kt < nkt; ++kt) {
+        bool nz = false;
+        for (int r = tm * 64; r < std::min(M, tm * 64 + 64) && !nz; ++r)
+          for (int k = kt * 16; k < kt * 16 + 16; ++k)
+            if (p[(size_t)r * K + k] != hzc(0.0, 0.0)) { nz = true; break; }
+        if (nz) list[(size_t)tm * stride + 1 + cnt++] = kt;
+      }
+      list[(size_t)tm * stride] = cnt;
+      visited += cnt;
+    }
+    // executed share: dense ranges run all their K tiles
+    long executed = 0;
+    for (int tm = 0; tm < ntm; ++tm) {
+      const bool dense = 2 * list[(size_t)tm * stride] > nkt;
+      executed += dense ? nkt : list[(size_t)tm * stride];
+      if (!segs.empty() && segs.back().dense == dense) segs.back().t1 = tm + 1;
+      else segs.push_back(MpoSite::SpSeg{tm, tm + 1, dense});
+    }
+    (void)visited;
+    frac = (double)executed / ((double)ntm * nkt);
+    wt.reserve(p.size());
+    kl.reserve((list.size() * sizeof(int) + sizeof(zc) - 1) / sizeof(zc));
+    HIP_CHECK(hipMemcpyAsync(wt.p, p.data(), p.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(kl.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));  // the host vectors go out of scope
+  };
+  sparse_form(w2l, mr, ml, s.w2lt, s.kl_l, s.kl_stride_l, s.sp_frac_l, s.seg_l);
+  sparse_form(w2r, ml, mr, s.w2rt, s.kl_r, s.kl_stride_r, s.sp_frac_r, s.seg_r);
   s.w2el.reserve(w2el.size());
   s.w2er.reserve(w2er.size());
   HIP_CHECK(hipMemcpyAsync(s.w2el.p, w2el.data(), w2el.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
@@ -371,6 +417,42 @@ int Engine::rccl_selftest() {
   return bad;
 }
 
+// W stage: Y_b[(i,q)][n] = W2[(i,q)][(p,j)] X_b[(p,j)][n] for nbatch slabs b (X_, Y_ workspaces).  With a
+// finite-state-machine MPO most (p, q) blocks of W are zero: rows of W2 ordered (q, i), per 64-row tile the list of
+// 16-wide K tiles that hold a non-zero; row ranges that need most K tiles go through the plain kernel, the others
+// through the list kernel, Y's rows are mapped back to (i, q).  Skipping exact zeros leaves Y bit-identical.
+double Engine::w_stage(const MpoSite* sp, int side, const zc* w2, int d, int mout, int min_, int ncol, int nbatch) {
+  ZgemmDesc g = zgemm_desc(w2, X_.p, Y_.p, d * mout, ncol, min_ * d);
+  g.batch = nbatch; g.strideA = 0; g.strideB = (long)min_ * d * ncol; g.strideC = (long)d * mout * ncol;
+  const bool use = sp && sparse_w_ && ncol >= 64 && (side == 0 ? sp->kl_l.p : sp->kl_r.p) &&
+                   (side == 0 ? sp->sp_frac_l : sp->sp_frac_r) <= 0.6;
+  if (!use) {
+    zgemm(st_, g);
+    return 1.0;
+  }
+  const zc* wt = side == 0 ? sp->w2lt.p : sp->w2rt.p;
+  const int* kl = reinterpret_cast<const int*>(side == 0 ? sp->kl_l.p : sp->kl_r.p);
+  const int stride = side == 0 ? sp->kl_stride_l : sp->kl_stride_r;
+  const auto& segs = side == 0 ? sp->seg_l : sp->seg_r;
+  const int M = d * mout, K = min_ * d;
+  // heavy ranges first: they are the long-running workgroups
+  for (int pass = 0; pass < 2; ++pass)
+    for (const auto& sgm : segs) {
+      if (sgm.dense != (pass == 0)) continue;
+      const int r0 = sgm.t0 * 64, r1 = std::min(M, sgm.t1 * 64);
+      ZgemmDesc h = g;
+      h.A = wt + (size_t)r0 * K;
+      h.M = r1 - r0;
+      h.rowmap_p = d; h.rowmap_s1 = (long)mout * ncol; h.rowmap_s2 = ncol; h.rowmap_r0 = r0;
+      if (!sgm.dense) { h.klist = kl + (size_t)sgm.t0 * stride; h.klist_stride = stride; }
+      h.tile_cfg = 1;
+      zgemm(st_, h);
+      cnt_.n_launch += 1;
+    }
+  cnt_.n_launch -= 1;  // the caller counts one launch for this stage
+  return side == 0 ? sp->sp_frac_l : sp->sp_frac_r;
+}
+
 // The blocks may be rectangular (bra bond != ket bond): L (dlo, ml, dli), R (dro, mr, dri),
 // psi (dli, d, dri) -> out (dlo, d, dro).  That is the adaptive-rank case
 // (tensor_shapes_out, _contraction.py:455-477); the plain sweep has dlo == dli, dro == dri.
@@ -387,11 +469,8 @@ void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const z
   }
   timer_end();
   timer_begin(11);
-  {  // Y_a[(i,t)][s] = W2L[(i,t)][(c,j)] X_a[(c,j)][s]
-    ZgemmDesc g = zgemm_desc(w.w2l.p, X_.p, Y_.p, d * mr, dri, ml * d);
-    g.batch = na; g.strideA = 0; g.strideB = (long)ml * d * dri; g.strideC = (long)d * mr * dri;
-    zgemm(st_, g);
-  }
+  // Y_a[(i,t)][s] = W2L[(i,t)][(c,j)] X_a[(c,j)][s]
+  const double s2_frac = w_stage(&w, 0, w.w2l.p, d, mr, ml, dri, na);
   timer_end();
   timer_begin(12);
   {  // out[(a,i)][r] = Y[(a,i)][(t,s)] R[r][(t,s)]
@@ -404,6 +483,7 @@ void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const z
   cnt_.n_launch += 3;
   cnt_.n_heff += 1;
   cnt_.heff_flops += 8.0 * ((double)na * dli * ml * d * dri + (double)na * dri * ml * mr * d * d + (double)na * dro * dri * mr * d);
+  cnt_.heff_flops_skipped += 8.0 * (1.0 - s2_frac) * ((double)na * dri * ml * mr * d * d);
 }
 
 void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
@@ -466,7 +546,7 @@ void Engine::keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1
 // W2 ((d*mout) x (min*d)) -> env_out (dbo, mout, dko).  Tb != Tk is the adaptive-rank
 // "bra" block (superblock_states_bra, _mps_cls.py:1950-1963).
 void Engine::env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const zc* w2, zc* env_out, int dbi, int dki,
-                             int min_, int d, int dbo, int dko, int mout) {
+                             int min_, int d, int dbo, int dko, int mout, const MpoSite* sp, int sp_side) {
   int m0, m1;
   const bool sharded = shard_range(dbi, m0, m1);
   const int nm = m1 - m0;
@@ -475,11 +555,8 @@ void Engine::env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const
     ZgemmDesc g = zgemm_desc(env_in + (size_t)m0 * min_ * dki, Tk, X_.p, nm * min_, d * dko, dki);
     zgemm(st_, g);
   }
-  {  // Y_m[(r,q)][j] = W2[(r,q)][(p,s)] X_m[(p,s)][j]
-    ZgemmDesc g = zgemm_desc(w2, X_.p, Y_.p, d * mout, dko, min_ * d);
-    g.batch = nm; g.strideA = 0; g.strideB = (long)min_ * d * dko; g.strideC = (long)d * mout * dko;
-    zgemm(st_, g);
-  }
+  // Y_m[(r,q)][j] = W2[(r,q)][(p,s)] X_m[(p,s)][j]
+  (void)w_stage(sp, sp_side, w2, d, mout, min_, dko, nm);
   {  // env'[i][(q,j)] = conj(Tb)[(m,r)][i] Y[(m,r)][(q,j)]   (sum over this rank's m)
     ZgemmDesc g = zgemm_desc(Tb + (size_t)m0 * d * dbo, Y_.p, env_out, dbo, mout * dko, nm * d);
     g.transA = 1; g.conjA = 1; g.lda = dbo;
@@ -494,7 +571,7 @@ void Engine::env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const
 }
 
 void Engine::env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out, int din, int min_, int d, int dout,
-                        int mout, const zc* w2e) {
+                        int mout, const zc* w2e, const MpoSite* sp, int sp_side) {
   SmallChain sc;
   if (w2e && small_ok() && chain_env(sc, T, w2e, din, min_, d, dout, mout)) {
     timer_begin(1);
@@ -506,7 +583,7 @@ void Engine::env_update(const zc* env_in, const zc* T, const zc* w2, zc* env_out
                              (double)din * dout * dout * mout * d);
     return;
   }
-  env_update_rect(env_in, T, T, w2, env_out, din, din, min_, d, dout, dout, mout);
+  env_update_rect(env_in, T, T, w2, env_out, din, din, min_, d, dout, dout, mout, sp, sp_side);
 }
 
 // ---------------------------------------------------------------------------
@@ -632,7 +709,7 @@ void Engine::build_right_envs() {
     const MpoSite& w = mpo(0, p);
     transpose_rev3(st_, site_[p].p, tmp1_.p, dl_[p], dd_[p], dr_[p]);
     envR_[p] = pool_get((size_t)dl_[p] * w.ml * dl_[p]);
-    env_update(envR_[p + 1].p, tmp1_.p, w.w2r.p, envR_[p].p, dr_[p], w.mr, dd_[p], dl_[p], w.ml, w.w2er.p);
+    env_update(envR_[p + 1].p, tmp1_.p, w.w2r.p, envR_[p].p, dr_[p], w.mr, dd_[p], dl_[p], w.ml, w.w2er.p, &w, 1);
     envR_ok_[p] = 1;
   }
 }
@@ -647,7 +724,7 @@ void Engine::build_left_envs() {
     const MpoSite& w = mpo(0, p);
     pool_put(std::move(envL_[p + 1]));
     envL_[p + 1] = pool_get((size_t)dr_[p] * w.mr * dr_[p]);
-    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl_[p], w.ml, dd_[p], dr_[p], w.mr, w.w2el.p);
+    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl_[p], w.ml, dd_[p], dr_[p], w.mr, w.w2el.p, &w, 0);
     envL_ok_[p + 1] = 1;
   }
 }
@@ -705,7 +782,7 @@ void Engine::sweep(double dt, bool forward) {
       gauge_[p] = MITDVP_GAUGE_A;
       // renormalize_op_psite: L_{p+1}
       envL_[p + 1] = pool_get((size_t)dr * w.mr * dr);
-      env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr, w.w2el.p);
+      env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr, w.w2el.p, &w, 0);
       envL_ok_[p + 1] = 1;
       // exp(+i K dt/2) on the bond matrix
       const zc* Lb = envL_[p + 1].p;
@@ -731,7 +808,7 @@ void Engine::sweep(double dt, bool forward) {
       std::swap(site_[p], spare);
       gauge_[p] = MITDVP_GAUGE_B;
       envR_[p] = pool_get((size_t)dl * w.ml * dl);
-      env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml, w.w2er.p);
+      env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml, w.w2er.p, &w, 1);
       envR_ok_[p] = 1;
       const zc* Lb = envL_[p].p;
       const zc* Rb = envR_[p].p;

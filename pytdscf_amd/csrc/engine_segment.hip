@@ -100,7 +100,7 @@ void Engine::split_center(bool forward) {
     gauge_[p] = MITDVP_GAUGE_A;
     pool_put(std::move(envL_[p + 1]));
     envL_[p + 1] = pool_get((size_t)dr * w.mr * dr);
-    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr, w.w2el.p);
+    env_update(envL_[p].p, site_[p].p, w.w2l.p, envL_[p + 1].p, dl, w.ml, d, dr, w.mr, w.w2el.p, &w, 0);
     envL_ok_[p + 1] = 1;
     bond_ = p + 1; bond_dim_ = dr;
   } else {
@@ -110,7 +110,7 @@ void Engine::split_center(bool forward) {
     gauge_[p] = MITDVP_GAUGE_B;
     pool_put(std::move(envR_[p]));
     envR_[p] = pool_get((size_t)dl * w.ml * dl);
-    env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml, w.w2er.p);
+    env_update(envR_[p + 1].p, tmp2_.p, w.w2r.p, envR_[p].p, dr, w.mr, d, dl, w.ml, w.w2er.p, &w, 1);
     envR_ok_[p] = 1;
     bond_ = p; bond_dim_ = dl;
   }

@@ -49,7 +49,7 @@ __device__ __forceinline__ int cd_row(int mode, int lk, int r) {
   return mode == 0 ? (lk + 4 * r) : (4 * lk + r);
 }
 
-template <int WM, int WN, int BK, bool TA, bool TB, bool M3>
+template <int WM, int WN, int BK, bool TA, bool TB, bool M3, bool SP = false>
 __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
   constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
   constexpr int LDAS = TA ? BM : (BK + 1);  // LDS row stride (complex elements)
@@ -139,7 +139,16 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
   // in registers into LDS stage `stage` (kv = number of valid k in that tile);
   // item >= NP loads element item-NP of the following tile (kv2 valid k).
   constexpr int NP = A_PT + B_PT;
-  auto side = [&](int item, zc* stage, int kv, int kv2) {
+  // SP: the K tiles to visit come from a list (block-sparse A); `ord` = position in that list of the tile being
+  // loaded.  K % BK == 0 there, so a listed tile is valid as a whole and an unlisted position loads nothing.
+  const int* kl = nullptr;
+  int nlist = 0;
+  if (SP) {
+    kl = d.klist + (long)tm * d.klist_stride;
+    nlist = kl[0];
+    kl += 1;
+  }
+  auto side = [&](int item, zc* stage, int kv, int kv2, int ord = 0) {
     if (item < A_PT) {
       const int p = item;
       const bool ok = kbA + p * KSA < kv;
@@ -156,14 +165,24 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
       stage[lb[p]] = v;
     } else if (item < NP + A_PT) {
       const int p = item - NP;
-      const bool ok = kbA + p * KSA < kv2;
-      ra[p] = *(ok ? pa[p] : A);
-      pa[p] += stepA;
+      if (SP) {
+        const bool ok = ord < nlist;
+        ra[p] = *(ok ? pa[p] + (long)kl[ok ? ord : 0] * stepA : A);
+      } else {
+        const bool ok = kbA + p * KSA < kv2;
+        ra[p] = *(ok ? pa[p] : A);
+        pa[p] += stepA;
+      }
     } else if (item < 2 * NP) {
       const int p = item - NP - A_PT;
-      const bool ok = kbB + p * KSB < kv2;
-      rb[p] = *(ok ? pb[p] : B);
-      pb[p] += stepB;
+      if (SP) {
+        const bool ok = ord < nlist;
+        rb[p] = *(ok ? pb[p] + (long)kl[ok ? ord : 0] * stepB : B);
+      } else {
+        const bool ok = kbB + p * KSB < kv2;
+        rb[p] = *(ok ? pb[p] : B);
+        pb[p] += stepB;
+      }
     }
   };
 
@@ -208,21 +227,22 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
     }
   };
 
-  const int nkt = (K + BK - 1) / BK;
+  const int nkt = SP ? nlist : (K + BK - 1) / BK;
   // prologue: tile 0 -> LDS stage 0, tile 1 -> registers
 #pragma unroll
-  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K);
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K, 0);
 #pragma unroll
-  for (int it = 0; it < NP; ++it) side(it, smem, K, 0);
+  for (int it = 0; it < NP; ++it) side(it, smem, SP ? (nlist > 0 ? BK : 0) : K, 0);
 #pragma unroll
-  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K - BK);
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K - BK, 1);
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
     const zc* st = smem + (kt & 1) * STAGE;
     zc* nst = smem + ((kt + 1) & 1) * STAGE;
-    const int kv1 = K - (kt + 1) * BK;  // valid k of the tile in registers (<= 0: no such tile)
-    const int kv2 = kv1 - BK;           // ... of the tile to load now
+    // valid k of the tile in registers (<= 0: no such tile) / of the tile to load now
+    const int kv1 = SP ? (kt + 1 < nlist ? BK : 0) : K - (kt + 1) * BK;
+    const int kv2 = SP ? 0 : kv1 - BK;
     zc fa[2][WM], fb[2][WN];
     ldfrag(st, 0, fa[0], fb[0]);
 #pragma unroll
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
         const int slot = k4 * WM + i;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < PER_SLOT; ++q) side(slot * PER_SLOT + q, nst, kv1, kv2);
+        for (int q = 0; q < PER_SLOT; ++q) side(slot * PER_SLOT + q, nst, kv1, kv2, kt + 2);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -304,7 +324,9 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
             v = make_double2(acc[0][i][j][r], acc[1][i][j][r]);
           }
           zc o = zmul(alpha, v);
-          zc* p = C + (long)row * ldc + col;
+          const int rr = row + d.rowmap_r0;
+          zc* p = C + (d.rowmap_p > 0 ? (long)(rr % d.rowmap_p) * d.rowmap_s1 + (long)(rr / d.rowmap_p) * d.rowmap_s2
+                                      : (long)row * ldc) + col;
           if (has_beta) o = zadd(o, zmul(beta, *p));
           *p = o;
         }
@@ -545,6 +567,18 @@ static void launch_tiles(hipStream_t st, const ZgemmDesc& d, int cfg, int m3) {
   }
 }
 
+// block-sparse A: 64x64 tiles, NN, K tiles from the list
+static void launch_sparse(hipStream_t st, const ZgemmDesc& d, int m3) {
+  if (d.transA || d.transB || d.K % 16 != 0 || d.ksplit) throw ArgError("zgemm: the block-sparse form needs NN operands and K % 16 == 0");
+  constexpr int BM = 64, BN = 64;
+  const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, d.batch);
+  constexpr size_t lds = 2 * (size_t)(BM * 17 + 16 * BN) * sizeof(zc);
+  if (m3) hipLaunchKernelGGL((zgemm_kernel<2, 2, 16, false, false, true, true>), grid, dim3(256), lds, st, d, ntm, ntn, g_cd_mode);
+  else hipLaunchKernelGGL((zgemm_kernel<2, 2, 16, false, false, false, true>), grid, dim3(256), lds, st, d, ntm, ntn, g_cd_mode);
+  HIP_CHECK(hipGetLastError());
+}
+
 void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
   if (d.K < 0) throw ArgError("zgemm: negative K");
@@ -556,6 +590,7 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   }
   int cfg = d.tile_cfg;
   const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
+  if (d.klist) { launch_sparse(st, d, m3); return; }
   auto tiles = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
   if (cfg < 0) {
     // 64x64 tiles (two resident workgroups per CU fill each other's barrier

@@ -270,6 +270,28 @@ class SiteShardedTDVP:
             self.link.send(c, 0)
         return None
 
+    def selftest(self) -> bool:
+        """Neighbour ping over the link (every junction, both directions) before the sweep relies on it."""
+        if self.world == 1:
+            return True
+        ok = True
+        probe = (np.arange(6, dtype=np.float64) + 10.0 * self.rank).astype(np.complex128).reshape(2, 3)
+        try:
+            for parity in (0, 1):
+                r = self.rank
+                if r % 2 == parity and r < self.world - 1:
+                    self.link.send(probe, r + 1)
+                    back = self.link.recv((2, 3), r + 1)
+                    ok = ok and np.array_equal(back, probe + 1.0)
+                elif r % 2 != parity and r > 0:
+                    got = self.link.recv((2, 3), r - 1)
+                    want = (np.arange(6, dtype=np.float64) + 10.0 * (r - 1)).astype(np.complex128).reshape(2, 3)
+                    ok = ok and np.array_equal(got, want)
+                    self.link.send(got + 1.0, r - 1)
+        except Exception:  # noqa: BLE001 -- the caller shares the verdict over all ranks
+            ok = False
+        return bool(ok)
+
     def traffic(self):
         return (self.link.bytes, self.link.messages) if self.link else (0, 0)
 

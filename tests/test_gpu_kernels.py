@@ -217,3 +217,34 @@ def test_concurrent_engines_from_host_threads():
         got = np.concatenate([c.reshape(-1) for c in e.get_mps()])
         assert np.array_equal(got, ref)  # deterministic kernels: bit-identical
         e.close()
+
+
+def test_block_sparse_w_stage_is_bitwise_the_dense_one(monkeypatch):
+    """The W stage of an apply / environment update skips the zero (c, t) blocks of a finite-state-machine MPO
+    (rows of W2 ordered (t, i), K-tile list per row tile, rows of Y mapped back): adding exact zeros changes
+    nothing, so a sweep must equal the dense W stage bit for bit -- and the oracle to the usual tolerance."""
+    import numpy as np
+
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L, d, M, D = 5, 16, 8, 64
+    mpo = orc.synthetic_mpo(L, d, M, seed=0)
+    mps = orc.synthetic_mps([d] * L, D, seed=1)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MITDVP_SPARSE_W", flag)
+        monkeypatch.setenv("MITDVP_SMALL_KERNELS", "0")  # the general three-launch chain is what carries the sparse stage
+        eng = TDVPEngine(L)
+        eng.set_mpo(mpo)
+        eng.set_mps(mps)
+        eng.propagate(0.3)
+        out[flag] = (eng.get_mps(), eng.expectation(), eng.counters())
+        eng.close()
+    assert out["1"][2]["heff_flops_skipped"] > 0 and out["0"][2]["heff_flops_skipped"] == 0
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert np.array_equal(a, b)
+    ref = orc.OracleMPS([c.copy() for c in mps], mpo)
+    ref.propagate(0.3)
+    assert abs(abs(orc.overlap(ref.cores, out["1"][0])) - 1) < 1e-10
+    assert abs(out["1"][1] - ref.expectation()) < 1e-8 * abs(ref.expectation())

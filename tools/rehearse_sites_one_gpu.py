@@ -1,0 +1,56 @@
+"""Two site-sharded ranks on ONE GPU (gloo) at the C4 interior shape (D = 1024, d = 16, M = 32, L = 8): one time
+step next to the serial engine on the same inputs -- exercises the 1024^2 pseudo-inverse, the full-size junction
+update and the host-staged halo messages.  Start with:  python tools/rehearse_sites_one_gpu.py  (spawns its ranks)."""
+import json, os, socket, subprocess, sys, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+if "WORLD_SIZE" not in os.environ:
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", MITDVP_DIST_BACKEND="gloo",
+               MITDVP_SMALL_KERNELS="0")
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK="0")) for r in range(2)]
+    rc = 0
+    for p in ps:
+        rc = rc or p.wait()
+    sys.exit(rc)
+
+import numpy as np
+from pytdscf_amd import TDVPEngine, synthetic as syn
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+
+L, d, D, M, dt = int(os.environ.get("RS_L", 8)), 16, int(os.environ.get("RS_D", 1024)), 32, 0.5
+comm = Comm()
+mpo = syn.synthetic_mpo(L, d, M, seed=0)
+t0 = time.time()
+eng = SiteShardedTDVP(comm, mpo, dims=[d] * L, bond_dim=D, seed=1)
+assert eng.selftest()
+t_setup = time.time() - t0
+t0 = time.time()
+eng.step(dt)
+comm.barrier()
+t_step = time.time() - t0
+g = eng.gather()
+if comm.rank == 0:
+    ser = TDVPEngine(L)
+    ser.set_mpo(mpo)
+    ser.init_random([d] * L, D, seed=1)
+    t0 = time.time()
+    ser.propagate(dt)
+    n = ser.norm()
+    t_ser = time.time() - t0
+    ref = ser.get_mps()
+    # <ref|g> and <g|g> with plain transfer contractions (bond 1024: a few seconds of NumPy)
+    def ov(a, b):
+        e = np.ones((1, 1), complex)
+        for x, y in zip(a, b):
+            e = np.einsum("ab,aic,bid->cd", e, x.conj(), y, optimize=True)
+        return e[0, 0]
+    gg = ov(g, g).real
+    print(json.dumps(dict(L=L, D=D, setup_s=t_setup, step_s=t_step, serial_step_s=t_ser, norm=float(np.sqrt(gg)),
+                          infidelity=float(1 - abs(ov(ref, g)) / np.sqrt(gg) / n), halo_GB=eng.traffic()[0] / 1e9)), flush=True)
+comm.barrier()
+eng.close()
+comm.close()
