@@ -188,6 +188,13 @@ int mitdvp_bond_exp(mitdvp_engine* h, double dt_au);      /* exp_superK_propagat
 int mitdvp_absorb_bond(mitdvp_engine* h, int forward);    /* trans_next_psite_APsiB, :1172-1206 */
 int mitdvp_get_bond(mitdvp_engine* h, double* reim_out, int* dim);   /* the pending bond matrix (joint_sigvec) */
 int mitdvp_set_bond(mitdvp_engine* h, int bond, const double* reim, int dim);
+/* Observables of a site-sharded state without gathering it (MPSCoefParallel.ovlp, _mps_parallel.py:855-983;
+ * expectation, :1210-1302): a boundary block is carried through ALL sites of this engine.  from_left: reim_in sits
+ * left of site 0, reim_out right of the last site (shape from the last site / MPO core); else the other way round.
+ * op_id >= 0: environment block (d, m, d) of that operator, bra conjugated; op_id < 0: transfer block (d, 1, d),
+ * conj_bra = 0 gives <Psi*|Psi> (the autocorrelation of the t/2 trick). */
+int mitdvp_fold_block(mitdvp_engine* h, int op_id, int conj_bra, int from_left, const double* reim_in, int d, int m,
+                      double* reim_out);
 
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */

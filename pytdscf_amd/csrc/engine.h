@@ -201,6 +201,7 @@ class Engine {
   void absorb_bond(bool forward);
   void get_bond(double* out, int* dim);
   void set_bond(int b, const double* reim, int dim);
+  void fold_block(int op_id, bool conj_bra, bool from_left, const double* in, int d, int m, double* out);
   hipStream_t stream() const { return st_; }
   const MpoSite& mpo(int op_id, int isite);
   mitdvp_config cfg;
@@ -310,7 +311,7 @@ class Engine {
   void size_workspaces();
   void build_right_envs();
   void local_site_exp(int p, double dt);
-  void require_ready();
+  void require_ready(bool open_ends = false);  // open_ends: outer bonds wider than 1 without boundary blocks (fold_block)
   hzc scale_site(double dt) const;
   hzc scale_bond(double dt) const;
   void read_partials(size_t off_elems, size_t count);

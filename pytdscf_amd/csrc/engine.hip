@@ -302,13 +302,13 @@ void Engine::size_workspaces() {
     if (site_[p].p) site_[p].grow_preserve((size_t)ms, (size_t)dl_[p] * dd_[p] * dr_[p], st_);
 }
 
-void Engine::require_ready() {
+void Engine::require_ready(bool open_ends) {
   for (int p = 0; p < L_; ++p) {
     if (!site_[p].p) throw ArgError("site tensor not set");
     if (p + 1 < L_ && dr_[p] != dl_[p + 1]) throw ArgError("bond dimension mismatch between neighbouring sites");
   }
   if (!segment_) {
-    if (dl_[0] != 1 || dr_[L_ - 1] != 1) throw ArgError("open boundary bonds must be 1");
+    if (!open_ends && (dl_[0] != 1 || dr_[L_ - 1] != 1)) throw ArgError("open boundary bonds must be 1");
   } else if ((envL_ok_[0] && bnd_dl_ != dl_[0]) || (envR_ok_[L_] && bnd_dr_ != dr_[L_ - 1])) {
     throw ArgError("segment: the outer bonds differ from the boundary blocks' dimension");
   }

@@ -191,4 +191,73 @@ void Engine::set_bond(int b, const double* reim, int dim) {
   center_ = -1;
 }
 
+// A boundary block carried through ALL sites of this engine: what the ranks of a site-sharded state pass along
+// to evaluate <Psi|Psi>, <Psi*|Psi> and <Psi|O|Psi> without gathering the tensors (MPSCoefParallel.ovlp /
+// expectation, _mps_parallel.py:855-983, :1210-1302; _ovlp_single_state_np_from_left / _from_right, :1473-1518).
+//   op_id >= 0: the block is an environment block (d, m, d) of that operator, the sites enter as conj(bra) | ket
+//               (contract_with_site_mpo, _contraction.py:148-397); the gauge tags are not consulted;
+//   op_id <  0: plain transfer block T[bra][ket] (m = 1); conj_bra = false gives <Psi*|Psi> (autocorrelation).
+// from_left: `in` sits left of site 0 and `out` right of the last site; otherwise the other way round.
+void Engine::fold_block(int op_id, bool conj_bra, bool from_left, const double* in, int d, int m, double* out) {
+  require_ready(true);
+  if (!in || !out) throw ArgError("fold_block: null block");
+  const int first = from_left ? 0 : L_ - 1;
+  const int d0 = from_left ? dl_[first] : dr_[first];
+  if (d != d0) throw ArgError("fold_block: block and site bond dimension differ");
+  if (op_id < 0 && m != 1) throw ArgError("fold_block: a plain transfer block has m = 1");
+  if (op_id >= 0) {
+    if (!conj_bra) throw ArgError("fold_block: operator blocks are defined with the conjugated bra only");
+    const MpoSite& w = mpo(op_id, first);
+    if (m != (from_left ? w.ml : w.mr)) throw ArgError("fold_block: block and MPO bond dimension differ");
+  }
+  size_t mx = (size_t)d * m * d;
+  for (int p = 0; p < L_; ++p) {
+    const int mm = op_id >= 0 ? std::max(mpo(op_id, p).ml, mpo(op_id, p).mr) : 1;
+    const size_t dd = std::max(dl_[p], dr_[p]);
+    mx = std::max(mx, dd * mm * dd);
+  }
+  DevBuf cur = pool_get(mx), nxt = pool_get(mx);
+  HIP_CHECK(hipMemcpyAsync(cur.p, in, (size_t)d * m * d * sizeof(zc), hipMemcpyHostToDevice, st_));
+  int dout = d, mout = m;
+  for (int k = 0; k < L_; ++k) {
+    const int p = from_left ? k : L_ - 1 - k;
+    const int dl = dl_[p], dd = dd_[p], dr = dr_[p];
+    if (op_id >= 0) {
+      const MpoSite& w = mpo(op_id, p);
+      if (w.d != dd) throw ArgError("fold_block: MPO physical dimension differs from the site tensor's");
+      if (from_left) {
+        env_update(cur.p, site_[p].p, w.w2l.p, nxt.p, dl, w.ml, dd, dr, w.mr, w.w2el.p, &w, 0);
+        dout = dr; mout = w.mr;
+      } else {
+        transpose_rev3(st_, site_[p].p, tmp1_.p, dl, dd, dr);
+        env_update(cur.p, tmp1_.p, w.w2r.p, nxt.p, dr, w.mr, dd, dl, w.ml, w.w2er.p, &w, 1);
+        dout = dl; mout = w.ml;
+      }
+      cnt_.n_launch += 3;
+    } else if (from_left) {
+      // U[a][(j,s)] = T[a][b] C[b][(j,s)];  T'[i][s] = sum_(a,j) op(C)[(a,j)][i] U[(a,j)][s]
+      ZgemmDesc u = zgemm_desc(cur.p, site_[p].p, tmp1_.p, dl, dd * dr, dl);
+      zgemm(st_, u);
+      ZgemmDesc t = zgemm_desc(site_[p].p, tmp1_.p, nxt.p, dr, dr, dl * dd);
+      t.transA = 1; t.conjA = conj_bra ? 1 : 0; t.lda = dr;
+      zgemm(st_, t);
+      dout = dr; cnt_.n_launch += 2;
+    } else {
+      // U[(b,j)][r] = C[(b,j)][s] T[r][s];  T'[a][b] = sum_(j,r) op(C)[a][(j,r)] U[b][(j,r)]
+      ZgemmDesc u = zgemm_desc(site_[p].p, cur.p, tmp1_.p, dl * dd, dr, dr);
+      u.transB = 1; u.ldb = dr;
+      zgemm(st_, u);
+      ZgemmDesc t = zgemm_desc(site_[p].p, tmp1_.p, nxt.p, dl, dl, dd * dr);
+      t.conjA = conj_bra ? 1 : 0; t.transB = 1; t.ldb = dd * dr;
+      zgemm(st_, t);
+      dout = dl; cnt_.n_launch += 2;
+    }
+    std::swap(cur, nxt);
+  }
+  HIP_CHECK(hipMemcpyAsync(out, cur.p, (size_t)dout * mout * dout * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  pool_put(std::move(cur));
+  pool_put(std::move(nxt));
+}
+
 }  // namespace mitdvp

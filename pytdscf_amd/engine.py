@@ -96,6 +96,10 @@ class TDVPEngine:
         self._ck(self._lib.mitdvp_init_random(self._h, arr, bond_dim, seed))
 
     def set_mpo(self, cores, op_id: int = 0, shift: complex = 0.0):
+        cores = list(cores)
+        if cores:
+            self._mpo_ends = getattr(self, "_mpo_ends", {})
+            self._mpo_ends[op_id] = (np.shape(cores[0])[0], np.shape(cores[-1])[-1])
         for i, w in enumerate(cores):
             a = _c128(w)
             if a.ndim != 4:
@@ -152,6 +156,21 @@ class TDVPEngine:
         if a.ndim != 2 or a.shape[0] != a.shape[1]:
             raise ValueError("bond matrix must be square")
         self._ck(self._lib.mitdvp_set_bond(self._h, bond, _dp(a), a.shape[0]))
+
+    def fold_block(self, block, *, op_id: int = -1, conj: bool = True, from_left: bool = True, out_shape=None):
+        """Carry a boundary block (D, M, D) through all sites of this engine (``mitdvp_fold_block``): the piece of
+        ``MPSCoefParallel.ovlp`` / ``expectation`` one rank computes.  ``op_id < 0``: plain transfer (M = 1)."""
+        a = _c128(block)
+        if a.ndim != 3 or a.shape[0] != a.shape[2]:
+            raise ValueError("boundary block must be (D, M, D)")
+        if out_shape is None:
+            last = self.get_site_shape(self.nsite - 1 if from_left else 0)
+            dn = last[2] if from_left else last[0]
+            ends = getattr(self, "_mpo_ends", {}).get(op_id, (1, 1))
+            out_shape = (dn, (ends[1] if from_left else ends[0]) if op_id >= 0 else 1, dn)
+        out = np.empty(out_shape, dtype=np.complex128)
+        self._ck(self._lib.mitdvp_fold_block(self._h, op_id, int(conj), int(from_left), _dp(a), a.shape[0], a.shape[1], _dp(out)))
+        return out
 
     # ---- hot path ------------------------------------------------------
     def propagate(self, dt_au: float):

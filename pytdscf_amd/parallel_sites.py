@@ -270,6 +270,82 @@ class SiteShardedTDVP:
             self.link.send(c, 0)
         return None
 
+    # ------------------------------------------------------------------ observables without gathering the state
+    # MPSCoefParallel.ovlp / norm / autocorr / expectation (_mps_parallel.py:855-1033, :1210-1302): transfer blocks
+    # are folded from both ends of the chain towards the middle junction, rank by rank, on the devices
+    # (mitdvp_fold_block); a rank's effective tensors are its block followed by X^+ of the junction to its right,
+    # which enters as one more site of physical dimension 1.
+    def _fold(self, block, from_left, op_id, conj, op_cores):
+        eng = self.block
+        parts = ["block"]
+        if self.rank < self.world - 1:
+            parts = parts + ["x"] if from_left else ["x"] + parts
+        for kind in parts:
+            if kind == "block":
+                m_out = 1 if op_id < 0 else (op_cores[self.hi - 1].shape[3] if from_left else op_cores[self.lo].shape[0])
+                shp = self.shapes[self.hi - 1][2] if from_left else self.shapes[self.lo][0]
+                block = eng.fold_block(block, op_id=op_id, conj=conj, from_left=from_left, out_shape=(shp, m_out, shp))
+            else:
+                D = self.X.shape[0]
+                x = TDVPEngine(1, device=self.device, **self.kw)
+                try:
+                    x.set_site(0, pinv_device(self.X, self.device).reshape(D, 1, D), "C")
+                    if op_id >= 0:
+                        M = block.shape[1]
+                        x.set_mpo([np.eye(M, dtype=np.complex128).reshape(M, 1, 1, M)], op_id=op_id)
+                    block = x.fold_block(block, op_id=op_id, conj=conj, from_left=from_left, out_shape=block.shape)
+                finally:
+                    x.close()
+        return block
+
+    def _fold_chain(self, op_id, conj, op_cores):
+        """every rank returns the scalar (it is formed at the middle junction and shared)."""
+        r, N = self.rank, self.world
+        one = np.ones((1, 1, 1), dtype=np.complex128)
+        if N == 1:
+            return complex(self._fold(one, True, op_id, conj, op_cores)[0, 0, 0])
+        mid = N // 2  # ranks < mid fold from the left, the others from the right (_mps_parallel.py:858-861)
+        val = 0.0 + 0.0j
+        if r < mid:
+            D = self.shapes[self.lo][0]
+            M = 1 if op_id < 0 else op_cores[self.lo].shape[0]
+            blk = one if r == 0 else self.link.recv((D, M, D), r - 1)
+            blk = self._fold(blk, True, op_id, conj, op_cores)
+            if r < mid - 1:
+                self.link.send(blk, r + 1)
+            else:
+                other = self.link.recv(blk.shape, mid)
+                val = complex(np.sum(blk * other))  # "ab,ab->" over bra and ket (and the MPO bond)
+        else:
+            D = self.shapes[self.hi - 1][2]
+            M = 1 if op_id < 0 else op_cores[self.hi - 1].shape[3]
+            blk = one if r == N - 1 else self.link.recv((D, M, D), r + 1)
+            blk = self._fold(blk, False, op_id, conj, op_cores)
+            self.link.send(blk, r - 1)
+        re = self.comm.sum_over_ranks(val.real)
+        im = self.comm.sum_over_ranks(val.imag)
+        return complex(re, im)
+
+    def overlap(self, conj=True):
+        """<Psi|Psi> (conj) or <Psi*|Psi> of the sharded state; collective over all ranks."""
+        return self._fold_chain(-1, conj, None)
+
+    def norm(self):
+        return float(np.sqrt(max(self.overlap(True).real, 0.0)))
+
+    def autocorr(self):
+        return self.overlap(False)
+
+    def expectation(self, op_cores=None):
+        """<Psi|O|Psi> for an operator given as MPO cores over the WHOLE chain (default: the Hamiltonian)."""
+        if op_cores is None:
+            return self._fold_chain(0, True, self.mpo)
+        cores = [np.ascontiguousarray(w, dtype=np.complex128) for w in op_cores]
+        if len(cores) != self.nsite:
+            raise ValueError("operator needs one MPO core per site of the chain")
+        self.block.set_mpo(cores[self.lo : self.hi], op_id=1)
+        return self._fold_chain(1, True, cores)
+
     def selftest(self) -> bool:
         """Neighbour ping over the link (every junction, both directions) before the sweep relies on it."""
         if self.world == 1:

@@ -78,8 +78,20 @@ eng = SiteShardedTDVP(comm, mpo, cores=mps, integrator={integ!r}, conserve_norm=
 g0 = eng.gather()
 for _ in range(nstep):
     eng.step(dt)
+obs = dict(norm=eng.norm(), auto=eng.autocorr(), energy=eng.expectation())
+op2 = orc.synthetic_mpo(L, d, 3, seed=7)
+obs["op2"] = eng.expectation(op2)
 g = eng.gather()
+def sandwich(bra, ket, ops=None):
+    e = np.ones((1, 1, 1), complex)
+    for p, (x, y) in enumerate(zip(bra, ket)):
+        w = ops[p] if ops is not None else np.eye(x.shape[1]).reshape(1, x.shape[1], x.shape[1], 1)
+        e = np.einsum("acb,aix,cijt,bjy->xty", e, x, w, y, optimize=True)
+    return complex(e[0, 0, 0])
 if comm.rank == 0:
+    gc = [c.conj() for c in g]
+    obs_gap = max(abs(obs["norm"] - np.sqrt(sandwich(gc, g).real)), abs(obs["auto"] - sandwich(g, g)),
+                  abs(obs["energy"] - sandwich(gc, g, mpo)), abs(obs["op2"] - sandwich(gc, g, op2)))
     ref = par.ParallelOracle([c.copy() for c in mps], mpo, comm.world, integrator={integ!r}, conserve_norm={cn})
     ser = orc.OracleMPS([c.copy() for c in mps], mpo, integrator={integ!r}, conserve_norm={cn})
     ser.build_right_envs()
@@ -91,7 +103,8 @@ if comm.rank == 0:
     out = dict(init=abs(abs(orc.overlap(g0, mps)) - 1),
                vs_oracle=abs(abs(orc.overlap(go, g)) / (nrm * ref.norm()) - 1),
                norm_gap=abs(nrm - ref.norm()),
-               vs_serial=abs(abs(orc.overlap(ser.cores, g)) / nrm - 1), norm=nrm,
+               vs_serial=abs(abs(orc.overlap(ser.cores, g)) / nrm - 1), norm=nrm, obs_gap=obs_gap,
+               energy=obs["energy"].real,
                bytes=eng.traffic()[0], messages=eng.traffic()[1])
     print("RESULT " + json.dumps(out), flush=True)
 comm.barrier()
@@ -119,6 +132,7 @@ def test_site_sharded_matches_its_oracle_and_the_serial_sweep(world, tmp_path):
     assert r["vs_oracle"] < 1e-8 and r["norm_gap"] < 1e-8
     assert r["vs_serial"] < (1e-12 if world == 1 else 1e-6)
     assert abs(r["norm"] - 1) < (1e-12 if world == 1 else 1e-4)  # O(dt^2) per junction (oracle: 1.2e-5 at N=3, dt=0.2)
+    assert r["obs_gap"] < 1e-10                   # norm, <Psi*|Psi>, energy, a second operator: folded rank by rank
     if world > 1:
         assert r["messages"] > 0                  # neighbour traffic only: 5 messages per junction and half step (+ gather)
 
