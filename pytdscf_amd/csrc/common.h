@@ -89,5 +89,6 @@ double mfma_peak_probe(hipStream_t st);
 // frees the split-K workspace that belongs to a stream (call before destroying the stream)
 void zgemm_release_stream(hipStream_t st);
 void mfma_layout_probe(hipStream_t st, int* host_out);
+int zgemm_cd_mode(hipStream_t st);  // C/D lane map of v_mfma_f64_16x16x4_f64 (probed once): 0: row = (lane>>4) + 4*reg, 1: 4*(lane>>4) + reg
 
 }  // namespace mitdvp

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -88,6 +89,219 @@ __global__ __launch_bounds__(256) void k_jacobi_step(zc* __restrict__ M, zc* __r
   if (W) rot(W + (size_t)p * nrow, W + (size_t)q * nrow, nrow);
 }
 
+
+// ---------------------------------------------------------------------------
+// Blocked tournament step (round 2).  The row-pair step above moves the whole matrix (M and W, 32 MB at
+// 1024 x 1024) through the chip once per pairing: n - 1 = 1023 times per sweep, which is what its 19 us per
+// launch are.  Here a pairing is between BLOCKS of JB = 8 rows, so a sweep needs n / 8 - 1 of them, two launches each:
+//   k_jacobi_block_rot (one workgroup per block pair, 16 rows):
+//     1. Gram matrix G = X X^H (16 x 16) on the matrix cores: with lane (i, k) holding X[i][c0 + k] the A and the B
+//        operand of v_mfma_f64_16x16x4_f64 are the SAME register (B[k][j] = X[j][c0 + k]), four real MFMAs per
+//        group of four columns; the waves split the columns;
+//     2. one cyclic Jacobi sweep on the Hermitian G in LDS: 8 independent rotations per step, 15 steps; every thread
+//        (i, j) derives the two rotations it needs itself and updates G <- J G J^H and V <- J V entry-wise (one
+//        barrier per step).  Same rotation formulas as the row-pair step, taken from G instead of from the rows:
+//        the angles depend on G_pp, G_qq, G_pq through scale-invariant ratios only, and G is formed afresh from the
+//        rows at every visit, so the relative accuracy of the one-sided method is kept;
+//   k_jacobi_block_apply (eight workgroups per block pair): rows <- V rows for M and W, again on the matrix cores
+//        (V is the A operand, a 16-column chunk of the rows the B operand), in place.
+// The convergence measure is the largest normalised |G_pq|^2 seen BEFORE its rotation.
+// ---------------------------------------------------------------------------
+constexpr int JB = 8, J2 = 2 * JB, JT = 512, JW = JT / 64, JAPPLY_Y = 8;
+typedef double jd4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void jblock_pair(int k, int nblk, int round, int& P, int& Q) {
+  if (k == 0) { P = nblk - 1; Q = round; }
+  else { P = (round + k) % (nblk - 1); Q = (round - k + (nblk - 1)) % (nblk - 1); }
+}
+
+// 1/sqrt(x) and 1/x for positive normal x: hardware seed (v_rsq_f64 / v_rcp_f64) + two Newton steps; the library
+// forms (special-case handling, denormal scaling) cost ~400 cycles of dependent latency each, and a rotation is a
+// chain of five of them that every step of the 16 x 16 sweep waits for
+__device__ __forceinline__ double jrsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+__device__ __forceinline__ double jrcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
+// rotation of the pair index i belongs to in step rnd of the 16-player tournament, as the row map
+// x_i' = d x_i + o x_partner;  rel = |G_pq|^2 / (G_pp G_qq) before the rotation (0 when the pair is skipped)
+__device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, int rnd, double tiny2, int& partner, zc& d, zc& o,
+                                           double& rel) {
+  int p, q;
+  bool is_p;
+  if (i == J2 - 1) { p = i; q = rnd; is_p = true; }
+  else if (i == rnd) { p = J2 - 1; q = i; is_p = false; }
+  else {
+    const int kk = (i - rnd + (J2 - 1)) % (J2 - 1);
+    if (kk <= JB - 1) { p = i; q = (rnd - kk + (J2 - 1)) % (J2 - 1); is_p = true; }
+    else { const int k2 = (J2 - 1) - kk; p = (rnd + k2) % (J2 - 1); q = i; is_p = false; }
+  }
+  partner = is_p ? q : p;
+  d = make_double2(1.0, 0.0); o = make_double2(0.0, 0.0); rel = 0.0;
+  const double a = Gc[p][p].x, b = Gc[q][q].x;
+  const zc g = Gc[p][q];
+  const double g2 = g.x * g.x + g.y * g.y;
+  if (!(g2 > 0.0) || !(a > tiny2) || !(b > tiny2)) return;
+  rel = g2 * jrcp(a * b);
+  if (rel <= 1e-32) return;
+  const double ig = jrsqrt(g2);
+  const double er = g.x * ig, ei = g.y * ig;  // e^{i phi}
+  const double zeta = 0.5 * (b - a) * ig;
+  const double z1 = 1.0 + zeta * zeta;
+  const double t = (zeta >= 0 ? 1.0 : -1.0) * jrcp(fabs(zeta) + z1 * jrsqrt(z1));
+  const double cs = jrsqrt(1.0 + t * t), sn = cs * t;
+  // x_p' = cs x_p - sn e^{i phi} x_q ;  x_q' = sn x_p + cs e^{i phi} x_q
+  if (is_p) { d = make_double2(cs, 0.0); o = make_double2(-sn * er, -sn * ei); }
+  else { d = make_double2(cs * er, cs * ei); o = make_double2(sn, 0.0); }
+}
+
+template <int GU>
+__global__ __launch_bounds__(JT) void k_jacobi_block_rot(const zc* __restrict__ M, int nrow, int ncol, int nblk, int round,
+                                                         unsigned long long* __restrict__ offmax, double tiny2, int cd_mode,
+                                                         zc* __restrict__ Vg, int* __restrict__ flags) {
+  __shared__ double Gp[JW][2][J2][J2 + 1];
+  __shared__ zc G[2][J2][J2 + 1];
+  __shared__ zc V[2][J2][J2 + 1];
+  __shared__ unsigned long long relmax_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int P, Q;
+  jblock_pair(blockIdx.x, nblk, round, P, Q);
+  auto rowidx = [&](int i) { return i < JB ? P * JB + i : Q * JB + (i - JB); };
+  if (tid == 0) relmax_sh = 0ull;
+  {
+    const int li = lane & 15, lk = lane >> 4;
+    const int r = rowidx(li);
+    const zc* xr = M + (size_t)(r < nrow ? r : 0) * ncol;
+    const bool rv = r < nrow;
+    jd4 arr = {0, 0, 0, 0}, aii = {0, 0, 0, 0}, air = {0, 0, 0, 0}, ari = {0, 0, 0, 0};
+    const int ngrp = (ncol + 3) / 4;
+    for (int g0 = wv; g0 < ngrp; g0 += JW * GU) {
+      zc x[GU];  // all loads of the pass in flight before the first MFMA
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int g = g0 + JW * u, c = g * 4 + lk;
+        x[u] = (rv && g < ngrp && c < ncol) ? xr[c] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        arr = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, x[u].x, arr, 0, 0, 0);
+        aii = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, x[u].y, aii, 0, 0, 0);
+        air = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, x[u].x, air, 0, 0, 0);
+        ari = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, x[u].y, ari, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = cd_mode == 0 ? (lk + 4 * q) : (4 * lk + q);
+      Gp[wv][0][row][li] = arr[q] + aii[q];  // Re sum x_i conj(x_j)
+      Gp[wv][1][row][li] = air[q] - ari[q];  // Im
+    }
+  }
+  __syncthreads();
+  const bool eig = tid < J2 * J2;
+  const int ti = (tid >> 4) & 15, tj = tid & 15;
+  if (eig) {
+    double gr = 0, gi = 0;
+#pragma unroll
+    for (int u = 0; u < JW; ++u) { gr += Gp[u][0][ti][tj]; gi += Gp[u][1][ti][tj]; }
+    G[0][ti][tj] = make_double2(gr, gi);
+    V[0][ti][tj] = make_double2(ti == tj ? 1.0 : 0.0, 0.0);
+  }
+  __syncthreads();
+  int cur = 0;
+  double relmax = 0.0;
+  for (int rnd = 0; rnd < J2 - 1; ++rnd) {
+    if (eig) {
+      int pi, pj;
+      zc di, oi, dj, oj;
+      double ri, rj;
+      jblock_rot(G[cur], ti, rnd, tiny2, pi, di, oi, ri);
+      jblock_rot(G[cur], tj, rnd, tiny2, pj, dj, oj, rj);
+      relmax = fmax(relmax, ri);
+      dj = zconj(dj); oj = zconj(oj);
+      // (J G)_{i l} for l = j and l = partner(j), then times J^H
+      const zc a1 = zadd(zmul(di, G[cur][ti][tj]), zmul(oi, G[cur][pi][tj]));
+      const zc a2 = zadd(zmul(di, G[cur][ti][pj]), zmul(oi, G[cur][pi][pj]));
+      G[cur ^ 1][ti][tj] = zadd(zmul(a1, dj), zmul(a2, oj));
+      V[cur ^ 1][ti][tj] = zadd(zmul(di, V[cur][ti][tj]), zmul(oi, V[cur][pi][tj]));
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (eig && relmax > 0.0) atomicMax(&relmax_sh, (unsigned long long)__double_as_longlong(relmax));
+  __syncthreads();
+  const bool any = relmax_sh > (unsigned long long)__double_as_longlong(1e-32);
+  if (tid == 0) {
+    flags[blockIdx.x] = any ? 1 : 0;
+    if (relmax_sh) atomicMax(offmax, relmax_sh);
+  }
+  if (eig && any) Vg[(size_t)blockIdx.x * J2 * J2 + ti * J2 + tj] = V[cur][ti][tj];
+}
+
+// rows <- V rows, in place: grid (block pairs, JAPPLY_Y); a wave takes 16-column chunks of [M | W]
+__global__ __launch_bounds__(256) void k_jacobi_block_apply(zc* __restrict__ M, zc* __restrict__ W, int nrow, int ncol,
+                                                            int nblk, int round, int cd_mode, const zc* __restrict__ Vg,
+                                                            const int* __restrict__ flags) {
+  if (!flags[blockIdx.x]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  int P, Q;
+  jblock_pair(blockIdx.x, nblk, round, P, Q);
+  auto rowidx = [&](int i) { return i < JB ? P * JB + i : Q * JB + (i - JB); };
+  // A operand: V[i = li][k = 4 s + lk]
+  zc v[4];
+#pragma unroll
+  for (int sI = 0; sI < 4; ++sI) v[sI] = Vg[(size_t)blockIdx.x * J2 * J2 + li * J2 + 4 * sI + lk];
+  int rin[4], rout[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    rin[q] = rowidx(4 * q + lk);
+    rout[q] = rowidx(cd_mode == 0 ? (lk + 4 * q) : (4 * lk + q));
+  }
+  const int ncm = (ncol + 15) / 16, ncw = W ? (nrow + 15) / 16 : 0;
+  const int nwave = 4 * gridDim.y;
+  constexpr int NCH = 4;  // chunks in flight per wave: loads of all of them before the first MFMA
+  for (int ch0 = blockIdx.y * 4 + wv; ch0 < ncm + ncw; ch0 += nwave * NCH) {
+    zc x[NCH][4];
+    zc* base[NCH];
+    int len[NCH], c[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int ch = ch0 + u * nwave;
+      const bool live = ch < ncm + ncw, isw = ch >= ncm;
+      base[u] = isw ? W : M;
+      len[u] = live ? (isw ? nrow : ncol) : 0;
+      c[u] = (isw ? ch - ncm : ch) * 16 + li;
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI)
+        x[u][sI] = (rin[sI] < nrow && c[u] < len[u]) ? base[u][(size_t)rin[sI] * len[u] + c[u]] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      jd4 yr = {0, 0, 0, 0}, yi = {0, 0, 0, 0};
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI) {
+        yr = __builtin_amdgcn_mfma_f64_16x16x4f64(v[sI].x, x[u][sI].x, yr, 0, 0, 0);
+        yr = __builtin_amdgcn_mfma_f64_16x16x4f64(-v[sI].y, x[u][sI].y, yr, 0, 0, 0);
+        yi = __builtin_amdgcn_mfma_f64_16x16x4f64(v[sI].x, x[u][sI].y, yi, 0, 0, 0);
+        yi = __builtin_amdgcn_mfma_f64_16x16x4f64(v[sI].y, x[u][sI].x, yi, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (rout[q] < nrow && c[u] < len[u]) base[u][(size_t)rout[q] * len[u] + c[u]] = make_double2(yr[q], yi[q]);
+    }
+  }
+}
+
 // row norms -> s[i]
 __global__ __launch_bounds__(256) void k_row_norms(const zc* __restrict__ M, int ncol, double* __restrict__ s) {
   __shared__ double sh[5];
@@ -133,10 +347,37 @@ static int jacobi_rows(hipStream_t st, zc* M, zc* W, int nr, int nc, unsigned lo
   double smax = 0.0;
   for (double v : s0) smax = std::max(smax, v);
   const double tiny2 = 1e-28 * smax * smax;
+  // blocked step from 64 rows on (below that the row-pair step has as many workgroups and less to do each)
+  static const int blocked = [] { const char* e = std::getenv("MITDVP_SVD_BLOCKED"); return e ? std::atoi(e) : 1; }();
+  const bool blk = blocked && nr >= 64;
+  const int nblk = ((nr + JB - 1) / JB + 1) & ~1;
+  const int cd_mode = blk ? zgemm_cd_mode(st) : 0;
+  struct Scratch {  // per block pair: the 16 x 16 rotation and a "rotated at all" flag
+    zc* p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+  } vg;
+  int* flags = nullptr;
+  if (blk) {
+    HIP_CHECK(hipMalloc((void**)&vg.p, (size_t)(nblk / 2) * (J2 * J2 + 1) * sizeof(zc)));
+    flags = reinterpret_cast<int*>(vg.p + (size_t)(nblk / 2) * J2 * J2);
+  }
   for (; sweeps < 60; ++sweeps) {
     HIP_CHECK(hipMemsetAsync(off_dev, 0, sizeof(unsigned long long), st));
-    for (int round = 0; round < np - 1; ++round)
-      hipLaunchKernelGGL(k_jacobi_step, dim3(np / 2), dim3(256), 0, st, M, W, nr, nc, np, round, off_dev, tiny2);
+    if (blk) {
+      for (int round = 0; round < nblk - 1; ++round) {
+        if (nc > JW * 16 * 4)
+          hipLaunchKernelGGL(k_jacobi_block_rot<32>, dim3(nblk / 2), dim3(JT), 0, st, M, nr, nc, nblk, round, off_dev, tiny2,
+                             cd_mode, vg.p, flags);
+        else
+          hipLaunchKernelGGL(k_jacobi_block_rot<16>, dim3(nblk / 2), dim3(JT), 0, st, M, nr, nc, nblk, round, off_dev, tiny2,
+                             cd_mode, vg.p, flags);
+        hipLaunchKernelGGL(k_jacobi_block_apply, dim3(nblk / 2, JAPPLY_Y), dim3(256), 0, st, M, W, nr, nc, nblk, round, cd_mode,
+                           vg.p, flags);
+      }
+    } else {
+      for (int round = 0; round < np - 1; ++round)
+        hipLaunchKernelGGL(k_jacobi_step, dim3(np / 2), dim3(256), 0, st, M, W, nr, nc, np, round, off_dev, tiny2);
+    }
     HIP_CHECK(hipGetLastError());
     unsigned long long bits = 0;
     HIP_CHECK(hipMemcpyAsync(&bits, off_dev, sizeof(bits), hipMemcpyDeviceToHost, st));

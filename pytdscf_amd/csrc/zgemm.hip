@@ -579,15 +579,18 @@ static void launch_sparse(hipStream_t st, const ZgemmDesc& d, int m3) {
   HIP_CHECK(hipGetLastError());
 }
 
+int zgemm_cd_mode(hipStream_t st) {
+  // the accumulator lane map is a property of the gfx950 ISA, not of a device: once per process
+  static std::once_flag probe_once;  // several engines may issue their first GEMM concurrently
+  std::call_once(probe_once, [&] { if (g_cd_mode < 0) mfma_layout_probe(st, nullptr); });
+  return g_cd_mode;
+}
+
 void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
   if (d.K < 0) throw ArgError("zgemm: negative K");
   if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
-  {
-    // the accumulator lane map is a property of the gfx950 ISA, not of a device: once per process
-    static std::once_flag probe_once;  // several engines may issue their first GEMM concurrently
-    std::call_once(probe_once, [&] { if (g_cd_mode < 0) mfma_layout_probe(st, nullptr); });
-  }
+  (void)zgemm_cd_mode(st);
   int cfg = d.tile_cfg;
   const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
   if (d.klist) { launch_sparse(st, d, m3); return; }
