@@ -339,6 +339,8 @@ def main():
             eng.init_random([d] * L, D, seed=1 + rank)
     if eng is not None:
         e0 = eng.expectation().real  # also builds nothing persistent; forces setup to finish
+    elif ss is not None:
+        e0 = ss.expectation().real  # folded rank by rank on the devices (collective), outside the timed region
 
     # one "unit" of work: a half-sweep; the site-sharded step is two half-sweeps + the junction updates
     unit = 2 if mode == "sites" else 1
@@ -412,6 +414,10 @@ def main():
     cnt = meas.counters()
     meas.set_profiling(False)
     halo = ss.traffic() if ss is not None else (0, 0)
+    e1 = None
+    if ss is not None:  # the sharded state's own norm and energy after the run (collective; not timed)
+        nrm = ss.norm()
+        e1 = ss.expectation().real
 
     if rank == 0:
         kh = cnt["n_heff"] / max(cnt["n_exp_site"], 1)
@@ -451,6 +457,7 @@ def main():
                 "mean_krylov_bond": round(kk, 2),
                 "norm_after": nrm,
                 "energy_before": e0,
+                "energy_after": e1,
                 "parallelism": {"single": "single GPU", "replicas": f"{args.gpus} independent replicas",
                                 "tp": f"bond-sharded over {args.gpus} GPUs (all-gather / all-reduce via {collectives})",
                                 "sites": f"site ranges over {args.gpus} GPUs (L/N sites per rank, neighbour send/recv of boundary "
@@ -458,6 +465,8 @@ def main():
                                          "roofline / breakdown are rank 0's block"}[mode],
                 "halo_GB": halo[0] / 1e9,
                 "halo_messages": halo[1],
+                "halo_path": (("device (engine -> RCCL -> engine, no host staging)" if ss.dev_halo else "host-staged")
+                              if ss is not None and world > 1 else None),
                 "collectives": int(cnt["n_collectives"]),
                 "collective_GB": cnt["collective_bytes"] / 1e9,
                 "wall_budget_s": args.max_seconds,

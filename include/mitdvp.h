@@ -188,6 +188,15 @@ int mitdvp_bond_exp(mitdvp_engine* h, double dt_au);      /* exp_superK_propagat
 int mitdvp_absorb_bond(mitdvp_engine* h, int forward);    /* trans_next_psite_APsiB, :1172-1206 */
 int mitdvp_get_bond(mitdvp_engine* h, double* reim_out, int* dim);   /* the pending bond matrix (joint_sigvec) */
 int mitdvp_set_bond(mitdvp_engine* h, int bond, const double* reim, int dim);
+/* Where the tensor arguments of mitdvp_set_site / replace_site / set_boundary_env / set_bond / fold_block (sources) and
+ * mitdvp_get_site / get_env / get_bond / fold_block (destinations) live: MITDVP_POINTER_HOST (default) or
+ * MITDVP_POINTER_DEVICE = device memory on the handle's GPU (the halo messages of the site-sharded sweep go from
+ * engine to RCCL and back without touching the host: the reference pickles NumPy arrays through mpi4py,
+ * _mps_parallel.py:541-807).  Device operands are copied by a kernel on the handle's stream, so they may have been
+ * allocated by another HIP runtime instance of the process (torch's); every call returns after the copy completed. */
+#define MITDVP_POINTER_HOST 0
+#define MITDVP_POINTER_DEVICE 1
+int mitdvp_set_pointer_mode(mitdvp_engine* h, int mode);
 /* Observables of a site-sharded state without gathering it (MPSCoefParallel.ovlp, _mps_parallel.py:855-983;
  * expectation, :1210-1302): a boundary block is carried through ALL sites of this engine.  from_left: reim_in sits
  * left of site 0, reim_out right of the last site (shape from the last site / MPO core); else the other way round.

@@ -123,6 +123,7 @@ def load() -> C.CDLL:
         "mitdvp_get_bond": (i, [vp, dp, ip]),
         "mitdvp_set_bond": (i, [vp, i, dp, i]),
         "mitdvp_fold_block": (i, [vp, i, i, i, dp, i, i, dp]),
+        "mitdvp_set_pointer_mode": (i, [vp, i]),
         "mitdvp_expect": (i, [vp, i, dp]),
         "mitdvp_autocorr": (i, [vp, dp]),
         "mitdvp_norm": (i, [vp, dp]),

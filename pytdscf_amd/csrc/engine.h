@@ -201,12 +201,17 @@ class Engine {
   void absorb_bond(bool forward);
   void get_bond(double* out, int* dim);
   void set_bond(int b, const double* reim, int dim);
+  // tensor arguments of the setters / getters: host memory (0, default) or device memory on this GPU (1)
+  void set_pointer_mode(int mode);
+  void copy_in(zc* dst, const double* src, size_t elems);   // + stream synchronise
+  void copy_out(double* dst, const zc* src, size_t elems);  // + stream synchronise
   void fold_block(int op_id, bool conj_bra, bool from_left, const double* in, int d, int m, double* out);
   hipStream_t stream() const { return st_; }
   const MpoSite& mpo(int op_id, int isite);
   mitdvp_config cfg;
 
  private:
+  int ptr_mode_ = 0;
   int L_;
   hipStream_t st_ = nullptr;
   std::vector<int> dl_, dd_, dr_, gauge_;

@@ -145,8 +145,7 @@ void Engine::set_site(int i, const double* reim, int l, int n, int r, int gauge)
   if (l < 1 || n < 1 || r < 1) throw ArgError("set_site: bad shape");
   const size_t e = (size_t)l * n * r;
   site_[i].reserve(e);
-  HIP_CHECK(hipMemcpyAsync(site_[i].p, reim, e * sizeof(zc), hipMemcpyHostToDevice, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  copy_in(site_[i].p, reim, e);
   dl_[i] = l; dd_[i] = n; dr_[i] = r; gauge_[i] = gauge;
   if (gauge == MITDVP_GAUGE_PSI) center_ = i;
   invalidate_env();
@@ -158,7 +157,21 @@ void Engine::get_site_shape(int i, int* l, int* n, int* r, int* gauge) const {
 void Engine::get_site(int i, double* out) {
   if (i < 0 || i >= L_ || !site_[i].p) throw ArgError("get_site: bad or unset site");
   const size_t e = (size_t)dl_[i] * dd_[i] * dr_[i];
-  HIP_CHECK(hipMemcpyAsync(out, site_[i].p, e * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  copy_out(out, site_[i].p, e);
+}
+
+void Engine::set_pointer_mode(int mode) {
+  if (mode != 0 && mode != 1) throw ArgError("set_pointer_mode: 0 (host) or 1 (device)");
+  ptr_mode_ = mode;
+}
+void Engine::copy_in(zc* dst, const double* src, size_t elems) {
+  if (ptr_mode_ == 0) HIP_CHECK(hipMemcpyAsync(dst, src, elems * sizeof(zc), hipMemcpyHostToDevice, st_));
+  else vec_copy_raw(st_, dst, reinterpret_cast<const zc*>(src), elems);
+  HIP_CHECK(hipStreamSynchronize(st_));
+}
+void Engine::copy_out(double* dst, const zc* src, size_t elems) {
+  if (ptr_mode_ == 0) HIP_CHECK(hipMemcpyAsync(dst, src, elems * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  else vec_copy_raw(st_, reinterpret_cast<zc*>(dst), src, elems);
   HIP_CHECK(hipStreamSynchronize(st_));
 }
 

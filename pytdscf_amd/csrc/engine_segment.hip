@@ -22,8 +22,7 @@ namespace mitdvp {
 void Engine::replace_site(int i, const double* reim, int gauge) {
   if (i < 0 || i >= L_ || !site_[i].p) throw ArgError("replace_site: bad or unset site");
   const size_t e = (size_t)dl_[i] * dd_[i] * dr_[i];
-  HIP_CHECK(hipMemcpyAsync(site_[i].p, reim, e * sizeof(zc), hipMemcpyHostToDevice, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  copy_in(site_[i].p, reim, e);
   gauge_[i] = gauge;
   if (gauge == MITDVP_GAUGE_PSI) center_ = i;
   else if (center_ == i) center_ = -1;
@@ -36,8 +35,7 @@ void Engine::set_boundary_env(int side, const double* reim, int d, int m) {
   DevBuf& b = side == 0 ? envL_[0] : envR_[L_];
   const size_t e = (size_t)d * m * d;
   b.reserve(e);
-  HIP_CHECK(hipMemcpyAsync(b.p, reim, e * sizeof(zc), hipMemcpyHostToDevice, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  copy_in(b.p, reim, e);
   (side == 0 ? bnd_dl_ : bnd_dr_) = d;
   (side == 0 ? bnd_ml_ : bnd_mr_) = m;
   (side == 0 ? envL_ok_[0] : envR_ok_[L_]) = 1;
@@ -61,8 +59,7 @@ void Engine::get_env(int side, int bond, double* out) {
   const bool ok = side == 0 ? envL_ok_[bond] : envR_ok_[bond];
   const DevBuf& b = side == 0 ? envL_[bond] : envR_[bond];
   if (!ok || !b.p) throw ArgError("get_env: this environment block is not built");
-  HIP_CHECK(hipMemcpyAsync(out, b.p, (size_t)d * m * d * sizeof(zc), hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  copy_out(out, b.p, (size_t)d * m * d);
 }
 
 // environment blocks of all sites on one side of the centre (construct_op_sites, _mps_cls.py:1738-1796)
@@ -172,8 +169,7 @@ void Engine::get_bond(double* out, int* dim) {
   if (bond_ < 0) throw ArgError("get_bond: no pending bond matrix");
   *dim = bond_dim_;
   if (out) {
-    HIP_CHECK(hipMemcpyAsync(out, sig_.p, (size_t)bond_dim_ * bond_dim_ * sizeof(zc), hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipStreamSynchronize(st_));
+    copy_out(out, sig_.p, (size_t)bond_dim_ * bond_dim_);
   }
 }
 
@@ -184,8 +180,7 @@ void Engine::set_bond(int b, const double* reim, int dim) {
   require_ready();  // workspaces first: growing sig_ afterwards would drop the matrix
   if (!((b < L_ && dl_[b] == dim) || (b > 0 && dr_[b - 1] == dim))) throw ArgError("set_bond: dimension matches neither neighbouring site");
   sig_.reserve((size_t)dim * dim);
-  HIP_CHECK(hipMemcpyAsync(sig_.p, reim, (size_t)dim * dim * sizeof(zc), hipMemcpyHostToDevice, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  copy_in(sig_.p, reim, (size_t)dim * dim);
   bond_ = b; bond_dim_ = dim;
   bond_site_ = std::min(std::max(b - 1, 0), L_ - 1);
   center_ = -1;
@@ -217,7 +212,7 @@ void Engine::fold_block(int op_id, bool conj_bra, bool from_left, const double* 
     mx = std::max(mx, dd * mm * dd);
   }
   DevBuf cur = pool_get(mx), nxt = pool_get(mx);
-  HIP_CHECK(hipMemcpyAsync(cur.p, in, (size_t)d * m * d * sizeof(zc), hipMemcpyHostToDevice, st_));
+  copy_in(cur.p, in, (size_t)d * m * d);
   int dout = d, mout = m;
   for (int k = 0; k < L_; ++k) {
     const int p = from_left ? k : L_ - 1 - k;
@@ -254,8 +249,7 @@ void Engine::fold_block(int op_id, bool conj_bra, bool from_left, const double* 
     }
     std::swap(cur, nxt);
   }
-  HIP_CHECK(hipMemcpyAsync(out, cur.p, (size_t)dout * mout * dout * sizeof(zc), hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  copy_out(out, cur.p, (size_t)dout * mout * dout);
   pool_put(std::move(cur));
   pool_put(std::move(nxt));
 }

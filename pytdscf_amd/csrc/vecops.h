@@ -33,6 +33,9 @@ void vec_scale(hipStream_t st, zc* y, long n, zc a);
 void vec_randn(hipStream_t st, zc* out, long n, uint64_t seed);
 void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld);
 // dst[r][c] = a * src[r][c] (+ dst[r][c]) for c < cols; columns cols..zero_to-1 of dst are zeroed
+// dst[0..n) = src[0..n): a kernel, not hipMemcpy -- the source or destination may belong to ANOTHER HIP runtime
+// instance in this process (torch's), which this one cannot look up but whose addresses are valid on the device
+void vec_copy_raw(hipStream_t st, zc* dst, const zc* src, size_t n);
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
             bool accumulate);
 // norm profiles for the adaptive-rank functional (plain device arrays, no partials)

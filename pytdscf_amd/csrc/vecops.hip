@@ -610,4 +610,14 @@ void transpose_rev3(hipStream_t st, const zc* in, zc* out, int na, int nj, int n
   transpose_batched(st, in, out, na, ns, (long)nj * ns, (long)nj * na, nj, ns, na);
 }
 
+__global__ __launch_bounds__(256) void k_copy_raw(zc* __restrict__ dst, const zc* __restrict__ src, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) dst[e] = src[e];
+}
+void vec_copy_raw(hipStream_t st, zc* dst, const zc* src, size_t n) {
+  if (!n) return;
+  const size_t nb = std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_copy_raw, dim3((unsigned)nb), dim3(256), 0, st, dst, src, n);
+  HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace mitdvp

@@ -22,6 +22,33 @@ def _c128(a) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(a, dtype=np.complex128))
 
 
+def _is_dev(x) -> bool:
+    """a torch tensor living on a GPU (complex128): handed to the library as a device pointer"""
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+class _Operand:
+    """What a setter passes down: a host array (NumPy) or a device tensor (torch, complex128, contiguous).
+    ``mode`` is the pointer mode the call needs (include/mitdvp.h, mitdvp_set_pointer_mode)."""
+
+    def __init__(self, x):
+        if _is_dev(x):
+            import torch
+
+            if x.dtype != torch.complex128:
+                raise TypeError("device operands must be complex128")
+            self.keep = x.contiguous()
+            self.shape = tuple(self.keep.shape)
+            self.ptr = C.cast(C.c_void_p(self.keep.data_ptr()), C.POINTER(C.c_double))
+            self.mode = 1
+        else:
+            self.keep = _c128(x)
+            self.shape = self.keep.shape
+            self.ptr = _dp(self.keep)
+            self.mode = 0
+        self.ndim = len(self.shape)
+
+
 class TDVPEngine:
     def __init__(
         self,
@@ -65,13 +92,35 @@ class TDVPEngine:
     def _ck(self, rc):
         _lib.check(rc, self._h)
 
+    # ---- host or device operands ------------------------------------------
+    def _with_mode(self, mode: int, call):
+        """run one library call with the pointer mode its operands need (0 host, 1 device)"""
+        if mode == 0:
+            return self._ck(call())
+        self._ck(self._lib.mitdvp_set_pointer_mode(self._h, 1))
+        try:
+            return self._ck(call())
+        finally:
+            self._ck(self._lib.mitdvp_set_pointer_mode(self._h, 0))
+
+    def _out(self, shape, device: bool):
+        """destination of a getter: NumPy array, or a torch complex128 tensor on this engine's GPU"""
+        if not device:
+            a = np.empty(shape, dtype=np.complex128)
+            return a, _dp(a), 0
+        import torch
+
+        t = torch.empty(tuple(shape), dtype=torch.complex128, device=torch.device("cuda", self.device))
+        torch.cuda.current_stream(t.device).synchronize()  # the allocator may hand back memory with work pending
+        return t, C.cast(C.c_void_p(t.data_ptr()), C.POINTER(C.c_double)), 1
+
     # ---- state ---------------------------------------------------------
     def set_site(self, isite: int, data, gauge: str = "C"):
-        a = _c128(data)
+        a = _Operand(data)
         if a.ndim != 3:
             raise ValueError("site tensor must be (D_l, d, D_r)")
         g = {"Psi": _lib.GAUGE_PSI, "A": _lib.GAUGE_A, "B": _lib.GAUGE_B, "C": _lib.GAUGE_C}[gauge]
-        self._ck(self._lib.mitdvp_set_site(self._h, isite, _dp(a), a.shape[0], a.shape[1], a.shape[2], g))
+        self._with_mode(a.mode, lambda: self._lib.mitdvp_set_site(self._h, isite, a.ptr, a.shape[0], a.shape[1], a.shape[2], g))
 
     def set_mps(self, cores, canonicalize: bool = False, scale: float = 1.0):
         """cores: site-0-centred canonical MPS (gauges Psi,B,...,B), or arbitrary
@@ -81,11 +130,11 @@ class TDVPEngine:
         if canonicalize:  # scale=None: keep the state's own normalisation (Liouville space)
             self._ck(self._lib.mitdvp_canonicalize(self._h, -1.0 if scale is None else scale))
 
-    def get_site(self, isite: int) -> np.ndarray:
+    def get_site(self, isite: int, device: bool = False):
         l, n, r, g = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self._ck(self._lib.mitdvp_get_site_shape(self._h, isite, C.byref(l), C.byref(n), C.byref(r), C.byref(g)))
-        out = np.empty((l.value, n.value, r.value), dtype=np.complex128)
-        self._ck(self._lib.mitdvp_get_site(self._h, isite, _dp(out)))
+        out, ptr, mode = self._out((l.value, n.value, r.value), device)
+        self._with_mode(mode, lambda: self._lib.mitdvp_get_site(self._h, isite, ptr))
         return out
 
     def get_mps(self):
@@ -113,20 +162,20 @@ class TDVPEngine:
     _GAUGE = {"Psi": _lib.GAUGE_PSI, "A": _lib.GAUGE_A, "B": _lib.GAUGE_B, "C": _lib.GAUGE_C}
 
     def replace_site(self, isite: int, data, gauge: str):
-        a = _c128(data)
-        self._ck(self._lib.mitdvp_replace_site(self._h, isite, _dp(a), self._GAUGE[gauge]))
+        a = _Operand(data)
+        self._with_mode(a.mode, lambda: self._lib.mitdvp_replace_site(self._h, isite, a.ptr, self._GAUGE[gauge]))
 
     def set_boundary_env(self, side: int, block):
-        a = _c128(block)
+        a = _Operand(block)
         if a.ndim != 3 or a.shape[0] != a.shape[2]:
             raise ValueError("boundary block must be (D, M, D)")
-        self._ck(self._lib.mitdvp_set_boundary_env(self._h, side, _dp(a), a.shape[0], a.shape[1]))
+        self._with_mode(a.mode, lambda: self._lib.mitdvp_set_boundary_env(self._h, side, a.ptr, a.shape[0], a.shape[1]))
 
-    def get_env(self, side: int, bond: int) -> np.ndarray:
+    def get_env(self, side: int, bond: int, device: bool = False):
         d, m = C.c_int(), C.c_int()
         self._ck(self._lib.mitdvp_get_env(self._h, side, bond, None, C.byref(d), C.byref(m)))
-        out = np.empty((d.value, m.value, d.value), dtype=np.complex128)
-        self._ck(self._lib.mitdvp_get_env(self._h, side, bond, _dp(out), C.byref(d), C.byref(m)))
+        out, ptr, mode = self._out((d.value, m.value, d.value), device)
+        self._with_mode(mode, lambda: self._lib.mitdvp_get_env(self._h, side, bond, ptr, C.byref(d), C.byref(m)))
         return out
 
     def build_envs(self, side: int):

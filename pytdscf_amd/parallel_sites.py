@@ -26,6 +26,8 @@ why the reference's own tests accept 1e-2; Hilbert space, one electronic state, 
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .engine import TDVPEngine, svd as device_svd
@@ -53,7 +55,12 @@ def pinv_device(x: np.ndarray, device: int = 0) -> np.ndarray:
 
 
 class _Link:
-    """Neighbour send / recv of complex128 arrays over torch.distributed (shapes are known to both sides)."""
+    """Neighbour send / recv of complex128 tensors over torch.distributed (shapes are known to both sides).
+
+    Host arrays (NumPy) are staged through a tensor of the backend's device.  With ``device=True`` the payload is a torch
+    tensor on this rank's GPU: over nccl (= RCCL, xGMI) it goes from the sender's HBM to the receiver's without touching
+    the host; over gloo (tests: ranks sharing one GPU) the same tensors are staged through the host for the transport
+    only, so the engine-side device path is what the tests exercise."""
 
     def __init__(self, comm):
         self.comm = comm
@@ -61,24 +68,44 @@ class _Link:
         self.bytes = 0
         self.messages = 0
 
-    def send(self, arr: np.ndarray, dst: int):
+    def send(self, arr, dst: int):
         import torch
 
-        a = np.ascontiguousarray(arr, dtype=np.complex128)
-        t = torch.from_numpy(a.view(np.float64).reshape(-1))
-        if self.comm.backend == "nccl":
-            t = t.to(self.comm.device)
+        if hasattr(arr, "data_ptr"):  # device tensor
+            t = torch.view_as_real(arr.contiguous()).reshape(-1)
+            nbytes = t.numel() * 8
+            if self.comm.backend != "nccl":
+                t = t.cpu()
+        else:
+            a = np.ascontiguousarray(arr, dtype=np.complex128)
+            nbytes = a.nbytes
+            t = torch.from_numpy(a.view(np.float64).reshape(-1))
+            if self.comm.backend == "nccl":
+                t = t.to(self.comm.device)
         self.dist.send(t, dst)
-        self.bytes += a.nbytes
+        self.bytes += nbytes
         self.messages += 1
 
-    def recv(self, shape, src: int) -> np.ndarray:
+    def recv(self, shape, src: int, device: bool = False):
         import torch
 
         n = int(np.prod(shape))
-        t = torch.empty(2 * n, dtype=torch.float64, device=self.comm.device if self.comm.backend == "nccl" else "cpu")
-        self.dist.recv(t, src)
-        return t.cpu().numpy().view(np.complex128).reshape(shape).copy()
+        nccl = self.comm.backend == "nccl"
+        if not device:
+            t = torch.empty(2 * n, dtype=torch.float64, device=self.comm.device if nccl else "cpu")
+            self.dist.recv(t, src)
+            return t.cpu().numpy().view(np.complex128).reshape(shape).copy()
+        dev = torch.device("cuda", self.comm.gpu)
+        out = torch.empty(tuple(shape), dtype=torch.complex128, device=dev)
+        flat = torch.view_as_real(out).reshape(-1)
+        if nccl:
+            self.dist.recv(flat, src)
+        else:
+            t = torch.empty(2 * n, dtype=torch.float64)
+            self.dist.recv(t, src)
+            flat.copy_(t)
+        torch.cuda.current_stream(dev).synchronize()  # the engine reads it from ITS stream next
+        return out
 
 
 class SiteShardedTDVP:
@@ -100,6 +127,12 @@ class SiteShardedTDVP:
         self.n = self.hi - self.lo
         self.kw = dict(integrator=integrator, thresh=thresh, conserve_norm=conserve_norm)
         self.link = _Link(comm) if self.world > 1 else None
+        # halo messages: "device" = engine -> torch tensor on the GPU -> RCCL (default over nccl), "host" = staged
+        # through NumPy arrays (default over gloo); MITDVP_HALO overrides (the tests run the device path over gloo)
+        halo = os.environ.get("MITDVP_HALO", "device" if (comm.backend == "nccl") else "host")
+        if halo not in ("device", "host"):
+            raise ValueError("MITDVP_HALO must be 'device' or 'host'")
+        self.dev_halo = self.world > 1 and halo == "device"
         self._setup(cores, dims, bond_dim, seed)
 
     # ------------------------------------------------------------------ set-up (not timed)
@@ -184,10 +217,11 @@ class SiteShardedTDVP:
         b, J, n, nb = self.block, self.joint, self.n, self.rank + 1
         shp_r = self.shapes[self.hi]
         Dr, Mr = shp_r[2], self.mpo[self.hi].shape[3]
-        psi_r = self.link.recv(shp_r, nb)
-        env_r = self.link.recv((Dr, Mr, Dr), nb)
-        psi_l = b.get_site(n - 1)
-        env_l = b.get_env(0, n - 1)
+        dv = self.dev_halo
+        psi_r = self.link.recv(shp_r, nb, device=dv)
+        env_r = self.link.recv((Dr, Mr, Dr), nb, device=dv)
+        psi_l = b.get_site(n - 1, device=dv)
+        env_l = b.get_env(0, n - 1, device=dv)
         J.set_site(0, psi_l, "C")
         J.set_site(1, psi_r, "C")
         J.set_boundary_env(0, env_l)
@@ -205,8 +239,8 @@ class SiteShardedTDVP:
         J.split_center(False)
         J.bond_exp(dt)
         Xn = J.get_bond()
-        A, B = J.get_site(0), J.get_site(1)
-        L1, R2 = J.get_env(0, 1), J.get_env(1, 1)
+        A, B = J.get_site(0, device=dv), J.get_site(1, device=dv)
+        L1, R2 = J.get_env(0, 1, device=dv), J.get_env(1, 1, device=dv)
         self.link.send(B, nb)
         self.link.send(Xn, nb)
         self.link.send(L1, nb)
@@ -220,12 +254,13 @@ class SiteShardedTDVP:
     def _junction_right(self):
         b, nb = self.block, self.rank - 1
         shp = self.shapes[self.lo]
-        self.link.send(b.get_site(0), nb)
-        self.link.send(b.get_env(1, 1), nb)
+        dv = self.dev_halo
+        self.link.send(b.get_site(0, device=dv), nb)
+        self.link.send(b.get_env(1, 1, device=dv), nb)
         D, Ml = shp[0], self.mpo[self.lo].shape[0]
-        B = self.link.recv(shp, nb)
+        B = self.link.recv(shp, nb, device=dv)
         Xn = self.link.recv((D, D), nb)
-        L1 = self.link.recv((D, Ml, D), nb)
+        L1 = self.link.recv((D, Ml, D), nb, device=dv)
         b.replace_site(0, B, "B")
         b.set_boundary_env(0, L1)
         b.set_bond(0, Xn)
@@ -347,22 +382,42 @@ class SiteShardedTDVP:
         return self._fold_chain(1, True, cores)
 
     def selftest(self) -> bool:
-        """Neighbour ping over the link (every junction, both directions) before the sweep relies on it."""
+        """Neighbour ping over the link (every junction, both directions) before the sweep relies on it.  The
+        device-resident form of the messages is pinged as well; if it fails on any rank, ALL ranks fall back to
+        host-staged messages (collective: every rank must call this)."""
         if self.world == 1:
             return True
+        ok = self._ping(False)
+        if self.dev_halo:
+            good = self._ping(True)
+            if self.comm.min_over_ranks(1.0 if good else 0.0) < 1.0:
+                self.dev_halo = False
+        return ok
+
+    def _ping(self, device: bool) -> bool:
         ok = True
-        probe = (np.arange(6, dtype=np.float64) + 10.0 * self.rank).astype(np.complex128).reshape(2, 3)
+
+        def mk(rank):
+            a = (np.arange(6, dtype=np.float64) + 10.0 * rank).astype(np.complex128).reshape(2, 3)
+            if not device:
+                return a
+            import torch
+
+            return torch.from_numpy(a).to(torch.device("cuda", self.comm.gpu))
+
+        def host(x):
+            return x.cpu().numpy() if hasattr(x, "data_ptr") else x
+
         try:
             for parity in (0, 1):
                 r = self.rank
                 if r % 2 == parity and r < self.world - 1:
-                    self.link.send(probe, r + 1)
-                    back = self.link.recv((2, 3), r + 1)
-                    ok = ok and np.array_equal(back, probe + 1.0)
+                    self.link.send(mk(r), r + 1)
+                    back = self.link.recv((2, 3), r + 1, device=device)
+                    ok = ok and np.array_equal(host(back), host(mk(r)) + 1.0)
                 elif r % 2 != parity and r > 0:
-                    got = self.link.recv((2, 3), r - 1)
-                    want = (np.arange(6, dtype=np.float64) + 10.0 * (r - 1)).astype(np.complex128).reshape(2, 3)
-                    ok = ok and np.array_equal(got, want)
+                    got = self.link.recv((2, 3), r - 1, device=device)
+                    ok = ok and np.array_equal(host(got), host(mk(r - 1)))
                     self.link.send(got + 1.0, r - 1)
         except Exception:  # noqa: BLE001 -- the caller shares the verdict over all ranks
             ok = False

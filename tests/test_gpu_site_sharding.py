@@ -75,6 +75,7 @@ L, d, M, D, dt, nstep = {L}, 3, 4, 8, 0.2, 2
 mpo = orc.synthetic_mpo(L, d, M, seed=0)
 mps = orc.synthetic_mps([d] * L, D, seed=1)
 eng = SiteShardedTDVP(comm, mpo, cores=mps, integrator={integ!r}, conserve_norm={cn})
+assert eng.selftest()
 g0 = eng.gather()
 for _ in range(nstep):
     eng.step(dt)
@@ -104,7 +105,7 @@ if comm.rank == 0:
                vs_oracle=abs(abs(orc.overlap(go, g)) / (nrm * ref.norm()) - 1),
                norm_gap=abs(nrm - ref.norm()),
                vs_serial=abs(abs(orc.overlap(ser.cores, g)) / nrm - 1), norm=nrm, obs_gap=obs_gap,
-               energy=obs["energy"].real,
+               energy=obs["energy"].real, halo="device" if eng.dev_halo else "host",
                bytes=eng.traffic()[0], messages=eng.traffic()[1])
     print("RESULT " + json.dumps(out), flush=True)
 comm.barrier()
@@ -113,11 +114,13 @@ comm.close()
 """
 
 
-def _run(world, tmp_path, L=8, integ="lanczos", cn=True):
+def _run(world, tmp_path, L=8, integ="lanczos", cn=True, halo=None):
     script = tmp_path / f"ss{world}.py"
     script.write_text(textwrap.dedent(WORKER.format(root=ROOT, L=L, integ=integ, cn=cn)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                MITDVP_DIST_BACKEND="gloo")
+    if halo:
+        env["MITDVP_HALO"] = halo
     rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
                           timeout=300)
     assert rcs == [0] * world, "\n".join(outs)
@@ -135,6 +138,19 @@ def test_site_sharded_matches_its_oracle_and_the_serial_sweep(world, tmp_path):
     assert r["obs_gap"] < 1e-10                   # norm, <Psi*|Psi>, energy, a second operator: folded rank by rank
     if world > 1:
         assert r["messages"] > 0                  # neighbour traffic only: 5 messages per junction and half step (+ gather)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_site_sharded_with_device_resident_halo_messages(world, tmp_path):
+    """MITDVP_HALO=device: the junction tensors go engine -> torch tensor on the GPU -> engine through the device
+    pointer mode of the C ABI (what runs over RCCL on a multi-GPU node); gloo stages them for the transport only.
+    Same numbers as the host-staged path."""
+    r = _run(world, tmp_path, L=9 if world == 3 else 8, halo="device")
+    h = _run(world, tmp_path, L=9 if world == 3 else 8, halo="host")
+    assert r["halo"] == "device" and h["halo"] == "host"
+    assert r["vs_oracle"] < 1e-8 and r["norm_gap"] < 1e-8 and r["obs_gap"] < 1e-10
+    assert abs(r["energy"] - h["energy"]) < 1e-13 and abs(r["norm"] - h["norm"]) < 1e-13
 
 
 @pytest.mark.gpu
