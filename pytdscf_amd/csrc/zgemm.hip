@@ -608,8 +608,18 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   // K_eff second stage): too few tiles to fill 256 CUs otherwise
   const int tb = cfg == 2 ? 32 : 64;
   const long nt = cfg == 0 ? tiles(128, m3 ? 64 : 128) : tiles(tb, tb);
-  if (d.batch == 1 && nt < 192 && d.K >= 1024) {
-    int splits = (int)std::min<long>((384 + nt - 1) / nt, d.K / 256);
+  // ... and for outputs with MANY tiles when the contraction is very long (stage S3 of an apply at D = 1024:
+  // K = M D = 32768, i.e. 2048 K tiles per workgroup; the third stage of an environment update: K = 16384).
+  // Workgroups that live that long drift apart and stop sharing their operand strips in the 4 MiB L2 of their XCD:
+  // FETCH_SIZE of S3 is 180 GB unsplit, 123 / 94 / 68 / 77 GB with 4 / 8 / 16 / 32 splits (tools/longk_probe.sh),
+  // for 2.1 GB of partial slabs at 8 splits and a kernel that gets 2 % faster (1.2 ms of 54; the ordered combine
+  // takes 0.4 ms of that back).  ~4096 columns of K per workgroup.
+  // MITDVP_LONGK_SPLITS: 0 = this rule (default), 1 = off, n = force n splits.
+  static const int longk_env = [] { const char* e = std::getenv("MITDVP_LONGK_SPLITS"); return e ? std::atoi(e) : 0; }();
+  const int longk = longk_env > 0 ? longk_env : (int)std::min<long>(8, d.K / 4096);
+  const bool long_k = d.batch == 1 && longk > 1 && nt >= 192 && d.K >= 8192 && cfg == 1 && !d.rowmap_p;
+  if (d.batch == 1 && ((nt < 192 && d.K >= 1024) || long_k)) {
+    int splits = long_k ? longk : (int)std::min<long>((384 + nt - 1) / nt, d.K / 256);
     if (splits >= 2) {
       int kc = (d.K + splits - 1) / splits;
       kc = (kc + 15) / 16 * 16;
