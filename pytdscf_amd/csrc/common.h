@@ -43,6 +43,23 @@ __host__ __device__ inline zc zadd(zc a, zc b) { return make_double2(a.x + b.x, 
 __host__ __device__ inline zc zsub(zc a, zc b) { return make_double2(a.x - b.x, a.y - b.y); }
 
 // ---------------------------------------------------------------- zgemm.hip
+// 1/sqrt(x) and 1/x for positive normal x: hardware seed (v_rsq_f64 / v_rcp_f64) + two Newton steps.  The library
+// forms (special cases, denormal scaling) cost ~400 cycles of dependent latency each; where a chain of them sits on
+// the critical path of a single-workgroup kernel (Jacobi rotations, Householder reflectors) these are used instead.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
 struct ZgemmDesc {
   const zc* A;
   const zc* B;

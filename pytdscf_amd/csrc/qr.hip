@@ -14,6 +14,7 @@
 #include "qr.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -39,6 +40,10 @@ __device__ __forceinline__ double qr_block_sum(double v, double* sh) {
   __syncthreads();
   return sh[4];
 }
+
+// value select: `c ? a : b` on two zc LVALUES is an lvalue select (a select of ADDRESSES), which pins register
+// arrays to scratch memory; by-value arguments keep it a pair of v_cndmask
+__device__ __forceinline__ zc zsel(bool c, zc a, zc b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 
 struct House {
   double beta;
@@ -285,6 +290,22 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
   }
 }
 
+// zlarfg for the normal range with the fast reciprocal / reciprocal square root (same formulas; 1-2 ulp)
+__device__ __forceinline__ House zlarfg_fast(zc alpha, double xnorm2) {
+  const double x = alpha.x * alpha.x + alpha.y * alpha.y + xnorm2;
+  if (!(x > 1e-200 && x < 1e200) || (xnorm2 == 0.0 && alpha.y == 0.0)) return zlarfg(alpha, xnorm2);
+  House h;
+  const double nrm = x * fast_rsqrt(x);
+  const double beta = alpha.x >= 0.0 ? -nrm : nrm;
+  const double ib = fast_rcp(beta);
+  h.beta = beta;
+  h.tau = make_double2((beta - alpha.x) * ib, -alpha.y * ib);
+  const double dr = alpha.x - beta, di = alpha.y;
+  const double iden = fast_rcp(dr * dr + di * di);
+  h.scale = make_double2(dr * iden, -di * iden);
+  return h;
+}
+
 // ---------------------------------------------------------------------------
 // Small matrices (one panel, m <= 16 * RPT rows): the WHOLE factorisation in one launch of one workgroup --
 // zgeqr2, R, zlarft's T (its inner products v_c^H v_j ride on the column products for free) and
@@ -298,10 +319,17 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 // (one more barrier; per-row cross-lane reads instead would go through the LDS crossbar 80 times per step
 // and wave, which made this kernel slower than the 45 launches it replaces).
 // Same arithmetic as the multi-launch panel (LAPACK's sign convention, beta real).
+// The row loops are branch-free (value selects): with a condition per row hipcc emitted an exec-mask branch and a
+// full s_waitcnt per row, one exposed LDS latency each; zlarfg takes the hardware reciprocal seeds.  6.9 -> 4.3 us per
+// column step at 320 x 32 (MITDVP_QR_TRACE=1 python tools/qr_trace.py).  Tried and dropped: 256 threads owning two
+// columns each with ONE pass and one barrier per step (the thread re-forms column j + 1 itself) -- 256 VGPRs, one wave
+// per SIMD and nothing to hide the LDS latency behind: 13 us per step.
 // ---------------------------------------------------------------------------
 template <int RPT>
 __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int n, zc* __restrict__ R,
-                                                  zc* __restrict__ Wout) {
+                                                  zc* __restrict__ Wout, long long* __restrict__ trace) {
+  // debugging (MITDVP_QR_TRACE): thread 0 stamps s_memrealtime (10 ns ticks) at the phase boundaries of every step
+  auto stamp = [&](int j, int k) __attribute__((always_inline)) { if (trace && threadIdx.x == 0) trace[j * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime(); };
   constexpr int NRG = 16, NW = 8;  // 16 row groups x 32 columns = 512 threads: 256 registers per thread
   __shared__ zc part[2][NW][32];
   __shared__ zc rowj[2][32];
@@ -319,7 +347,7 @@ __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int
   }
   for (int e = tid; e < 32 * 33; e += 512) (&Ts[0][0])[e] = make_double2(0.0, 0.0);
   // the owners of column jn put it into LDS (row index order)
-  auto stage_col = [&](int jn, int buf) {
+  auto stage_col = [&](int jn, int buf) __attribute__((always_inline)) {
     if (c == jn) {
 #pragma unroll
       for (int q = 0; q < RPT; ++q) xc[buf][rg + NRG * q] = a[q];
@@ -327,23 +355,26 @@ __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int
   };
   // products sum_{i > jn} conj(A[i,jn]) A[i,c] over my rows, for EVERY column c: c >= jn feeds the
   // reflector of column jn (k_qr_col), c < jn is v_c^H x_jn, what zlarft needs for T's column jn
-  auto publish = [&](int jn, int buf) {
+  // branch-free on purpose: with a conditional per row hipcc emits an exec-mask branch (and a full s_waitcnt) per
+  // row, which exposes one LDS latency per row -- 2.7 us of a 6.9 us step went into the update loop that way
+  auto publish = [&](int jn, int buf) __attribute__((always_inline)) {
     double sr = 0.0, si = 0.0;
+    zc rv = make_double2(0.0, 0.0);
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int i = rg + NRG * q;
-      const zc x = xc[buf][i];
-      if (i > jn && i < m && c < n) {
-        sr += x.x * a[q].x + x.y * a[q].y;
-        si += x.x * a[q].y - x.y * a[q].x;
-      }
-      if (i == jn) rowj[buf][c] = a[q];
+      zc x = xc[buf][i];  // rows >= m hold zeros (in the column and in a[])
+      x = zsel(i > jn, x, make_double2(0.0, 0.0));
+      sr += x.x * a[q].x + x.y * a[q].y;
+      si += x.x * a[q].y - x.y * a[q].x;
+      rv = zsel(i == jn, a[q], rv);
     }
+    if (rg == (jn & (NRG - 1))) rowj[buf][c] = rv;
     sr += __shfl_xor(sr, 32, 64);
     si += __shfl_xor(si, 32, 64);
     if (lane < 32) part[buf][w][c] = make_double2(sr, si);
   };
-  auto total = [&](int buf, int col) -> zc {
+  auto total = [&](int buf, int col) __attribute__((always_inline)) -> zc {
     double sr = 0.0, si = 0.0;
 #pragma unroll
     for (int u = 0; u < NW; ++u) { const zc p = part[buf][u][col]; sr += p.x; si += p.y; }
@@ -355,27 +386,35 @@ __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int
   __syncthreads();
   for (int j = 0; j < n; ++j) {
     const int buf = j & 1;
+    stamp(j, 0);
     const zc yj = total(buf, j), yc = total(buf, c);
-    const House h = zlarfg(rowj[buf][j], yj.x);
+    const House h = zlarfg_fast(rowj[buf][j], yj.x);
     zc f = make_double2(0.0, 0.0);
     const bool active = c > j && c < n;
     if (active) f = zmul(zconj(h.tau), zadd(zmul(zconj(h.scale), yc), rowj[buf][c]));
+    if (trace && threadIdx.x == 0 && f.x == 12345.678) trace[1023] = 1;  // keeps f ahead of the stamp
+    stamp(j, 1);
     // G[c][j] = v_c^H v_j = conj(A[j,c]) + scale_j * conj(sum_{i>j} conj(x_i) v_c[i])   (c < j)
     if (rg == 0 && c < j) Ts[c][j] = zadd(zconj(rowj[buf][c]), zmul(h.scale, zconj(yc)));
     if (tid == 0) taus[j] = h.tau;
+    const bool mine = c == j;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int i = rg + NRG * q;
-      if (i >= j && i < m) {
-        const zc v = (i == j) ? make_double2(1.0, 0.0) : zmul(xc[buf][i], h.scale);
-        if (active) a[q] = zsub(a[q], zmul(v, f));
-        else if (c == j) a[q] = (i == j) ? make_double2(h.beta, 0.0) : v;
-      }
+      zc v = zmul(xc[buf][i], h.scale);
+      v = zsel(i == j, make_double2(1.0, 0.0), v);
+      const zc upd = zsub(a[q], zmul(v, f));  // f = 0 in the columns left of j: unchanged
+      const zc own = zsel(i == j, make_double2(h.beta, 0.0), v);
+      a[q] = zsel(i >= j, zsel(mine, own, upd), a[q]);
     }
+    stamp(j, 2);
     if (j + 1 < n) stage_col(j + 1, buf ^ 1);
     __syncthreads();
+    stamp(j, 3);
     if (j + 1 < n) publish(j + 1, buf ^ 1);
+    stamp(j, 4);
     __syncthreads();
+    stamp(j, 5);
   }
   // reflectors and R back to memory (A is overwritten like LAPACK's zgeqrf does); R: upper triangle
 #pragma unroll
@@ -403,6 +442,7 @@ __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int
   }
 }
 
+
 // Q[i][c] = delta_ic - sum_s V[i][s] W[s][c], V = unit lower trapezoid stored in the factored A
 __global__ __launch_bounds__(256) void k_qr_small_q(const zc* __restrict__ A, int m, int n, const zc* __restrict__ W,
                                                     zc* __restrict__ Q) {
@@ -424,11 +464,29 @@ __global__ __launch_bounds__(256) void k_qr_small_q(const zc* __restrict__ A, in
 static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work) {
   if (n > 32 || m > 320) return 0;
   const int rpt = (m + 15) / 16;
-  if (rpt <= 2) hipLaunchKernelGGL(k_qr_small<2>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
-  else if (rpt <= 4) hipLaunchKernelGGL(k_qr_small<4>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
-  else if (rpt <= 8) hipLaunchKernelGGL(k_qr_small<8>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
-  else if (rpt <= 12) hipLaunchKernelGGL(k_qr_small<12>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
-  else hipLaunchKernelGGL(k_qr_small<20>, dim3(1), dim3(512), 0, st, A, m, n, R, work);
+  static const bool tracing = std::getenv("MITDVP_QR_TRACE") != nullptr;
+  static long long* trace = nullptr;
+  if (tracing && !trace) {
+    HIP_CHECK(hipMalloc(&trace, 1024 * sizeof(long long)));
+    HIP_CHECK(hipMemset(trace, 0, 1024 * sizeof(long long)));
+  }
+  if (rpt <= 2) hipLaunchKernelGGL(k_qr_small<2>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
+  else if (rpt <= 4) hipLaunchKernelGGL(k_qr_small<4>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
+  else if (rpt <= 8) hipLaunchKernelGGL(k_qr_small<8>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
+  else if (rpt <= 12) hipLaunchKernelGGL(k_qr_small<12>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
+  else hipLaunchKernelGGL(k_qr_small<20>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
+  if (tracing) {  // mean duration of the phases of a column step (10 ns ticks -> us)
+    long long h[1024];
+    HIP_CHECK(hipMemcpyAsync(h, trace, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const int np = 6;
+    double ph[8] = {0};
+    for (int j = 0; j + 1 < n; ++j)
+      for (int k = 0; k + 1 < np; ++k) ph[k] += (double)(h[j * 8 + k + 1] - h[j * 8 + k]) * 0.01 / (n - 1);
+    fprintf(stderr, "[qr_trace] m=%d n=%d  step %.2f us:", m, n, (double)(h[(n - 1) * 8] - h[0]) * 0.01 / (n - 1));
+    for (int k = 0; k + 1 < np; ++k) fprintf(stderr, " %.2f", ph[k]);
+    fprintf(stderr, "\n");
+  }
   if (Q) hipLaunchKernelGGL(k_qr_small_q, dim3((m + 7) / 8), dim3(256), 0, st, A, m, n, work, Q);
   HIP_CHECK(hipGetLastError());
   return Q ? 2 : 1;

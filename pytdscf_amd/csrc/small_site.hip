@@ -91,14 +91,13 @@ struct Sync {
 
 // fixed-order sum of the SS_WAVES per-wave partials p[0..SS_WAVES)
 __device__ __forceinline__ double wtree(const double* p) {
-  double a[SS_WAVES];
-#pragma unroll
-  for (int i = 0; i < SS_WAVES; ++i) a[i] = p[i];
-#pragma unroll
-  for (int st = SS_WAVES / 2; st > 0; st >>= 1)
-#pragma unroll
-    for (int i = 0; i < st; ++i) a[i] += a[i + st];
-  return a[0];
+  // written out (halving tree: i += i + 8, then 4, 2, 1): as loops over a local array hipcc kept the array in scratch
+  static_assert(SS_WAVES == 16, "wtree is written for 16 waves");
+  const double b0 = p[0] + p[8], b1 = p[1] + p[9], b2 = p[2] + p[10], b3 = p[3] + p[11];
+  const double b4 = p[4] + p[12], b5 = p[5] + p[13], b6 = p[6] + p[14], b7 = p[7] + p[15];
+  const double c0 = b0 + b4, c1 = b1 + b5, c2 = b2 + b6, c3 = b3 + b7;
+  const double d0 = c0 + c2, d1 = c1 + c3;
+  return d0 + d1;
 }
 
 __device__ __forceinline__ double wave_sum64(double v) {

@@ -115,23 +115,6 @@ __device__ __forceinline__ void jblock_pair(int k, int nblk, int round, int& P, 
   else { P = (round + k) % (nblk - 1); Q = (round - k + (nblk - 1)) % (nblk - 1); }
 }
 
-// 1/sqrt(x) and 1/x for positive normal x: hardware seed (v_rsq_f64 / v_rcp_f64) + two Newton steps; the library
-// forms (special-case handling, denormal scaling) cost ~400 cycles of dependent latency each, and a rotation is a
-// chain of five of them that every step of the 16 x 16 sweep waits for
-__device__ __forceinline__ double jrsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double h = 0.5 * x;
-  y = y * (1.5 - h * y * y);
-  y = y * (1.5 - h * y * y);
-  return y;
-}
-__device__ __forceinline__ double jrcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * (2.0 - x * y);
-  y = y * (2.0 - x * y);
-  return y;
-}
-
 // rotation of the pair index i belongs to in step rnd of the 16-player tournament, as the row map
 // x_i' = d x_i + o x_partner;  rel = |G_pq|^2 / (G_pp G_qq) before the rotation (0 when the pair is skipped)
 __device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, int rnd, double tiny2, int& partner, zc& d, zc& o,
@@ -151,14 +134,14 @@ __device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, int rn
   const zc g = Gc[p][q];
   const double g2 = g.x * g.x + g.y * g.y;
   if (!(g2 > 0.0) || !(a > tiny2) || !(b > tiny2)) return;
-  rel = g2 * jrcp(a * b);
+  rel = g2 * fast_rcp(a * b);
   if (rel <= 1e-32) return;
-  const double ig = jrsqrt(g2);
+  const double ig = fast_rsqrt(g2);
   const double er = g.x * ig, ei = g.y * ig;  // e^{i phi}
   const double zeta = 0.5 * (b - a) * ig;
   const double z1 = 1.0 + zeta * zeta;
-  const double t = (zeta >= 0 ? 1.0 : -1.0) * jrcp(fabs(zeta) + z1 * jrsqrt(z1));
-  const double cs = jrsqrt(1.0 + t * t), sn = cs * t;
+  const double t = (zeta >= 0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + z1 * fast_rsqrt(z1));
+  const double cs = fast_rsqrt(1.0 + t * t), sn = cs * t;
   // x_p' = cs x_p - sn e^{i phi} x_q ;  x_q' = sn x_p + cs e^{i phi} x_q
   if (is_p) { d = make_double2(cs, 0.0); o = make_double2(-sn * er, -sn * ei); }
   else { d = make_double2(cs * er, cs * ei); o = make_double2(sn, 0.0); }
