@@ -198,7 +198,9 @@ __device__ __forceinline__ double ks_allreduce(double v, int KS) {
   return v;
 }
 
-// C = scl * A B.
+// C = scl * A B.  (Measured and dropped, round 2: a 2 x 2 block of outputs per thread -- half the LDS reads per
+// multiply-add, but four times the cross-lane reduction work: the stages got 25 % slower.  At 16 waves per CU this
+// kernel is bound by VALU issue slots, ~500 instructions per wave and stage of which the multiply-adds are a quarter.)
 __device__ __forceinline__ void lds_gemm(const zc* __restrict__ A, int lda, const zc* __restrict__ B, int ldb,
                                          zc* __restrict__ C, int ldc, int M, int N, int K, double scl) {
   const int mn = M * N;

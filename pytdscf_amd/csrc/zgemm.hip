@@ -613,11 +613,14 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   // Workgroups that live that long drift apart and stop sharing their operand strips in the 4 MiB L2 of their XCD:
   // FETCH_SIZE of S3 is 180 GB unsplit, 123 / 94 / 68 / 77 GB with 4 / 8 / 16 / 32 splits (tools/longk_probe.sh),
   // for 2.1 GB of partial slabs at 8 splits and a kernel that gets 2 % faster (1.2 ms of 54; the ordered combine
-  // takes 0.4 ms of that back).  ~4096 columns of K per workgroup.
+  // takes 0.4 ms of that back).  ~4096 columns of K per workgroup.  Same-box A/B: C4 +0.5 % sweeps/s (8 splits), C5
+  // +1.7 % (its S3: 32 x 8 tiles, K = 8192, 2 splits: 0.857 -> 0.812 ms).  The third stage of an environment update
+  // (A transposed, K = 16384, 16 x 512 tiles) does not gain (+0.3 % time) and stays unsplit.
   // MITDVP_LONGK_SPLITS: 0 = this rule (default), 1 = off, n = force n splits.
   static const int longk_env = [] { const char* e = std::getenv("MITDVP_LONGK_SPLITS"); return e ? std::atoi(e) : 0; }();
   const int longk = longk_env > 0 ? longk_env : (int)std::min<long>(8, d.K / 4096);
-  const bool long_k = d.batch == 1 && longk > 1 && nt >= 192 && d.K >= 8192 && cfg == 1 && !d.rowmap_p;
+  const bool long_k = d.batch == 1 && longk > 1 && nt >= 192 && d.K >= 8192 && cfg == 1 && !d.rowmap_p &&
+                      (longk_env > 0 || !d.transA);
   if (d.batch == 1 && ((nt < 192 && d.K >= 1024) || long_k)) {
     int splits = long_k ? longk : (int)std::min<long>((384 + nt - 1) / nt, d.K / 256);
     if (splits >= 2) {
