@@ -204,6 +204,13 @@ int mitdvp_set_pointer_mode(mitdvp_engine* h, int mode);
  * conj_bra = 0 gives <Psi*|Psi> (the autocorrelation of the t/2 trick). */
 int mitdvp_fold_block(mitdvp_engine* h, int op_id, int conj_bra, int from_left, const double* reim_in, int d, int m,
                       double* reim_out);
+/* the same through the sites [first, first + count) only (count = 0: the block is copied) */
+int mitdvp_fold_block_range(mitdvp_engine* h, int op_id, int conj_bra, int from_left, int first, int count, const double* reim_in,
+                            int d, int m, double* reim_out);
+/* Reduced density of ONE site of a site-sharded state (MPSCoefParallel.get_reduced_densities, _mps_parallel.py:1035-1208):
+ * rho[j][j'] from the site tensor and the transfer blocks of everything left / right of it, left[bra][ket] (D_l x D_l),
+ * right[bra][ket] (D_r x D_r) as mitdvp_fold_block (op_id < 0, conj_bra = 1) produces them.  reim_out: d x d, host. */
+int mitdvp_site_rdm_blocks(mitdvp_engine* h, int isite, const double* left, const double* right, double* reim_out);
 
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */

@@ -124,6 +124,8 @@ def load() -> C.CDLL:
         "mitdvp_set_bond": (i, [vp, i, dp, i]),
         "mitdvp_fold_block": (i, [vp, i, i, i, dp, i, i, dp]),
         "mitdvp_set_pointer_mode": (i, [vp, i]),
+        "mitdvp_fold_block_range": (i, [vp, i, i, i, i, i, dp, i, i, dp]),
+        "mitdvp_site_rdm_blocks": (i, [vp, i, dp, dp, dp]),
         "mitdvp_expect": (i, [vp, i, dp]),
         "mitdvp_autocorr": (i, [vp, dp]),
         "mitdvp_norm": (i, [vp, dp]),

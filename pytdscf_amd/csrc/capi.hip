@@ -153,6 +153,13 @@ int mitdvp_get_bond(mitdvp_engine* h, double* reim_out, int* dim) { ENG_CALL(h, 
 int mitdvp_set_bond(mitdvp_engine* h, int bond, const double* reim, int dim) {
   ENG_CALL(h, { NEED(reim); h->e->set_bond(bond, reim, dim); });
 }
+int mitdvp_fold_block_range(mitdvp_engine* h, int op_id, int conj_bra, int from_left, int first, int count, const double* reim_in,
+                            int d, int m, double* reim_out) {
+  ENG_CALL(h, { NEED(reim_in, reim_out); h->e->fold_block(op_id, conj_bra != 0, from_left != 0, reim_in, d, m, reim_out, first, count); });
+}
+int mitdvp_site_rdm_blocks(mitdvp_engine* h, int isite, const double* left, const double* right, double* reim_out) {
+  ENG_CALL(h, { NEED(left, right, reim_out); h->e->site_rdm_blocks(isite, left, right, reim_out); });
+}
 int mitdvp_set_pointer_mode(mitdvp_engine* h, int mode) { ENG_CALL(h, h->e->set_pointer_mode(mode)); }
 int mitdvp_fold_block(mitdvp_engine* h, int op_id, int conj_bra, int from_left, const double* reim_in, int d, int m,
                       double* reim_out) {

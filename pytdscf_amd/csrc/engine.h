@@ -205,7 +205,9 @@ class Engine {
   void set_pointer_mode(int mode);
   void copy_in(zc* dst, const double* src, size_t elems);   // + stream synchronise
   void copy_out(double* dst, const zc* src, size_t elems);  // + stream synchronise
-  void fold_block(int op_id, bool conj_bra, bool from_left, const double* in, int d, int m, double* out);
+  void fold_block(int op_id, bool conj_bra, bool from_left, const double* in, int d, int m, double* out, int first = 0,
+                  int count = -1);
+  void site_rdm_blocks(int isite, const double* TL, const double* TR, double* out);
   hipStream_t stream() const { return st_; }
   const MpoSite& mpo(int op_id, int isite);
   mitdvp_config cfg;

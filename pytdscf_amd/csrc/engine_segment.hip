@@ -192,21 +192,27 @@ void Engine::set_bond(int b, const double* reim, int dim) {
 //   op_id >= 0: the block is an environment block (d, m, d) of that operator, the sites enter as conj(bra) | ket
 //               (contract_with_site_mpo, _contraction.py:148-397); the gauge tags are not consulted;
 //   op_id <  0: plain transfer block T[bra][ket] (m = 1); conj_bra = false gives <Psi*|Psi> (autocorrelation).
-// from_left: `in` sits left of site 0 and `out` right of the last site; otherwise the other way round.
-void Engine::fold_block(int op_id, bool conj_bra, bool from_left, const double* in, int d, int m, double* out) {
+// from_left: `in` sits left of the first site of the range and `out` right of its last site; otherwise the other way
+// round.  The range is [first0, first0 + count) (default: all sites; count = 0 copies the block).
+void Engine::fold_block(int op_id, bool conj_bra, bool from_left, const double* in, int d, int m, double* out, int first0,
+                        int count) {
   require_ready(true);
+  if (count < 0) count = L_ - first0;
+  if (first0 < 0 || count < 0 || first0 + count > L_) throw ArgError("fold_block: bad site range");
   if (!in || !out) throw ArgError("fold_block: null block");
-  const int first = from_left ? 0 : L_ - 1;
-  const int d0 = from_left ? dl_[first] : dr_[first];
+  const int first = count > 0 ? (from_left ? first0 : first0 + count - 1) : std::min(first0, L_ - 1);
+  const int d0 = count > 0 ? (from_left ? dl_[first] : dr_[first]) : d;
   if (d != d0) throw ArgError("fold_block: block and site bond dimension differ");
   if (op_id < 0 && m != 1) throw ArgError("fold_block: a plain transfer block has m = 1");
   if (op_id >= 0) {
     if (!conj_bra) throw ArgError("fold_block: operator blocks are defined with the conjugated bra only");
-    const MpoSite& w = mpo(op_id, first);
-    if (m != (from_left ? w.ml : w.mr)) throw ArgError("fold_block: block and MPO bond dimension differ");
+    if (count > 0) {
+      const MpoSite& w = mpo(op_id, first);
+      if (m != (from_left ? w.ml : w.mr)) throw ArgError("fold_block: block and MPO bond dimension differ");
+    }
   }
   size_t mx = (size_t)d * m * d;
-  for (int p = 0; p < L_; ++p) {
+  for (int p = first0; p < first0 + count; ++p) {
     const int mm = op_id >= 0 ? std::max(mpo(op_id, p).ml, mpo(op_id, p).mr) : 1;
     const size_t dd = std::max(dl_[p], dr_[p]);
     mx = std::max(mx, dd * mm * dd);
@@ -214,8 +220,8 @@ void Engine::fold_block(int op_id, bool conj_bra, bool from_left, const double* 
   DevBuf cur = pool_get(mx), nxt = pool_get(mx);
   copy_in(cur.p, in, (size_t)d * m * d);
   int dout = d, mout = m;
-  for (int k = 0; k < L_; ++k) {
-    const int p = from_left ? k : L_ - 1 - k;
+  for (int k = 0; k < count; ++k) {
+    const int p = from_left ? first0 + k : first0 + count - 1 - k;
     const int dl = dl_[p], dd = dd_[p], dr = dr_[p];
     if (op_id >= 0) {
       const MpoSite& w = mpo(op_id, p);
@@ -252,6 +258,42 @@ void Engine::fold_block(int op_id, bool conj_bra, bool from_left, const double* 
   copy_out(out, cur.p, (size_t)dout * mout * dout);
   pool_put(std::move(cur));
   pool_put(std::move(nxt));
+}
+
+// rho[j][j'] = <j| Tr_rest |Psi><Psi| |j'> at one site of a state whose parts left and right of the site are given as
+// transfer blocks in the fold_block convention: TL[bra][ket] (dl x dl), TR[bra][ket] (dr x dr).  Reduced densities of
+// a site-sharded state (MPSCoefParallel.get_reduced_densities, _mps_parallel.py:1035-1208): the blocks arrive from the
+// neighbouring ranks.  `out` (d x d) is host memory.
+void Engine::site_rdm_blocks(int isite, const double* TL, const double* TR, double* out) {
+  require_ready(true);
+  if (isite < 0 || isite >= L_) throw ArgError("site_rdm_blocks: bad site index");
+  if (!TL || !TR || !out) throw ArgError("site_rdm_blocks: null argument");
+  const int dl = dl_[isite], d = dd_[isite], dr = dr_[isite];
+  DevBuf tl = pool_get((size_t)dl * dl), tr = pool_get((size_t)dr * dr), rho = pool_get((size_t)dl * d * d);
+  copy_in(tl.p, TL, (size_t)dl * dl);
+  copy_in(tr.p, TR, (size_t)dr * dr);
+  // U[a'][(j,s)] = sum_a TL[a'][a] C[a][(j,s)]
+  ZgemmDesc u = zgemm_desc(tl.p, site_[isite].p, tmp1_.p, dl, d * dr, dl);
+  zgemm(st_, u);
+  // V[(a',j)][s'] = sum_s U[(a',j)][s] TR[s'][s]
+  ZgemmDesc v = zgemm_desc(tmp1_.p, tr.p, tmp2_.p, dl * d, dr, dr);
+  v.transB = 1; v.ldb = dr;
+  zgemm(st_, v);
+  // rho_a'[j][j'] = sum_s' V[a'][j][s'] conj(C[a'][j'][s']); summed over a' on the host (d x d numbers per a')
+  ZgemmDesc r = zgemm_desc(tmp2_.p, site_[isite].p, rho.p, d, d, dr);
+  r.transB = 1; r.conjB = 1; r.ldb = dr; r.ldc = d;
+  r.batch = dl; r.strideA = (long)d * dr; r.strideB = (long)d * dr; r.strideC = (long)d * d;
+  if (dl > 65535) throw ArgError("site_rdm_blocks: bond dimension above 65535");
+  zgemm(st_, r);
+  cnt_.n_launch += 3;
+  std::vector<hzc> h((size_t)dl * d * d);
+  HIP_CHECK(hipMemcpyAsync(h.data(), rho.p, h.size() * sizeof(zc), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  hzc* o = reinterpret_cast<hzc*>(out);
+  for (int e = 0; e < d * d; ++e) o[e] = hzc(0, 0);
+  for (int a = 0; a < dl; ++a)
+    for (int e = 0; e < d * d; ++e) o[e] += h[(size_t)a * d * d + e];
+  pool_put(std::move(tl)); pool_put(std::move(tr)); pool_put(std::move(rho));
 }
 
 }  // namespace mitdvp

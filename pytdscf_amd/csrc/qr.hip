@@ -81,6 +81,23 @@ __device__ __forceinline__ House zlarfg(zc alpha, double xnorm2) {
   return h;
 }
 
+// zlarfg for the normal range with the fast reciprocal / reciprocal square root (same formulas; 1-2 ulp)
+__device__ __forceinline__ House zlarfg_fast(zc alpha, double xnorm2) {
+  const double x = alpha.x * alpha.x + alpha.y * alpha.y + xnorm2;
+  if (!(x > 1e-200 && x < 1e200) || (xnorm2 == 0.0 && alpha.y == 0.0)) return zlarfg(alpha, xnorm2);
+  House h;
+  const double nrm = x * fast_rsqrt(x);
+  const double beta = alpha.x >= 0.0 ? -nrm : nrm;
+  const double ib = fast_rcp(beta);
+  h.beta = beta;
+  h.tau = make_double2((beta - alpha.x) * ib, -alpha.y * ib);
+  const double dr = alpha.x - beta, di = alpha.y;
+  const double iden = fast_rcp(dr * dr + di * di);
+  h.scale = make_double2(dr * iden, -di * iden);
+  return h;
+}
+
+
 // ---------------------------------------------------------------------------
 // Panel factorisation (zgeqr2), ONE launch per column.
 //
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void k_qr_col(zc* __restrict__ A, long lda, in
   }
   __syncthreads();
   // (2) reflector scalars
-  const House h = zlarfg(alpha_in, ysum[jj].x);
+  const House h = zlarfg_fast(alpha_in, ysum[jj].x);
   const bool active = c > j && c < j1;
   // w_c = conj(scale) y_c + A[j,c]
   zc f = make_double2(0.0, 0.0);
@@ -288,22 +305,6 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
     const int i = e / n, c = e % n;
     R[e] = c >= i ? A[(long)i * lda + c] : make_double2(0.0, 0.0);
   }
-}
-
-// zlarfg for the normal range with the fast reciprocal / reciprocal square root (same formulas; 1-2 ulp)
-__device__ __forceinline__ House zlarfg_fast(zc alpha, double xnorm2) {
-  const double x = alpha.x * alpha.x + alpha.y * alpha.y + xnorm2;
-  if (!(x > 1e-200 && x < 1e200) || (xnorm2 == 0.0 && alpha.y == 0.0)) return zlarfg(alpha, xnorm2);
-  House h;
-  const double nrm = x * fast_rsqrt(x);
-  const double beta = alpha.x >= 0.0 ? -nrm : nrm;
-  const double ib = fast_rcp(beta);
-  h.beta = beta;
-  h.tau = make_double2((beta - alpha.x) * ib, -alpha.y * ib);
-  const double dr = alpha.x - beta, di = alpha.y;
-  const double iden = fast_rcp(dr * dr + di * di);
-  h.scale = make_double2(dr * iden, -di * iden);
-  return h;
 }
 
 // ---------------------------------------------------------------------------

@@ -206,19 +206,35 @@ class TDVPEngine:
             raise ValueError("bond matrix must be square")
         self._ck(self._lib.mitdvp_set_bond(self._h, bond, _dp(a), a.shape[0]))
 
-    def fold_block(self, block, *, op_id: int = -1, conj: bool = True, from_left: bool = True, out_shape=None):
+    def site_rdm_blocks(self, isite: int, left, right) -> np.ndarray:
+        """rho[j][j'] of one site given the transfer blocks (bra, ket) of everything left / right of it."""
+        a, b = _c128(left), _c128(right)
+        l, n, r = self.get_site_shape(isite)[:3]
+        if a.shape != (l, l) or b.shape != (r, r):
+            raise ValueError("transfer blocks must be (D_l, D_l) and (D_r, D_r)")
+        out = np.empty((n, n), dtype=np.complex128)
+        self._ck(self._lib.mitdvp_site_rdm_blocks(self._h, isite, _dp(a), _dp(b), _dp(out)))
+        return out
+
+    def fold_block(self, block, *, op_id: int = -1, conj: bool = True, from_left: bool = True, out_shape=None, first: int = 0,
+                   count: int | None = None):
         """Carry a boundary block (D, M, D) through all sites of this engine (``mitdvp_fold_block``): the piece of
         ``MPSCoefParallel.ovlp`` / ``expectation`` one rank computes.  ``op_id < 0``: plain transfer (M = 1)."""
         a = _c128(block)
         if a.ndim != 3 or a.shape[0] != a.shape[2]:
             raise ValueError("boundary block must be (D, M, D)")
+        if count is None:
+            count = self.nsite - first
+        if count == 0:
+            return a.copy()
         if out_shape is None:
-            last = self.get_site_shape(self.nsite - 1 if from_left else 0)
+            last = self.get_site_shape(first + count - 1 if from_left else first)
             dn = last[2] if from_left else last[0]
             ends = getattr(self, "_mpo_ends", {}).get(op_id, (1, 1))
             out_shape = (dn, (ends[1] if from_left else ends[0]) if op_id >= 0 else 1, dn)
         out = np.empty(out_shape, dtype=np.complex128)
-        self._ck(self._lib.mitdvp_fold_block(self._h, op_id, int(conj), int(from_left), _dp(a), a.shape[0], a.shape[1], _dp(out)))
+        self._ck(self._lib.mitdvp_fold_block_range(self._h, op_id, int(conj), int(from_left), first, count, _dp(a), a.shape[0],
+                                                   a.shape[1], _dp(out)))
         return out
 
     # ---- hot path ------------------------------------------------------

@@ -321,17 +321,21 @@ class SiteShardedTDVP:
                 shp = self.shapes[self.hi - 1][2] if from_left else self.shapes[self.lo][0]
                 block = eng.fold_block(block, op_id=op_id, conj=conj, from_left=from_left, out_shape=(shp, m_out, shp))
             else:
-                D = self.X.shape[0]
-                x = TDVPEngine(1, device=self.device, **self.kw)
-                try:
-                    x.set_site(0, pinv_device(self.X, self.device).reshape(D, 1, D), "C")
-                    if op_id >= 0:
-                        M = block.shape[1]
-                        x.set_mpo([np.eye(M, dtype=np.complex128).reshape(M, 1, 1, M)], op_id=op_id)
-                    block = x.fold_block(block, op_id=op_id, conj=conj, from_left=from_left, out_shape=block.shape)
-                finally:
-                    x.close()
+                block = self._fold_x(block, from_left, op_id, conj)
         return block
+
+    def _fold_x(self, block, from_left, op_id, conj):
+        """the block through X^+ of the junction to the right: one more site of physical dimension 1"""
+        D = self.X.shape[0]
+        x = TDVPEngine(1, device=self.device, **self.kw)
+        try:
+            x.set_site(0, pinv_device(self.X, self.device).reshape(D, 1, D), "C")
+            if op_id >= 0:
+                M = block.shape[1]
+                x.set_mpo([np.eye(M, dtype=np.complex128).reshape(M, 1, 1, M)], op_id=op_id)
+            return x.fold_block(block, op_id=op_id, conj=conj, from_left=from_left, out_shape=block.shape)
+        finally:
+            x.close()
 
     def _fold_chain(self, op_id, conj, op_cores):
         """every rank returns the scalar (it is formed at the middle junction and shared)."""
@@ -380,6 +384,47 @@ class SiteShardedTDVP:
             raise ValueError("operator needs one MPO core per site of the chain")
         self.block.set_mpo(cores[self.lo : self.hi], op_id=1)
         return self._fold_chain(1, True, cores)
+
+    def site_rdm(self, site: int):
+        """Reduced density rho[j][j'] of one site of the sharded state (MPSCoefParallel.get_reduced_densities,
+        _mps_parallel.py:1035-1208, one-site keys): transfer blocks are folded towards the owner of the site from both
+        ends of the chain, rank by rank; every rank returns the (d, d) matrix.  Collective."""
+        r, N = self.rank, self.world
+        if not 0 <= site < self.nsite:
+            raise ValueError("site index out of range")
+        owner = next(k for k, (lo, hi) in enumerate(self.ranges) if lo <= site < hi)
+        one = np.ones((1, 1, 1), dtype=np.complex128)
+        d = self.shapes[site][1]
+        rho = np.zeros((d, d), dtype=np.complex128)
+        if r < owner:  # pass the left part on
+            D = self.shapes[self.lo][0]
+            blk = one if r == 0 else self.link.recv((D, 1, D), r - 1)
+            self.link.send(self._fold(blk, True, -1, True, None), r + 1)
+        elif r > owner:
+            D = self.shapes[self.hi - 1][2]
+            blk = one if r == N - 1 else self.link.recv((D, 1, D), r + 1)
+            self.link.send(self._fold(blk, False, -1, True, None), r - 1)
+        else:
+            Dl, Dr = self.shapes[self.lo][0], self.shapes[self.hi - 1][2]
+            tl = one if r == 0 else self.link.recv((Dl, 1, Dl), r - 1)
+            tr = one if r == N - 1 else self.link.recv((Dr, 1, Dr), r + 1)
+            p = site - self.lo
+            tl = self.block.fold_block(tl, op_id=-1, conj=True, from_left=True, first=0, count=p,
+                                       out_shape=(self.shapes[site][0], 1, self.shapes[site][0]))
+            if r < N - 1:  # X^+ of the junction to the right sits between this block and the next
+                tr = self._fold_x(tr, False, -1, True)
+            tr = self.block.fold_block(tr, op_id=-1, conj=True, from_left=False, first=p + 1, count=self.n - p - 1,
+                                       out_shape=(self.shapes[site][2], 1, self.shapes[site][2]))
+            rho = self.block.site_rdm_blocks(p, tl[:, 0, :], tr[:, 0, :])
+        if N > 1:  # share: only the owner holds non-zero entries
+            import torch
+
+            t = torch.from_numpy(np.ascontiguousarray(rho).view(np.float64).reshape(-1).copy())
+            if self.comm.backend == "nccl":
+                t = t.to(self.comm.device)
+            self.comm.dist.all_reduce(t)
+            rho = t.cpu().numpy().view(np.complex128).reshape(d, d)
+        return rho
 
     def selftest(self) -> bool:
         """Neighbour ping over the link (every junction, both directions) before the sweep relies on it.  The

@@ -82,6 +82,7 @@ for _ in range(nstep):
 obs = dict(norm=eng.norm(), auto=eng.autocorr(), energy=eng.expectation())
 op2 = orc.synthetic_mpo(L, d, 3, seed=7)
 obs["op2"] = eng.expectation(op2)
+rdms = {{p: eng.site_rdm(p) for p in (0, L // 2 - 1, L // 2, L - 1)}}
 g = eng.gather()
 def sandwich(bra, ket, ops=None):
     e = np.ones((1, 1, 1), complex)
@@ -91,7 +92,17 @@ def sandwich(bra, ket, ops=None):
     return complex(e[0, 0, 0])
 if comm.rank == 0:
     gc = [c.conj() for c in g]
-    obs_gap = max(abs(obs["norm"] - np.sqrt(sandwich(gc, g).real)), abs(obs["auto"] - sandwich(g, g)),
+    def rdm(cores, p):
+        l = np.ones((1, 1), complex)
+        for x in cores[:p]:
+            l = np.einsum("ab,aic,bid->cd", l, x.conj(), x, optimize=True)   # [bra][ket]
+        r = np.ones((1, 1), complex)
+        for x in reversed(cores[p + 1:]):
+            r = np.einsum("cd,aic,bid->ab", r, x.conj(), x, optimize=True)
+        x = cores[p]
+        return np.einsum("ab,bjs,ts,akt->jk", l, x, r, x.conj(), optimize=True)  # rho[j][j'] = ket j, bra j'
+    rdm_gap = max(np.abs(rdms[p] - rdm(g, p)).max() for p in rdms)
+    obs_gap = max(rdm_gap, abs(obs["norm"] - np.sqrt(sandwich(gc, g).real)), abs(obs["auto"] - sandwich(g, g)),
                   abs(obs["energy"] - sandwich(gc, g, mpo)), abs(obs["op2"] - sandwich(gc, g, op2)))
     ref = par.ParallelOracle([c.copy() for c in mps], mpo, comm.world, integrator={integ!r}, conserve_norm={cn})
     ser = orc.OracleMPS([c.copy() for c in mps], mpo, integrator={integ!r}, conserve_norm={cn})
