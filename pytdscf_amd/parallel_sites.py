@@ -30,7 +30,7 @@ import os
 
 import numpy as np
 
-from .engine import TDVPEngine, svd as device_svd
+from .engine import TDVPEngine, svd as device_svd, zgemm as device_zgemm
 
 RCOND = 1e-13  # _site_cls.py:24
 
@@ -47,11 +47,11 @@ def split_sites(nsite: int, nrank: int) -> list[tuple[int, int]]:
 
 
 def pinv_device(x: np.ndarray, device: int = 0) -> np.ndarray:
-    """Moore-Penrose inverse through the device SVD (np.linalg.pinv(x, rcond=RCOND))."""
+    """Moore-Penrose inverse (np.linalg.pinv(x, rcond=RCOND)): SVD and the product V diag(1/s) U^H on the device."""
     U, s, Vh, _ = device_svd(x, device=device)
     keep = s > RCOND * s.max()
     inv = np.where(keep, 1.0 / np.where(keep, s, 1.0), 0.0)
-    return (Vh.conj().T * inv[None, :]) @ U.conj().T
+    return device_zgemm(Vh, U * inv[None, :], transA=True, conjA=True, transB=True, conjB=True, device=device)
 
 
 class _Link:
