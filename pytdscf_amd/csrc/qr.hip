@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 // full s_waitcnt per row, one exposed LDS latency each; zlarfg takes the hardware reciprocal seeds.  6.9 -> 4.3 us per
 // column step at 320 x 32 (MITDVP_QR_TRACE=1 python tools/qr_trace.py).  Tried and dropped: 256 threads owning two
 // columns each with ONE pass and one barrier per step (the thread re-forms column j + 1 itself) -- 256 VGPRs, one wave
-// per SIMD and nothing to hide the LDS latency behind: 13 us per step.
+// per SIMD and nothing to hide the LDS latency behind: 13 us per step; the same single pass with this kernel's 512-thread
+// layout: 256 VGPRs with spills, 6.4 us per step.
 // ---------------------------------------------------------------------------
 template <int RPT>
 __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int n, zc* __restrict__ R,
