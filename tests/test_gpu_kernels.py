@@ -248,3 +248,79 @@ def test_block_sparse_w_stage_is_bitwise_the_dense_one(monkeypatch):
     ref.propagate(0.3)
     assert abs(abs(orc.overlap(ref.cores, out["1"][0])) - 1) < 1e-10
     assert abs(out["1"][1] - ref.expectation()) < 1e-8 * abs(ref.expectation())
+
+
+@pytest.mark.parametrize("form", ["nn", "nt"])
+def test_zgemm_long_contraction_with_many_tiles_is_split(form):
+    """>= 192 output tiles and K >= 8192 (stage S3 of an apply at large D): the contraction is split inside the launch
+    and combined in a fixed order -- same numbers as the plain product to rounding, deterministic."""
+    from pytdscf_amd import engine as E
+
+    m, n, k = 1024, 896, 8192
+    rng = np.random.default_rng(11)
+    A = crandn(rng, m, k)
+    B = crandn(rng, n, k) if form == "nt" else crandn(rng, k, n)
+    out = E.zgemm(A, B, transB=form == "nt")
+    out2 = E.zgemm(A, B, transB=form == "nt")
+    ref = A @ (B.T if form == "nt" else B)
+    assert np.abs(out - ref).max() < 1e-13 * np.abs(ref).max() * np.sqrt(k)
+    assert np.array_equal(out, out2)
+
+
+def test_fold_block_ranges_and_site_rdm_from_blocks():
+    """mitdvp_fold_block_range / mitdvp_site_rdm_blocks (the per-rank pieces of the site-sharded observables) on a
+    single engine with ragged bonds and tensors in no particular gauge, against plain einsum."""
+    from pytdscf_amd import TDVPEngine
+
+    rng = np.random.default_rng(5)
+    dims = [(3, 2, 5), (5, 3, 4), (4, 2, 6), (6, 3, 2)]  # open outer bonds wider than 1: a block of a longer chain
+    cores = [crandn(rng, *s) for s in dims]
+    M = [2, 3, 2, 3, 2]
+    mpo = [crandn(rng, M[p], dims[p][1], dims[p][1], M[p + 1]) for p in range(4)]
+    eng = TDVPEngine(4)
+    for p, c in enumerate(cores):
+        eng.set_site(p, c, "C")
+    eng.set_mpo(mpo, op_id=2)
+
+    def left(t, x, conj=True):
+        return np.einsum("ab,aic,bid->cd", t, x.conj() if conj else x, x, optimize=True)
+
+    def right(t, x, conj=True):
+        return np.einsum("cd,aic,bid->ab", t, x.conj() if conj else x, x, optimize=True)
+
+    for conj in (True, False):
+        t0 = crandn(rng, 3, 3)
+        ref = t0
+        for x in cores[:3]:
+            ref = left(ref, x, conj)
+        got = eng.fold_block(t0[:, None, :], op_id=-1, conj=conj, from_left=True, first=0, count=3)
+        assert got.shape == (6, 1, 6) and np.abs(got[:, 0, :] - ref).max() < 1e-12 * np.abs(ref).max()
+        t1 = crandn(rng, 2, 2)
+        ref = t1
+        for x in reversed(cores[1:]):
+            ref = right(ref, x, conj)
+        got = eng.fold_block(t1[:, None, :], op_id=-1, conj=conj, from_left=False, first=1, count=3)
+        assert np.abs(got[:, 0, :] - ref).max() < 1e-12 * np.abs(ref).max()
+    # operator block through all sites, both directions
+    e0 = crandn(rng, 3, 2, 3)
+    ref = e0
+    for x, w in zip(cores, mpo):
+        ref = np.einsum("acb,aix,cijt,bjy->xty", ref, x.conj(), w, x, optimize=True)
+    got = eng.fold_block(e0, op_id=2, from_left=True)
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+    e1 = crandn(rng, 2, 2, 2)
+    ref = e1
+    for x, w in zip(reversed(cores), reversed(mpo)):
+        ref = np.einsum("xty,aix,cijt,bjy->acb", ref, x.conj(), w, x, optimize=True)
+    got = eng.fold_block(e1, op_id=2, from_left=False)
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+    # count = 0 hands the block back; a block of the wrong size is refused
+    assert np.array_equal(eng.fold_block(e0, op_id=-1, first=2, count=0), e0)
+    with pytest.raises(ValueError):
+        eng.fold_block(crandn(rng, 4, 1, 4), op_id=-1, from_left=True)
+    # one-site reduced density from the blocks on both sides
+    tl, tr = crandn(rng, 5, 5), crandn(rng, 4, 4)
+    ref = np.einsum("ab,bjs,ts,akt->jk", tl, cores[1], tr, cores[1].conj(), optimize=True)
+    got = eng.site_rdm_blocks(1, tl, tr)
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+    eng.close()
