@@ -241,6 +241,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    # stdout carries ONE JSON line and nothing else: whatever the libraries below print on file descriptor 1
+    # (gloo's "Rank 0 is connected to ..." banner, RCCL notices) is sent to stderr, the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # wall clock of the whole job: a self-launched rank inherits the parent's start
     t_start = T_PROCESS_START
     if "MITDVP_BENCH_T0" in os.environ:
@@ -532,7 +538,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, nthr, dt)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         out["wall_s"] = elapsed()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if eng is not None:
         eng.close()
     if ss is not None:

@@ -22,8 +22,9 @@ KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 
 def _line(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out
+    # stdout carries the JSON line and NOTHING else (library banners -- gloo, RCCL -- are sent to stderr)
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out
     return json.loads(lines[0])
 
 
