@@ -200,7 +200,10 @@ __device__ __forceinline__ double ks_allreduce(double v, int KS) {
 
 // C = scl * A B.  (Measured and dropped, round 2: a 2 x 2 block of outputs per thread -- half the LDS reads per
 // multiply-add, but four times the cross-lane reduction work: the stages got 25 % slower.  At 16 waves per CU this
-// kernel is bound by VALU issue slots, ~500 instructions per wave and stage of which the multiply-adds are a quarter.)
+// kernel is bound by VALU issue slots, ~500 instructions per wave and stage of which the multiply-adds are a quarter.
+// The same products as 16 x 16 MFMA tiles (one wave per tile, zero-padded edges): equal stage times (2.8 / 3.2 / 2.5 us) --
+// four or five tiles keep four or five of the sixteen waves busy on a dependent read -> MFMA chain -- and the second code
+// path cost the kernel 6 % through register spills: dropped as well.)
 __device__ __forceinline__ void lds_gemm(const zc* __restrict__ A, int lda, const zc* __restrict__ B, int ldb,
                                          zc* __restrict__ C, int ldc, int M, int N, int K, double scl) {
   const int mn = M * N;
