@@ -168,3 +168,23 @@ def test_site_sharded_with_device_resident_halo_messages(world, tmp_path):
 def test_site_sharded_arnoldi_without_renormalisation(tmp_path):
     r = _run(2, tmp_path, integ="arnoldi", cn=False)
     assert r["vs_oracle"] < 1e-8 and r["vs_serial"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_pseudo_inverse_on_the_device_matches_numpy():
+    """multiply_sigvec_pinv's pseudo-inverse (_site_cls.py:709-754, RCOND 1e-13): device SVD + device product."""
+    from pytdscf_amd.parallel_sites import RCOND, pinv_device
+
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((24, 24)) + 1j * rng.standard_normal((24, 24))
+    u, s, vh = np.linalg.svd(x)
+    s[-5:] = 0.0                      # rank-deficient: the cut-off branch
+    s[:19] = np.logspace(0, -9, 19)   # graded
+    x = (u * s) @ vh
+    got = pinv_device(x)
+    inv = np.where(s > RCOND * s.max(), 1.0 / np.where(s > 0, s, 1.0), 0.0)
+    ref = (vh.conj().T * inv) @ u.conj().T          # the pseudo-inverse by construction
+    # entries up to 1e9; a relative error eps * s_max / s_min = 1e-7 in the smallest kept singular value is what
+    # double precision allows (np.linalg.pinv itself is no closer to the constructed inverse)
+    assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max()
+    assert np.abs(x @ got @ x - x).max() < 1e-6     # Moore-Penrose: x x^+ x = x (rounding: eps |x| |x^+| |x| ~ 1e-7)
