@@ -28,17 +28,23 @@ t0 = time.time()
 eng = SiteShardedTDVP(comm, mpo, dims=[d] * L, bond_dim=D, seed=1)
 assert eng.selftest()
 t_setup = time.time() - t0
+nsteps = int(os.environ.get("RS_STEPS", 1))
+trace = [(0, eng.norm(), eng.expectation().real)]  # folded rank by rank on the device, no gather
 t0 = time.time()
-eng.step(dt)
+for k in range(nsteps):
+    eng.step(dt)
+    if nsteps > 1:
+        trace.append((k + 1, eng.norm(), eng.expectation().real))
 comm.barrier()
-t_step = time.time() - t0
+t_step = (time.time() - t0) / nsteps
 g = eng.gather()
 if comm.rank == 0:
     ser = TDVPEngine(L)
     ser.set_mpo(mpo)
     ser.init_random([d] * L, D, seed=1)
     t0 = time.time()
-    ser.propagate(dt)
+    for _ in range(nsteps):
+        ser.propagate(dt)
     n = ser.norm()
     t_ser = time.time() - t0
     ref = ser.get_mps()
@@ -49,7 +55,7 @@ if comm.rank == 0:
             e = np.einsum("ab,aic,bid->cd", e, x.conj(), y, optimize=True)
         return e[0, 0]
     gg = ov(g, g).real
-    print(json.dumps(dict(L=L, D=D, setup_s=t_setup, step_s=t_step, serial_step_s=t_ser, norm=float(np.sqrt(gg)),
+    print(json.dumps(dict(L=L, D=D, steps=nsteps, norm_energy_trace=trace, serial_energy=ser.expectation().real, setup_s=t_setup, step_s=t_step, serial_step_s=t_ser, norm=float(np.sqrt(gg)),
                           infidelity=float(1 - abs(ov(ref, g)) / np.sqrt(gg) / n), halo_GB=eng.traffic()[0] / 1e9)), flush=True)
 comm.barrier()
 eng.close()
