@@ -426,6 +426,63 @@ class SiteShardedTDVP:
             rho = t.cpu().numpy().view(np.complex128).reshape(d, d)
         return rho
 
+    def site_rdms(self, sites=None):
+        """One-site reduced densities of many sites in ONE two-way pass over the ranks (2 (N - 1) messages whatever the
+        number of sites): the left transfer blocks travel rank 0 -> N - 1, the right ones back, every rank then walks
+        its own sites with both.  Returns {site: rho (d, d)} on every rank.  Collective."""
+        r, N = self.rank, self.world
+        sites = list(range(self.nsite)) if sites is None else sorted(set(int(p) for p in sites))
+        if any(not 0 <= p < self.nsite for p in sites):
+            raise ValueError("site index out of range")
+        one = np.ones((1, 1, 1), dtype=np.complex128)
+        Dl, Dr = self.shapes[self.lo][0], self.shapes[self.hi - 1][2]
+        # left block at this rank's first site; pass the block at the next rank's first site on
+        tl_in = one if r == 0 else self.link.recv((Dl, 1, Dl), r - 1)
+        if r < N - 1:
+            self.link.send(self._fold(tl_in, True, -1, True, None), r + 1)
+        tr_in = one if r == N - 1 else self.link.recv((Dr, 1, Dr), r + 1)
+        if r > 0:
+            self.link.send(self._fold(tr_in, False, -1, True, None), r - 1)
+        mine = [p for p in sites if self.lo <= p < self.hi]
+        out = {}
+        if mine:
+            b, n = self.block, self.n
+            tr = self._fold_x(tr_in, False, -1, True) if r < N - 1 else tr_in
+            rights = {n - 1: tr}  # block right of local site q, for q down to the first wanted site
+            for q in range(n - 2, mine[0] - self.lo - 1, -1):
+                D = self.shapes[self.lo + q][2]
+                rights[q] = b.fold_block(rights[q + 1], op_id=-1, conj=True, from_left=False, first=q + 1, count=1, out_shape=(D, 1, D))
+            tl, at = tl_in, 0
+            for p in mine:
+                q = p - self.lo
+                if q > at:
+                    D = self.shapes[p][0]
+                    tl = b.fold_block(tl, op_id=-1, conj=True, from_left=True, first=at, count=q - at, out_shape=(D, 1, D))
+                    at = q
+                out[p] = b.site_rdm_blocks(q, tl[:, 0, :], rights[q][:, 0, :])
+        if N == 1:
+            return out
+        # share: every rank contributes the entries of its own sites
+        import torch
+
+        ds = [self.shapes[p][1] for p in sites]
+        flat = np.zeros(sum(d * d for d in ds), dtype=np.complex128)
+        off = 0
+        for p, d in zip(sites, ds):
+            if p in out:
+                flat[off : off + d * d] = out[p].reshape(-1)
+            off += d * d
+        t = torch.from_numpy(flat.view(np.float64).copy())
+        if self.comm.backend == "nccl":
+            t = t.to(self.comm.device)
+        self.comm.dist.all_reduce(t)
+        flat = t.cpu().numpy().view(np.complex128)
+        res, off = {}, 0
+        for p, d in zip(sites, ds):
+            res[p] = flat[off : off + d * d].reshape(d, d).copy()
+            off += d * d
+        return res
+
     def selftest(self) -> bool:
         """Neighbour ping over the link (every junction, both directions) before the sweep relies on it.  The
         device-resident form of the messages is pinged as well; if it fails on any rank, ALL ranks fall back to

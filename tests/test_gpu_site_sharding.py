@@ -83,6 +83,8 @@ obs = dict(norm=eng.norm(), auto=eng.autocorr(), energy=eng.expectation())
 op2 = orc.synthetic_mpo(L, d, 3, seed=7)
 obs["op2"] = eng.expectation(op2)
 rdms = {{p: eng.site_rdm(p) for p in (0, L // 2 - 1, L // 2, L - 1)}}
+rdms_all = eng.site_rdms()
+rdms_some = eng.site_rdms([1, L - 2])
 g = eng.gather()
 def sandwich(bra, ket, ops=None):
     e = np.ones((1, 1, 1), complex)
@@ -102,6 +104,9 @@ if comm.rank == 0:
         x = cores[p]
         return np.einsum("ab,bjs,ts,akt->jk", l, x, r, x.conj(), optimize=True)  # rho[j][j'] = ket j, bra j'
     rdm_gap = max(np.abs(rdms[p] - rdm(g, p)).max() for p in rdms)
+    assert sorted(rdms_all) == list(range(L)) and sorted(rdms_some) == [1, L - 2]
+    rdm_gap = max([rdm_gap] + [np.abs(rdms_all[p] - rdm(g, p)).max() for p in range(L)]
+                  + [np.abs(rdms_some[p] - rdm(g, p)).max() for p in rdms_some])
     obs_gap = max(rdm_gap, abs(obs["norm"] - np.sqrt(sandwich(gc, g).real)), abs(obs["auto"] - sandwich(g, g)),
                   abs(obs["energy"] - sandwich(gc, g, mpo)), abs(obs["op2"] - sandwich(gc, g, op2)))
     ref = par.ParallelOracle([c.copy() for c in mps], mpo, comm.world, integrator={integ!r}, conserve_norm={cn})
