@@ -214,6 +214,12 @@ class Engine {
 
  private:
   int ptr_mode_ = 0;
+  // H_eff applies of the current local exponential: the last MPO-bond block of the right environment is the identity
+  // (sites right of the centre are right-canonical and the MPO passes "nothing applied yet" through: the reference
+  // short-circuits such blocks as well, _mps_mpo.py:510-523) -- verified numerically per site, see local_site_exp
+  bool trim_r_ = false;
+  bool trim_identity_ = true;  // MITDVP_TRIM_IDENTITY=0 switches the shortcut off
+  bool right_block_is_identity(const zc* R, int dr, int m);
   int L_;
   hipStream_t st_ = nullptr;
   std::vector<int> dl_, dd_, dr_, gauge_;

@@ -26,6 +26,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   max_diag_krylov_ = c.max_diag_krylov > 0 ? c.max_diag_krylov : 64;
   if (const char* e = std::getenv("MITDVP_SMALL_KERNELS")) small_kernels_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_SPARSE_W")) sparse_w_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MITDVP_TRIM_IDENTITY")) trim_identity_ = std::atoi(e) != 0;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -486,7 +487,18 @@ void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const z
   const double s2_frac = w_stage(&w, 0, w.w2l.p, d, mr, ml, dri, na);
   timer_end();
   timer_begin(12);
-  {  // out[(a,i)][r] = Y[(a,i)][(t,s)] R[r][(t,s)]
+  const bool trim = trim_r_ && !sharded && dro == dri && mr > 1;
+  if (trim) {
+    // R[:, mr-1, :] is the identity: its K block of the contraction is a strided copy of Y, the GEMM runs over the
+    // other mr - 1 blocks and adds to it
+    const zc one = make_double2(1.0, 0.0);
+    copy2d(st_, out + (size_t)a0 * d * dro, dro, Y_.p + (size_t)(mr - 1) * dri, (long)mr * dri, (long)na * d, dro, 0, one, false);
+    ZgemmDesc g = zgemm_desc(Y_.p, R, out + (size_t)a0 * d * dro, na * d, dro, (mr - 1) * dri);
+    g.lda = (long)mr * dri; g.transB = 1; g.ldb = (long)mr * dri; g.beta = one;
+    zgemm(st_, g);
+    cnt_.n_launch += 1;
+    cnt_.heff_flops_skipped += 8.0 * (double)na * d * dro * dri;
+  } else {  // out[(a,i)][r] = Y[(a,i)][(t,s)] R[r][(t,s)]
     ZgemmDesc g = zgemm_desc(Y_.p, R, out + (size_t)a0 * d * dro, na * d, dro, mr * dri);
     g.transB = 1; g.ldb = (long)mr * dri;
     zgemm(st_, g);
@@ -742,6 +754,16 @@ void Engine::build_left_envs() {
   }
 }
 
+// R[r][m-1][s] == delta_rs to 1e-13 (orthonormality of the tensors right of the site, to rounding)
+bool Engine::right_block_is_identity(const zc* R, int dr, int m) {
+  double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
+  ident_deviation(st_, R + (size_t)(m - 1) * dr, (long)m * dr, dr, dev);
+  double h = 1.0;
+  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(double), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  return h < 1e-13;
+}
+
 void Engine::local_site_exp(int p, double dt) {
   const MpoSite& w = mpo(0, p);
   if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
@@ -751,6 +773,9 @@ void Engine::local_site_exp(int p, double dt) {
   const zc* Rb = envR_[p + 1].p;
   const hzc shift = op(0).shift;
   auto mv = [&](const zc* in, zc* out) { heff_apply(Lb, w, Rb, in, out, dl, d, dr, shift); };
+  // large bonds: one check per site (two tiny launches and a synchronisation) buys 1 / M_r of stage S3 in every apply
+  trim_r_ = trim_identity_ && dr >= 256 && w.mr > 1 && right_block_is_identity(Rb, dr, w.mr);
+  struct Reset { bool& f; ~Reset() { f = false; } } reset{trim_r_};
   if (cfg.relax == 2)  // improved relaxation, _mps_cls.py:1078-1084
     kprev_[p] = krylov_diag(mv, site_[p].p, (long)dl * d * dr);
   else

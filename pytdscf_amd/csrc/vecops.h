@@ -36,6 +36,8 @@ void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld);
 // dst[0..n) = src[0..n): a kernel, not hipMemcpy -- the source or destination may belong to ANOTHER HIP runtime
 // instance in this process (torch's), which this one cannot look up but whose addresses are valid on the device
 void vec_copy_raw(hipStream_t st, zc* dst, const zc* src, size_t n);
+// max |blk[r][s] - delta_rs| over an n x n block with leading dimension ld -> *out_dev (one double, overwritten)
+void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_dev);
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
             bool accumulate);
 // norm profiles for the adaptive-rank functional (plain device arrays, no partials)

@@ -620,4 +620,25 @@ void vec_copy_raw(hipStream_t st, zc* dst, const zc* src, size_t n) {
   HIP_CHECK(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void k_ident_dev(const zc* __restrict__ blk, long ld, int n, unsigned long long* __restrict__ out) {
+  double m = 0.0;
+  const long tot = (long)n * n;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / n), c = (int)(e % n);
+    const zc v = blk[(long)r * ld + c];
+    m = fmax(m, fmax(fabs(v.x - (r == c ? 1.0 : 0.0)), fabs(v.y)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+  // non-negative doubles order like their bit patterns
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_dev) {
+  HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(double), st));
+  const long tot = (long)n * n;
+  const int nb = (int)std::min<long>((tot + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_ident_dev, dim3(nb), dim3(256), 0, st, blk, ld, n, reinterpret_cast<unsigned long long*>(out_dev));
+  HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace mitdvp

@@ -324,3 +324,38 @@ def test_fold_block_ranges_and_site_rdm_from_blocks():
     got = eng.site_rdm_blocks(1, tl, tr)
     assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
     eng.close()
+
+
+def test_identity_block_of_the_right_environment_is_short_circuited(monkeypatch):
+    """Bonds >= 256: when the last MPO-bond block of the right environment is the identity to 1e-13 (sites right of the
+    centre right-canonical, "nothing applied yet" passed through by the MPO) its K block of stage S3 becomes a strided
+    copy (the reference short-circuits such blocks too, _mps_mpo.py:510-523).  Same state as the full contraction to
+    rounding; with a random dense MPO (no identity block) the check says no and nothing is skipped."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L, d, M, D = 4, 16, 4, 256
+    mps = orc.synthetic_mps([d] * L, D, seed=1)
+    fsm = orc.synthetic_mpo(L, d, M, seed=0)
+    rng = np.random.default_rng(3)
+    dense = []
+    for p in range(L):
+        ml, mr = (1 if p == 0 else M), (1 if p == L - 1 else M)
+        w = 0.02 * crandn(rng, ml, d, d, mr)
+        dense.append(w)
+    out = {}
+    for name, mpo in (("fsm", fsm), ("dense", dense)):
+        for flag in ("1", "0"):
+            monkeypatch.setenv("MITDVP_TRIM_IDENTITY", flag)
+            monkeypatch.setenv("MITDVP_SPARSE_W", "0")  # count only this shortcut in heff_flops_skipped
+            eng = TDVPEngine(L, integrator="arnoldi" if name == "dense" else "lanczos")
+            eng.set_mpo(mpo)
+            eng.set_mps(mps)
+            eng.sweep(0.2, True)
+            out[name, flag] = (eng.get_mps(), eng.counters()["heff_flops_skipped"])
+            eng.close()
+    assert out["fsm", "1"][1] > 0 and out["fsm", "0"][1] == 0 and out["dense", "1"][1] == 0
+    for name in ("fsm", "dense"):
+        a, b = out[name, "1"][0], out[name, "0"][0]
+        assert abs(abs(orc.overlap(a, b)) / np.sqrt(abs(orc.overlap(a, a)) * abs(orc.overlap(b, b))) - 1) < 1e-12
+        assert max(np.abs(x - y).max() for x, y in zip(a, b)) < 1e-11
