@@ -507,11 +507,11 @@ def main():
                 "n_apply": cnt["n_heff"],
                 "complex_product": gemm_mode,
                 "executed_share_of_algorithmic": done_share * (0.75 if gemm_mode == "3m" else 1.0),
-                "w_stage": ("block-sparse: zero blocks of the finite-state-machine MPO skipped; identity block of the right "
-                            "environment short-circuited in stage S3" if done_share < 0.999 else "dense"),
+                "w_stage": ("block-sparse: zero blocks of the finite-state-machine MPO skipped; identity blocks of the two "
+                            "environments short-circuited in stages S1 / S3" if done_share < 0.999 else "dense"),
                 "note": ("achieved / frac = flop the matrix cores EXECUTE per second: the 3M (Karatsuba) complex product "
-                         "runs 6 real flop per complex MAC, the W stage skips the zero blocks of the MPO and stage S3 the identity block of "
-                         "the right environment; "
+                         "runs 6 real flop per complex MAC, the W stage skips the zero blocks of the MPO and stages S1 / S3 the identity "
+                         "blocks of the environments; "
                          "algorithmic_tflops counts the 8 flop of the textbook dense product (SURVEY 8d F_H) over the "
                          "same HIP-event time") if gemm_mode == "3m"
                         else "4M complex product: executed = algorithmic flops",

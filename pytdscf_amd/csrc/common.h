@@ -86,6 +86,10 @@ struct ZgemmDesc {
   int rowmap_p;
   long rowmap_s1, rowmap_s2;
   int rowmap_r0;  // added to the row index before the map (a GEMM over a row range of a larger mapped matrix)
+  // A not transposed: logical row r of A is stored at row r + r / (arow_skip - 1) + 1, i.e. every arow_skip-th stored
+  // row (rows 0, arow_skip, ...) is left out of the product (0 = off).  Stage S1 of an apply whose left environment
+  // has an identity block in MPO-bond state 0: those rows of X are copies of psi.
+  int arow_skip;
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
 void zgemm(hipStream_t st, const ZgemmDesc& d);
@@ -98,6 +102,7 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.mode3m = -1;
   d.ksplit = 0;
   d.klist = nullptr; d.klist_stride = 0; d.rowmap_p = 0; d.rowmap_s1 = 0; d.rowmap_s2 = 0; d.rowmap_r0 = 0;
+  d.arow_skip = 0;
   return d;
 }
 int zgemm_default_mode();

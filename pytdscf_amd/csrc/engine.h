@@ -218,6 +218,8 @@ class Engine {
   // (sites right of the centre are right-canonical and the MPO passes "nothing applied yet" through: the reference
   // short-circuits such blocks as well, _mps_mpo.py:510-523) -- verified numerically per site, see local_site_exp
   bool trim_r_ = false;
+  bool trim_l_ = false;  // the same for the FIRST MPO-bond block of the left environment (stage S1: rows (a, c = 0) of X = psi)
+  bool left_block_is_identity(const zc* L, int dl, int m);
   bool trim_identity_ = true;  // MITDVP_TRIM_IDENTITY=0 switches the shortcut off
   bool right_block_is_identity(const zc* R, int dr, int m);
   int L_;

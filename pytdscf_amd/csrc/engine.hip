@@ -477,7 +477,21 @@ void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const z
   const bool sharded = shard_range(dlo, a0, a1);
   const int na = a1 - a0;
   timer_begin(10);
-  {  // X[(a,c)][(j,s)] = L[(a,c)][b] psi[b][(j,s)]
+  const bool triml = trim_l_ && !sharded && dlo == dli && ml > 1;
+  if (triml) {
+    // L[:, 0, :] is the identity: rows (a, c = 0) of X are psi itself, the GEMM runs over the other ml - 1 rows of
+    // every slab (A rows gathered, C rows scattered with the same map)
+    const zc one = make_double2(1.0, 0.0);
+    const long row = (long)d * dri;
+    copy2d(st_, X_.p, (long)ml * row, psi, row, na, (int)row, 0, one, false);
+    ZgemmDesc g = zgemm_desc(L, psi, X_.p + row, na * (ml - 1), d * dri, dli);
+    g.arow_skip = ml;
+    g.rowmap_p = ml - 1; g.rowmap_s1 = row; g.rowmap_s2 = (long)ml * row; g.rowmap_r0 = 0;
+    g.tile_cfg = 1;
+    zgemm(st_, g);
+    cnt_.n_launch += 1;
+    cnt_.heff_flops_skipped += 8.0 * (double)na * dli * d * dri;
+  } else {  // X[(a,c)][(j,s)] = L[(a,c)][b] psi[b][(j,s)]
     ZgemmDesc g = zgemm_desc(L + (size_t)a0 * ml * dli, psi, X_.p, na * ml, d * dri, dli);
     zgemm(st_, g);
   }
@@ -764,6 +778,16 @@ bool Engine::right_block_is_identity(const zc* R, int dr, int m) {
   return h < 1e-13;
 }
 
+// L[a][0][b] == delta_ab to 1e-13 (the tensors left of the site are left-canonical)
+bool Engine::left_block_is_identity(const zc* L, int dl, int m) {
+  double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
+  ident_deviation(st_, L, (long)m * dl, dl, dev);
+  double h = 1.0;
+  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(double), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  return h < 1e-13;
+}
+
 void Engine::local_site_exp(int p, double dt) {
   const MpoSite& w = mpo(0, p);
   if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
@@ -775,7 +799,8 @@ void Engine::local_site_exp(int p, double dt) {
   auto mv = [&](const zc* in, zc* out) { heff_apply(Lb, w, Rb, in, out, dl, d, dr, shift); };
   // large bonds: one check per site (two tiny launches and a synchronisation) buys 1 / M_r of stage S3 in every apply
   trim_r_ = trim_identity_ && dr >= 256 && w.mr > 1 && right_block_is_identity(Rb, dr, w.mr);
-  struct Reset { bool& f; ~Reset() { f = false; } } reset{trim_r_};
+  trim_l_ = trim_identity_ && dl >= 256 && w.ml > 1 && left_block_is_identity(Lb, dl, w.ml);
+  struct Reset { bool& f; bool& g; ~Reset() { f = false; g = false; } } reset{trim_r_, trim_l_};
   if (cfg.relax == 2)  // improved relaxation, _mps_cls.py:1078-1084
     kprev_[p] = krylov_diag(mv, site_[p].p, (long)dl * d * dr);
   else

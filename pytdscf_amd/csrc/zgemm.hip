@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
     int m, k;
     if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
     const int gm = min(m0 + m, M - 1);
-    pa[p] = A + (TA ? (long)k * lda + gm : (long)gm * lda + k);
+    const long ga = (!TA && d.arow_skip > 1) ? (long)gm + gm / (d.arow_skip - 1) + 1 : (long)gm;  // stored row of A
+    pa[p] = A + (TA ? (long)k * lda + gm : ga * lda + k);
     la[p] = TA ? k * LDAS + m : m * LDAS + k;
   }
 #pragma unroll
@@ -589,6 +590,7 @@ int zgemm_cd_mode(hipStream_t st) {
 void zgemm(hipStream_t st, const ZgemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
   if (d.K < 0) throw ArgError("zgemm: negative K");
+  if (d.arow_skip && (d.transA || d.arow_skip < 2 || d.klist)) throw ArgError("zgemm: arow_skip needs a plain, untransposed A");
   if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
   (void)zgemm_cd_mode(st);
   int cfg = d.tile_cfg;
