@@ -1,18 +1,32 @@
 """CPU oracle of the SITE-RANGE SHARDED (real-space parallel) one-site TDVP -- test infrastructure.
 
-PARITY UNPINNED with respect to the reference: its implementation of this scheme
-(``/root/reference/pytdscf/_mps_parallel.py``, ``MPSCoefParallel.propagate`` :106-268,
-``propagate_joint_two_sites`` :270-470, ``distribute_superblock_states`` :1520-1607, split rule
-``_const_cls.py:236-250``) needs ``mpi4py`` and several ranks, neither of which exists in the development
-container, so no golden vectors could be produced from it.  This file restates the same algorithm
-(Secular, Gourianov, Lubasch, Dolgov, Clark, Jaksch, PRB 101, 235123: blocks Phi_r joined by inverse
-bond matrices, Psi = Phi_0 X_0^+ Phi_1 X_1^+ ...) from the operation sequence of those functions and is
-pinned instead by what can be checked: (a) with one rank it IS the serial oracle (``tdvp_oracle.OracleMPS``,
-itself pinned to the reference); (b) for Hamiltonians without terms across the junctions it equals the
-serial sweep to rounding; (c) its deviation from the serial sweep vanishes as dt -> 0 (second order per
-step).  The reference's extra regularisations of small singular values (SQRT_EPSRHO = 1e-4,
-``_site_cls.py:22, :207-246, :657-664``, the reason its own tests accept 1e-2 on the norm) are NOT
-reproduced: the pseudo-inverse uses RCOND = 1e-13 (``_site_cls.py:24, :734``) only.
+PARITY: PINNED to the reference (round 3).  The reference's implementation of this scheme
+(``/root/reference/pytdscf/_mps_parallel.py``: ``MPSCoefParallel.propagate`` :106-268,
+``propagate_joint_two_sites`` :270-470, split rule ``_const_cls.py:236-250``) was run in the development container
+on 2 and 3 ranks -- forked processes under a process-backed stand-in for the third-party ``mpi4py``
+(``tests/golden/make_golden_parallel.py``) -- and its per-step states, norms and <Psi*|Psi> are committed as
+``tests/golden/parallel_chain_r2.npz`` / ``parallel_chain_r3.npz`` (well-conditioned entangled start, where the
+regularisations below are inactive: this file equals them to 1e-14, ``tests/test_oracle_parallel.py``) and
+``parallel_exciton.npz`` (the model of the reference's own ``tests/test_mpi_exiciton_propagate.py`` from its
+zero-padded product start, where they are what shapes the result; reference-held pin :220).
+
+What the fixtures taught about the reference (all reproduced or stated here):
+  * ``distribute_superblock_states`` (:1520-1607) is consistent for PRODUCT starts only: its A world goes through
+    ``CC2ALambdaB`` (``_mps_cls.py:3601-3630``), whose right factor is the row space of the two-site SVD, i.e. rotated
+    against the B world the even ranks keep, and the even ranks start with ``joint_sigvec_not_pinv = pinv(Lambda)``.
+    For Lambda = (1, 0, ..) both are harmless.  ``ParallelOracle`` distributes any canonical chain consistently (QR
+    bond matrices); the chain fixtures were produced by filling the reference's state object with the equally
+    consistent Gamma-Lambda form of the same chain.
+  * the four local solves of a junction update share ONE warm-up memory, that of the last site the left rank's sweep
+    propagated (``_Debug.site_now`` is set by the sweep only, ``_mps_cls.py:880``; the junction update never sets it).
+  * with ``regularize=True`` the left junction site is rebuilt from an SVD of its (D_l D_r x d) unfolding with small
+    singular values lifted (``SiteCoef.gauge_trf``, ``_site_cls.py:207-246``), and the new joint matrix is
+    ``truncate_sigvec(p=const.p_svd, regularize=True, keepdim=True)`` (``_site_cls.py:586-690``): SVD, cumulative-weight
+    cut, kept values below SQRT_EPSRHO = 1e-4 lifted to s + eps exp(-s/eps), zeros kept on the cut ones, A <- A U,
+    B <- Vh B, boundary blocks rebuilt.  Both are options here (``regularize``, ``p_svd``; the reference runs with both
+    on, ``_mps_parallel.py:369, :437-444``); off, the scheme is Secular et al., PRB 101, 235123 as it stands.
+  * ``to_MPSCoefMPO`` (the checkpoint) concatenates per-rank B worlds saved at different half steps; the fixtures
+    therefore hold the state as ``MPSCoefParallel.ovlp`` reads it (:872-897), not that chain.
 
 All ranks are simulated in one process, in the order the real ranks would act; what one rank reads
 from another is exactly what ``pytdscf_amd/parallel_sites.py`` sends over RCCL / gloo.
@@ -32,10 +46,41 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 
 import numpy as np
+import scipy.linalg
 
 from . import tdvp_oracle as orc
 
 RCOND = 1e-13  # _site_cls.py:24
+SQRT_EPSRHO = 1e-4  # _site_cls.py:22
+
+
+def _lift(sig: np.ndarray) -> np.ndarray:
+    """Small singular values lifted: s -> s + eps exp(-s / eps) below eps (_site_cls.py:232-236, :657-664)."""
+    return np.where(sig > SQRT_EPSRHO, sig, sig + SQRT_EPSRHO * np.exp(-sig / SQRT_EPSRHO))
+
+
+def regularize_site(psi: np.ndarray) -> np.ndarray:
+    """SiteCoef.gauge_trf(regularize=True), NumPy branch (_site_cls.py:207-246): SVD of the (D_l D_r x d)
+    unfolding, singular values lifted, tensor rebuilt."""
+    ldim, ndim, rdim = psi.shape
+    U, sig, Vh = scipy.linalg.svd(np.ascontiguousarray(psi.transpose(0, 2, 1).reshape(-1, ndim)), full_matrices=False)
+    return np.dot(U, np.dot(np.diag(_lift(sig)), Vh)).reshape(ldim, rdim, ndim).transpose(0, 2, 1)
+
+
+def truncate_joint(A: np.ndarray, sigma: np.ndarray, B: np.ndarray, p: float, regularize: bool):
+    """truncate_sigvec(Asite, sigvec, Bsite, p, regularize, keepdim=True) (_site_cls.py:586-690): returns
+    (A U, diag(s' / |s'|) padded with zeros to the old size, Vh B)."""
+    U, s, Vh = scipy.linalg.svd(sigma, full_matrices=False)
+    cumsum = np.cumsum(s.real)
+    idx = int(np.argmax(cumsum / cumsum[-1] >= (1 - p)) + 1)
+    thin = s[:idx]
+    A2 = np.tensordot(A, U, axes=(2, 0))
+    B2 = np.tensordot(Vh, B, axes=(1, 0))
+    if regularize and sigma.shape != (1, 1):
+        thin = _lift(thin)
+    full = np.zeros_like(s)
+    full[:idx] = thin
+    return A2, np.diag(full / np.linalg.norm(thin)).astype(np.complex128), B2
 
 
 def split_sites(nsite: int, nrank: int) -> list[tuple[int, int]]:
@@ -114,13 +159,14 @@ class Block:
                 self.cores[p - 1] = np.tensordot(self.cores[p - 1], s, axes=(2, 0))
 
 
-def joint_update(bl: Block, br: Block, X: np.ndarray, dt: float):
+def joint_update(bl: Block, br: Block, X: np.ndarray, dt: float, regularize: bool = False, p_svd: float | None = None):
     """propagate_joint_two_sites (_mps_parallel.py:270-470) for the junction between ``bl`` (centre on
     its last site) and ``br`` (centre on its first site).  Returns the new X; both blocks end with
-    orthonormal junction sites (A | B) and refreshed boundary environments."""
+    orthonormal junction sites (A | B) and refreshed boundary environments.  All four solves use the warm-up
+    memory of the last site the left block's sweep propagated (see the module header)."""
     pl, pr = bl.n - 1, 0
     Wl, Wr = bl.mpo[pl], br.mpo[pr]
-    gl, gr = bl.lo + pl, br.lo + pr
+    mem = bl.lo + bl.n - 2
     Lenv = bl.left[pl]  # through the A sites of the left block
     Renv = br.right[pr]  # through the B sites of the right block
     # psi_L X^+ (multiply_sigvec_pinv, _site_cls.py:709-754), then centre on the left site
@@ -129,16 +175,23 @@ def joint_update(bl: Block, br: Block, X: np.ndarray, dt: float):
     B = np.ascontiguousarray(B)
     theta = np.tensordot(theta, s, axes=(2, 0))
     R1 = orc.env_update_right(Renv, B, Wr)
-    theta = bl._exp(-0.5j * dt, lambda x: orc.heff_apply(Lenv, Wl, R1, x), theta, gl)
+    theta = bl._exp(-0.5j * dt, lambda x: orc.heff_apply(Lenv, Wl, R1, x), theta, mem)
+    if regularize:  # trans_next_psite_AsigmaB(..., regularize=True), :362-370
+        theta = regularize_site(theta)
     A, s = orc.qr_psi2Asigma(theta)
     L1 = orc.env_update_left(Lenv, A, Wl)
-    s = bl._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R1, x), s, gl)
+    s = bl._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R1, x), s, mem)
     psi_r = np.tensordot(s, B, axes=(1, 0))
-    psi_r = br._exp(-0.5j * dt, lambda x: orc.heff_apply(L1, Wr, Renv, x), psi_r, gr)
+    psi_r = bl._exp(-0.5j * dt, lambda x: orc.heff_apply(L1, Wr, Renv, x), psi_r, mem)
     s, B = orc.qr_psi2sigmaB(psi_r)
     B = np.ascontiguousarray(B)
     R2 = orc.env_update_right(Renv, B, Wr)
-    s = br._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R2, x), s, gr)
+    s = bl._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R2, x), s, mem)
+    if p_svd is not None:  # truncate=True branch, :437-466
+        A, s, B = truncate_joint(A, s, B, p_svd, regularize)
+        B = np.ascontiguousarray(B)
+        L1 = orc.env_update_left(Lenv, A, Wl)
+        R2 = orc.env_update_right(Renv, B, Wr)
     bl.cores[pl], br.cores[pr] = A, B
     # what each side needs next: its own block's environment through the junction site, and the
     # neighbour's as its new boundary block
@@ -154,10 +207,17 @@ def joint_update(bl: Block, br: Block, X: np.ndarray, dt: float):
 class ParallelOracle:
     """N blocks in one process.  ``cores``: site-0-centred canonical MPS (Psi, B, ..., B)."""
 
-    def __init__(self, cores, mpo, nrank, integrator="lanczos", thresh=1e-9, conserve_norm=True):
+    def __init__(self, cores, mpo, nrank, integrator="lanczos", thresh=1e-9, conserve_norm=True, ranges=None,
+                 regularize=False, p_svd=None):
+        """``regularize`` / ``p_svd``: the reference's lifting of small singular values and the cumulative-weight
+        truncation of the joint matrix (it runs with regularize=True, p_svd=const.p_svd, default 1e-7)."""
+        self.regularize = regularize
+        self.p_svd = p_svd
         self.nsite = len(cores)
         self.nrank = nrank
-        self.ranges = split_sites(self.nsite, nrank)
+        # explicit [lo, hi) ranges = the reference's parallel_split_indices [(first, last), ...] (_const_cls.py:236-250)
+        self.ranges = [tuple(r) for r in ranges] if ranges is not None else split_sites(self.nsite, nrank)
+        assert len(self.ranges) == nrank and self.ranges[0][0] == 0 and self.ranges[-1][1] == self.nsite
         if any(hi - lo < 2 for lo, hi in self.ranges) and nrank > 1:
             raise ValueError("every rank needs at least two sites")
         cores = [np.array(c, dtype=np.complex128) for c in cores]
@@ -224,7 +284,7 @@ class ParallelOracle:
     def _junctions(self, dt, parity):
         for j in range(parity, self.nrank - 1, 2):
             bl, br = self.blocks[j], self.blocks[j + 1]
-            Xn = joint_update(bl, br, self.X[j], dt)
+            Xn = joint_update(bl, br, self.X[j], dt, self.regularize, self.p_svd)
             self.X[j] = Xn
             # A X' B -> psi x^+ psi: both neighbours take the weight (send_joint_sigvec_to_right, :541-597)
             R2 = br.right_after_first
