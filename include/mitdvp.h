@@ -212,6 +212,58 @@ int mitdvp_fold_block_range(mitdvp_engine* h, int op_id, int conj_bra, int from_
  * right[bra][ket] (D_r x D_r) as mitdvp_fold_block (op_id < 0, conj_bra = 1) produces them.  reim_out: d x d, host. */
 int mitdvp_site_rdm_blocks(mitdvp_engine* h, int isite, const double* left, const double* right, double* reim_out);
 
+/* -- one RANK of the site-range sharded sweep, driven natively -------------------------------------
+ * MPSCoefParallel.propagate (_mps_parallel.py:106-268) as ONE call per time step: the block's two half-sweeps, the
+ * joint update of the two sites facing each other across a rank boundary (propagate_joint_two_sites, :270-470:
+ * psi_L X^+ psi_R -> A X' B through the pseudo-inverse of the joint matrix, multiply_sigvec_pinv _site_cls.py:709-754)
+ * and the neighbour messages around it -- the reference's mpi4py send / recv pairs send_Psi_to_left (:698-707),
+ * send_op_sys_to_left (:761-807), send_B_to_right (:728-740), send_joint_sigvec_to_right (:541-597),
+ * send_op_sys_to_right (:612-628) -- as grouped ncclSend / ncclRecv of device buffers between chain neighbours on the
+ * block engine's stream (RCCL over xGMI, librccl resolved with dlopen).  A shard owns two engines: its block
+ * (nsite_block sites, outer bonds wider than 1) and, except on the last rank, the two-site engine of the junction to
+ * its right; mitdvp_shard_engine hands them out (borrowed: never mitdvp_destroy them) so that set-up -- MPO cores,
+ * site tensors, boundary blocks, mitdvp_build_envs -- uses the entry points above.  State between steps as in the
+ * reference's diagram (:115-122): even ranks [Psi B .. B], odd ranks [A .. A Psi], every block's junction-side end
+ * site carrying the weight of the joint matrix X (held by the LEFT rank of each junction: joint_sigvec_not_pinv). */
+typedef struct mitdvp_shard mitdvp_shard;
+/* dr_next: right bond dimension of the first site of rank + 1 (ignored on the last rank) */
+int mitdvp_shard_create(const mitdvp_config* cfg, int rank, int world, int nsite_block, int dr_next, mitdvp_shard** out);
+void mitdvp_shard_destroy(mitdvp_shard* h);
+const char* mitdvp_shard_last_error(const mitdvp_shard* h); /* h may be NULL */
+int mitdvp_shard_engine(mitdvp_shard* h, int which /* 0 block, 1 junction engine */, mitdvp_engine** out);
+/* the reference's treatment of small singular values at a junction: regularize != 0 lifts singular values below
+ * SQRT_EPSRHO = 1e-4 to s + eps exp(-s / eps) -- in the (D_l D_r x d) unfolding of the left junction site before its
+ * QR (SiteCoef.gauge_trf(regularize=True), _site_cls.py:207-246) and in the new joint matrix; p_svd >= 0 replaces
+ * the new joint matrix by truncate_sigvec(p = p_svd, keepdim = True) (:586-690: SVD, cumulative-weight cut, zeros on
+ * the cut values, A <- A U, B <- Vh B, blocks rebuilt).  The reference runs with both (regularize = 1, p_svd =
+ * const.p_svd, default 1e-7; _mps_parallel.py:369, :437-444); defaults here: 0, -1 (off). */
+int mitdvp_shard_set_options(mitdvp_shard* h, int regularize, double p_svd);
+int mitdvp_shard_set_joint(mitdvp_shard* h, const double* reim, int dim);       /* host, (dim, dim) */
+int mitdvp_shard_get_joint(mitdvp_shard* h, double* reim_out, int* dim);        /* reim_out may be NULL */
+/* Transport.  Production: every rank calls mitdvp_shard_attach_rccl with the 128-byte id one rank got from
+ * mitdvp_rccl_unique_id (distributed out of band), one rank per GPU.  Ranks SHARING a GPU (one-GPU test boxes; RCCL
+ * refuses two ranks on one device) install a callback instead: op 0 sends / op 1 receives nbytes of host memory
+ * to / from rank `peer`, blocking, 0 on success; the shard stages the device buffers through it. */
+typedef int (*mitdvp_p2p_fn)(void* user, int op, int peer, void* host_buf, size_t nbytes);
+int mitdvp_shard_set_transport(mitdvp_shard* h, mitdvp_p2p_fn fn, void* user);
+int mitdvp_shard_attach_rccl(mitdvp_shard* h, const char id[128]);
+/* neighbour ping over every junction, both directions (collective over the ranks); number of wrong values */
+int mitdvp_shard_selftest(mitdvp_shard* h, int* mismatches);
+/* one grouped ncclSend + ncclRecv of `elems` complex numbers from this rank to itself (needs attach_rccl) */
+int mitdvp_shard_self_sendrecv(mitdvp_shard* h, size_t elems, int* mismatches);
+int mitdvp_shard_step(mitdvp_shard* h, double dt_au);                            /* MPSCoefParallel.propagate */
+/* the pieces of a step (tests, other schedules): propagate_along_sweep over the block with skip_end_site (:147-175),
+ * and the joint updates of the junctions whose LEFT rank has parity `parity` (0: (3)->(4), 1: (2)->(1) of :115-122) */
+int mitdvp_shard_sweep(mitdvp_shard* h, double dt_au, int forward, int skip_end);
+int mitdvp_shard_junctions(mitdvp_shard* h, double dt_au, int parity);
+int mitdvp_shard_traffic(mitdvp_shard* h, double* bytes, long* messages);        /* halo traffic sent so far */
+/* warm-up memory of the local solves at a site (_Debug.niter_krylov[isite], _integrator.py:178-186) */
+int mitdvp_get_krylov_memory(mitdvp_engine* h, int isite, int* k);
+int mitdvp_set_krylov_memory(mitdvp_engine* h, int isite, int k);
+/* the one-launch small-bond kernels need all their workgroups resident: switch them off (0) for engines that share
+ * their GPU with other processes; default on (or MITDVP_SMALL_KERNELS) */
+int mitdvp_set_small_kernels(mitdvp_engine* h, int on);
+
 /* -- observables -------------------------------------------------------- */
 int mitdvp_expect(mitdvp_engine* h, int op_id, double out[2]);       /* _mps_cls.py:540-612 */
 int mitdvp_autocorr(mitdvp_engine* h, double out[2]);                /* wavefunction.py:226-257, conj=False */

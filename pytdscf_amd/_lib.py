@@ -71,6 +71,7 @@ class Counters(C.Structure):
 
 
 COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+P2P_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t)  # mitdvp_p2p_fn
 
 _lib = None
 
@@ -178,6 +179,24 @@ def load() -> C.CDLL:
         "mitdvp_get_gemm_mode": (i, []),
         "mitdvp_mfma_peak_probe": (i, [i, dp]),
         "mitdvp_mfma_layout_probe": (i, [i, ip]),
+        "mitdvp_shard_create": (i, [C.POINTER(Config), i, i, i, i, C.POINTER(vp)]),
+        "mitdvp_shard_destroy": (None, [vp]),
+        "mitdvp_shard_last_error": (C.c_char_p, [vp]),
+        "mitdvp_shard_engine": (i, [vp, i, C.POINTER(vp)]),
+        "mitdvp_shard_set_options": (i, [vp, i, d]),
+        "mitdvp_shard_set_joint": (i, [vp, dp, i]),
+        "mitdvp_shard_get_joint": (i, [vp, dp, ip]),
+        "mitdvp_shard_set_transport": (i, [vp, P2P_FN, vp]),
+        "mitdvp_shard_attach_rccl": (i, [vp, C.c_char_p]),
+        "mitdvp_shard_selftest": (i, [vp, ip]),
+        "mitdvp_shard_self_sendrecv": (i, [vp, C.c_size_t, ip]),
+        "mitdvp_shard_step": (i, [vp, d]),
+        "mitdvp_shard_sweep": (i, [vp, d, i, i]),
+        "mitdvp_shard_junctions": (i, [vp, d, i]),
+        "mitdvp_shard_traffic": (i, [vp, dp, C.POINTER(C.c_long)]),
+        "mitdvp_get_krylov_memory": (i, [vp, i, ip]),
+        "mitdvp_set_krylov_memory": (i, [vp, i, i]),
+        "mitdvp_set_small_kernels": (i, [vp, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -187,10 +206,11 @@ def load() -> C.CDLL:
     return lib
 
 
-def check(rc: int, handle=None):
+def check(rc: int, handle=None, shard: bool = False):
     if rc == OK:
         return
-    msg = load().mitdvp_last_error(handle).decode(errors="replace")
+    lib = load()
+    msg = (lib.mitdvp_shard_last_error if shard else lib.mitdvp_last_error)(handle).decode(errors="replace")
     if rc == ENOTCONV:
         # same exception type as the reference (_integrator.py:430, :653)
         raise ValueError(msg)

@@ -1,14 +1,9 @@
 // capi.hip -- extern "C" surface declared in include/mitdvp.h.
 #include <mutex>
 
+#include "capi_internal.h"
 #include "engine_internal.h"
 #include "engine_krylov.inc"
-
-struct mitdvp_engine {
-  std::unique_ptr<mitdvp::Engine> e;
-  std::string err;
-  int device = 0;
-};
 
 namespace {
 thread_local std::string g_err;
@@ -107,7 +102,7 @@ const char* mitdvp_last_error(const mitdvp_engine* h) { return h ? h->err.c_str(
 
 #define ENG_CALL(h, body)                                   \
   if (!(h) || !(h)->e) { g_err = "null handle"; return MITDVP_EINVAL; } \
-  return guard((h), [&] { body; })
+  return guard((h), [&] { body; (h)->e->check_device_errors(); })
 // argument pointers that must not be NULL (reported as MITDVP_EINVAL instead of a crash)
 #define NEED(...)                                                       \
   do {                                                                  \
@@ -160,6 +155,9 @@ int mitdvp_fold_block_range(mitdvp_engine* h, int op_id, int conj_bra, int from_
 int mitdvp_site_rdm_blocks(mitdvp_engine* h, int isite, const double* left, const double* right, double* reim_out) {
   ENG_CALL(h, { NEED(left, right, reim_out); h->e->site_rdm_blocks(isite, left, right, reim_out); });
 }
+int mitdvp_get_krylov_memory(mitdvp_engine* h, int isite, int* k) { ENG_CALL(h, { NEED(k); *k = h->e->kprev_get(isite); }); }
+int mitdvp_set_krylov_memory(mitdvp_engine* h, int isite, int k) { ENG_CALL(h, h->e->kprev_set(isite, k)); }
+int mitdvp_set_small_kernels(mitdvp_engine* h, int on) { ENG_CALL(h, h->e->set_small_kernels(on != 0)); }
 int mitdvp_set_pointer_mode(mitdvp_engine* h, int mode) { ENG_CALL(h, h->e->set_pointer_mode(mode)); }
 int mitdvp_fold_block(mitdvp_engine* h, int op_id, int conj_bra, int from_left, const double* reim_in, int d, int m,
                       double* reim_out) {

@@ -91,7 +91,11 @@ struct PhaseTimer {
   bool closed;  // the end event was recorded (an exception between begin and end leaves it open)
 };
 
+class SiteShard;
+
 class Engine {
+  friend class SiteShard;  // shard.hip: the junction update works on the tensors and blocks of two engines in place
+
  public:
   explicit Engine(const mitdvp_config& cfg);
   ~Engine();
@@ -209,6 +213,17 @@ class Engine {
                   int count = -1);
   void site_rdm_blocks(int isite, const double* TL, const double* TR, double* out);
   hipStream_t stream() const { return st_; }
+  // warm-up memory of the local solves at site p (_Debug.niter_krylov[p]); the device copy of the one-launch
+  // exponentials is reconciled
+  int kprev_get(int p);
+  void kprev_set(int p, int k);
+  // MITDVP_SMALL_KERNELS for this engine only (several ranks / engines sharing a GPU cannot rely on the persistent
+  // kernels' co-residency)
+  void set_small_kernels(bool on);
+  // what the one-launch kernels recorded on the device since the last check (not converged / an exchange timed out):
+  // raised here.  The C surface calls it at the end of EVERY entry point, so no call returns tensors, blocks or
+  // observables computed by a launch that gave up (fold_block, get_env, expect, ... launch them without a sweep).
+  void check_device_errors() { ss_check(); }
   const MpoSite& mpo(int op_id, int isite);
   mitdvp_config cfg;
 

@@ -110,6 +110,29 @@ void Engine::ss_pull_kprev() {
     if (exp_small_[p]) kprev_[p] = h[p];
 }
 
+int Engine::kprev_get(int p) {
+  if (p < 0 || p >= L_) throw ArgError("kprev_get: bad site index");
+  if (!exp_small_.empty() && exp_small_[p]) ss_pull_kprev();
+  return kprev_[p];
+}
+
+void Engine::kprev_set(int p, int k) {
+  if (p < 0 || p >= L_) throw ArgError("kprev_set: bad site index");
+  kprev_[p] = k;
+  if (ss_.kprev && !exp_small_.empty() && exp_small_[p]) {
+    HIP_CHECK(hipMemcpyAsync(ss_.kprev + p, &kprev_[p], sizeof(int), hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+}
+
+void Engine::set_small_kernels(bool on) {
+  if (on == small_kernels_) return;
+  ss_check();
+  ss_pull_kprev();
+  small_kernels_ = on;
+  ss_shape_key_.clear();  // the plan is rebuilt at the next require_ready
+}
+
 void Engine::ss_check() {
   if (!ss_dirty_ || !ss_.words) return;
   ss_dirty_ = false;

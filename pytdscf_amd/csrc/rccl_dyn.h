@@ -16,6 +16,11 @@ struct RcclApi {
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclAllReduce) all_reduce = nullptr;
+  // point-to-point halo of the site-sharded sweep (shard.hip): grouped ncclSend / ncclRecv between chain neighbours
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
 
   static const RcclApi& get() {
@@ -42,6 +47,10 @@ struct RcclApi {
     a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(sym("ncclCommDestroy"));
     a.all_gather = reinterpret_cast<decltype(a.all_gather)>(sym("ncclAllGather"));
     a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(sym("ncclAllReduce"));
+    a.send = reinterpret_cast<decltype(a.send)>(sym("ncclSend"));
+    a.recv = reinterpret_cast<decltype(a.recv)>(sym("ncclRecv"));
+    a.group_start = reinterpret_cast<decltype(a.group_start)>(sym("ncclGroupStart"));
+    a.group_end = reinterpret_cast<decltype(a.group_end)>(sym("ncclGroupEnd"));
     a.error_string = reinterpret_cast<decltype(a.error_string)>(sym("ncclGetErrorString"));
     return a;
   }

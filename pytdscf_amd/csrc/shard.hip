@@ -1,0 +1,501 @@
+// shard.hip -- ONE RANK of the site-range sharded (real-space parallel) one-site TDVP, driven natively:
+// the block's half-sweeps, the joint update of the two sites facing each other across a rank boundary and
+// the neighbour messages around it are one C-ABI call per time step (mitdvp_shard_step).
+//
+// Reference: /root/reference/pytdscf/_mps_parallel.py -- MPSCoefParallel.propagate (:106-268),
+// propagate_joint_two_sites (:270-470), the mpi4py messages send_Psi_to_left (:698-707), send_op_sys_to_left
+// (:761-807), send_B_to_right (:728-740), send_joint_sigvec_to_right (:541-597), send_op_sys_to_right (:612-628);
+// regularisation of small singular values SiteCoef.gauge_trf(regularize=True) (_site_cls.py:207-246) and
+// truncate_sigvec(p, regularize=True, keepdim=True) (:586-690); pseudo-inverse multiply_sigvec_pinv (:709-754).
+//
+// Transport: chain neighbours exchange device buffers with grouped ncclSend / ncclRecv on the block engine's stream
+// (RCCL over xGMI: one link per neighbour pair, no collective anywhere on the data path).  Ranks that share a GPU
+// (the one-GPU test box: RCCL refuses two ranks on one device) plug in a host callback instead
+// (mitdvp_shard_set_transport); the junction code is the same.
+#include <mutex>
+
+#include "capi_internal.h"
+#include "engine_internal.h"
+#include "engine_krylov.inc"
+#include "rccl_dyn.h"
+
+namespace mitdvp {
+
+namespace {
+constexpr double RCOND = 1e-13;        // _site_cls.py:24
+constexpr double SQRT_EPSRHO = 1e-4;   // _site_cls.py:22
+inline double lift(double s) { return s > SQRT_EPSRHO ? s : s + SQRT_EPSRHO * std::exp(-s / SQRT_EPSRHO); }
+}  // namespace
+
+typedef mitdvp_p2p_fn P2PFn;  // op 0: send, 1: receive (include/mitdvp.h)
+
+class SiteShard {
+ public:
+  // the engines are owned by the C handle (mitdvp_shard): block = this rank's sites, joint = the two-site engine of
+  // the junction to the right (nullptr on the last rank); dr_next = right bond of the right neighbour's first site
+  SiteShard(Engine* block, Engine* joint, int rank, int world, int nsite_block, int dr_next)
+      : rank_(rank), world_(world), n_(nsite_block), block_(block), joint_(joint), dr_next_(dr_next) {}
+  ~SiteShard() {
+    if (comm_) (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(comm_));
+  }
+
+  void set_options(int regularize, double p_svd) { regularize_ = regularize != 0; p_svd_ = p_svd; }
+  void set_transport(P2PFn fn, void* user) { fn_ = fn; user_ = user; }
+  void attach_rccl(const char id_bytes[128]) {
+    const RcclApi& r = RcclApi::get();
+    if (comm_) { (void)r.comm_destroy(static_cast<ncclComm_t>(comm_)); comm_ = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id) < 128 ? sizeof(id) : 128);
+    ncclComm_t comm = nullptr;
+    rccl_check(r.comm_init_rank(&comm, world_, id, rank_), "ncclCommInitRank");
+    comm_ = comm;
+  }
+
+  // the joint matrix of the junction to the right (joint_sigvec_not_pinv of the left rank)
+  void set_joint(const double* reim, int dim) {
+    if (!joint_) throw ArgError("shard: the last rank holds no joint matrix");
+    if (dim < 1 || !reim) throw ArgError("shard: bad joint matrix");
+    X_.reserve((size_t)dim * dim);
+    xdim_ = dim;
+    block_->copy_in(X_.p, reim, (size_t)dim * dim);
+  }
+  void get_joint(double* out, int* dim) {
+    if (!joint_ || xdim_ < 1) throw ArgError("shard: no joint matrix");
+    *dim = xdim_;
+    if (out) block_->copy_out(out, X_.p, (size_t)xdim_ * xdim_);
+  }
+
+  // propagate_along_sweep over the block (_mps_cls.py:798-1014); with skip_end the end site keeps the centre but is
+  // not propagated (:876-877)
+  void sweep_block(double dt, bool forward, bool skip_end) {
+    Engine& b = *block_;
+    const int end = forward ? n_ - 1 : 0;
+    for (int p = forward ? 0 : n_ - 1; forward ? p < n_ : p >= 0; p += forward ? 1 : -1) {
+      if (skip_end && p == end) return;
+      b.site_exp(dt);
+      if (p == end) return;
+      b.split_center(forward);
+      b.bond_exp(dt);
+      b.absorb_bond(forward);
+    }
+  }
+
+  // MPSCoefParallel.propagate: one time step of this rank
+  void step(double dt) {
+    if (world_ == 1) {
+      sweep_block(dt, true, false);
+      sweep_block(dt, false, false);
+      return;
+    }
+    bool fwd = rank_ % 2 == 0;
+    sweep_block(dt, fwd, !((fwd && rank_ == world_ - 1) || (!fwd && rank_ == 0)));
+    junctions(dt, 0);
+    fwd = !fwd;
+    sweep_block(dt, fwd, !((fwd && rank_ == world_ - 1) || (!fwd && rank_ == 0)));
+    junctions(dt, 1);
+  }
+
+  void junctions(double dt, int parity) {
+    if (rank_ % 2 == parity && rank_ < world_ - 1) junction_left(dt);
+    else if (rank_ % 2 != parity && rank_ > 0) junction_right();
+  }
+
+  // neighbour ping over every junction (both directions); returns the number of mismatching values
+  int selftest() {
+    if (world_ == 1) return 0;
+    int bad = 0;
+    const int n = 6;
+    DevBuf buf;
+    buf.reserve(n);
+    std::vector<hzc> h(n);
+    hipStream_t st = block_->st_;
+    auto fill = [&](int r, double add) {
+      for (int i = 0; i < n; ++i) h[i] = hzc(i + 10.0 * r + add, -(double)i);
+      HIP_CHECK(hipMemcpyAsync(buf.p, h.data(), n * sizeof(zc), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    };
+    auto check = [&](int r, double add) {
+      std::vector<hzc> g(n);
+      HIP_CHECK(hipMemcpyAsync(g.data(), buf.p, n * sizeof(zc), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      for (int i = 0; i < n; ++i)
+        if (g[i] != hzc(i + 10.0 * r + add, -(double)i)) ++bad;
+    };
+    for (int parity = 0; parity < 2; ++parity) {
+      if (rank_ % 2 == parity && rank_ < world_ - 1) {
+        fill(rank_, 0.0);
+        xfer_begin(); send_dev(buf.p, n, rank_ + 1); xfer_end();
+        xfer_begin(); recv_dev(buf.p, n, rank_ + 1); xfer_end();
+        check(rank_, 1.0);
+      } else if (rank_ % 2 != parity && rank_ > 0) {
+        xfer_begin(); recv_dev(buf.p, n, rank_ - 1); xfer_end();
+        check(rank_ - 1, 0.0);
+        fill(rank_ - 1, 1.0);
+        xfer_begin(); send_dev(buf.p, n, rank_ - 1); xfer_end();
+      }
+    }
+    return bad;
+  }
+
+  // a grouped ncclSend / ncclRecv of `elems` complex numbers from this rank to itself: the RCCL point-to-point path
+  // on a one-rank communicator (what the one-GPU test box can exercise)
+  int self_sendrecv(size_t elems) {
+    if (!comm_) throw ArgError("shard: no RCCL communicator (mitdvp_shard_attach_rccl)");
+    DevBuf a, b;
+    a.reserve(elems); b.reserve(elems);
+    hipStream_t st = block_->st_;
+    vec_randn(st, a.p, (long)elems, 4242);
+    HIP_CHECK(hipMemsetAsync(b.p, 0, elems * sizeof(zc), st));
+    xfer_begin(); send_dev(a.p, elems, rank_); recv_dev(b.p, elems, rank_); xfer_end();
+    std::vector<hzc> ha(elems), hb(elems);
+    HIP_CHECK(hipMemcpyAsync(ha.data(), a.p, elems * sizeof(zc), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(hb.data(), b.p, elems * sizeof(zc), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    int bad = 0;
+    for (size_t i = 0; i < elems; ++i) bad += ha[i] != hb[i];
+    return bad;
+  }
+
+  void traffic(double* bytes, long* messages) const { *bytes = bytes_; *messages = messages_; }
+  bool native_transport() const { return comm_ != nullptr && fn_ == nullptr; }
+
+ private:
+  int rank_, world_, n_;
+  Engine* block_;
+  Engine* joint_;
+  int dr_next_ = 0;  // right bond dimension of the right neighbour's first site
+  DevBuf X_, psi_r_, env_r_, xin_, tmpa_, tmpb_;
+  int xdim_ = 0;
+  bool regularize_ = false;
+  double p_svd_ = -1.0;  // < 0: the joint matrix is not truncated
+  P2PFn fn_ = nullptr;
+  void* user_ = nullptr;
+  void* comm_ = nullptr;
+  bool in_group_ = false;
+  std::vector<char> stage_;
+  double bytes_ = 0;
+  long messages_ = 0;
+
+  // ---- transport ------------------------------------------------------------------------------------------
+  void xfer_begin() {
+    HIP_CHECK(hipStreamSynchronize(block_->st_));
+    if (joint_) HIP_CHECK(hipStreamSynchronize(joint_->st_));  // operands may come from either engine
+    if (!fn_) {
+      if (!comm_) throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)");
+      rccl_check(RcclApi::get().group_start(), "ncclGroupStart");
+      in_group_ = true;
+    }
+  }
+  void send_dev(const zc* p, size_t elems, int peer) {
+    bytes_ += 16.0 * (double)elems;
+    messages_ += 1;
+    if (fn_) {
+      stage_.resize(elems * sizeof(zc));
+      HIP_CHECK(hipMemcpy(stage_.data(), p, elems * sizeof(zc), hipMemcpyDeviceToHost));
+      if (fn_(user_, 0, peer, stage_.data(), elems * sizeof(zc)) != 0) throw HipError("shard: the send callback failed");
+      return;
+    }
+    rccl_check(RcclApi::get().send(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclSend");
+  }
+  void recv_dev(zc* p, size_t elems, int peer) {
+    if (fn_) {
+      stage_.resize(elems * sizeof(zc));
+      if (fn_(user_, 1, peer, stage_.data(), elems * sizeof(zc)) != 0) throw HipError("shard: the receive callback failed");
+      HIP_CHECK(hipMemcpy(p, stage_.data(), elems * sizeof(zc), hipMemcpyHostToDevice));
+      return;
+    }
+    rccl_check(RcclApi::get().recv(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclRecv");
+  }
+  void xfer_end() {
+    if (in_group_) {
+      in_group_ = false;
+      rccl_check(RcclApi::get().group_end(), "ncclGroupEnd");
+      HIP_CHECK(hipStreamSynchronize(block_->st_));  // the joint engine reads the buffers from ITS stream next
+    }
+  }
+
+  struct DeviceMode {  // the engines' tensor arguments are device pointers while the shard drives them
+    Engine& e; int old;
+    explicit DeviceMode(Engine& en) : e(en), old(en.ptr_mode_) { e.ptr_mode_ = 1; }
+    ~DeviceMode() { e.ptr_mode_ = old; }
+  };
+  static const double* dp(const zc* p) { return reinterpret_cast<const double*>(p); }
+
+  // x (D x D) -> pinv(x, rcond) = V diag(1/s) U^H on the engine's stream (multiply_sigvec_pinv, _site_cls.py:734)
+  void pinv_dev(Engine& J, const zc* x, int D, zc* out) {
+    DevBuf U = J.pool_get((size_t)D * D), Vh = J.pool_get((size_t)D * D), work = J.pool_get(svd_work_elems(D, D)),
+           sc = J.pool_get((size_t)D / 2 + 1);
+    std::vector<double> s(D);
+    int sweeps = 0;
+    svd_jacobi(J.st_, x, D, D, U.p, s.data(), Vh.p, work.p, &sweeps);
+    for (int k = 0; k < D; ++k) s[k] = s[k] > RCOND * s[0] ? 1.0 / s[k] : 0.0;
+    HIP_CHECK(hipMemcpyAsync(sc.p, s.data(), D * sizeof(double), hipMemcpyHostToDevice, J.st_));
+    scale_cols(J.st_, U.p, D, D, D, reinterpret_cast<const double*>(sc.p));
+    // out[i][j] = sum_k conj(Vh[k][i]) (inv_k conj(U[j][k]))
+    ZgemmDesc g = zgemm_desc(Vh.p, U.p, out, D, D, D);
+    g.transA = 1; g.conjA = 1; g.lda = D;
+    g.transB = 1; g.conjB = 1; g.ldb = D;
+    zgemm(J.st_, g);
+    HIP_CHECK(hipStreamSynchronize(J.st_));  // s (host) was read by the async copy
+    J.pool_put(std::move(U)); J.pool_put(std::move(Vh)); J.pool_put(std::move(work)); J.pool_put(std::move(sc));
+  }
+
+  // SiteCoef.gauge_trf(regularize=True) on the centre tensor (_site_cls.py:207-246): SVD of the (D_l D_r x d)
+  // unfolding, small singular values lifted, tensor rebuilt.  (Directions whose singular value is exactly zero get
+  // no weight here; LAPACK hands the reference an arbitrary unit vector for them.)
+  void regularize_center(Engine& J) {
+    const int p = J.center_;
+    if (p < 0) throw ArgError("shard: no centre site to regularise");
+    const int dl = J.dl_[p], d = J.dd_[p], dr = J.dr_[p];
+    const int r = dl * dr, k = std::min(r, d);
+    DevBuf M = J.pool_get((size_t)r * d), U = J.pool_get((size_t)r * k), Vh = J.pool_get((size_t)k * d),
+           work = J.pool_get(svd_work_elems(r, d)), sc = J.pool_get((size_t)k / 2 + 1);
+    permute_0213(J.st_, J.site_[p].p, M.p, dl, d, dr, 1);  // (dl, d, dr) -> (dl, dr, d)
+    std::vector<double> s(k);
+    int sweeps = 0;
+    svd_jacobi(J.st_, M.p, r, d, U.p, s.data(), Vh.p, work.p, &sweeps);
+    for (int i = 0; i < k; ++i) s[i] = lift(s[i]);
+    HIP_CHECK(hipMemcpyAsync(sc.p, s.data(), k * sizeof(double), hipMemcpyHostToDevice, J.st_));
+    scale_cols(J.st_, U.p, r, k, k, reinterpret_cast<const double*>(sc.p));
+    ZgemmDesc g = zgemm_desc(U.p, Vh.p, M.p, r, d, k);
+    zgemm(J.st_, g);
+    permute_0213(J.st_, M.p, J.site_[p].p, dl, dr, d, 1);  // back to (dl, d, dr)
+    HIP_CHECK(hipStreamSynchronize(J.st_));
+    J.pool_put(std::move(M)); J.pool_put(std::move(U)); J.pool_put(std::move(Vh)); J.pool_put(std::move(work));
+    J.pool_put(std::move(sc));
+  }
+
+  // truncate_sigvec(Asite, sigvec, Bsite, p, regularize, keepdim=True) (_site_cls.py:586-690) on the two-site engine
+  // (site 0 = A, pending bond matrix, site 1 = B): A <- A U, B <- Vh B, sigma <- diag(s' / |s'|) with zeros on the cut
+  // values; both blocks through the new tensors are rebuilt (_mps_parallel.py:447-464)
+  void truncate_joint(Engine& J) {
+    const int D = J.bond_dim_;
+    const int dl = J.dl_[0], d0 = J.dd_[0], d1 = J.dd_[1], dr = J.dr_[1];
+    DevBuf U = J.pool_get((size_t)D * D), Vh = J.pool_get((size_t)D * D), work = J.pool_get(svd_work_elems(D, D));
+    std::vector<double> s(D);
+    int sweeps = 0;
+    svd_jacobi(J.st_, J.sig_.p, D, D, U.p, s.data(), Vh.p, work.p, &sweeps);
+    double tot = 0, cum = 0;
+    for (double v : s) tot += v;
+    int idx = D;
+    for (int k = 0; k < D; ++k) {  // idx = argmax(cumsum / total >= 1 - p) + 1
+      cum += s[k];
+      if (cum / tot >= 1.0 - p_svd_) { idx = k + 1; break; }
+    }
+    double nrm2 = 0;
+    std::vector<double> thin(idx);
+    for (int k = 0; k < idx; ++k) {
+      thin[k] = (regularize_ && D > 1) ? lift(s[k]) : s[k];
+      nrm2 += thin[k] * thin[k];
+    }
+    std::vector<hzc> xn((size_t)D * D, hzc(0, 0));
+    for (int k = 0; k < idx; ++k) xn[(size_t)k * D + k] = hzc(thin[k] / std::sqrt(nrm2), 0);
+    DevBuf a2 = J.pool_get(J.site_[0].n), b2 = J.pool_get(J.site_[1].n);
+    {
+      ZgemmDesc g = zgemm_desc(J.site_[0].p, U.p, a2.p, dl * d0, D, D);
+      zgemm(J.st_, g);
+    }
+    {
+      ZgemmDesc g = zgemm_desc(Vh.p, J.site_[1].p, b2.p, D, d1 * dr, D);
+      zgemm(J.st_, g);
+    }
+    HIP_CHECK(hipMemcpyAsync(J.sig_.p, xn.data(), xn.size() * sizeof(zc), hipMemcpyHostToDevice, J.st_));
+    HIP_CHECK(hipStreamSynchronize(J.st_));
+    std::swap(J.site_[0], a2);
+    std::swap(J.site_[1], b2);
+    const MpoSite& w0 = J.mpo(0, 0);
+    const MpoSite& w1 = J.mpo(0, 1);
+    J.env_update(J.envL_[0].p, J.site_[0].p, w0.w2l.p, J.envL_[1].p, dl, w0.ml, d0, D, w0.mr, w0.w2el.p, &w0, 0);
+    transpose_rev3(J.st_, J.site_[1].p, J.tmp2_.p, D, d1, dr);
+    J.env_update(J.envR_[2].p, J.tmp2_.p, w1.w2r.p, J.envR_[1].p, dr, w1.mr, d1, D, w1.ml, w1.w2er.p, &w1, 1);
+    J.ss_check();
+    J.pool_put(std::move(U)); J.pool_put(std::move(Vh)); J.pool_put(std::move(work));
+    J.pool_put(std::move(a2)); J.pool_put(std::move(b2));
+  }
+
+  // The left rank of a junction (propagate_joint_two_sites, _mps_parallel.py:270-470): receives psi_R and the block
+  // right of it, updates both sites (site L +dt/2, bond -dt/2, site R +dt/2, bond -dt/2), returns B, X' and the block
+  // left of B; its own last site becomes A X' again (send_joint_sigvec_to_right, :541-597).
+  void junction_left(double dt) {
+    Engine& b = *block_;
+    Engine& J = *joint_;
+    const int nb = rank_ + 1, pl = n_ - 1;
+    const int dl = b.dl_[pl], d0 = b.dd_[pl], D = b.dr_[pl];
+    if (xdim_ != D) throw ArgError("shard: joint matrix and block bond dimension differ");
+    const MpoSite& w0 = J.mpo(0, 0);
+    const MpoSite& w1 = J.mpo(0, 1);
+    const int d1 = w1.d, Mr = w1.mr;
+    if (dr_next_ < 1) throw ArgError("shard: the right neighbour's bond dimension was not given at creation");
+    const int Dr = dr_next_;
+    psi_r_.reserve((size_t)D * d1 * Dr);
+    env_r_.reserve((size_t)Dr * Mr * Dr);
+    xfer_begin();
+    recv_dev(psi_r_.p, (size_t)D * d1 * Dr, nb);
+    recv_dev(env_r_.p, (size_t)Dr * Mr * Dr, nb);
+    xfer_end();
+    if (!b.envL_ok_[pl]) throw ArgError("shard: the block's left environment at its last site is missing");
+    DeviceMode mj(J), mb(b);
+    J.set_site(0, dp(b.site_[pl].p), dl, d0, D, MITDVP_GAUGE_C);
+    J.set_site(1, dp(psi_r_.p), D, d1, Dr, MITDVP_GAUGE_C);
+    J.set_boundary_env(0, dp(b.envL_[pl].p), dl, w0.ml);
+    J.set_boundary_env(1, dp(env_r_.p), Dr, Mr);
+    // all four local solves share the warm-up memory of the last site the block's sweep propagated
+    // (_Debug.site_now is set by the sweep only, _mps_cls.py:880)
+    const int mem = n_ - 2;
+    J.require_ready();
+    J.kprev_set(0, b.kprev_get(mem));
+    xin_.reserve((size_t)D * D);
+    pinv_dev(J, X_.p, D, xin_.p);
+    J.set_bond(1, dp(xin_.p), D);  // psi_L X^+
+    J.absorb_bond(false);
+    J.replace_site(1, dp(psi_r_.p), MITDVP_GAUGE_PSI);
+    J.split_center(false);  // psi_R = sigma B, block through B
+    J.absorb_bond(false);
+    J.site_exp(dt);
+    if (regularize_) regularize_center(J);  // trans_next_psite_AsigmaB(regularize=True), :362-370
+    J.split_center(true);
+    J.bond_exp(dt);
+    J.kprev_set(1, J.kprev_get(0));
+    J.absorb_bond(true);
+    J.site_exp(dt);
+    J.split_center(false);
+    J.bond_exp(dt);
+    b.kprev_set(mem, J.kprev_get(1));
+    if (p_svd_ >= 0.0) truncate_joint(J);  // truncate=True, :437-466
+    HIP_CHECK(hipStreamSynchronize(J.st_));
+    // B, X', the block left of B
+    xfer_begin();
+    send_dev(J.site_[1].p, (size_t)D * d1 * Dr, nb);
+    send_dev(J.sig_.p, (size_t)D * D, nb);
+    send_dev(J.envL_[1].p, (size_t)D * w0.mr * D, nb);
+    xfer_end();
+    HIP_CHECK(hipMemcpyAsync(X_.p, J.sig_.p, (size_t)D * D * sizeof(zc), hipMemcpyDeviceToDevice, b.st_));
+    HIP_CHECK(hipStreamSynchronize(b.st_));
+    b.replace_site(pl, dp(J.site_[0].p), MITDVP_GAUGE_A);
+    b.set_boundary_env(1, dp(J.envR_[1].p), D, w0.mr);
+    b.set_bond(n_, dp(X_.p), D);
+    b.absorb_bond(false);
+  }
+
+  // The right rank: sends its centre tensor and the block right of it, takes B, X' and the block left of B.
+  void junction_right() {
+    Engine& b = *block_;
+    const int nb = rank_ - 1;
+    const int D = b.dl_[0], d = b.dd_[0], dr = b.dr_[0];
+    const MpoSite& w = b.mpo(0, 0);
+    if (b.center_ != 0) throw ArgError("shard: the block's first site must be the centre before a junction update");
+    if (!b.envR_ok_[1]) throw ArgError("shard: the block's right environment at its first site is missing");
+    xfer_begin();
+    send_dev(b.site_[0].p, (size_t)D * d * dr, nb);
+    send_dev(b.envR_[1].p, (size_t)dr * w.mr * dr, nb);
+    xfer_end();
+    tmpa_.reserve((size_t)D * d * dr);
+    tmpb_.reserve((size_t)D * w.ml * D);
+    xin_.reserve((size_t)D * D);
+    xfer_begin();
+    recv_dev(tmpa_.p, (size_t)D * d * dr, nb);
+    recv_dev(xin_.p, (size_t)D * D, nb);
+    recv_dev(tmpb_.p, (size_t)D * w.ml * D, nb);
+    xfer_end();
+    DeviceMode mb(b);
+    b.replace_site(0, dp(tmpa_.p), MITDVP_GAUGE_B);
+    b.set_boundary_env(0, dp(tmpb_.p), D, w.ml);
+    b.set_bond(0, dp(xin_.p), D);
+    b.absorb_bond(true);
+  }
+};
+
+}  // namespace mitdvp
+
+// --------------------------------------------------------------------------------------------------- C ABI
+struct mitdvp_shard {
+  mitdvp_engine block, joint;  // handed out by mitdvp_shard_engine; they live exactly as long as the shard
+  std::unique_ptr<mitdvp::SiteShard> s;
+  std::string err;
+  int device = 0;
+  ~mitdvp_shard() { s.reset(); }  // the shard (its RCCL communicator, its buffers) goes before the engines
+};
+
+namespace {
+thread_local std::string g_serr;
+
+template <class F>
+int sguard(mitdvp_shard* h, F&& f) {
+  std::string* dst = h ? &h->err : &g_serr;
+  try {
+    if (h) {
+      hipError_t e = hipSetDevice(h->device);
+      if (e != hipSuccess) { *dst = hipGetErrorString(e); return MITDVP_EHIP; }
+    }
+    f();
+    return MITDVP_OK;
+  } catch (const mitdvp::NotConverged& ex) { *dst = ex.what(); return MITDVP_ENOTCONV;
+  } catch (const mitdvp::ArgError& ex) { *dst = ex.what(); return MITDVP_EINVAL;
+  } catch (const mitdvp::HipError& ex) { *dst = ex.what(); return MITDVP_EHIP;
+  } catch (const std::bad_alloc&) { *dst = "out of host memory"; return MITDVP_ENOMEM;
+  } catch (const std::exception& ex) { *dst = ex.what(); return MITDVP_ESTATE; }
+}
+}  // namespace
+
+#define SH_CALL(h, body)                                                \
+  if (!(h) || !(h)->s) { g_serr = "null handle"; return MITDVP_EINVAL; } \
+  return sguard((h), [&] { body; })
+#define SH_NEED(p) \
+  if (!(p)) throw mitdvp::ArgError("null pointer argument")
+
+extern "C" {
+
+int mitdvp_shard_create(const mitdvp_config* cfg, int rank, int world, int nsite_block, int dr_next, mitdvp_shard** out) {
+  if (!cfg || !out) { g_serr = "null argument"; return MITDVP_EINVAL; }
+  *out = nullptr;
+  auto* h = new mitdvp_shard();
+  h->device = h->block.device = h->joint.device = cfg->device;
+  int rc = sguard(nullptr, [&] {
+    if (world < 1 || rank < 0 || rank >= world) throw mitdvp::ArgError("shard: bad rank / world");
+    if (nsite_block < (world > 1 ? 2 : 1)) throw mitdvp::ArgError("shard: a block needs at least two sites");
+    if (rank < world - 1 && dr_next < 1) throw mitdvp::ArgError("shard: dr_next (right bond of the next rank's first site) must be given");
+    mitdvp_config c = *cfg;
+    c.nsite = nsite_block;
+    h->block.e.reset(new mitdvp::Engine(c));
+    if (rank < world - 1) {
+      c.nsite = 2;
+      h->joint.e.reset(new mitdvp::Engine(c));
+    }
+    h->s.reset(new mitdvp::SiteShard(h->block.e.get(), h->joint.e.get(), rank, world, nsite_block, dr_next));
+  });
+  if (rc != MITDVP_OK) { delete h; return rc; }
+  *out = h;
+  return MITDVP_OK;
+}
+void mitdvp_shard_destroy(mitdvp_shard* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  delete h;
+}
+const char* mitdvp_shard_last_error(const mitdvp_shard* h) { return h ? h->err.c_str() : g_serr.c_str(); }
+
+int mitdvp_shard_engine(mitdvp_shard* h, int which, mitdvp_engine** out) {
+  SH_CALL(h, {
+    SH_NEED(out);
+    if (which != 0 && which != 1) throw mitdvp::ArgError("shard_engine: 0 = block, 1 = junction engine");
+    if (which == 1 && !h->joint.e) throw mitdvp::ArgError("shard_engine: the last rank has no junction engine");
+    *out = which == 0 ? &h->block : &h->joint;
+  });
+}
+int mitdvp_shard_set_options(mitdvp_shard* h, int regularize, double p_svd) { SH_CALL(h, h->s->set_options(regularize, p_svd)); }
+int mitdvp_shard_set_joint(mitdvp_shard* h, const double* reim, int dim) { SH_CALL(h, { SH_NEED(reim); h->s->set_joint(reim, dim); }); }
+int mitdvp_shard_get_joint(mitdvp_shard* h, double* reim_out, int* dim) { SH_CALL(h, { SH_NEED(dim); h->s->get_joint(reim_out, dim); }); }
+int mitdvp_shard_set_transport(mitdvp_shard* h, mitdvp_p2p_fn fn, void* user) { SH_CALL(h, h->s->set_transport(fn, user)); }
+int mitdvp_shard_attach_rccl(mitdvp_shard* h, const char id[128]) { SH_CALL(h, { SH_NEED(id); h->s->attach_rccl(id); }); }
+int mitdvp_shard_selftest(mitdvp_shard* h, int* mismatches) { SH_CALL(h, { SH_NEED(mismatches); *mismatches = h->s->selftest(); }); }
+int mitdvp_shard_self_sendrecv(mitdvp_shard* h, size_t elems, int* mismatches) {
+  SH_CALL(h, { SH_NEED(mismatches); *mismatches = h->s->self_sendrecv(elems); });
+}
+int mitdvp_shard_sweep(mitdvp_shard* h, double dt_au, int forward, int skip_end) { SH_CALL(h, h->s->sweep_block(dt_au, forward != 0, skip_end != 0)); }
+int mitdvp_shard_junctions(mitdvp_shard* h, double dt_au, int parity) { SH_CALL(h, h->s->junctions(dt_au, parity)); }
+int mitdvp_shard_step(mitdvp_shard* h, double dt_au) { SH_CALL(h, h->s->step(dt_au)); }
+int mitdvp_shard_traffic(mitdvp_shard* h, double* bytes, long* messages) {
+  SH_CALL(h, { SH_NEED(bytes); SH_NEED(messages); h->s->traffic(bytes, messages); });
+}
+
+}  // extern "C"

@@ -623,7 +623,9 @@ void zgemm(hipStream_t st, const ZgemmDesc& d) {
   const int longk = longk_env > 0 ? longk_env : (int)std::min<long>(8, d.K / 4096);
   const bool long_k = d.batch == 1 && longk > 1 && nt >= 192 && d.K >= 8192 && cfg == 1 && !d.rowmap_p &&
                       (longk_env > 0 || !d.transA);
-  if (d.batch == 1 && ((nt < 192 && d.K >= 1024) || long_k)) {
+  // (a row map scatters C rows into the real output buffer: the partial slabs of a split are plain M x N arrays,
+  // so mapped outputs are never split)
+  if (d.batch == 1 && !d.rowmap_p && ((nt < 192 && d.K >= 1024) || long_k)) {
     int splits = long_k ? longk : (int)std::min<long>((384 + nt - 1) / nt, d.K / 256);
     if (splits >= 2) {
       int kc = (d.K + splits - 1) / splits;

@@ -78,10 +78,30 @@ class TDVPEngine:
         self.device = device
         _lib.check(lib.mitdvp_create(C.byref(cfg), C.byref(self._h)))
 
+    @classmethod
+    def borrow(cls, handle, nsite: int, device: int):
+        """Wrap an engine handle that something else owns (``mitdvp_shard_engine``): ``close`` only forgets it."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = handle
+        self._borrowed = True
+        self.nsite = nsite
+        self.device = device
+        return self
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.mitdvp_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.mitdvp_destroy(self._h)
             self._h = None
+
+    def krylov_memory(self, isite: int) -> int:
+        k = C.c_int()
+        self._ck(self._lib.mitdvp_get_krylov_memory(self._h, isite, C.byref(k)))
+        return k.value
+
+    def set_small_kernels(self, on: bool):
+        self._ck(self._lib.mitdvp_set_small_kernels(self._h, int(bool(on))))
 
     def __del__(self):
         try:

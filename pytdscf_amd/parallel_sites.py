@@ -10,26 +10,33 @@ of the joint bond matrix (``propagate_joint_two_sites`` :270-470; ``multiply_sig
 ``_site_cls.py:709-754``, RCOND = 1e-13).  The state is Psi = Phi_0 X_0^+ Phi_1 X_1^+ ... (Secular et al.,
 PRB 101, 235123); the scheme is an approximation to the serial sweep whose error vanishes as dt^2.
 
-Here: one process per GPU, one engine per rank holding its block (``mitdvp_set_boundary_env`` and the
-sweep pieces ``mitdvp_site_exp / split_center / bond_exp / absorb_bond``), a persistent two-site engine
-per junction on the left rank for the joint update, and neighbour-only traffic: per junction and half
-step one centre tensor (D d D), one environment block (D M D), one B tensor, one bond matrix (D D) and
-one environment block back -- ``torch.distributed`` send / recv (backend nccl = RCCL over xGMI; gloo on
-the CPU test hosts and when ranks share a GPU).  No collective on the data path.
+Here: one process per GPU and ONE library call per time step (``mitdvp_shard_step``, ``csrc/shard.hip``): the
+block's half-sweeps, the joint update on the left rank of every junction (a persistent two-site engine) and the
+neighbour messages around it -- per junction and half step one centre tensor (D d D), one environment block
+(D M D), one B tensor, one bond matrix (D D) and one environment block back -- as grouped ``ncclSend`` / ``ncclRecv``
+of device buffers issued by the library itself on the engine's stream (RCCL over xGMI; no collective on the data
+path, no Python and no torch between two time steps).  ``torch.distributed`` is the CONTROL plane only: rendezvous,
+the 128-byte ncclUniqueId, barriers and scalar reductions; when ranks share a GPU (tests; RCCL refuses that) it also
+carries the messages, through the library's host-callback transport.
 
 Set-up replicates a full-chain engine on every rank (same seed / same input tensors) and derives the
-block from it on the device; it is not part of the timed region.  Differences from the reference, on
-purpose: no SQRT_EPSRHO regularisation of small singular values (``_site_cls.py:22, :207-246, :657-664``),
-no SVD truncation of the joint matrix (``p_svd = 0``): both change results at the 1e-4 level and are
-why the reference's own tests accept 1e-2; Hilbert space, one electronic state, fixed bond dimension.
+block from it on the device; it is not part of the timed region.  ``regularize`` / ``p_svd`` switch on the
+reference's lifting of small singular values (SQRT_EPSRHO = 1e-4, ``_site_cls.py:22, :207-246, :657-664``) and the
+cumulative-weight truncation of the joint matrix (``truncate_sigvec``, :586-690); with both on (the reference's
+setting) the path reproduces ``MPSCoefParallel`` to 1e-8 (``tests/test_gpu_site_sharding.py`` against
+``tests/golden/parallel_*.npz``); both are off by default.  Hilbert space, one electronic state, fixed bond
+dimension.
 """
 
 from __future__ import annotations
 
 import os
 
+import ctypes as C
+
 import numpy as np
 
+from . import _lib
 from .engine import TDVPEngine, svd as device_svd, zgemm as device_zgemm
 
 RCOND = 1e-13  # _site_cls.py:24
@@ -55,12 +62,8 @@ def pinv_device(x: np.ndarray, device: int = 0) -> np.ndarray:
 
 
 class _Link:
-    """Neighbour send / recv of complex128 tensors over torch.distributed (shapes are known to both sides).
-
-    Host arrays (NumPy) are staged through a tensor of the backend's device.  With ``device=True`` the payload is a torch
-    tensor on this rank's GPU: over nccl (= RCCL, xGMI) it goes from the sender's HBM to the receiver's without touching
-    the host; over gloo (tests: ranks sharing one GPU) the same tensors are staged through the host for the transport
-    only, so the engine-side device path is what the tests exercise."""
+    """Neighbour send / recv of complex128 HOST arrays over torch.distributed: the control plane's messages (set-up,
+    observables folded rank by rank, gathers in tests).  The halo of a time step does not go through here."""
 
     def __init__(self, comm):
         self.comm = comm
@@ -71,48 +74,65 @@ class _Link:
     def send(self, arr, dst: int):
         import torch
 
-        if hasattr(arr, "data_ptr"):  # device tensor
-            t = torch.view_as_real(arr.contiguous()).reshape(-1)
-            nbytes = t.numel() * 8
-            if self.comm.backend != "nccl":
-                t = t.cpu()
-        else:
-            a = np.ascontiguousarray(arr, dtype=np.complex128)
-            nbytes = a.nbytes
-            t = torch.from_numpy(a.view(np.float64).reshape(-1))
-            if self.comm.backend == "nccl":
-                t = t.to(self.comm.device)
+        a = np.ascontiguousarray(arr, dtype=np.complex128)
+        t = torch.from_numpy(a.view(np.float64).reshape(-1))
+        if self.comm.backend == "nccl":
+            t = t.to(self.comm.device)
         self.dist.send(t, dst)
-        self.bytes += nbytes
+        self.bytes += a.nbytes
         self.messages += 1
 
-    def recv(self, shape, src: int, device: bool = False):
+    def recv(self, shape, src: int):
         import torch
 
         n = int(np.prod(shape))
         nccl = self.comm.backend == "nccl"
-        if not device:
-            t = torch.empty(2 * n, dtype=torch.float64, device=self.comm.device if nccl else "cpu")
-            self.dist.recv(t, src)
-            return t.cpu().numpy().view(np.complex128).reshape(shape).copy()
-        dev = torch.device("cuda", self.comm.gpu)
-        out = torch.empty(tuple(shape), dtype=torch.complex128, device=dev)
-        flat = torch.view_as_real(out).reshape(-1)
-        if nccl:
-            self.dist.recv(flat, src)
-        else:
-            t = torch.empty(2 * n, dtype=torch.float64)
-            self.dist.recv(t, src)
-            flat.copy_(t)
-        torch.cuda.current_stream(dev).synchronize()  # the engine reads it from ITS stream next
-        return out
+        t = torch.empty(2 * n, dtype=torch.float64, device=self.comm.device if nccl else "cpu")
+        self.dist.recv(t, src)
+        return t.cpu().numpy().view(np.complex128).reshape(shape).copy()
+
+    def raw_callback(self):
+        """mitdvp_p2p_fn over torch.distributed (ranks sharing a GPU, or RCCL unavailable to the library)."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+
+        def cb(user, op, peer, buf, nbytes):
+            try:
+                t = torch.frombuffer((C.c_char * nbytes).from_address(buf), dtype=torch.uint8)
+                if self.comm.backend == "nccl":
+                    if op == 0:
+                        self.dist.send(t.to(self.comm.device), peer)
+                    else:
+                        d = torch.empty(nbytes, dtype=torch.uint8, device=self.comm.device)
+                        self.dist.recv(d, peer)
+                        t.copy_(d.cpu())
+                elif op == 0:
+                    self.dist.send(t, peer)
+                else:
+                    self.dist.recv(t, peer)
+                return 0
+            except Exception:  # noqa: BLE001 -- reported through the library's error code
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        return _lib.P2P_FN(cb)
 
 
 class SiteShardedTDVP:
-    """One rank of the site-sharded sweep.  All ranks construct it with the same arguments."""
+    """One rank of the site-sharded sweep.  All ranks construct it with the same arguments.
+
+    ``split``: explicit ranges [(first, last), ...] as the reference's ``parallel_split_indices``; default: contiguous
+    near-equal ranges.  ``regularize`` / ``p_svd``: the reference's junction regularisation (module docstring).
+    ``transport``: "rccl" (library-native, default with one rank per GPU), "callback" (torch.distributed carries the
+    messages; default when ranks share a GPU)."""
 
     def __init__(self, comm, mpo, *, cores=None, dims=None, bond_dim=None, seed=1, integrator="lanczos", thresh=1e-9,
-                 conserve_norm=True, device=None):
+                 conserve_norm=True, device=None, split=None, regularize=False, p_svd=None, transport=None):
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
         self.device = comm.gpu if device is None else device
@@ -120,25 +140,38 @@ class SiteShardedTDVP:
             raise RuntimeError("SiteShardedTDVP needs a GPU: the MI355X engine has no CPU fallback")
         self.mpo = [np.ascontiguousarray(w, dtype=np.complex128) for w in mpo]
         self.nsite = len(self.mpo)
-        self.ranges = split_sites(self.nsite, self.world)
+        if split is not None:
+            self.ranges = [(int(a), int(b) + 1) for a, b in split]
+            if len(self.ranges) != self.world or self.ranges[0][0] != 0 or self.ranges[-1][1] != self.nsite or any(
+                self.ranges[k][1] != self.ranges[k + 1][0] for k in range(self.world - 1)
+            ):
+                raise ValueError("split must be contiguous [(first, last), ...] ranges, one per rank, covering the chain")
+        else:
+            self.ranges = split_sites(self.nsite, self.world)
         if self.world > 1 and any(hi - lo < 2 for lo, hi in self.ranges):
             raise ValueError("site sharding needs at least two sites per rank")
         self.lo, self.hi = self.ranges[self.rank]
         self.n = self.hi - self.lo
         self.kw = dict(integrator=integrator, thresh=thresh, conserve_norm=conserve_norm)
+        self.regularize, self.p_svd = bool(regularize), p_svd
         self.link = _Link(comm) if self.world > 1 else None
-        # halo messages: "device" = engine -> torch tensor on the GPU -> RCCL (default over nccl), "host" = staged
-        # through NumPy arrays (default over gloo); MITDVP_HALO overrides (the tests run the device path over gloo)
-        halo = os.environ.get("MITDVP_HALO", "device" if (comm.backend == "nccl") else "host")
-        if halo not in ("device", "host"):
-            raise ValueError("MITDVP_HALO must be 'device' or 'host'")
-        self.dev_halo = self.world > 1 and halo == "device"
-        self._setup(cores, dims, bond_dim, seed)
+        shared = bool(getattr(comm, "shared_gpu", False))
+        self.transport = transport or os.environ.get("MITDVP_HALO_TRANSPORT") or ("callback" if shared else "rccl")
+        if self.transport not in ("rccl", "callback"):
+            raise ValueError("transport must be 'rccl' or 'callback'")
+        self._h = None
+        self._cb = None
+        self._setup(cores, dims, bond_dim, seed, shared)
 
     # ------------------------------------------------------------------ set-up (not timed)
-    def _setup(self, cores, dims, bond_dim, seed):
+    def _ck(self, rc):
+        _lib.check(rc, self._h, shard=True)
+
+    def _setup(self, cores, dims, bond_dim, seed, shared):
         L, r, N = self.nsite, self.rank, self.world
         g = TDVPEngine(L, device=self.device, **self.kw)  # replicated full chain: B world, then A world
+        if shared:
+            g.set_small_kernels(False)  # persistent kernels need the GPU to themselves
         g.set_mpo(self.mpo)
         if cores is not None:
             g.set_mps(cores)
@@ -166,8 +199,33 @@ class SiteShardedTDVP:
         if not even and hi == L:
             acores.append(g.get_site(L - 1))  # the A world's centre
         g.close()
-        self.X = X_right  # joint matrix of the junction to the right (held by the left rank of every junction)
-        b = TDVPEngine(n, device=self.device, **self.kw)
+        # the native shard: block engine + two-site junction engine + transport
+        lib = _lib.load()
+        cfg = _lib.Config()
+        cfg.nsite = n
+        cfg.device = self.device
+        cfg.integrator = {"lanczos": _lib.LANCZOS, "arnoldi": _lib.ARNOLDI}[self.kw["integrator"]]
+        cfg.conserve_norm = int(bool(self.kw["conserve_norm"]))
+        cfg.thresh = self.kw["thresh"]
+        cfg.max_krylov = 20
+        h = C.c_void_p()
+        dr_next = self.shapes[hi][2] if r < N - 1 else 0
+        _lib.check(lib.mitdvp_shard_create(C.byref(cfg), r, N, n, dr_next, C.byref(h)), None, shard=True)
+        self._h, self._lib = h, lib
+        self._ck(lib.mitdvp_shard_set_options(h, int(self.regularize), -1.0 if self.p_svd is None else float(self.p_svd)))
+        eh = C.c_void_p()
+        self._ck(lib.mitdvp_shard_engine(h, 0, C.byref(eh)))
+        b = TDVPEngine.borrow(eh, n, self.device)
+        self.joint = None
+        if r < N - 1:
+            jh = C.c_void_p()
+            self._ck(lib.mitdvp_shard_engine(h, 1, C.byref(jh)))
+            self.joint = TDVPEngine.borrow(jh, 2, self.device)
+            self.joint.set_mpo([self.mpo[hi - 1], self.mpo[hi]])
+        if shared:
+            b.set_small_kernels(False)
+            if self.joint is not None:
+                self.joint.set_small_kernels(False)
         b.set_mpo(self.mpo[lo:hi])
         if even:
             for i, c in enumerate(bcores):
@@ -189,103 +247,47 @@ class SiteShardedTDVP:
                 b.absorb_bond(False)
             b.build_envs(0)
         self.block = b
-        # two-site engine of the junction to the right (persistent: its Krylov memory carries over the steps)
-        self.joint = None
-        if r < N - 1:
-            self.joint = TDVPEngine(2, device=self.device, **self.kw)
-            self.joint.set_mpo([self.mpo[hi - 1], self.mpo[hi]])
+        if r < N - 1:  # joint matrix of the junction to the right (held by the left rank of every junction)
+            x = np.ascontiguousarray(X_right, dtype=np.complex128)
+            self._ck(lib.mitdvp_shard_set_joint(h, x.ctypes.data_as(C.POINTER(C.c_double)), x.shape[0]))
+        if N > 1:
+            self._attach_transport()
+
+    def _attach_transport(self):
+        """library-native RCCL between chain neighbours, or torch.distributed through the callback transport; all
+        ranks end up with the same kind (the verdict of the self-test is shared)."""
+        lib, h, comm = self._lib, self._h, self.comm
+        if self.transport == "rccl":
+            ok = 1.0
+            try:
+                ident = C.create_string_buffer(128)
+                if comm.rank == 0:
+                    _lib.check(lib.mitdvp_rccl_unique_id(ident))
+                box = [ident.raw]
+                comm.dist.broadcast_object_list(box, src=0)
+                self._ck(lib.mitdvp_shard_attach_rccl(h, box[0]))
+            except Exception as exc:  # noqa: BLE001 -- all ranks fall back together below
+                print(f"[site sharding] rank {comm.rank}: RCCL attach failed ({exc}); falling back to the callback transport", flush=True)
+                ok = 0.0
+            if comm.min_over_ranks(ok) < 1.0:
+                self.transport = "callback"
+        if self.transport == "callback":
+            self._cb = self.link.raw_callback()
+            self._ck(lib.mitdvp_shard_set_transport(h, self._cb, None))
+
+    @property
+    def X(self):
+        """joint matrix of the junction to the right (joint_sigvec_not_pinv), host copy"""
+        dim = C.c_int()
+        self._ck(self._lib.mitdvp_shard_get_joint(self._h, None, C.byref(dim)))
+        x = np.empty((dim.value, dim.value), dtype=np.complex128)
+        self._ck(self._lib.mitdvp_shard_get_joint(self._h, x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(dim)))
+        return x
 
     # ------------------------------------------------------------------ the step
-    def _sweep_block(self, dt, forward, skip_end):
-        """propagate_along_sweep over the block, piece by piece (_mps_cls.py:798-1014)."""
-        b, n = self.block, self.n
-        sites = range(0, n) if forward else range(n - 1, -1, -1)
-        end = n - 1 if forward else 0
-        for p in sites:
-            if skip_end and p == end:
-                return
-            b.site_exp(dt)
-            if p == end:
-                return
-            b.split_center(forward)
-            b.bond_exp(dt)
-            b.absorb_bond(forward)
-
-    def _junction_left(self, dt):
-        """The left rank of a junction: receives psi_R and the block right of it, updates both sites,
-        returns B, X and the block left of B (propagate_joint_two_sites, _mps_parallel.py:270-470)."""
-        b, J, n, nb = self.block, self.joint, self.n, self.rank + 1
-        shp_r = self.shapes[self.hi]
-        Dr, Mr = shp_r[2], self.mpo[self.hi].shape[3]
-        dv = self.dev_halo
-        psi_r = self.link.recv(shp_r, nb, device=dv)
-        env_r = self.link.recv((Dr, Mr, Dr), nb, device=dv)
-        psi_l = b.get_site(n - 1, device=dv)
-        env_l = b.get_env(0, n - 1, device=dv)
-        J.set_site(0, psi_l, "C")
-        J.set_site(1, psi_r, "C")
-        J.set_boundary_env(0, env_l)
-        J.set_boundary_env(1, env_r)
-        J.set_bond(1, pinv_device(self.X, self.device))  # psi_L X^+
-        J.absorb_bond(False)
-        J.replace_site(1, psi_r, "Psi")
-        J.split_center(False)  # psi_R = sigma B, block through B
-        J.absorb_bond(False)
-        J.site_exp(dt)
-        J.split_center(True)
-        J.bond_exp(dt)
-        J.absorb_bond(True)
-        J.site_exp(dt)
-        J.split_center(False)
-        J.bond_exp(dt)
-        Xn = J.get_bond()
-        A, B = J.get_site(0, device=dv), J.get_site(1, device=dv)
-        L1, R2 = J.get_env(0, 1, device=dv), J.get_env(1, 1, device=dv)
-        self.link.send(B, nb)
-        self.link.send(Xn, nb)
-        self.link.send(L1, nb)
-        self.X = Xn
-        # A X' -> psi: the block's last site carries the junction's weight again (send_joint_sigvec_to_right, :541-597)
-        b.replace_site(n - 1, A, "A")
-        b.set_boundary_env(1, R2)
-        b.set_bond(n, Xn)
-        b.absorb_bond(False)
-
-    def _junction_right(self):
-        b, nb = self.block, self.rank - 1
-        shp = self.shapes[self.lo]
-        dv = self.dev_halo
-        self.link.send(b.get_site(0, device=dv), nb)
-        self.link.send(b.get_env(1, 1, device=dv), nb)
-        D, Ml = shp[0], self.mpo[self.lo].shape[0]
-        B = self.link.recv(shp, nb, device=dv)
-        Xn = self.link.recv((D, D), nb)
-        L1 = self.link.recv((D, Ml, D), nb, device=dv)
-        b.replace_site(0, B, "B")
-        b.set_boundary_env(0, L1)
-        b.set_bond(0, Xn)
-        b.absorb_bond(True)
-
-    def _junctions(self, dt, parity):
-        r, N = self.rank, self.world
-        if r % 2 == parity and r < N - 1:
-            self._junction_left(dt)
-        elif r % 2 != parity and r > 0:
-            self._junction_right()
-
     def step(self, dt):
-        """One time step = two half-sweeps of every block + one joint update of every junction."""
-        r, N = self.rank, self.world
-        if N == 1:
-            self._sweep_block(dt, True, False)
-            self._sweep_block(dt, False, False)
-            return
-        fwd = r % 2 == 0
-        self._sweep_block(dt, fwd, skip_end=not ((fwd and r == N - 1) or (not fwd and r == 0)))
-        self._junctions(dt, 0)
-        fwd = not fwd
-        self._sweep_block(dt, fwd, skip_end=not ((fwd and r == N - 1) or (not fwd and r == 0)))
-        self._junctions(dt, 1)
+        """One time step = two half-sweeps of every block + one joint update of every junction: one library call."""
+        self._ck(self._lib.mitdvp_shard_step(self._h, float(dt)))
 
     # ------------------------------------------------------------------ the whole state (tests, observables)
     def gather(self):
@@ -484,51 +486,29 @@ class SiteShardedTDVP:
         return res
 
     def selftest(self) -> bool:
-        """Neighbour ping over the link (every junction, both directions) before the sweep relies on it.  The
-        device-resident form of the messages is pinged as well; if it fails on any rank, ALL ranks fall back to
-        host-staged messages (collective: every rank must call this)."""
+        """Neighbour ping through the step's own transport (every junction, both directions) before the sweep relies
+        on it; the verdict is shared, so all ranks agree.  Collective."""
         if self.world == 1:
             return True
-        ok = self._ping(False)
-        if self.dev_halo:
-            good = self._ping(True)
-            if self.comm.min_over_ranks(1.0 if good else 0.0) < 1.0:
-                self.dev_halo = False
-        return ok
-
-    def _ping(self, device: bool) -> bool:
-        ok = True
-
-        def mk(rank):
-            a = (np.arange(6, dtype=np.float64) + 10.0 * rank).astype(np.complex128).reshape(2, 3)
-            if not device:
-                return a
-            import torch
-
-            return torch.from_numpy(a).to(torch.device("cuda", self.comm.gpu))
-
-        def host(x):
-            return x.cpu().numpy() if hasattr(x, "data_ptr") else x
-
+        bad = C.c_int(-1)
         try:
-            for parity in (0, 1):
-                r = self.rank
-                if r % 2 == parity and r < self.world - 1:
-                    self.link.send(mk(r), r + 1)
-                    back = self.link.recv((2, 3), r + 1, device=device)
-                    ok = ok and np.array_equal(host(back), host(mk(r)) + 1.0)
-                elif r % 2 != parity and r > 0:
-                    got = self.link.recv((2, 3), r - 1, device=device)
-                    ok = ok and np.array_equal(host(got), host(mk(r - 1)))
-                    self.link.send(got + 1.0, r - 1)
-        except Exception:  # noqa: BLE001 -- the caller shares the verdict over all ranks
-            ok = False
-        return bool(ok)
+            self._ck(self._lib.mitdvp_shard_selftest(self._h, C.byref(bad)))
+        except Exception as exc:  # noqa: BLE001 -- shared below
+            print(f"[site sharding] rank {self.rank}: transport self-test raised {exc}", flush=True)
+        return self.comm.min_over_ranks(1.0 if bad.value == 0 else 0.0) >= 1.0
 
     def traffic(self):
-        return (self.link.bytes, self.link.messages) if self.link else (0, 0)
+        """(bytes, messages) of halo traffic this rank has SENT in its time steps"""
+        if self._h is None or self.world == 1:
+            return (0, 0)
+        b, m = C.c_double(), C.c_long()
+        self._ck(self._lib.mitdvp_shard_traffic(self._h, C.byref(b), C.byref(m)))
+        return (int(b.value), int(m.value))
 
     def close(self):
-        self.block.close()
-        if self.joint is not None:
-            self.joint.close()
+        if self._h is not None:
+            self.block.close()
+            if self.joint is not None:
+                self.joint.close()
+            self._lib.mitdvp_shard_destroy(self._h)
+            self._h = None

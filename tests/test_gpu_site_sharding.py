@@ -1,8 +1,9 @@
-"""GPU: site-range sharding (pytdscf_amd/parallel_sites.py) with 2 and 3 ranks sharing the test GPU over
-gloo, against (a) the oracle of the same algorithm (oracle/tdvp_parallel_oracle.py) at 1e-8 and (b) the
-serial sweep at the looser bar SURVEY 8(e) sets for this approximate scheme (the reference accepts 1e-2
-on the norm and 1e-1 on energies; here infidelity < 1e-6, norm to 1e-4 at dt = 0.2).  Plus the CPU
-test of the neighbour link (world size 2, gloo)."""
+"""GPU: site-range sharding (pytdscf_amd/parallel_sites.py over csrc/shard.hip) with 2 and 3 ranks sharing the test
+GPU (messages through the library's callback transport over gloo), against (a) the REFERENCE's MPSCoefParallel --
+fixtures tests/golden/parallel_*.npz, 1e-8 -- (b) the oracle of the same algorithm at 1e-8 and (c) the serial sweep at
+the looser bar SURVEY 8(e) sets for this approximate scheme (the reference accepts 1e-2 on the norm and 1e-1 on
+energies; here infidelity < 1e-6, norm to 1e-4 at dt = 0.2).  Plus the library's RCCL point-to-point path on a
+one-rank communicator and the CPU test of the neighbour link (world size 2, gloo)."""
 
 import json
 import os
@@ -121,7 +122,7 @@ if comm.rank == 0:
                vs_oracle=abs(abs(orc.overlap(go, g)) / (nrm * ref.norm()) - 1),
                norm_gap=abs(nrm - ref.norm()),
                vs_serial=abs(abs(orc.overlap(ser.cores, g)) / nrm - 1), norm=nrm, obs_gap=obs_gap,
-               energy=obs["energy"].real, halo="device" if eng.dev_halo else "host",
+               energy=obs["energy"].real, transport=eng.transport,
                bytes=eng.traffic()[0], messages=eng.traffic()[1])
     print("RESULT " + json.dumps(out), flush=True)
 comm.barrier()
@@ -130,13 +131,20 @@ comm.close()
 """
 
 
-def _run(world, tmp_path, L=8, integ="lanczos", cn=True, halo=None):
+def _launch(script, world, timeout=300):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               MITDVP_DIST_BACKEND="gloo")
+    rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
+                          timeout=timeout)
+    assert rcs == [0] * world, "\n".join(outs)
+    return json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
+
+
+def _run(world, tmp_path, L=8, integ="lanczos", cn=True):
     script = tmp_path / f"ss{world}.py"
     script.write_text(textwrap.dedent(WORKER.format(root=ROOT, L=L, integ=integ, cn=cn)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                MITDVP_DIST_BACKEND="gloo")
-    if halo:
-        env["MITDVP_HALO"] = halo
     rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
                           timeout=300)
     assert rcs == [0] * world, "\n".join(outs)
@@ -156,17 +164,156 @@ def test_site_sharded_matches_its_oracle_and_the_serial_sweep(world, tmp_path):
         assert r["messages"] > 0                  # neighbour traffic only: 5 messages per junction and half step (+ gather)
 
 
+REF_WORKER = """
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+comm = Comm()
+g = np.load(os.path.join({root!r}, "tests", "golden", {name!r}))
+n = 8
+mpo = [g[f"mpo{{i}}"] for i in range(n)]
+start = [g[f"start{{i}}"] for i in range(n)]
+dt = float(g["dt_au"])
+eng = SiteShardedTDVP(comm, mpo, cores=start, split=[tuple(int(x) for x in r) for r in g["split"]],
+                      regularize=True, p_svd=float(g["p_svd"]))
+assert eng.selftest()
+worst = dict(fid=0.0, norm=0.0, auto=0.0, sv=0.0, norm_folded=0.0)
+for k in range(int(g["nstep"]) + 1):
+    mine = eng.gather()
+    n2f, acf = eng.overlap(True), eng.overlap(False)       # folded rank by rank on the devices
+    sv = np.linalg.svd(eng.X, compute_uv=False) if comm.rank < comm.world - 1 else None
+    box = [None] * comm.world
+    comm.dist.all_gather_object(box, sv)
+    if comm.rank == 0:
+        ref = [g[f"step{{k}}_site{{i}}"] for i in range(n)]
+        n2r, n2 = abs(orc.overlap(ref, ref)), abs(orc.overlap(mine, mine))
+        worst["fid"] = max(worst["fid"], abs(abs(orc.overlap(ref, mine)) / np.sqrt(n2 * n2r) - 1))
+        worst["norm"] = max(worst["norm"], abs(n2 - float(g["norm"][k])))
+        worst["norm_folded"] = max(worst["norm_folded"], abs(n2f.real - float(g["norm"][k])))
+        worst["auto"] = max(worst["auto"], abs(acf - complex(g["autocorr"][k])))
+        for j in range(comm.world - 1):
+            worst["sv"] = max(worst["sv"], np.abs(box[j] - np.linalg.svd(g[f"step{{k}}_joint{{j}}"], compute_uv=False)).max())
+    if k < int(g["nstep"]):
+        eng.step(dt)
+kry = [eng.block.krylov_memory(i) for i in range(eng.n)]
+box = [None] * comm.world
+comm.dist.all_gather_object(box, kry)
+if comm.rank == 0:
+    worst["krylov_equal"] = all(box[r] == [int(x) for x in g["krylov"][r][: len(box[r])]] for r in range(comm.world))
+    worst["norm_after_first_step"] = float(g["norm"][1])
+    worst["transport"] = eng.transport
+    print("RESULT " + json.dumps(worst), flush=True)
+comm.barrier()
+eng.close()
+comm.close()
+"""
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_site_sharded_with_device_resident_halo_messages(world, tmp_path):
-    """MITDVP_HALO=device: the junction tensors go engine -> torch tensor on the GPU -> engine through the device
-    pointer mode of the C ABI (what runs over RCCL on a multi-GPU node); gloo stages them for the transport only.
-    Same numbers as the host-staged path."""
-    r = _run(world, tmp_path, L=9 if world == 3 else 8, halo="device")
-    h = _run(world, tmp_path, L=9 if world == 3 else 8, halo="host")
-    assert r["halo"] == "device" and h["halo"] == "host"
-    assert r["vs_oracle"] < 1e-8 and r["norm_gap"] < 1e-8 and r["obs_gap"] < 1e-10
-    assert abs(r["energy"] - h["energy"]) < 1e-13 and abs(r["norm"] - h["norm"]) < 1e-13
+@pytest.mark.parametrize(
+    "name, world", [("parallel_chain_r2.npz", 2), ("parallel_chain_r3.npz", 3), ("parallel_chain_graded.npz", 2)]
+)
+def test_site_sharded_reproduces_the_reference_parallel_tdvp(name, world, tmp_path):
+    """MPSCoefParallel.propagate (_mps_parallel.py:106-470) run by the REFERENCE on 2 / 3 ranks
+    (tests/golden/make_golden_parallel.py): the state after every step, <Psi|Psi>, <Psi*|Psi>, the spectrum of every
+    joint matrix and every rank's Krylov counts.  ``graded``: Schmidt values down to 1e-6 at the junction, p_svd = 1e-5 --
+    the lifting of small singular values and the truncation of the joint matrix act (the reference's <Psi|Psi> falls to
+    0.39 after one step); entries of X^+ reach 1e6 there, hence the looser bar."""
+    script = tmp_path / "ref.py"
+    script.write_text(textwrap.dedent(REF_WORKER.format(root=ROOT, name=name)))
+    r = _launch(script, world)
+    tol = 1e-6 if "graded" in name else 1e-8
+    assert r["transport"] == "callback"            # ranks share the GPU: gloo carries the library's messages
+    assert r["fid"] < tol and r["norm"] < tol and r["norm_folded"] < tol and r["auto"] < tol and r["sv"] < tol, r
+    assert r["krylov_equal"], r
+    if "graded" in name:
+        assert r["norm_after_first_step"] < 0.5
+
+
+EXC_WORKER = """
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from pytdscf_amd import mps as M, operators as O
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+comm = Comm()
+g = np.load(os.path.join({root!r}, "tests", "golden", "parallel_exciton.npz"))
+pot = [g[f"pot{{i}}"] for i in range(4)]
+kin = [g[f"kin{{i}}"] for i in range(3)]
+mpo = O.merge_operator_terms([(pot, [0, 1, 2, 3]), (kin, [0, 1, 2])], dims=[8, 8, 8, 2])
+start = orc.canonicalize_site0(M.product_state_cores([g[f"weight{{i}}"] for i in range(4)], bond_dim=int(g["bond_dim"])))
+eng = SiteShardedTDVP(comm, mpo, cores=start, split=[(0, 1), (2, 3)], regularize=True, p_svd=float(g["p_svd"]))
+dt = float(g["dt_au"])
+out = dict(energy=[], norm2=[], infid=[])
+for k in range(21):
+    if k in (0, 1, 2, 5, 10, 19, 20):
+        e, n2 = eng.expectation().real, eng.overlap(True).real
+        mine = eng.gather()
+        if comm.rank == 0:
+            out["energy"].append(e / n2)
+            out["norm2"].append(n2)
+            if k != 19:
+                ref = [g[f"step{{k}}_site{{i}}"] for i in range(4)]
+                out["infid"].append(1 - abs(orc.overlap(ref, mine)) / np.sqrt(abs(orc.overlap(ref, ref)) * abs(orc.overlap(mine, mine))))
+    eng.step(dt)
+if comm.rank == 0:
+    out["energy_ref"] = [float(g["energy_ref"][k].real) for k in (0, 1, 2, 5, 10, 19, 20)]
+    print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+eng.close()
+comm.close()
+"""
+
+
+@pytest.mark.gpu
+def test_reference_mpi_exciton_model_two_ranks(tmp_path):
+    """The reference's own MPI test (tests/test_mpi_exiciton_propagate.py: 4 sites, parallel_split_indices
+    [(0, 1), (2, 3)], zero-padded product start, 20 steps of 0.05 fs): its pin -- energy 0.01000 to rel 1e-1 (:220) --
+    and the serial run's pin 0.010000180312707298 (tests/test_exiciton_propagate.py:178).  From a rank-1 junction the
+    lifted null directions are whatever each SVD's completion is (the reference's authors: "not always reproducible";
+    its own <Psi|Psi> drifts to 1.03 here), so beyond the pins: energy within 2e-2 of the reference's estimator at the
+    same step (a fifth of its own bar), <Psi|Psi> within 0.1 of 1, state within 5e-3 of the reference's in fidelity."""
+    script = tmp_path / "exc.py"
+    script.write_text(textwrap.dedent(EXC_WORKER.format(root=ROOT)))
+    r = _launch(script, 2)
+    e19 = r["energy"][5]
+    assert e19 == pytest.approx(0.01000, rel=1e-1)                       # the reference-held pin
+    assert e19 == pytest.approx(0.010000180312707298, rel=2e-2)          # the serial pin, at the scheme's accuracy
+    for e, er in zip(r["energy"], r["energy_ref"]):
+        assert e == pytest.approx(er, rel=2e-2)
+    assert r["infid"][0] < 1e-12 and max(r["infid"]) < 5e-3, r
+    assert max(abs(x - 1) for x in r["norm2"]) < 0.1, r
+
+
+@pytest.mark.gpu
+def test_library_rccl_point_to_point_on_a_one_rank_communicator():
+    """ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd resolved from librccl by the library itself (csrc/rccl_dyn.h)
+    and used on the engine's stream: a grouped send + receive from the rank to itself -- what the one-GPU box can
+    exercise of the halo transport that runs between GPUs at world size > 1."""
+    import ctypes as C
+
+    from pytdscf_amd import _lib
+
+    lib = _lib.load()
+    cfg = _lib.Config()
+    cfg.nsite, cfg.device, cfg.integrator, cfg.conserve_norm, cfg.thresh, cfg.max_krylov = 2, 0, 0, 1, 1e-9, 20
+    h = C.c_void_p()
+    _lib.check(lib.mitdvp_shard_create(C.byref(cfg), 0, 1, 2, 0, C.byref(h)), None, shard=True)
+    try:
+        ident = C.create_string_buffer(128)
+        _lib.check(lib.mitdvp_rccl_unique_id(ident))
+        _lib.check(lib.mitdvp_shard_attach_rccl(h, ident.raw), h, shard=True)
+        bad = C.c_int(-1)
+        for elems in (7, 1 << 16, (1 << 20) + 3):
+            _lib.check(lib.mitdvp_shard_self_sendrecv(h, elems, C.byref(bad)), h, shard=True)
+            assert bad.value == 0
+    finally:
+        lib.mitdvp_shard_destroy(h)
 
 
 @pytest.mark.gpu
