@@ -257,6 +257,13 @@ def main():
 
     from pytdscf_amd.dist import Comm, replica_throughput
 
+    # Site-range sharding moves its halo with the library's own RCCL communicator (ncclSend / ncclRecv between chain
+    # neighbours, csrc/shard.hip); torch.distributed is the control plane only (rendezvous, the ncclUniqueId, barriers,
+    # scalar reductions) and runs over gloo there, so that the process holds ONE RCCL instance on its GPU.
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    L_w = WORKLOADS[args.workload][0]
+    if env_world > 1 and (args.parallel == "sites" or (args.parallel == "auto" and L_w >= 4 * env_world)):
+        os.environ.setdefault("MITDVP_DIST_BACKEND", "gloo")
     comm = Comm()  # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
     rank, world = comm.rank, comm.world
     if comm.gpu is None:
@@ -466,13 +473,20 @@ def main():
                 "energy_after": e1,
                 "parallelism": {"single": "single GPU", "replicas": f"{args.gpus} independent replicas",
                                 "tp": f"bond-sharded over {args.gpus} GPUs (all-gather / all-reduce via {collectives})",
-                                "sites": f"site ranges over {args.gpus} GPUs (L/N sites per rank, neighbour send/recv of boundary "
-                                         f"tensors via torch.distributed/{comm.backend}, joint two-site update through pinv(X)); "
+                                "sites": f"site ranges over {args.gpus} GPUs (L/N sites per rank, one library call per time step: "
+                                         "half-sweeps + joint two-site update through pinv(X) + neighbour halo "
+                                         f"[{ss.transport if ss is not None else None}]); control plane torch.distributed/{comm.backend}; "
                                          "roofline / breakdown are rank 0's block"}[mode],
                 "halo_GB": halo[0] / 1e9,
                 "halo_messages": halo[1],
-                "halo_path": (("device (engine -> RCCL -> engine, no host staging)" if ss.dev_halo else "host-staged")
+                "halo_path": (("library RCCL: grouped ncclSend / ncclRecv of device buffers on the engine's stream"
+                               if ss.transport == "rccl" else f"callback transport: torch.distributed/{comm.backend}, host-staged")
                               if ss is not None and world > 1 else None),
+                # the site-sharded scheme is an approximation (the reference's own; error ~ dt^2 per junction): how far
+                # the sharded state drifted over the run
+                "approximate": mode == "sites",
+                "accuracy": ({"norm_minus_1": nrm - 1.0, "energy_drift_rel": (e1 - e0) / abs(e0) if e0 else None}
+                             if ss is not None else None),
                 "collectives": int(cnt["n_collectives"]),
                 "collective_GB": cnt["collective_bytes"] / 1e9,
                 "wall_budget_s": args.max_seconds,

@@ -181,6 +181,12 @@ int mitdvp_get_env(mitdvp_engine* h, int side, int bond, double* reim_out, int* 
 /* construct_op_sites (_mps_cls.py:1738-1796): all blocks on one side of the centre (0: left, 1: right) */
 int mitdvp_build_envs(mitdvp_engine* h, int side);
 int mitdvp_site_exp(mitdvp_engine* h, double dt_au);      /* exp_superH_propagation_direct, _mps_cls.py:1016-1100 */
+/* ONE H_eff apply at the centre site, sigma = H_eff x (multiplyH_MPS_direct_MPO.dot, _contraction.py:1182-1243), issued
+ * exactly as the local exponential issues its applies: identity blocks of the environments short-circuited when the
+ * numerical check finds them (the reference's eye shortcut, _mps_mpo.py:510-523), zero blocks of the MPO core skipped.
+ * reim_in NULL: x = the centre tensor.  *flags (may be NULL): bit 0 first stage trimmed, bit 1 third stage trimmed,
+ * bit 2 block-sparse W stage, bit 3 the one-launch small-bond kernel.  For parity tests of the kernels a sweep runs. */
+int mitdvp_heff_apply_center(mitdvp_engine* h, const double* reim_in, double* reim_out, int* flags);
 /* trans_next_psite_AsigmaB (:1798-1850): centre -> A sigma (forward) or sigma B; the block through the site is built,
  * sigma stays in the engine as the pending bond matrix */
 int mitdvp_split_center(mitdvp_engine* h, int forward);

@@ -194,6 +194,7 @@ def load() -> C.CDLL:
         "mitdvp_shard_sweep": (i, [vp, d, i, i]),
         "mitdvp_shard_junctions": (i, [vp, d, i]),
         "mitdvp_shard_traffic": (i, [vp, dp, C.POINTER(C.c_long)]),
+        "mitdvp_heff_apply_center": (i, [vp, dp, dp, ip]),
         "mitdvp_get_krylov_memory": (i, [vp, i, ip]),
         "mitdvp_set_krylov_memory": (i, [vp, i, i]),
         "mitdvp_set_small_kernels": (i, [vp, i]),

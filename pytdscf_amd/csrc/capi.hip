@@ -155,6 +155,9 @@ int mitdvp_fold_block_range(mitdvp_engine* h, int op_id, int conj_bra, int from_
 int mitdvp_site_rdm_blocks(mitdvp_engine* h, int isite, const double* left, const double* right, double* reim_out) {
   ENG_CALL(h, { NEED(left, right, reim_out); h->e->site_rdm_blocks(isite, left, right, reim_out); });
 }
+int mitdvp_heff_apply_center(mitdvp_engine* h, const double* reim_in, double* reim_out, int* flags) {
+  ENG_CALL(h, { NEED(reim_out); h->e->heff_apply_center(reim_in, reim_out, flags); });
+}
 int mitdvp_get_krylov_memory(mitdvp_engine* h, int isite, int* k) { ENG_CALL(h, { NEED(k); *k = h->e->kprev_get(isite); }); }
 int mitdvp_set_krylov_memory(mitdvp_engine* h, int isite, int k) { ENG_CALL(h, h->e->kprev_set(isite, k)); }
 int mitdvp_set_small_kernels(mitdvp_engine* h, int on) { ENG_CALL(h, h->e->set_small_kernels(on != 0)); }

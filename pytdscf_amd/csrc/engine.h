@@ -200,6 +200,7 @@ class Engine {
   void get_env(int side, int bond, double* out);
   void build_envs(int side);
   void site_exp(double dt);
+  void heff_apply_center(const double* in, double* out, int* flags);
   void split_center(bool forward);
   void bond_exp(double dt);
   void absorb_bond(bool forward);

@@ -78,6 +78,36 @@ void Engine::site_exp(double dt) {
   ss_check();
 }
 
+// One H_eff apply at the centre site EXACTLY as a local exponential issues it (local_site_exp): the identity checks of
+// both environment blocks decide the trimmed S1 / S3 forms, the MPO's zero blocks the list kernel of the W stage.
+// in == nullptr: the centre tensor itself.  flags: bit 0 S1 trimmed, bit 1 S3 trimmed, bit 2 block-sparse W stage,
+// bit 3 the one-launch small-bond kernel took the apply.
+void Engine::heff_apply_center(const double* in, double* out, int* flags) {
+  require_ready();
+  if (center_ < 0) throw ArgError("heff_apply_center: no centre site");
+  const int p = center_;
+  if (!envL_ok_[p] || !envR_ok_[p + 1]) throw ArgError("heff_apply_center: the environment blocks around the centre are not built");
+  const MpoSite& w = mpo(0, p);
+  if (dd_[p] != w.d) throw ArgError("MPO physical dimension differs from the site tensor's");
+  const int dl = dl_[p], d = dd_[p], dr = dr_[p];
+  const size_t n = (size_t)dl * d * dr;
+  const zc* Lb = envL_[p].p;
+  const zc* Rb = envR_[p + 1].p;
+  DevBuf x = pool_get(n), y = pool_get(n);
+  if (in) copy_in(x.p, in, n);
+  else HIP_CHECK(hipMemcpyAsync(x.p, site_[p].p, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+  trim_r_ = trim_identity_ && dr >= 256 && w.mr > 1 && right_block_is_identity(Rb, dr, w.mr);
+  trim_l_ = trim_identity_ && dl >= 256 && w.ml > 1 && left_block_is_identity(Lb, dl, w.ml);
+  struct Reset { bool& f; bool& g; ~Reset() { f = false; g = false; } } reset{trim_r_, trim_l_};
+  SmallChain sc;
+  const bool small = small_ok() && chain_heff(sc, Lb, w, Rb, dl, d, dr, false);
+  const bool sparse = !small && sparse_w_ && dr >= 64 && w.kl_l.p && w.sp_frac_l <= 0.6;
+  if (flags) *flags = (trim_l_ && !small ? 1 : 0) | (trim_r_ && !small ? 2 : 0) | (sparse ? 4 : 0) | (small ? 8 : 0);
+  heff_apply(Lb, w, Rb, x.p, y.p, dl, d, dr, op(0).shift);
+  copy_out(out, y.p, n);
+  pool_put(std::move(x)); pool_put(std::move(y));
+}
+
 // forward: site p <- A, sigma (dr x dr) kept, L_{p+1} built; backward: site p <- B, sigma (dl x dl), R_p built
 void Engine::split_center(bool forward) {
   require_ready();

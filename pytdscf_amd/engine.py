@@ -95,6 +95,18 @@ class TDVPEngine:
                 self._lib.mitdvp_destroy(self._h)
             self._h = None
 
+    def heff_apply_center(self, x=None):
+        """sigma = H_eff x at the centre site, through the very kernels a local exponential uses; returns
+        (sigma, flags): bit 0 / 1 identity block of the left / right environment short-circuited, bit 2 block-sparse
+        W stage, bit 3 one-launch small-bond kernel."""
+        c = next(p for p in range(self.nsite) if self.get_site_shape(p)[3] == _lib.GAUGE_PSI)
+        l, n, r, _ = self.get_site_shape(c)
+        out = np.empty((l, n, r), dtype=np.complex128)
+        flags = C.c_int(0)
+        src = None if x is None else _c128(x)
+        self._ck(self._lib.mitdvp_heff_apply_center(self._h, None if src is None else _dp(src), _dp(out), C.byref(flags)))
+        return out, flags.value
+
     def krylov_memory(self, isite: int) -> int:
         k = C.c_int()
         self._ck(self._lib.mitdvp_get_krylov_memory(self._h, isite, C.byref(k)))

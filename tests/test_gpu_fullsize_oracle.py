@@ -161,3 +161,100 @@ def test_c5_shape_liouvillian_sweep_properties():
     eng.propagate(-dt)
     assert abs(eng.autocorr() - a0) < 1e-6 * abs(a0)
     eng.close()
+
+
+def test_c4_interior_apply_and_environment_update_through_the_sweeps_own_kernels():
+    """The kernels bench.py times at D = 1024 -- the block-sparse W stage (list kernel + row map) selected by the
+    finite-state-machine core of the bench's generator, the gathered-row first stage and the copy + accumulate third
+    stage selected by the identity blocks of CANONICAL environments -- against the oracle over the whole output
+    (_contraction.py:1182-1243; identity shortcuts _mps_mpo.py:510-523).  A 7-site chain reaches the C4 interior shape
+    (1024 x 16 x 1024) at its middle site; mitdvp_heff_apply_center issues the apply as a local exponential does and
+    reports which variants ran."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+    from pytdscf_amd import synthetic as syn
+
+    L, d, D, M = 7, 16, 1024, 32
+    mpo = syn.synthetic_mpo(L, d, M, seed=0)
+    eng = TDVPEngine(L)
+    eng.set_mpo(mpo)
+    eng.init_random([d] * L, D, seed=1)
+    c = 3
+    assert eng.get_site_shape(c)[:3] == (D, d, D)
+    eng.build_envs(1)
+    for _ in range(c):  # centre to the middle site: left-canonical sites and their blocks behind it
+        eng.split_center(True)
+        eng.absorb_bond(True)
+    got, flags = eng.heff_apply_center()
+    assert flags & 7 == 7, flags  # S1 trimmed, S3 trimmed, block-sparse W stage: the bench's configuration
+    Lb, Rb, psi = eng.get_env(0, c), eng.get_env(1, c + 1), eng.get_site(c)
+    assert np.abs(Lb[:, 0, :] - np.eye(D)).max() < 1e-12 and np.abs(Rb[:, M - 1, :] - np.eye(D)).max() < 1e-12
+    ch = max(1, min(D, int(6.4e7 // (M * d * D))))
+    want = orc.heff_apply_chunked(Lb, mpo[c], Rb, psi, ch)
+    assert _rel(got, want) < 1e-12
+    del got, want
+    # a second, random input vector through the same operands (nothing about the apply may depend on x being the state)
+    x = _crandn(np.random.default_rng(5), D, d, D)
+    got, _ = eng.heff_apply_center(x)
+    assert _rel(got, orc.heff_apply_chunked(Lb, mpo[c], Rb, x, ch)) < 1e-12
+    del got, x
+    # the environment update of the same site inside split_center (its W stage is block-sparse too), three bands of the
+    # new block against the oracle as above, plus the identity block the next site's apply will rely on
+    eng.split_center(True)
+    A, gl = eng.get_site(c), eng.get_env(0, c + 1)
+    scale = np.abs(gl).max()
+    for j0 in (0, D // 2 - 32, D - 64):
+        wl = _env_left_band(orc, Lb, A, mpo[c], j0, j0 + 64)
+        assert np.abs(gl[:, :, j0 : j0 + 64] - wl).max() < 1e-12 * scale
+    assert np.abs(gl[:, 0, :] - np.eye(D)).max() < 1e-12
+    eng.close()
+
+
+def test_c5_real_workload_one_time_step():
+    """BASELINE configs[4] as bench.py runs it: the dissipative, non-Hermitian generator synthetic_liouvillian_mpo(L=128,
+    M=16, gamma=0.002), D = 512, Arnoldi, conserve_norm off, the full chain.  One whole time step in both complex-product
+    modes (3M / 4M: different arithmetic, different tiles) must agree; a step is undone by the step with -dt (the
+    splitting is symmetric whatever the generator); one interior site exponential (512 x 4 x 512, M = 16) equals the
+    oracle's short-iterative Arnoldi (_integrator.py:287-432) with the same Krylov count."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+    from pytdscf_amd import engine as E
+    from pytdscf_amd import synthetic as syn
+
+    L, D, dt = 128, 512, 0.5
+    mpo = syn.synthetic_liouvillian_mpo(L, 16, seed=0, gamma=0.002)
+    res = {}
+    for mode in ("3m", "4m"):
+        E.set_gemm_mode(mode)
+        try:
+            eng = TDVPEngine(L, integrator="arnoldi", conserve_norm=False)
+            eng.set_mpo(mpo)
+            eng.init_random([4] * L, D, seed=1)
+            assert max(eng.bond_dims()) == D
+            a0, n0 = eng.autocorr(), eng.norm()
+            eng.propagate(dt)
+            res[mode] = (eng.norm(), eng.autocorr(), eng.expectation(), eng.krylov_stats())
+            if mode == "3m":
+                assert abs(res[mode][0] - n0) > 1e-6  # the generator is dissipative: the norm is NOT conserved
+                eng.propagate(-dt)
+                assert abs(eng.norm() - n0) < 1e-6 and abs(eng.autocorr() - a0) < 1e-6 * abs(a0)
+                # one interior site exponential against the oracle's Arnoldi
+                eng.build_envs(1)
+                c = L // 2
+                for _ in range(c):
+                    eng.split_center(True)
+                    eng.absorb_bond(True)
+                assert eng.get_site_shape(c)[:3] == (D, 4, D)
+                Lb, Rb, psi = eng.get_env(0, c), eng.get_env(1, c + 1), eng.get_site(c)
+                k0 = eng.krylov_memory(c)
+                eng.site_exp(dt)
+                want, k = orc.sil_arnoldi(-0.5j * dt, lambda v: orc.heff_apply(Lb, mpo[c], Rb, v), psi, 1e-9, k0, False, None)
+                assert eng.krylov_memory(c) == k
+                assert _rel(eng.get_site(c), want) < 1e-9
+            eng.close()
+        finally:
+            E.set_gemm_mode("3m")
+    n3, a3, e3, k3 = res["3m"]
+    n4, a4, e4, k4 = res["4m"]
+    assert k3 == k4
+    assert abs(n3 - n4) < 1e-10 and abs(a3 - a4) < 1e-9 * abs(a3) and abs(e3 - e4) < 1e-9 * abs(e3)
