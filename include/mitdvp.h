@@ -263,6 +263,12 @@ int mitdvp_shard_step(mitdvp_shard* h, double dt_au);                           
 int mitdvp_shard_sweep(mitdvp_shard* h, double dt_au, int forward, int skip_end);
 int mitdvp_shard_junctions(mitdvp_shard* h, double dt_au, int parity);
 int mitdvp_shard_traffic(mitdvp_shard* h, double* bytes, long* messages);        /* halo traffic sent so far */
+/* Panel factorisation of the QR gauge move (SiteCoef.gauge_trf, _site_cls.py:138-292 = LAPACK zgeqrf + zungqr):
+ * 1 (default) = CholeskyQR2 of each 32-column panel + reconstruction of LAPACK's Householder vectors / T / tau / signs
+ * of diag(R) from the orthonormal panel, falling back to 0 = one Householder step per launch (unconditionally stable)
+ * when a conditioning check on the device fails.  Process-wide, like mitdvp_set_gemm_mode. */
+int mitdvp_set_qr_fast(int on);
+int mitdvp_get_qr_fast(void);
 /* warm-up memory of the local solves at a site (_Debug.niter_krylov[isite], _integrator.py:178-186) */
 int mitdvp_get_krylov_memory(mitdvp_engine* h, int isite, int* k);
 int mitdvp_set_krylov_memory(mitdvp_engine* h, int isite, int k);

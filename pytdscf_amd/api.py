@@ -456,34 +456,42 @@ class Simulator:
         self.jobname, self.model, self.t2_trick, self.verbose = jobname, model, t2_trick, verbose
 
     # ---- checkpoint / restart (simulator_cls.py:413-418, :500-506, :577-589) ------------
-    # The reference pickles its WFunc object graph with dill (wf_{jobname}{ext}.pkl); that
-    # format is the reference's classes, so the shell keeps the same file stem, extensions
-    # and call sites but stores the site tensors + gauge tags as wf_{jobname}{ext}.npz.
+    # dill pickles wf_{jobname}{ext}.pkl at the reference's call sites and with the attribute graph its readers use
+    # (wf.ci_coef.superblock_states[istate][isite].data / .gauge / .isite): pytdscf_amd/checkpoint.py.  Restart also
+    # accepts the wf_*.npz container earlier versions of the shell wrote.
     def _wf_path(self, ext):
-        return f"wf_{self.jobname}{ext}.npz"
+        return f"wf_{self.jobname}{ext}.pkl"
 
     def save_wavefunction(self, wf, ext=""):
-        eng = wf.engine
-        if self.model.nstate > 1:
-            st = eng.get_states()
-            np.savez(self._wf_path(ext), nsite=np.array(eng.nsite), nstate=np.array(eng.nstate),
-                     space=np.array(self.model.space),
-                     **{f"site{s_}_{i}": c for s_, cs in enumerate(st) for i, c in enumerate(cs)})
-            return
-        gauges = np.array([eng.get_site_shape(i)[3] for i in range(eng.nsite)])
-        np.savez(self._wf_path(ext), nsite=np.array(eng.nsite), gauges=gauges, space=np.array(self.model.space),
-                 **{f"site{i}": c for i, c in enumerate(eng.get_mps())})
+        from . import checkpoint
+
+        checkpoint.save(self._wf_path(ext), wf.engine, self.model.space, self.model.nstate)
+
+    def _load_states(self, ext):
+        """[[(tensor, gauge), ...] per state] from wf_{jobname}{ext}.pkl (or the older .npz)"""
+        from . import checkpoint
+
+        path = self._wf_path(ext)
+        n = len(self.model.dims)
+        if os.path.exists(path):
+            ci = checkpoint.load(path).ci_coef
+            states = [[(np.asarray(s_.data), s_.gauge) for s_ in st] for st in ci.superblock_states]
+        elif os.path.exists(path[:-4] + ".npz"):
+            z = np.load(path[:-4] + ".npz")
+            names = {0: "Psi", 1: "A", 2: "B", -1: "C"}
+            if "nstate" in z:
+                states = [[(z[f"site{s_}_{i}"], "C") for i in range(int(z["nsite"]))] for s_ in range(int(z["nstate"]))]
+            else:
+                states = [[(z[f"site{i}"], names[int(g)]) for i, g in zip(range(int(z["nsite"])), z["gauges"])]]
+        else:
+            raise FileNotFoundError(f"restart=True but {path} does not exist")
+        if len(states) != self.model.nstate or any(len(st) != n or [c.shape[1] for c, _ in st] != list(self.model.dims) for st in states):
+            raise ValueError(f"{path} does not match the model's sites / states")
+        return states
 
     def _load_cores(self, ext):
-        path = self._wf_path(ext)
-        if not os.path.exists(path):
-            raise FileNotFoundError(f"restart=True but {path} does not exist")
-        z = np.load(path)
-        n = int(z["nsite"])
-        if n != len(self.model.dims) or [z[f"site{i}"].shape[1] for i in range(n)] != list(self.model.dims):
-            raise ValueError(f"{path} does not match the model's sites")
-        names = {0: "Psi", 1: "A", 2: "B", -1: "C"}
-        return [z[f"site{i}"] for i in range(n)], [names[int(g)] for g in z["gauges"]]
+        st = self._load_states(ext)[0]
+        return [c for c, _ in st], [g for _, g in st]
 
     def _engine_multistate(self, integrator, conserve_norm, thresh, relax=False, restart_ext=None):
         """nstate > 1: one MPS per electronic state, Hamiltonian / observable blocks per state pair."""
@@ -498,14 +506,8 @@ class Simulator:
         if restart_ext is None:
             eng.set_states([m.initial_cores(s_) for s_ in range(m.nstate)], weights=m.estate_weights())
         else:
-            path = self._wf_path(restart_ext)
-            if not os.path.exists(path):
-                raise FileNotFoundError(f"restart=True but {path} does not exist")
-            z = np.load(path)
-            if int(z["nsite"]) != len(m.dims) or "nstate" not in z or int(z["nstate"]) != m.nstate:
-                raise ValueError(f"{path} does not match the model's sites / states")
-            for s_ in range(m.nstate):  # saved in the site-0-centred canonical form
-                eng.set_state(s_, [z[f"site{s_}_{i}"] for i in range(len(m.dims))])
+            for s_, st in enumerate(self._load_states(restart_ext)):  # saved in the site-0-centred canonical form
+                eng.set_state(s_, [c for c, _ in st])
         return eng, ids
 
     def _engine(self, integrator, conserve_norm, thresh, relax=False, restart_ext=None):
@@ -622,11 +624,12 @@ class Simulator:
                 eng.propagate(dt_au)
             self.save_wavefunction(wf, savefile_ext)
             if reduced_density is not None and self.rdm_trace:
-                # the reference writes reduced_density.nc (netCDF4, properties.py:156-209); same
-                # content as arrays: time[t] and rho_{key}[t, ...] per requested key
-                keys = list(self.rdm_trace[0][1])
-                np.savez(os.path.join(outdir, "reduced_density.npz"), time=np.array([t for t, _ in self.rdm_trace]),
-                         **{f"rho_{k}": np.array([r[k] for _, r in self.rdm_trace]) for k in keys})
+                # reduced_density.nc in the reference's layout (properties.py:156-209): time(step) and
+                # rho_{key}_{istate}(step, Q.., Q..); NETCDF4 compound type with netCDF4, NetCDF-3 + (re, im) axis without
+                from .util.nc_writer import write_reduced_density_nc
+
+                write_reduced_density_nc(os.path.join(outdir, "reduced_density.nc"), [t for t, _ in self.rdm_trace],
+                                         [r for _, r in self.rdm_trace])
         finally:
             for f in files.values():
                 f.close()

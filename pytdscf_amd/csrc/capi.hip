@@ -155,6 +155,8 @@ int mitdvp_fold_block_range(mitdvp_engine* h, int op_id, int conj_bra, int from_
 int mitdvp_site_rdm_blocks(mitdvp_engine* h, int isite, const double* left, const double* right, double* reim_out) {
   ENG_CALL(h, { NEED(left, right, reim_out); h->e->site_rdm_blocks(isite, left, right, reim_out); });
 }
+int mitdvp_set_qr_fast(int on) { mitdvp::qr_set_fast(on); return MITDVP_OK; }
+int mitdvp_get_qr_fast(void) { return mitdvp::qr_get_fast(); }
 int mitdvp_heff_apply_center(mitdvp_engine* h, const double* reim_in, double* reim_out, int* flags) {
   ENG_CALL(h, { NEED(reim_out); h->e->heff_apply_center(reim_in, reim_out, flags); });
 }

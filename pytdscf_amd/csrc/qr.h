@@ -18,4 +18,9 @@ size_t qr_work_elems(int m, int n, int next = 0);
 void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next = 0,
                     SmallSync* sy = nullptr);
 
+// panel factorisation: 1 = CholeskyQR2 + Householder reconstruction with the per-column kernels as the fallback
+// (default), 0 = per-column kernels only
+void qr_set_fast(int on);
+int qr_get_fast();
+
 }  // namespace mitdvp

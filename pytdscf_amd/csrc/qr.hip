@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <type_traits>
 
@@ -638,6 +639,23 @@ __global__ __launch_bounds__(512) void k_qr_panel(QrPanelArgs g) {
 // megabytes of partials per column)
 static int qr_rows_for(int m) { return m <= 16384 ? 32 : (m <= 131072 ? 128 : 256); }
 
+// qr_fast.hip: CholeskyQR2 panel + Householder reconstruction
+size_t qr_fast_work_elems(int m, int n);
+int qr_fast_panel(hipStream_t st, zc* A, long lda, int m, int j0, int nbp, zc* Vp, zc* Tp, zc* tau, zc* ws, int* flag);
+
+// MITDVP_QR_FAST=0 / qr_set_fast(0): always the per-column Householder panel (A/B runs)
+static int g_qr_fast = -1;
+static bool qr_fast_enabled() {
+  if (g_qr_fast < 0) g_qr_fast = !(std::getenv("MITDVP_QR_FAST") && std::atoi(std::getenv("MITDVP_QR_FAST")) == 0) ? 1 : 0;
+  return g_qr_fast != 0;
+}
+void qr_set_fast(int on) { g_qr_fast = on ? 1 : 0; }
+int qr_get_fast() { return qr_fast_enabled() ? 1 : 0; }
+// shapes whose panels keep failing the conditioning checks (rank-deficient / strongly graded tensors) skip the fast
+// attempt for a while: 2, 4, ... 64 factorisations after each consecutive failure
+struct QrBackoff { int fails = 0, skip = 0; };
+static thread_local std::map<long, QrBackoff> g_qr_backoff;
+
 size_t qr_work_elems(int m, int n, int next) {
   const int nblk = (m + 31) / 32;  // upper bound over all row-block sizes
   const int npan = (n + QR_NB - 1) / QR_NB;
@@ -649,10 +667,17 @@ size_t qr_work_elems(int m, int n, int next) {
   e += n;                          // tau
   e += 2 * (size_t)nblk * QR_NB;   // partial y, double buffered
   e += 2 * QR_NB;                  // exported row, double buffered
+  e += qr_fast_work_elems(m, n);   // CholeskyQR2 panels: input copy, panel buffers, flag
   return e;
 }
 
+static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast);
+
 void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy) {
+  qr_impl(st, A, m, n, Q, R, work, nlaunch, next, sy, qr_fast_enabled());
+}
+
+static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast) {
   if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
   if (next < 0 || n + next > m) throw ArgError("qr: more orthogonal-complement columns requested than exist");
   if (n <= 0) return;
@@ -698,6 +723,22 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   zc* tau = T + (size_t)npan * QR_NB * QR_NB;
   zc* py[2] = {tau + n, tau + n + (size_t)nblk_max * QR_NB};
   zc* rowb[2] = {py[1] + (size_t)nblk_max * QR_NB, py[1] + (size_t)nblk_max * QR_NB + QR_NB};
+  // CholeskyQR2 panels + Householder reconstruction (qr_fast.hip): the input is kept so that the per-column kernels can
+  // redo the factorisation when a conditioning check fails
+  zc* backup = rowb[1] + QR_NB;
+  zc* fws = backup + (size_t)m * n;
+  int* fflag = reinterpret_cast<int*>(fws + qr_fast_work_elems(m, n) - (size_t)m * n - 8);
+  const long bkey = (long)m * 100003L + n;
+  if (fast && m >= 2 * QR_NB) {
+    QrBackoff& bo = g_qr_backoff[bkey];
+    if (bo.skip > 0) { bo.skip -= 1; fast = false; }
+  } else {
+    fast = false;
+  }
+  if (fast) {
+    HIP_CHECK(hipMemcpyAsync(backup, A, (size_t)m * n * sizeof(zc), hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemsetAsync(fflag, 0, sizeof(int), st));
+  }
   long nl = 0;
   const zc one = make_double2(1.0, 0.0), mone = make_double2(-1.0, 0.0);
 
@@ -727,7 +768,9 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     while ((mp + rb - 1) / rb > GX_MAXG && rb < 256) rb *= 2;
     if (const char* e = std::getenv("MITDVP_QR_RB")) rb = std::max(32, std::min(256, std::atoi(e)));
     const int gpan = (mp + rb - 1) / rb;
-    if (panel_on && sy && sy->slots && gpan <= GX_MAXG) {
+    if (fast) {
+      nl += qr_fast_panel(st, A, lda, m, j0, nbp, Vp, Tp, tau, fws, fflag);
+    } else if (panel_on && sy && sy->slots && gpan <= GX_MAXG) {
       // one persistent launch: column steps, T and the unit-lower copy of the panel
       sy->launches += 1;
       if ((sy->launches & 0xFFFFFu) == 0u) sy->launches += 1;  // tag 0 is the cleared state
@@ -771,6 +814,21 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
       zgemm(st, u);
       nl += 3;
     }
+  }
+  if (fast) {  // one look at the conditioning checks of all panels
+    int bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, fflag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    QrBackoff& bo = g_qr_backoff[bkey];
+    if (bad) {
+      bo.fails = std::min(bo.fails + 1, 6);
+      bo.skip = 1 << bo.fails;
+      HIP_CHECK(hipMemcpyAsync(A, backup, (size_t)m * n * sizeof(zc), hipMemcpyDeviceToDevice, st));
+      if (nlaunch) *nlaunch += nl;
+      qr_impl(st, A, m, n, Q, R, work, nlaunch, next, sy, false);
+      return;
+    }
+    bo.fails = 0;
   }
   // R
   if (R) {

@@ -662,6 +662,16 @@ def set_gemm_mode(mode: str):
     _lib.load().mitdvp_set_gemm_mode({"4m": 0, "3m": 1}[mode.lower()])
 
 
+def set_qr_fast(on: bool):
+    """QR panels by CholeskyQR2 + Householder reconstruction (True, library default) or one Householder step per
+    launch only (False); process-wide."""
+    _lib.load().mitdvp_set_qr_fast(int(bool(on)))
+
+
+def get_qr_fast() -> bool:
+    return bool(_lib.load().mitdvp_get_qr_fast())
+
+
 def device_count() -> int:
     """HIP devices visible to this process (0 on a CPU-only box); does not create a context."""
     n = C.c_int()

@@ -1,11 +1,11 @@
 """``read_nc(filename, sites)`` -- the reader analysis scripts use for the reduced densities a
 propagation saved (pytdscf/util/read_nc.py): ``{"time": t[step], (i, j): rho[step, ...], ...}``.
 
-The reference writes ``{jobname}_prop/reduced_density.nc`` with netCDF4 compound types (HDF5;
-properties.py:156-209); this image has no HDF5 stack, so the shell writes the same content as
-``reduced_density.npz`` (arrays ``time`` and ``rho_{key}``).  The reader takes either: an ``.npz``
-written by the shell, or -- where the ``netCDF4`` package exists -- an ``.nc`` file written by the
-reference (variables ``rho_{key}_0`` with real / imag members)."""
+The reference writes ``{jobname}_prop/reduced_density.nc`` as NETCDF4 with a compound complex type
+(properties.py:156-209).  The shell writes the same variables (``pytdscf_amd/util/nc_writer.py``): NETCDF4 with the
+compound type where the ``netCDF4`` package exists, otherwise NetCDF-3 with a trailing (real, imag) dimension.  This
+reader takes all three: the shell's NetCDF-3 file, a NETCDF4 file written by the shell or by the reference, and the
+``.npz`` container older runs of the shell wrote."""
 
 from __future__ import annotations
 
@@ -14,9 +14,14 @@ import os
 import numpy as np
 
 
+def _is_hdf5(filename: str) -> bool:
+    with open(filename, "rb") as f:
+        return f.read(8) == b"\x89HDF\r\n\x1a\n"
+
+
 def read_nc(filename: str, sites) -> dict:
     if not os.path.exists(filename) and filename.endswith(".nc") and os.path.exists(filename[:-3] + ".npz"):
-        filename = filename[:-3] + ".npz"  # same directory, the shell's container format
+        filename = filename[:-3] + ".npz"
     data = {}
     if filename.endswith(".npz"):
         with np.load(filename) as z:
@@ -27,14 +32,26 @@ def read_nc(filename: str, sites) -> dict:
                     raise ValueError(f"Density data for site {key} varname='{name}' not found in {filename}")
                 data[key] = np.array(z[name])
         return data
+    if not _is_hdf5(filename):  # NetCDF-3 written by the shell: trailing (real, imag) dimension
+        from scipy.io import netcdf_file
+
+        with netcdf_file(filename, "r", mmap=False) as f:
+            data["time"] = np.array(f.variables["time"][:])
+            for key in sites:
+                name = f"rho_{tuple(key)}_0"
+                if name not in f.variables:
+                    raise ValueError(f"Density data for site {key} varname='{name}' not found in {filename}")
+                v = np.array(f.variables[name][:])
+                data[key] = v[..., 0] + 1.0j * v[..., 1]
+        return data
     try:
         import netCDF4 as nc
     except ImportError as e:  # pragma: no cover - not installable in this image
-        raise ImportError("reading a netCDF4 file needs the netCDF4 package; the shell writes reduced_density.npz") from e
+        raise ImportError("reading a NETCDF4 (HDF5) file needs the netCDF4 package") from e
     with nc.Dataset(filename, "r") as f:  # pragma: no cover
         data["time"] = np.array(f.variables["time"][:])
         for key in sites:
-            name = f"rho_{key}_0"
+            name = f"rho_{tuple(key)}_0"
             if name not in f.variables:
                 raise ValueError(f"Density data for site {key} varname='{name}' not found in {filename}")
             v = f.variables[name][:]

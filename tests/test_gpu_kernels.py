@@ -159,6 +159,68 @@ def test_gauge_trf_rank_deficient():
     assert np.abs(np.tensordot(A, s, axes=(2, 0)) - psi).max() < 1e-14
 
 
+@pytest.mark.parametrize("shape", [(128, 4, 128), (512, 4, 512), (100, 5, 77), (64, 3, 160), (40, 16, 300)])
+def test_qr_panels_by_cholesky_qr2_and_householder_reconstruction(shape):
+    """The panel factorisation of the gauge move (csrc/qr_fast.hip): CholeskyQR2 of each 32-column panel, then LAPACK's
+    Householder vectors / T / tau / signs of diag(R) reconstructed from the orthonormal panel.  Q and R must equal
+    scipy's (the reference's zgeqrf + zungqr, _site_cls.py:264-282) to 1e-11 like the per-column Householder kernels,
+    and both forms must agree with each other far below that."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import engine as E
+
+    dl, d, dr = shape
+    rng = np.random.default_rng(dl + 7 * d + 13 * dr)
+    psi = crandn(rng, dl, d, dr)
+    res = {}
+    for fast in (True, False):
+        E.set_qr_fast(fast)
+        try:
+            res[fast] = [E.gauge_trf(psi, "Psi2Asigma") if dl * d >= dr else None,
+                         E.gauge_trf(psi, "Psi2sigmaB") if dr * d >= dl else None]
+        finally:
+            E.set_qr_fast(True)
+    if res[True][0] is not None:
+        A, s = res[True][0]
+        Ar, sr = orc.qr_psi2Asigma(psi)
+        np.testing.assert_allclose(A, Ar, atol=1e-11)
+        np.testing.assert_allclose(s, sr, atol=1e-11 * np.abs(sr).max())
+        Am = A.reshape(dl * d, dr)
+        assert np.abs(Am.conj().T @ Am - np.eye(dr)).max() < 1e-14 * dr
+        assert np.abs(np.tril(s, -1)).max() == 0.0 and np.abs(np.diag(s).imag).max() == 0.0
+        assert np.abs(A - res[False][0][0]).max() < 1e-12 and np.abs(s - res[False][0][1]).max() < 1e-12 * np.abs(sr).max()
+    if res[True][1] is not None:
+        B, s = res[True][1]
+        sr, Br = orc.qr_psi2sigmaB(psi)
+        np.testing.assert_allclose(B, Br, atol=1e-11)
+        np.testing.assert_allclose(s, sr, atol=1e-11 * np.abs(sr).max())
+        assert np.abs(B - res[False][1][0]).max() < 1e-12
+
+
+def test_qr_fast_panels_fall_back_on_rank_deficient_and_graded_input():
+    """CholeskyQR2 cannot factor a rank-deficient panel: the device-side pivot checks must send zero-padded product
+    states (the reference's starts, _site_cls.py:444-448) and strongly graded tensors to the Householder kernels, whose
+    orthonormal completion is what the reference's LAPACK call returns."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import engine as E
+
+    assert E.get_qr_fast()
+    psi = np.zeros((96, 4, 96), dtype=np.complex128)
+    psi[0, :, 0] = [0.5, 0.5, 0.5, 0.5]
+    for _ in range(3):  # repeated: the back-off after a failed attempt must not change results
+        A, s = E.gauge_trf(psi, "Psi2Asigma")
+        Am = A.reshape(384, 96)
+        assert np.abs(Am.conj().T @ Am - np.eye(96)).max() < 1e-13
+        assert np.abs(np.tensordot(A, s, axes=(2, 0)) - psi).max() < 1e-14
+    rng = np.random.default_rng(8)
+    x = crandn(rng, 96, 4, 96) * (10.0 ** (-0.25 * np.arange(96)))[None, None, :]  # columns graded over 24 decades
+    A, s = E.gauge_trf(x, "Psi2Asigma")
+    Ar, sr = orc.qr_psi2Asigma(x)
+    Am = A.reshape(384, 96)
+    assert np.abs(Am.conj().T @ Am - np.eye(96)).max() < 1e-13
+    assert np.abs(np.tensordot(A, s, axes=(2, 0)) - x).max() < 1e-14
+    np.testing.assert_allclose(s, sr, atol=1e-11)
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 7), (33, 33), (64, 20), (20, 64), (128, 128), (257, 257)])
 def test_jacobi_svd_vs_lapack(shape):
     """One-sided Jacobi SVD: singular values to working precision (small ones as

@@ -123,3 +123,36 @@ def test_product_side_synthetic_inputs_equal_the_oracles():
     assert all(np.array_equal(a, b) for a, b in zip(orc.synthetic_liouvillian_mpo(5, 8, seed=2), syn.synthetic_liouvillian_mpo(5, 8, seed=2)))
     assert syn.bond_dims([3] * 5, 4) == orc.bond_dims([3] * 5, 4)
     assert [c.shape for c in syn.random_mps_cores([3] * 5, 4)] == [(a, 3, b) for a, b in orc.bond_dims([3] * 5, 4)]
+
+
+def test_reduced_density_nc_layout_and_reader(tmp_path):
+    """reduced_density.nc as the reference lays it out (Properties._create_nc_file / _export_reduced_densities,
+    properties.py:122-209): dimension step (unlimited), state, Q{idof}; time(step); rho_{key}_{istate}(step, Q.., Q..).
+    Without the netCDF4 package the compound complex type becomes a trailing (real, imag) dimension of a NetCDF-3 file;
+    the reader (the reference's util/read_nc.py contract) returns {"time": ..., key: complex array} either way."""
+    from scipy.io import netcdf_file
+
+    from pytdscf_amd.util import read_nc
+    from pytdscf_amd.util.nc_writer import write_reduced_density_nc
+
+    rng = np.random.default_rng(3)
+    times = [0.0, 0.1, 0.2]
+    recs = [{(3, 3): rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)),
+             (0, 0, 3, 3): rng.standard_normal((4, 4, 2, 2)) + 1j * rng.standard_normal((4, 4, 2, 2)),
+             (1,): rng.standard_normal(5) + 0j} for _ in times]
+    path = str(tmp_path / "reduced_density.nc")
+    fmt = write_reduced_density_nc(path, times, recs)
+    assert fmt in ("NETCDF4", "NETCDF3")
+    got = read_nc(path, [(3, 3), (0, 0, 3, 3), (1,)])
+    np.testing.assert_array_equal(got["time"], times)
+    for k in recs[0]:
+        np.testing.assert_array_equal(got[k], np.array([r[k] for r in recs]))
+    with pytest.raises(ValueError):
+        read_nc(path, [(2, 2)])
+    if fmt == "NETCDF3":
+        with netcdf_file(path, "r", mmap=False) as f:
+            assert f.dimensions["step"] is None and f.dimensions["state"] == 1  # unlimited record dimension
+            assert f.dimensions["Q3"] == 2 and f.dimensions["Q0"] == 4 and f.dimensions["Q1"] == 5
+            assert f.variables["rho_(3, 3)_0"].dimensions == ("step", "Q3", "Q3", "complex")
+            assert f.variables["rho_(0, 0, 3, 3)_0"].dimensions == ("step", "Q0", "Q0", "Q3", "Q3", "complex")
+            assert f.variables["time"].dimensions == ("step",)

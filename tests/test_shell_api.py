@@ -82,14 +82,12 @@ def test_exciton_script_on_gpu(golden, tmp_path, monkeypatch):
     assert abs(wf.norm() - 1) < 1e-12
     lines = open(tmp_path / "LVC_Exciton_test_prop" / "autocorr.dat").read().splitlines()
     assert lines[0].startswith("# time [fs]") and len(lines) == 21
-    z = np.load(tmp_path / "LVC_Exciton_test_prop" / "reduced_density.npz")
-    assert z["time"].shape == (20,) and z["rho_(3, 3)"].shape == (20, 2, 2)
-    np.testing.assert_allclose(z["rho_(3, 3)"][-1], g["ref_pin_rdm33"], atol=1e-9)
-    # the analysis-side reader of the reference (util/read_nc.py), also when asked for the .nc name
+    # reduced_density.nc in the reference's layout (properties.py:156-209), read back by the analysis-side reader of
+    # the reference (util/read_nc.py)
     from pytdscf_amd.util import read_nc
 
     data = read_nc(str(tmp_path / "LVC_Exciton_test_prop" / "reduced_density.nc"), [(3, 3)])
-    assert data["time"].shape == (20,)
+    assert data["time"].shape == (20,) and data[(3, 3)].shape == (20, 2, 2)
     np.testing.assert_allclose(data[(3, 3)][-1], g["ref_pin_rdm33"], atol=1e-9)
     # and the spectrum chain on the auto-correlation file just written
     from pytdscf_amd import spectra
@@ -217,7 +215,16 @@ def test_restart_from_saved_wavefunction(golden, tmp_path, monkeypatch):
     ref = wf_all.get_mps()
     sim2 = Simulator("ckpt", _exciton_model(g), backend="hip")
     sim2.propagate(stepsize=0.1, maxstep=3, savefile_ext="_half")
-    assert (tmp_path / "wf_ckpt_half.npz").exists()
+    assert (tmp_path / "wf_ckpt_half.pkl").exists()
+    # the dill checkpoint carries the attribute graph the reference's readers walk (simulator_cls.py:577-589,
+    # :501-507): wf.ci_coef.superblock_states[istate][isite].data / .gauge / .isite
+    import dill
+
+    with open(tmp_path / "wf_ckpt_half.pkl", "rb") as f:
+        saved = dill.load(f)
+    sites = saved.ci_coef.superblock_states[0]
+    assert saved.ci_coef.nsite == 4 and [s_.gauge for s_ in sites] == ["Psi", "B", "B", "B"] and [s_.isite for s_ in sites] == [0, 1, 2, 3]
+    assert sites[1].data.shape[1] == 8 and sites[3].data.dtype == np.complex128
     e2, wf2 = sim2.propagate(stepsize=0.1, maxstep=3, restart=True, loadfile_ext="_half", savefile_ext="_rest")
     assert e2 == pytest.approx(e_all, rel=1e-9)
     assert abs(abs(orc.overlap(ref, wf2.get_mps())) - 1) < 1e-9
@@ -250,7 +257,7 @@ def test_relax_operate_propagate_workflow(golden, tmp_path, monkeypatch):
     n_o, ref, _ = orc.operate(gs, dip, maxstep=10)
     assert norm == pytest.approx(n_o, rel=1e-9)
     assert abs(abs(orc.overlap(ref, wf_op.get_mps())) - 1) < 1e-9
-    assert (tmp_path / "wf_wfl_operate.npz").exists()
+    assert (tmp_path / "wf_wfl_operate.pkl").exists()
     _, wf_t = Simulator("wfl", m_h, backend="hip").propagate(stepsize=0.05, maxstep=2, restart=True)  # loadfile_ext="_operate"
     from pytdscf_amd import units
 
@@ -480,7 +487,7 @@ def test_multistate_script_on_gpu(golden, tmp_path, monkeypatch):
     nrm, wf_o = sim6.operate(maxstep=10)
     assert nrm == pytest.approx(float(g["operate_n10_norm"]), rel=1e-10)
     np.testing.assert_allclose(wf_o.pop_states(), g["operate_n10_pops"], atol=1e-10)
-    assert (tmp_path / "wf_ms6_operate.npz").exists()
+    assert (tmp_path / "wf_ms6_operate.pkl").exists()
     e6, wf6 = sim6.propagate(stepsize=0.05, maxstep=2, restart=True)  # loadfile_ext="_operate"
     assert wf6.norm() == pytest.approx(1.0, abs=1e-12)
     np.testing.assert_allclose(sum(wf6.pop_states()), 1.0, atol=1e-12)

@@ -2,6 +2,11 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytdscf_amd import TDVPEngine
+from pytdscf_amd import engine as E
+
+if len(sys.argv) > 1:  # python tools/qr_time.py 0|1 : panel algorithm (0 per-column Householder, 1 CholeskyQR2 + reconstruction)
+    E.set_qr_fast(bool(int(sys.argv[1])))
+print("qr_fast", E.get_qr_fast())
 
 shapes = [("C4i", 16, 1024, 8), ("C5", 4, 512, 12), ("C3", 32, 128, 6), ("C2", 10, 32, 10), ("C4", 16, 1024, 5), ("mid", 8, 256, 10)]
 for name, d, D, L in shapes:
