@@ -53,6 +53,23 @@ size_t small_chain_lds(const SmallChain& c, bool exp_mode);
 // choose nsc / cs for a chain whose other fields are set; false when the chain does not qualify
 bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu);
 
+// Persistent launches (kernels whose workgroups exchange data inside the launch and must all be resident) of several
+// engines on one GPU are chained through a per-device event while more than one engine uses them: construct around
+// the launch.  persistent_register(+1 / -1): an engine starts / stops using the family on the current device.
+void persistent_register(int delta);
+class PersistentLaunch {
+ public:
+  explicit PersistentLaunch(hipStream_t st);
+  ~PersistentLaunch();
+  PersistentLaunch(const PersistentLaunch&) = delete;
+  PersistentLaunch& operator=(const PersistentLaunch&) = delete;
+
+ private:
+  hipStream_t st_;
+  int slot_;
+  bool chained_ = false;
+};
+
 void small_sync_alloc(SmallSync& s, int nsite, hipStream_t st);
 void small_sync_free(SmallSync& s);
 

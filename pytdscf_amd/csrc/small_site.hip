@@ -790,8 +790,65 @@ bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
   return false;
 }
 
+// ---- persistent launches of several engines on one GPU ---------------------------------------------------------
+// k_small_site / k_qr_panel exchange data BETWEEN their workgroups inside one launch, so all workgroups of a launch
+// must be resident together.  Two such grids from two engines (an ensemble of trajectories on one GPU, host threads)
+// could each get part of the chip and wait for the rest of themselves until the 2 s timeout.  Per device, process
+// wide: while more than one engine uses the family, every persistent launch first waits (on the device, no host
+// synchronisation) for the event the previous persistent launch recorded, whatever engine and stream issued it.
+namespace {
+struct PersistentChain {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  bool recorded = false;
+  hipStream_t last = nullptr;
+  int users = 0;
+};
+PersistentChain g_pchain[64];
+inline int current_device_slot() {
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  return dev >= 0 && dev < 64 ? dev : 63;
+}
+}  // namespace
+
+void persistent_register(int delta) {
+  PersistentChain& c = g_pchain[current_device_slot()];
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.users += delta;
+  if (delta > 0 && c.users == 2) {
+    // the engine that was alone so far recorded nothing: let its launches drain once, from now on the chain orders them
+    HIP_CHECK(hipDeviceSynchronize());
+    c.recorded = false;
+  }
+}
+
+PersistentLaunch::PersistentLaunch(hipStream_t st) : st_(st), slot_(current_device_slot()) {
+  PersistentChain& c = g_pchain[slot_];
+  c.mu.lock();
+  chained_ = c.users > 1;
+  if (!chained_) return;
+  try {
+    if (!c.ev) HIP_CHECK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+    if (c.recorded && c.last != st) HIP_CHECK(hipStreamWaitEvent(st, c.ev, 0));
+  } catch (...) {
+    c.mu.unlock();
+    throw;
+  }
+}
+
+PersistentLaunch::~PersistentLaunch() {
+  PersistentChain& c = g_pchain[slot_];
+  if (chained_ && c.ev && hipEventRecord(c.ev, st_) == hipSuccess) {
+    c.recorded = true;
+    c.last = st_;
+  }
+  c.mu.unlock();
+}
+
 void small_sync_alloc(SmallSync& s, int nsite, hipStream_t st) {
   if (s.words) return;
+  persistent_register(+1);
   HIP_CHECK(hipMalloc(&s.words, 16 * sizeof(unsigned)));
   HIP_CHECK(hipMalloc(&s.slots, (size_t)2 * SS_MAXG * SS_NGR * sizeof(unsigned long long)));
   HIP_CHECK(hipMalloc(&s.stats, 4 * sizeof(long long)));
@@ -805,6 +862,9 @@ void small_sync_alloc(SmallSync& s, int nsite, hipStream_t st) {
 }
 
 void small_sync_free(SmallSync& s) {
+  if (s.words) {
+    try { persistent_register(-1); } catch (...) {}
+  }
   if (s.words) (void)hipFree(s.words);
   if (s.slots) (void)hipFree(s.slots);
   if (s.stats) (void)hipFree(s.stats);
@@ -850,7 +910,10 @@ static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
   }
   g.trace = tracing ? trace_buf : nullptr;
   if (tracing) HIP_CHECK(hipMemsetAsync(trace_buf, 0, 1024 * sizeof(long long), st));
-  hipLaunchKernelGGL(k_small_site, dim3(c.na * c.nsc), dim3(SS_THREADS), lds, st, g);
+  {
+    PersistentLaunch chain(st);  // ordered after the previous persistent launch of ANY engine on this GPU
+    hipLaunchKernelGGL(k_small_site, dim3(c.na * c.nsc), dim3(SS_THREADS), lds, st, g);
+  }
   HIP_CHECK(hipGetLastError());
   if (tracing) {  // debugging aid: phase timeline of workgroup 0, microseconds since its first stamp
     long long h[1024];

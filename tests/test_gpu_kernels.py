@@ -281,6 +281,55 @@ def test_concurrent_engines_from_host_threads():
         e.close()
 
 
+def test_persistent_launches_of_eight_engines_from_eight_host_threads():
+    """8 engines x 200 time steps from 8 host threads on one GPU, every local exponential a persistent one-launch
+    kernel (k_small_site needs all its workgroups resident together): the per-device event chain (small_site.hip,
+    PersistentLaunch) orders the persistent launches of ALL engines, so no two partially resident grids can wait for
+    each other until the exchange time-out.  Results are bit-identical to the same engines run one after the other."""
+    import threading
+
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L, d, M, D, nstep, neng = 6, 4, 4, 16, 200, 8
+    mpo = orc.synthetic_mpo(L, d, M, seed=2)
+
+    def make(seed):
+        e = TDVPEngine(L)
+        e.set_mpo(mpo)
+        e.init_random([d] * L, D, seed=seed)
+        return e
+
+    errors = []
+
+    def run(e, n):
+        try:
+            for _ in range(n):
+                e.propagate(0.3)
+        except Exception as exc:  # noqa: BLE001 -- a time-out would surface here as MitdvpError
+            errors.append(exc)
+
+    ref = make(1)
+    run(ref, nstep)
+    assert not errors
+    c0 = ref.counters()
+    assert c0["n_launch"] < 40 * 2 * nstep  # the one-launch family is what ran (a multi-launch sweep needs > 500)
+    want = np.concatenate([c.reshape(-1) for c in ref.get_mps()])
+    ref.close()
+    engs = [make(1) for _ in range(neng)]  # the same trajectory eight times: any cross-talk shows as a difference
+    th = [threading.Thread(target=run, args=(e, nstep)) for e in engs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for e in engs:
+        got = np.concatenate([c.reshape(-1) for c in e.get_mps()])
+        assert np.array_equal(got, want)
+        assert abs(e.norm() - 1) < 1e-12
+        e.close()
+
+
 def test_block_sparse_w_stage_is_bitwise_the_dense_one(monkeypatch):
     """The W stage of an apply / environment update skips the zero (c, t) blocks of a finite-state-machine MPO
     (rows of W2 ordered (t, i), K-tile list per row tile, rows of Y mapped back): adding exact zeros changes
