@@ -269,6 +269,8 @@ int mitdvp_shard_traffic(mitdvp_shard* h, double* bytes, long* messages);       
  * when a conditioning check on the device fails.  Process-wide, like mitdvp_set_gemm_mode. */
 int mitdvp_set_qr_fast(int on);
 int mitdvp_get_qr_fast(void);
+/* device time (HIP events) of one m x n factorisation with Q and R formed, random full-rank input */
+int mitdvp_bench_qr(int device, int m, int n, int reps, double* ms_out, long* launches);
 /* warm-up memory of the local solves at a site (_Debug.niter_krylov[isite], _integrator.py:178-186) */
 int mitdvp_get_krylov_memory(mitdvp_engine* h, int isite, int* k);
 int mitdvp_set_krylov_memory(mitdvp_engine* h, int isite, int k);

@@ -561,6 +561,39 @@ int mitdvp_bench_heff(int device, int dl, int d, int dr, int ml, int mr, int rep
   });
 }
 
+// device time of one (m x n) QR (Q and R formed), averaged over reps; launches per factorisation in *launches
+int mitdvp_bench_qr(int device, int m, int n, int reps, double* ms_out, long* launches) {
+  return guard(nullptr, [&] {
+    using namespace mitdvp;
+    NEED(ms_out);
+    if (m < n || n < 1 || reps < 1) throw ArgError("bench_qr: need m >= n >= 1, reps >= 1");
+    Engine e(unit_cfg(device));
+    hipStream_t st = e.stream();
+    Dev A((size_t)m * n), A0((size_t)m * n), Q((size_t)m * n), R((size_t)n * n), work(qr_work_elems(m, n));
+    vec_randn(st, A0.p(), (long)m * n, 21);
+    long nl = 0;
+    auto once = [&] {
+      HIP_CHECK(hipMemcpyAsync(A.p(), A0.p(), (size_t)m * n * sizeof(zc), hipMemcpyDeviceToDevice, st));
+      qr_householder(st, A.p(), m, n, Q.p(), R.p(), work.p(), &nl, 0, nullptr);
+    };
+    once();
+    nl = 0;
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, st));
+    for (int i = 0; i < reps; ++i) once();
+    HIP_CHECK(hipEventRecord(b, st));
+    HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms / reps;
+    if (launches) *launches = nl / reps;
+    HIP_CHECK(hipEventDestroy(a));
+    HIP_CHECK(hipEventDestroy(b));
+  });
+}
+
 int mitdvp_heff_selfcheck(int device, int dl, int d, int dr, int ml, int mr, double out[4]) {
   return guard(nullptr, [&] {
     using namespace mitdvp;

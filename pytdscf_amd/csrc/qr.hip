@@ -726,8 +726,12 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   // CholeskyQR2 panels + Householder reconstruction (qr_fast.hip): the input is kept so that the per-column kernels can
   // redo the factorisation when a conditioning check fails
   zc* backup = rowb[1] + QR_NB;
-  zc* fws = backup + (size_t)m * n;
-  int* fflag = reinterpret_cast<int*>(fws + qr_fast_work_elems(m, n) - (size_t)m * n - 8);
+  zc* vall = backup + (size_t)m * n;  // fast path: every panel's V (unit lower trapezoid, contiguous), kept for the Q formation
+  zc* fws = vall + (size_t)m * n;
+  int* fflag = reinterpret_cast<int*>(fws + qr_fast_work_elems(m, n) - 2 * (size_t)m * n - 8);
+  auto vpanel = [&](int ip) {  // panel ip starts at row / column 32 ip: sum_{q < ip} (m - 32 q) 32 elements before it
+    return vall + ((size_t)ip * m - (size_t)QR_NB * ip * (ip - 1) / 2) * QR_NB;
+  };
   const long bkey = (long)m * 100003L + n;
   if (fast && m >= 2 * QR_NB) {
     QrBackoff& bo = g_qr_backoff[bkey];
@@ -762,6 +766,7 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
       }
     };
     zc* Tp = T + (size_t)ip * QR_NB * QR_NB;
+    if (fast) Vp = vpanel(ip);
     // rows per workgroup: as few as the 64-workgroup exchange allows -- the column update of a step is spread
     // over (rows / rb) compute units, and that, not the exchange, is what a step waits for when rb is large
     int rb = 32;
@@ -843,7 +848,8 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   for (int ip = npan - 1; ip >= 0; --ip) {
     const int j0 = ip * QR_NB, j1 = min(n, j0 + QR_NB), nbp = j1 - j0, mp = m - j0;
     const int nq = nqt - j0;
-    extract_v(j0, nbp);
+    if (fast) Vp = vpanel(ip);
+    else extract_v(j0, nbp);
     zc* Tp = T + (size_t)ip * QR_NB * QR_NB;
     zc* Q2 = Q + (long)j0 * nqt + j0;
     ZgemmDesc w = zgemm_desc(Vp, Q2, W, nbp, nq, mp);  // W = V^H Q2

@@ -23,7 +23,8 @@ namespace mitdvp {
 
 namespace {
 constexpr int NB = QR_NB;          // 32
-constexpr int FQ_ROWS = 128;       // panel rows per workgroup of the tall-skinny kernels
+constexpr int FQ_NQ = 1;             // matrix elements per thread of the 32 x 32 kernels (1024 / FQ_NQ threads)
+constexpr int FQ_RS = NB / FQ_NQ;     // row stride between a thread's elements
 constexpr double CHOL_TOL = 1e-11;  // pivot / diagonal below this: the panel is too ill-conditioned for CholeskyQR2
 
 __device__ __forceinline__ zc cmul(zc a, zc b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -40,11 +41,12 @@ __device__ __forceinline__ zc cdiv(zc a, zc b) {
 
 // partial Gram matrices of a tall panel: part[blk][i][j] = sum_{rows of blk} conj(P[r][i]) P[r][j]
 // (P = mp x nb, leading dimension ld; the rows of a workgroup are summed in a fixed order: deterministic)
-__global__ __launch_bounds__(256) void k_fq_gram(const zc* __restrict__ P, long ld, int mp, int nb, zc* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_fq_gram(const zc* __restrict__ P, long ld, int mp, int nb, zc* __restrict__ part,
+                                                 int rows_per_blk) {
   __shared__ zc tile[32][NB + 1];
   const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
-  const long r0 = (long)blockIdx.x * FQ_ROWS;
-  const int nr = (int)min((long)FQ_ROWS, mp - r0);
+  const long r0 = (long)blockIdx.x * rows_per_blk;
+  const int nr = (int)min((long)rows_per_blk, mp - r0);
   zc acc[2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};
   for (int base = 0; base < nr; base += 32) {
     const int rows = min(32, nr - base);
@@ -71,80 +73,173 @@ __global__ __launch_bounds__(256) void k_fq_gram(const zc* __restrict__ P, long 
 }
 
 // G = sum of the partials; G = R^H R (upper Cholesky factor, real positive diagonal); Rinv = R^-1.
-// second != 0: additionally Rtot = R * Rprev (the panel's triangular factor after both rounds).
+// second != 0: additionally Rtot = R * Rprev (the panel's triangular factor after both rounds), else Rtot = R.
+// One workgroup, FQ_NQ matrix elements per thread.  The 32 pivots are a chain of rank-1 updates in LDS
+// with ONE barrier per step (row k is used unscaled, G[k][i]* G[k][j] / G[k][k], and scaled once at the end); the
+// inverse is the same chain run backwards on [R | I] (Gauss-Jordan), again one barrier per step.  (Measured on the
+// way here: a single wave holding the matrix in registers, 94 us per call -- ~12 000 dependent instructions; one
+// element per thread with three barriers per step, 45 us -- a 16-wave barrier costs ~0.3 us.)
 // A pivot that is not clearly positive raises *flag (sticky) and leaves the identity behind.
-__global__ __launch_bounds__(1024) void k_fq_chol(const zc* __restrict__ part, int nblk, int nb, zc* __restrict__ Rinv_out,
-                                                  const zc* __restrict__ Rprev, zc* __restrict__ Rtot, int second,
-                                                  int* __restrict__ flag) {
-  __shared__ zc G[NB][NB + 1];
-  __shared__ zc R[NB][NB + 1];
-  __shared__ zc Ri[NB][NB + 1];
+__global__ __launch_bounds__(1024 / FQ_NQ) void k_fq_chol(const zc* __restrict__ part, int nblk, int nb, zc* __restrict__ Rinv_out,
+                                                 const zc* __restrict__ Rprev, zc* __restrict__ Rtot, int second,
+                                                 int* __restrict__ flag) {
+  __shared__ zc G[NB][NB + 1];   // Gram matrix -> R (upper)
+  __shared__ zc W[NB][NB + 1];   // inverse being built
+  __shared__ zc P1[NB][NB + 1];  // Rprev (a global load inside the product loop below costs a memory latency per term)
   __shared__ double d0[NB];
-  __shared__ int bad;
-  const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
-  zc g = make_double2(0.0, 0.0);
-  if (i < nb && j < nb)
-    for (int b = 0; b < nblk; ++b) g = cadd(g, part[(size_t)b * NB * NB + i * NB + j]);
-  G[i][j] = g;
-  R[i][j] = make_double2(0.0, 0.0);
-  Ri[i][j] = make_double2(0.0, 0.0);
-  if (threadIdx.x == 0) bad = 0;
+  const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;  // my elements: (i0 + 8 q, j), q = 0..3
+#pragma unroll
+  for (int q = 0; q < FQ_NQ; ++q) {
+    const int i = i0 + FQ_RS * q;
+    P1[i][j] = second ? Rprev[i * NB + j] : make_double2(0.0, 0.0);
+    zc g = make_double2(0.0, 0.0);
+    if (i < nb && j < nb) {
+      const zc* pp = part + i * NB + j;
+      int b = 0;
+      for (; b + 8 <= nblk; b += 8) {  // eight loads in flight (one exposed memory latency per batch, not per partial)
+        zc v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(b + u) * NB * NB];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g = cadd(g, v[u]);
+      }
+      for (; b < nblk; ++b) g = cadd(g, pp[(size_t)b * NB * NB]);
+    }
+    if (i >= nb || j >= nb) g = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);  // pad with the identity
+    if (i == j) g.y = 0.0;
+    G[i][j] = g;
+    W[i][j] = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+    if (i == j) d0[i] = g.x;
+  }
   __syncthreads();
-  if (i == j) d0[i] = G[i][i].x;
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
+  if (second) {
+    // After the first round the panel is orthonormal to eps cond^2: G = I + E with a tiny E, and to first order
+    // chol(I + E) = I + U, U = triu(E, 1) + diag(E) / 2, (I + U)^-1 = I - U; the neglected terms are O(|E|^2), i.e.
+    // below rounding when |E| < 1e-8 -- no chain of 32 pivots, no inverse.  Larger E: the full factorisation below.
+    __shared__ double emax_s[16];
+    double e = 0.0;
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      const zc g = G[i][j];
+      e = fmax(e, fmax(fabs(g.x - (i == j ? 1.0 : 0.0)), fabs(g.y)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e = fmax(e, __shfl_xor(e, o, 64));
+    if ((threadIdx.x & 63) == 0) emax_s[threadIdx.x >> 6] = e;
+    __syncthreads();
+    double emax = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) emax = fmax(emax, emax_s[w]);
+    if (emax < 1e-8) {
+#pragma unroll
+      for (int q = 0; q < FQ_NQ; ++q) {
+        const int i = i0 + FQ_RS * q;
+        const zc g = G[i][j];
+        const zc u = j > i ? g : (j == i ? make_double2(0.5 * (g.x - 1.0), 0.0) : make_double2(0.0, 0.0));
+        W[i][j] = u;  // U
+        Rinv_out[i * NB + j] = make_double2((i == j ? 1.0 : 0.0) - u.x, -u.y);
+      }
+      __syncthreads();
+      if (Rtot) {
+#pragma unroll
+        for (int q = 0; q < FQ_NQ; ++q) {
+          const int i = i0 + FQ_RS * q;
+          zc t = P1[i][j];  // (I + U) Rprev
+          for (int k = i; k <= j; ++k) t = cadd(t, cmul(W[i][k], P1[k][j]));
+          Rtot[i * NB + j] = t;
+        }
+      }
+      return;
+    }
+    __syncthreads();
+  }
+  bool bad = false;
+  for (int k = 0; k < NB; ++k) {
     const double d = G[k][k].x;
     const bool ok = second ? (d > 0.5 && d < 2.0) : (d > CHOL_TOL * d0[k] && d0[k] > 0.0);
-    if (!ok) {
-      if (threadIdx.x == 0) bad = 1;
-      break;  // uniform: every thread reads the same G[k][k]
+    if (!ok) { bad = true; break; }  // uniform: every thread read the same word
+    const double id = fast_rcp(d);
+    const zc gkj = G[k][j];
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      if (i > k && j >= i) {
+        const zc gki = G[k][i];
+        G[i][j] = csub(G[i][j], cmulc(gki, make_double2(gkj.x * id, gkj.y * id)));
+      }
     }
-    const double r = sqrt(d), ir = 1.0 / r;
-    __syncthreads();
-    if (i == k && j >= k && j < nb) R[k][j] = j == k ? make_double2(r, 0.0) : make_double2(G[k][j].x * ir, G[k][j].y * ir);
-    __syncthreads();
-    if (i > k && j > k && i < nb && j < nb) G[i][j] = csub(G[i][j], cmulc(R[k][i], R[k][j]));
     __syncthreads();
   }
-  __syncthreads();
   if (bad) {
     if (threadIdx.x == 0) atomicExch(flag, 1);
-    Rinv_out[i * NB + j] = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
-    if (second) Rtot[i * NB + j] = Rprev[i * NB + j];
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      Rinv_out[i * NB + j] = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+      if (Rtot) Rtot[i * NB + j] = second ? P1[i][j] : (i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0));
+    }
     return;
   }
-  // inverse of the upper-triangular factor, column j by back substitution (thread (0, j) walks its column)
-  if (i == 0 && j < nb) {
-    Ri[j][j] = make_double2(1.0 / R[j][j].x, 0.0);
-    for (int r = j - 1; r >= 0; --r) {
-      zc s = make_double2(0.0, 0.0);
-      for (int k = r + 1; k <= j; ++k) s = cadd(s, cmul(R[r][k], Ri[k][j]));
-      const double ir = -1.0 / R[r][r].x;
-      Ri[r][j] = make_double2(s.x * ir, s.y * ir);
+  // rows scaled: R[k][j] = G[k][j] / sqrt(G[k][k])
+  {
+    zc r[FQ_NQ];
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      const double dd = G[i][i].x;
+      const double is = 1.0 / sqrt(dd);
+      r[q] = j > i ? make_double2(G[i][j].x * is, G[i][j].y * is) : (j == i ? make_double2(dd * is, 0.0) : make_double2(0.0, 0.0));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) G[i0 + FQ_RS * q][j] = r[q];
+    __syncthreads();
+    if (threadIdx.x < NB) d0[threadIdx.x] = 1.0 / G[threadIdx.x][threadIdx.x].x;  // 1 / R[k][k] for the chain below
+    __syncthreads();
+  }
+  if (Rtot) {
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      zc t = G[i][j];
+      if (second) {
+        t = make_double2(0.0, 0.0);
+        for (int k = i; k <= j; ++k) t = cadd(t, cmul(G[i][k], P1[k][j]));
+      }
+      Rtot[i * NB + j] = t;
     }
   }
-  __syncthreads();
-  Rinv_out[i * NB + j] = (i < nb && j < nb) ? Ri[i][j] : (i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0));
-  if (second) {
-    zc s = make_double2(0.0, 0.0);
-    if (i < nb && j < nb)
-      for (int k = i; k <= j; ++k) s = cadd(s, cmul(R[i][k], Rprev[k * NB + j]));
-    Rtot[i * NB + j] = s;
-  } else if (Rtot) {
-    Rtot[i * NB + j] = (i < nb && j < nb) ? R[i][j] : make_double2(0.0, 0.0);
+  // W <- R^-1 by Gauss-Jordan on [R | I], rows from the bottom up; row k is final when its turn comes and enters
+  // scaled by 1 / R[k][k] on the fly (rows are scaled once at the end)
+  for (int k = NB - 1; k > 0; --k) {
+    const double ir = d0[k];
+    const zc wkj = make_double2(W[k][j].x * ir, W[k][j].y * ir);
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      if (i < k && j >= k) W[i][j] = csub(W[i][j], cmul(G[i][k], wkj));
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < FQ_NQ; ++q) {
+    const int i = i0 + FQ_RS * q;
+    const double ir = d0[i];
+    Rinv_out[i * NB + j] = make_double2(W[i][j].x * ir, W[i][j].y * ir);
   }
 }
 
 // out[r][:] = in[r][:] * M  for the rows [row_off, mp) of a tall panel (M: nb x nb in a 32 x 32 buffer);
 // out2 (nullable) receives the same values with its own leading dimension
 __global__ __launch_bounds__(256) void k_fq_apply(const zc* __restrict__ in, long ldi, int mp, int nb, const zc* __restrict__ M,
-                                                  zc* __restrict__ out, long ldo, zc* __restrict__ out2, long ldo2, int row_off) {
+                                                  zc* __restrict__ out, long ldo, zc* __restrict__ out2, long ldo2, int row_off,
+                                                  int rows_per_blk) {
   __shared__ zc Ms[NB][NB + 1];
   __shared__ zc tile[8][NB + 1];
   const int t = threadIdx.x, tr = t >> 5, tc = t & 31;
   for (int e = t; e < NB * NB; e += 256) Ms[e >> 5][e & 31] = M[e];
-  const long r0 = row_off + (long)blockIdx.x * FQ_ROWS;
-  const int nr = (int)min((long)FQ_ROWS, mp - r0);
+  const long r0 = row_off + (long)blockIdx.x * rows_per_blk;
+  const int nr = (int)min((long)rows_per_blk, mp - r0);
   for (int base = 0; base < nr; base += 8) {
     const long r = r0 + base + tr;
     const bool live = base + tr < nr;
@@ -164,76 +259,118 @@ __global__ __launch_bounds__(256) void k_fq_apply(const zc* __restrict__ in, lon
 // Householder reconstruction of one panel from its orthonormal factor (top nb x nb block Qt of Q, row stride ldq) and
 // its triangular factor Rtot (positive diagonal): LU of (Q - [D; 0]) with D_j = -sign(Re pivot_j) chosen when column j
 // is eliminated.  Writes, in LAPACK's layout, into the panel of A: R' = D Rtot on and above the diagonal, the unit-lower
-// V1 = L below it; Vp's top block (unit diagonal, zeros above); T (compact WY: T V1^H = -U D); tau = diag(T); Uinv
-// (for V2 = Q2 U^-1).  An LU pivot smaller than 1/2 (it is >= 1 for an orthonormal Q) raises *flag.
-__global__ __launch_bounds__(1024) void k_fq_reconstruct(const zc* __restrict__ Qt, long ldq, const zc* __restrict__ Rtot, int nb,
-                                                         zc* __restrict__ A, long lda, zc* __restrict__ Vp, zc* __restrict__ T,
-                                                         zc* __restrict__ tau, zc* __restrict__ Uinv, int* __restrict__ flag) {
-  __shared__ zc Q[NB][NB + 1];
-  __shared__ zc Y[NB][NB + 1];
-  __shared__ zc Ui[NB][NB + 1];
-  __shared__ zc Ts[NB][NB + 1];
+// V1 = L below it; Vp's top block (unit diagonal, zeros above); T (compact WY: T = -U D V1^-H, leading dimension nb);
+// tau = diag(T); Uinv (for V2 = Q2 U^-1).  An LU pivot smaller than 1/2 (it is >= 1 for an orthonormal Q) raises *flag.
+// One workgroup, FQ_NQ elements per thread, one barrier per step (see k_fq_chol): 32 elimination steps
+// (multipliers formed on the fly, column k scaled at the end), then U^-1 and V1^-H together in one backward
+// Gauss-Jordan chain, then the 32 x 32 product for T.
+__global__ __launch_bounds__(1024 / FQ_NQ) void k_fq_reconstruct(const zc* __restrict__ Qt, long ldq, const zc* __restrict__ Rtot, int nb,
+                                                        zc* __restrict__ A, long lda, zc* __restrict__ Vp, zc* __restrict__ T,
+                                                        zc* __restrict__ tau, zc* __restrict__ Uinv, int* __restrict__ flag) {
+  __shared__ zc Q[NB][NB + 1];    // -> L (strictly lower, unscaled until the end) and U (strictly upper); diagonal: pivots
+  __shared__ zc Wu[NB][NB + 1];   // U^-1
+  __shared__ zc Wy[NB][NB + 1];   // (V1^H)^-1, V1^H unit upper triangular
+  __shared__ zc Ud[NB];           // diagonal of U
   __shared__ double D[NB];
-  __shared__ int bad;
-  const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
-  Q[i][j] = (i < nb && j < nb) ? Qt[(long)i * ldq + j] : make_double2(0.0, 0.0);
-  Y[i][j] = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
-  Ui[i][j] = make_double2(0.0, 0.0);
-  Ts[i][j] = make_double2(0.0, 0.0);
-  if (threadIdx.x == 0) bad = 0;
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    if (threadIdx.x == 0) {
-      const zc piv = Q[k][k];
-      const double dk = piv.x >= 0.0 ? -1.0 : 1.0;  // zlarfg: beta = -sign(Re alpha) |x|, sign(0) = +
-      D[k] = dk;
-      const zc u = make_double2(piv.x - dk, piv.y);
-      Q[k][k] = u;
-      if (!(u.x * u.x + u.y * u.y > 0.25)) bad = 1;
-    }
-    __syncthreads();
-    if (bad) break;
-    if (j == k && i > k && i < nb) Y[i][k] = cdiv(Q[i][k], Q[k][k]);
-    __syncthreads();
-    if (i > k && j > k && i < nb && j < nb) Q[i][j] = csub(Q[i][j], cmul(Y[i][k], Q[k][j]));
-    __syncthreads();
+  const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int q = 0; q < FQ_NQ; ++q) {
+    const int i = i0 + FQ_RS * q;
+    Q[i][j] = (i < nb && j < nb) ? Qt[(long)i * ldq + j] : (i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0));
+    Wu[i][j] = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+    Wy[i][j] = Wu[i][j];
   }
   __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < NB; ++k) {
+    const zc piv = Q[k][k];
+    const double dk = piv.x >= 0.0 ? -1.0 : 1.0;  // zlarfg: beta = -sign(Re alpha) |x|, sign(0) = +
+    const zc u = make_double2(piv.x - dk, piv.y);
+    const double un = u.x * u.x + u.y * u.y;
+    if (!(un > 0.25)) { bad = true; break; }  // uniform
+    if (threadIdx.x == 0) { D[k] = dk; Ud[k] = u; }
+    const double iun = fast_rcp(un);
+    const zc iu = make_double2(u.x * iun, -u.y * iun);
+    const zc qkj = Q[k][j];
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      if (i > k && j > k) Q[i][j] = csub(Q[i][j], cmul(cmul(Q[i][k], iu), qkj));
+    }
+    __syncthreads();
+  }
   if (bad) {
     if (threadIdx.x == 0) atomicExch(flag, 1);
     return;
   }
-  // U = upper triangle of Q now; its inverse by back substitution (thread (0, j): column j)
-  if (i == 0 && j < nb) {
-    Ui[j][j] = cdiv(make_double2(1.0, 0.0), Q[j][j]);
-    for (int r = j - 1; r >= 0; --r) {
-      zc s = make_double2(0.0, 0.0);
-      for (int k = r + 1; k <= j; ++k) s = cadd(s, cmul(Q[r][k], Ui[k][j]));
-      Ui[r][j] = cdiv(make_double2(-s.x, -s.y), Q[r][r]);
+  {  // column k of L scaled by 1 / U[k][k]; the diagonal takes U's
+    zc v[FQ_NQ];
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      const zc ud = Ud[j];
+      const double un = ud.x * ud.x + ud.y * ud.y;
+      v[q] = i > j ? cmul(Q[i][j], make_double2(ud.x / un, -ud.y / un)) : (i == j ? ud : Q[i][j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) Q[i0 + FQ_RS * q][j] = v[q];
+    if (threadIdx.x < NB) {  // Ud <- 1 / U[k][k] for the chain below
+      const zc ud = Ud[threadIdx.x];
+      const double un = ud.x * ud.x + ud.y * ud.y;
+      Ud[threadIdx.x] = make_double2(ud.x / un, -ud.y / un);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < FQ_NQ; ++q) {
+    const int i = i0 + FQ_RS * q;
+    if (i < nb && j < nb) {
+      const zc r = Rtot[i * NB + j];
+      A[(long)i * lda + j] = j >= i ? make_double2(D[i] * r.x, D[i] * r.y) : Q[i][j];
+      Vp[i * nb + j] = i > j ? Q[i][j] : (i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0));
     }
   }
-  // T V1^H = -U D: row i of T left to right (thread (i, 0))
-  if (j == 0 && i < nb) {
-    for (int c = i; c < nb; ++c) {
-      zc s = make_double2(-Q[i][c].x * D[c], -Q[i][c].y * D[c]);
-      for (int k = i; k < c; ++k) s = csub(s, cmul(Ts[i][k], make_double2(Y[c][k].x, -Y[c][k].y)));
-      Ts[i][c] = s;
+  // Wu <- U^-1 and Wy <- (V1^H)^-1 (V1^H[i][k] = conj(L[k][i]) for k > i, unit diagonal), rows from the bottom up
+  for (int k = NB - 1; k > 0; --k) {
+    const zc wkj = cmul(Wu[k][j], Ud[k]);
+    const zc ykj = Wy[k][j];
+#pragma unroll
+    for (int q = 0; q < FQ_NQ; ++q) {
+      const int i = i0 + FQ_RS * q;
+      if (i < k && j >= k) {
+        Wu[i][j] = csub(Wu[i][j], cmul(Q[i][k], wkj));
+        const zc l = Q[k][i];  // L[k][i]
+        Wy[i][j] = csub(Wy[i][j], cmul(make_double2(l.x, -l.y), ykj));
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
-  T[i * NB + j] = Ts[i][j];
-  Uinv[i * NB + j] = (i < nb && j < nb) ? Ui[i][j] : (i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0));
-  if (i == 0 && j < nb) tau[j] = Ts[j][j];
-  if (i < nb && j < nb) {
-    const zc r = Rtot[i * NB + j];
-    A[(long)i * lda + j] = j >= i ? make_double2(D[i] * r.x, D[i] * r.y) : Y[i][j];
-    Vp[i * nb + j] = j > i ? make_double2(0.0, 0.0) : Y[i][j];
+#pragma unroll
+  for (int q = 0; q < FQ_NQ; ++q) {
+    const int i = i0 + FQ_RS * q;
+    Uinv[i * NB + j] = cmul(Wu[i][j], Ud[i]);
+    // T = -(U D) (V1^H)^-1
+    zc t = make_double2(0.0, 0.0);
+    if (j >= i)
+      for (int k = i; k <= j; ++k) t = csub(t, cmul(make_double2(Q[i][k].x * D[k], Q[i][k].y * D[k]), Wy[k][j]));
+    if (i < nb && j < nb) {
+      T[i * nb + j] = t;
+      if (i == j) tau[j] = t;
+    }
   }
 }
 
+static int fq_rows_per_blk(int m) {  // at most 128 workgroups (= partial Gram matrices), at least 32 rows each
+  int r = (m + 127) / 128;
+  r = (r + 31) / 32 * 32;
+  return r < 32 ? 32 : r;
+}
+
 size_t qr_fast_work_elems(int m, int n) {
-  const size_t nblk = ((size_t)m + FQ_ROWS - 1) / FQ_ROWS;
+  const size_t nblk = 128;
   return (size_t)m * n            // copy of the input (the factorisation is redone from it when a check fails)
+         + (size_t)m * n          // the V panels of all block reflectors (the Q formation reuses them)
          + 2 * (size_t)m * NB     // Q1, Q2: the panel after the first / second round
          + nblk * NB * NB         // partial Gram matrices
          + 5 * (size_t)NB * NB    // R1^-1, R2^-1, R1, R2 R1, U^-1
@@ -247,28 +384,29 @@ int qr_fast_panel(hipStream_t st, zc* A, long lda, int m, int j0, int nbp, zc* V
   zc* P = A + (long)j0 * lda + j0;
   zc* Q1 = ws;
   zc* Q2 = Q1 + (size_t)m * NB;
-  const int nblk = (mp + FQ_ROWS - 1) / FQ_ROWS;
+  const int rpb = fq_rows_per_blk(mp);
+  const int nblk = (mp + rpb - 1) / rpb;
   zc* part = Q2 + (size_t)m * NB;
-  zc* small = part + (size_t)((m + FQ_ROWS - 1) / FQ_ROWS) * NB * NB;
+  zc* small = part + (size_t)128 * NB * NB;
   zc* R1inv = small;
   zc* R2inv = small + NB * NB;
   zc* R1 = small + 2 * NB * NB;
   zc* Rtot = small + 3 * NB * NB;
   zc* Uinv = small + 4 * NB * NB;
   // round 1
-  hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, P, lda, mp, nbp, part);
-  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024), 0, st, part, nblk, nbp, R1inv, (const zc*)nullptr, R1, 0, flag);
-  hipLaunchKernelGGL(k_fq_apply, dim3(nblk), dim3(256), 0, st, P, lda, mp, nbp, R1inv, Q1, (long)NB, (zc*)nullptr, 0L, 0);
+  hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, P, lda, mp, nbp, part, rpb);
+  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R1inv, (const zc*)nullptr, R1, 0, flag);
+  hipLaunchKernelGGL(k_fq_apply, dim3(nblk), dim3(256), 0, st, P, lda, mp, nbp, R1inv, Q1, (long)NB, (zc*)nullptr, 0L, 0, rpb);
   // round 2
-  hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, part);
-  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024), 0, st, part, nblk, nbp, R2inv, R1, Rtot, 1, flag);
-  hipLaunchKernelGGL(k_fq_apply, dim3(nblk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, R2inv, Q2, (long)NB, (zc*)nullptr, 0L, 0);
+  hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, part, rpb);
+  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R2inv, R1, Rtot, 1, flag);
+  hipLaunchKernelGGL(k_fq_apply, dim3(nblk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, R2inv, Q2, (long)NB, (zc*)nullptr, 0L, 0, rpb);
   // Householder reconstruction: top block, then V2 = Q2[nbp:] U^-1 into the panel and into Vp
-  hipLaunchKernelGGL(k_fq_reconstruct, dim3(1), dim3(1024), 0, st, Q2, (long)NB, Rtot, nbp, P, lda, Vp, Tp, tau + j0, Uinv, flag);
+  hipLaunchKernelGGL(k_fq_reconstruct, dim3(1), dim3(1024 / FQ_NQ), 0, st, Q2, (long)NB, Rtot, nbp, P, lda, Vp, Tp, tau + j0, Uinv, flag);
   int nl = 7;
   if (mp > nbp) {
-    const int nb2 = (mp - nbp + FQ_ROWS - 1) / FQ_ROWS;
-    hipLaunchKernelGGL(k_fq_apply, dim3(nb2), dim3(256), 0, st, Q2, (long)NB, mp, nbp, Uinv, P, lda, Vp, (long)nbp, nbp);
+    const int nb2 = (mp - nbp + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_fq_apply, dim3(nb2), dim3(256), 0, st, Q2, (long)NB, mp, nbp, Uinv, P, lda, Vp, (long)nbp, nbp, rpb);
     ++nl;
   }
   HIP_CHECK(hipGetLastError());

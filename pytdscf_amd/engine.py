@@ -668,6 +668,13 @@ def set_qr_fast(on: bool):
     _lib.load().mitdvp_set_qr_fast(int(bool(on)))
 
 
+def bench_qr(m: int, n: int, reps: int = 10, device: int = 0):
+    """(milliseconds, launches) per m x n QR gauge move on the device (HIP events around `reps` factorisations)."""
+    ms, nl = C.c_double(), C.c_long()
+    _lib.check(_lib.load().mitdvp_bench_qr(device, m, n, reps, C.byref(ms), C.byref(nl)))
+    return ms.value, nl.value
+
+
 def get_qr_fast() -> bool:
     return bool(_lib.load().mitdvp_get_qr_fast())
 
