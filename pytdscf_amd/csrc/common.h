@@ -90,6 +90,8 @@ struct ZgemmDesc {
   // row (rows 0, arow_skip, ...) is left out of the product (0 = off).  Stage S1 of an apply whose left environment
   // has an identity block in MPO-bond state 0: those rows of X are copies of psi.
   int arow_skip;
+  // scheduling experiments of the MFMA kernel (MITDVP_ZGEMM_TUNE; 0 = the tuned default), see zgemm.hip
+  int tune;
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
 void zgemm(hipStream_t st, const ZgemmDesc& d);
@@ -103,6 +105,7 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.ksplit = 0;
   d.klist = nullptr; d.klist_stride = 0; d.rowmap_p = 0; d.rowmap_s1 = 0; d.rowmap_s2 = 0; d.rowmap_r0 = 0;
   d.arow_skip = 0;
+  d.tune = -1;
   return d;
 }
 int zgemm_default_mode();

@@ -93,6 +93,21 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
     K = min(d.ksplit, d.K - (int)kb);
   }
 
+  // Two workgroups share a CU, i.e. two waves running this same program share every SIMD; left alone they tend to
+  // meet in the same phase (matrix work beside matrix work, then both at their loads and barrier).
+  //   tune bit 0: static priority for the second-dispatched workgroup of a CU
+  //   tune bit 1: start it half a K tile late
+  //   tune bit 2: pair by block parity instead of dispatch round
+  if (d.tune > 0) {
+    const bool second = (d.tune & 4) ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
+    if (second) {
+      if (d.tune & 1) __builtin_amdgcn_s_setprio(1);
+      if (d.tune & 2) {
+        __builtin_amdgcn_s_sleep(24);
+        __builtin_amdgcn_s_sleep(24);
+      }
+    }
+  }
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
@@ -587,7 +602,14 @@ int zgemm_cd_mode(hipStream_t st) {
   return g_cd_mode;
 }
 
-void zgemm(hipStream_t st, const ZgemmDesc& d) {
+static int zgemm_tune_default() {
+  static const int v = [] { const char* e = std::getenv("MITDVP_ZGEMM_TUNE"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
+void zgemm(hipStream_t st, const ZgemmDesc& d0) {
+  ZgemmDesc d = d0;
+  if (d.tune < 0) d.tune = zgemm_tune_default();
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return;
   if (d.K < 0) throw ArgError("zgemm: negative K");
   if (d.arow_skip && (d.transA || d.arow_skip < 2 || d.klist)) throw ArgError("zgemm: arow_skip needs a plain, untransposed A");

@@ -258,18 +258,38 @@ class SiteShardedTDVP:
         ranks end up with the same kind (the verdict of the self-test is shared)."""
         lib, h, comm = self._lib, self._h, self.comm
         if self.transport == "rccl":
-            ok = 1.0
+            # The communicator is created on a helper thread with a deadline: an RCCL bootstrap that cannot reach its
+            # peers blocks for ever and cannot be cancelled, and a bench that hangs measures nothing.  On a time-out
+            # (or any error) ALL ranks fall back to the callback transport together; the helper thread is left behind
+            # (a communicator that completes later is never used: the callback takes precedence in the library).
+            import threading
+
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: bootstrap over loopback (the host name may not resolve)
+            state = {"ok": False, "err": None}
+            ident = C.create_string_buffer(128)
             try:
-                ident = C.create_string_buffer(128)
                 if comm.rank == 0:
                     _lib.check(lib.mitdvp_rccl_unique_id(ident))
                 box = [ident.raw]
                 comm.dist.broadcast_object_list(box, src=0)
-                self._ck(lib.mitdvp_shard_attach_rccl(h, box[0]))
+
+                def attach():
+                    try:
+                        self._ck(lib.mitdvp_shard_attach_rccl(h, box[0]))
+                        state["ok"] = True
+                    except Exception as exc:  # noqa: BLE001
+                        state["err"] = exc
+
+                th = threading.Thread(target=attach, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("MITDVP_RCCL_ATTACH_TIMEOUT", "120")))
+                if th.is_alive():
+                    state["err"] = TimeoutError("ncclCommInitRank did not return in time")
             except Exception as exc:  # noqa: BLE001 -- all ranks fall back together below
-                print(f"[site sharding] rank {comm.rank}: RCCL attach failed ({exc}); falling back to the callback transport", flush=True)
-                ok = 0.0
-            if comm.min_over_ranks(ok) < 1.0:
+                state["err"] = exc
+            if state["err"] is not None or not state["ok"]:
+                print(f"[site sharding] rank {comm.rank}: RCCL attach failed ({state['err']}); falling back to the callback transport", flush=True)
+            if comm.min_over_ranks(1.0 if state["ok"] else 0.0) < 1.0:
                 self.transport = "callback"
         if self.transport == "callback":
             self._cb = self.link.raw_callback()
