@@ -181,6 +181,9 @@ class TDVPEngine:
         if cores:
             self._mpo_ends = getattr(self, "_mpo_ends", {})
             self._mpo_ends[op_id] = (np.shape(cores[0])[0], np.shape(cores[-1])[-1])
+            # MPO bond left / right of every site: the block a ranged fold hands back has the bond at the END of its range
+            self._mpo_bonds = getattr(self, "_mpo_bonds", {})
+            self._mpo_bonds[op_id] = [(np.shape(c)[0], np.shape(c)[-1]) for c in cores]
         for i, w in enumerate(cores):
             a = _c128(w)
             if a.ndim != 4:
@@ -262,8 +265,13 @@ class TDVPEngine:
         if out_shape is None:
             last = self.get_site_shape(first + count - 1 if from_left else first)
             dn = last[2] if from_left else last[0]
-            ends = getattr(self, "_mpo_ends", {}).get(op_id, (1, 1))
-            out_shape = (dn, (ends[1] if from_left else ends[0]) if op_id >= 0 else 1, dn)
+            m_out = 1
+            if op_id >= 0:
+                bonds = getattr(self, "_mpo_bonds", {}).get(op_id)
+                if bonds is None:
+                    raise ValueError("fold_block: this operator's cores were not set through set_mpo; pass out_shape")
+                m_out = bonds[first + count - 1][1] if from_left else bonds[first][0]
+            out_shape = (dn, m_out, dn)
         out = np.empty(out_shape, dtype=np.complex128)
         self._ck(self._lib.mitdvp_fold_block_range(self._h, op_id, int(conj), int(from_left), first, count, _dp(a), a.shape[0],
                                                    a.shape[1], _dp(out)))

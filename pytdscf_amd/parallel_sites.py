@@ -448,6 +448,40 @@ class SiteShardedTDVP:
             rho = t.cpu().numpy().view(np.complex128).reshape(d, d)
         return rho
 
+    def reduced_density(self, key):
+        """General reduced density of the sharded state for a key like the reference's ``reduced_density=([key, ...], n)``
+        -- ascending site indices, an index given twice keeps ket and bra of that site, once its diagonal
+        (``MPSCoefParallel.get_reduced_densities``, _mps_parallel.py:1035-1208; ``properties.py:69-82``).  One-site keys
+        (i, i) are folded rank by rank without moving tensors (``site_rdm``); any other key gathers the chain on rank 0
+        (Psi = Phi_0 X_0^+ Phi_1 ...), re-canonicalises it there keeping its norm and uses the single-GPU contraction --
+        an analysis call for states that fit one GPU, not part of a time step.  Every rank returns the array.  Collective."""
+        key = tuple(int(k) for k in key)
+        if key != tuple(sorted(key)) or any(not 0 <= k < self.nsite for k in key):
+            raise ValueError(f"Reduced density key {key} must be ascending site indices")
+        if len(key) == 2 and key[0] == key[1]:
+            return self.site_rdm(key[0])
+        legs = [0] * self.nsite
+        for k in key:
+            legs[k] += 1
+        if max(legs) > 2:
+            raise ValueError("a site index may appear at most twice in a reduced-density key")
+        cores = self.gather()
+        rho = None
+        if self.rank == 0:
+            g = TDVPEngine(self.nsite, device=self.device, **self.kw)
+            try:
+                if getattr(self.comm, "shared_gpu", False):
+                    g.set_small_kernels(False)
+                g.set_mps(cores, canonicalize=True, scale=None)
+                rho = g.reduced_density(legs)
+            finally:
+                g.close()
+        if self.world > 1:
+            box = [rho]
+            self.comm.dist.broadcast_object_list(box, src=0)
+            rho = box[0]
+        return rho
+
     def site_rdms(self, sites=None):
         """One-site reduced densities of many sites in ONE two-way pass over the ranks (2 (N - 1) messages whatever the
         number of sites): the left transfer blocks travel rank 0 -> N - 1, the right ones back, every rank then walks
