@@ -648,7 +648,9 @@ void zgemm(hipStream_t st, const ZgemmDesc& d0) {
   // (a row map scatters C rows into the real output buffer: the partial slabs of a split are plain M x N arrays,
   // so mapped outputs are never split)
   if (d.batch == 1 && !d.rowmap_p && ((nt < 192 && d.K >= 1024) || long_k)) {
-    int splits = long_k ? longk : (int)std::min<long>((384 + nt - 1) / nt, d.K / 256);
+    // short outputs: enough slabs to give every CU its two workgroups (MITDVP_SPLITK_TARGET workgroups, default 512 = two per CU; 384 before round 3: the C5 K_eff second stage 512 x 512 x 8192 ran 333 us, now 273)
+    static const int sk_target = [] { const char* e = std::getenv("MITDVP_SPLITK_TARGET"); return e ? std::max(64, std::atoi(e)) : 512; }();
+    int splits = long_k ? longk : (int)std::min<long>((sk_target + nt - 1) / nt, d.K / 256);
     if (splits >= 2) {
       int kc = (d.K + splits - 1) / splits;
       kc = (kc + 15) / 16 * 16;

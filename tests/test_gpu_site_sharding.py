@@ -110,8 +110,8 @@ if comm.rank == 0:
     rdm_gap = max([rdm_gap] + [np.abs(rdms_all[p] - rdm(g, p)).max() for p in range(L)]
                   + [np.abs(rdms_some[p] - rdm(g, p)).max() for p in rdms_some])
     # multi-site keys (pairs across ranks, a diagonal leg): against the oracle's contraction of the gathered chain
-    g0 = orc.canonicalize_site0([c.copy() for c in g], scale=None)   # the oracle's contraction wants the canonical form
-    rdm_gap = max([rdm_gap] + [np.abs(rd_multi[k] - orc.reduced_density(g0, [k.count(p) for p in range(L)])).max() for k in rd_multi])
+    gcan = orc.canonicalize_site0([c.copy() for c in g], scale=None)   # the oracle's contraction wants the canonical form
+    rdm_gap = max([rdm_gap] + [np.abs(rd_multi[k] - orc.reduced_density(gcan, [k.count(p) for p in range(L)])).max() for k in rd_multi])
     obs_gap = max(rdm_gap, abs(obs["norm"] - np.sqrt(sandwich(gc, g).real)), abs(obs["auto"] - sandwich(g, g)),
                   abs(obs["energy"] - sandwich(gc, g, mpo)), abs(obs["op2"] - sandwich(gc, g, op2)))
     ref = par.ParallelOracle([c.copy() for c in mps], mpo, comm.world, integrator={integ!r}, conserve_norm={cn})
