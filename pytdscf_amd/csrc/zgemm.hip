@@ -164,7 +164,16 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
     nlist = kl[0];
     kl += 1;
   }
+  // MITDVP_ABLATE (compile time, TIMING EXPERIMENTS ONLY -- the product is wrong with any bit set): 8 no barrier in the
+  // K loop, 16 no global loads in the K loop, 32 no LDS stores in the K loop.  A second library built with
+  // -DMITDVP_ABLATE=n (make ABLATE=n) and loaded through MITDVP_LIB; never the shipped one.
+#ifndef MITDVP_ABLATE
+#define MITDVP_ABLATE 0
+#endif
+  constexpr bool abl_nobar = (MITDVP_ABLATE & 8) != 0, abl_noload = (MITDVP_ABLATE & 16) != 0, abl_nostore = (MITDVP_ABLATE & 32) != 0;
   auto side = [&](int item, zc* stage, int kv, int kv2, int ord = 0) {
+    if (item < NP && abl_nostore && stage != smem) return;
+    if (item >= NP && abl_noload && ord >= 2) return;
     if (item < A_PT) {
       const int p = item;
       const bool ok = kbA + p * KSA < kv;
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
+    if (!abl_nobar) __syncthreads();
   }
 
   // ---- epilogue: C = alpha*acc + beta*C -----------------------------------
