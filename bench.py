@@ -26,10 +26,13 @@ GPU) and forwards rank 0's JSON line.  --parallel:
   sites     (default when every rank gets >= 4 sites) contiguous site ranges per
             rank, "scaling": "strong": all ranks sweep their blocks at once, the two
             sites facing each other across a rank boundary are updated together
-            through the pseudo-inverse of the joint bond matrix; neighbour send /
-            recv of boundary tensors only (RCCL over xGMI), no collective.  The
-            reference's real-space parallel TDVP (_mps_parallel.py): approximate,
-            deviation from the serial sweep ~ dt^2 (pytdscf_amd/parallel_sites.py).
+            through the pseudo-inverse of the joint bond matrix; ONE library call
+            per time step and rank (mitdvp_shard_step): the halo is the library's own
+            grouped ncclSend / ncclRecv of device buffers between chain neighbours
+            (RCCL over xGMI), no collective; torch.distributed (gloo) is the control
+            plane only.  The reference's real-space parallel TDVP (_mps_parallel.py):
+            approximate, deviation from the serial sweep ~ dt^2; the JSON line carries
+            "approximate": true and the norm / energy drift of the run ("accuracy").
   tp        (when D % N == 0) ONE sweep shared by all GPUs, "scaling":
             "strong": every H_eff / K_eff apply and environment update is sharded
             over the bra-side bond index (each rank contracts D/N rows of the

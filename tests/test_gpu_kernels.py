@@ -470,3 +470,33 @@ def test_identity_block_of_the_right_environment_is_short_circuited(monkeypatch)
         a, b = out[name, "1"][0], out[name, "0"][0]
         assert abs(abs(orc.overlap(a, b)) / np.sqrt(abs(orc.overlap(a, a)) * abs(orc.overlap(b, b))) - 1) < 1e-12
         assert max(np.abs(x - y).max() for x, y in zip(a, b)) < 1e-11
+
+
+def test_ranged_fold_block_sizes_its_output_from_the_mpo_bond_at_the_end_of_the_range():
+    """mitdvp_fold_block_range through the Python handle without out_shape: the block that comes back has the MPO
+    bond of the LAST core of the range (not of the chain's end cores), in both directions; values equal the oracle's
+    environment updates (contract_with_site_mpo, _contraction.py:148-397)."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L, d, D = 5, 3, 6
+    rng = np.random.default_rng(4)
+    bonds = [1, 2, 4, 3, 2, 1]
+    mpo = [crandn(rng, bonds[p], d, d, bonds[p + 1]) for p in range(L)]
+    mps = orc.synthetic_mps([d] * L, D, seed=2)
+    eng = TDVPEngine(L)
+    eng.set_mpo(mpo)
+    eng.set_mps(mps)
+    dl = mps[1].shape[0]
+    blk = crandn(rng, dl, bonds[1], dl)
+    got = eng.fold_block(blk, op_id=0, from_left=True, first=1, count=2)
+    want = orc.env_update_left(orc.env_update_left(blk, mps[1], mpo[1]), mps[2], mpo[2])
+    assert got.shape == want.shape == (mps[2].shape[2], bonds[3], mps[2].shape[2])
+    assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+    dr = mps[3].shape[2]
+    blk = crandn(rng, dr, bonds[4], dr)
+    got = eng.fold_block(blk, op_id=0, from_left=False, first=2, count=2)
+    want = orc.env_update_right(orc.env_update_right(blk, mps[3], mpo[3]), mps[2], mpo[2])
+    assert got.shape == want.shape == (mps[2].shape[0], bonds[2], mps[2].shape[0])
+    assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+    eng.close()
