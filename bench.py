@@ -163,7 +163,10 @@ def committed_traffic(name, L, d, D, M):
     """HBM-side bytes per H_eff apply from the committed PMC passes (separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per MI355X_MICROARCH.md), newest round first;
     None for shapes that were not measured."""
-    for fn in ("r02_%s_traffic.json" % name, "r01_%s_traffic.json" % name):
+    cands = ["r03_%s_traffic.json" % name, "r02_%s_traffic.json" % name, "r01_%s_traffic.json" % name]
+    if name == "heff":  # per-shape files of the other large-bond workloads (round 3)
+        cands = ["r03_heff_traffic_D%d_d%d_M%d.json" % (D, d, M)] + cands
+    for fn in cands:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except (OSError, ValueError):

@@ -238,6 +238,7 @@ class Engine {
   bool left_block_is_identity(const zc* L, int dl, int m);
   bool trim_identity_ = true;  // MITDVP_TRIM_IDENTITY=0 switches the shortcut off
   bool right_block_is_identity(const zc* R, int dr, int m);
+  void identity_blocks(const zc* L, int dl, int ml, const zc* R, int dr, int mr, bool* left, bool* right);
   int L_;
   hipStream_t st_ = nullptr;
   std::vector<int> dl_, dd_, dr_, gauge_;

@@ -770,22 +770,31 @@ void Engine::build_left_envs() {
 
 // R[r][m-1][s] == delta_rs to 1e-13 (orthonormality of the tensors right of the site, to rounding)
 bool Engine::right_block_is_identity(const zc* R, int dr, int m) {
-  double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
-  ident_deviation(st_, R + (size_t)(m - 1) * dr, (long)m * dr, dr, dev);
-  double h = 1.0;
-  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(double), hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
-  return h < 1e-13;
+  bool l = false, r = false;
+  identity_blocks(nullptr, 0, 0, R, dr, m, &l, &r);
+  return r;
 }
 
 // L[a][0][b] == delta_ab to 1e-13 (the tensors left of the site are left-canonical)
 bool Engine::left_block_is_identity(const zc* L, int dl, int m) {
+  bool l = false, r = false;
+  identity_blocks(L, dl, m, nullptr, 0, 0, &l, &r);
+  return l;
+}
+
+// both checks of a site with ONE host synchronisation (two small reduction launches, one 16-byte copy); a null block
+// is not checked
+void Engine::identity_blocks(const zc* L, int dl, int ml, const zc* R, int dr, int mr, bool* left, bool* right) {
   double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
-  ident_deviation(st_, L, (long)m * dl, dl, dev);
-  double h = 1.0;
-  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(double), hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
-  return h < 1e-13;
+  double h[2] = {1.0, 1.0};
+  if (L) ident_deviation(st_, L, (long)ml * dl, dl, dev);
+  if (R) ident_deviation(st_, R + (size_t)(mr - 1) * dr, (long)mr * dr, dr, dev + 1);
+  if (L || R) {
+    HIP_CHECK(hipMemcpyAsync(h, dev, 2 * sizeof(double), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  *left = L && h[0] < 1e-13;
+  *right = R && h[1] < 1e-13;
 }
 
 void Engine::local_site_exp(int p, double dt) {
@@ -798,8 +807,8 @@ void Engine::local_site_exp(int p, double dt) {
   const hzc shift = op(0).shift;
   auto mv = [&](const zc* in, zc* out) { heff_apply(Lb, w, Rb, in, out, dl, d, dr, shift); };
   // large bonds: one check per site (two tiny launches and a synchronisation) buys 1 / M_r of stage S3 in every apply
-  trim_r_ = trim_identity_ && dr >= 256 && w.mr > 1 && right_block_is_identity(Rb, dr, w.mr);
-  trim_l_ = trim_identity_ && dl >= 256 && w.ml > 1 && left_block_is_identity(Lb, dl, w.ml);
+  identity_blocks(trim_identity_ && dl >= 256 && w.ml > 1 ? Lb : nullptr, dl, w.ml,
+                  trim_identity_ && dr >= 256 && w.mr > 1 ? Rb : nullptr, dr, w.mr, &trim_l_, &trim_r_);
   struct Reset { bool& f; bool& g; ~Reset() { f = false; g = false; } } reset{trim_r_, trim_l_};
   if (cfg.relax == 2)  // improved relaxation, _mps_cls.py:1078-1084
     kprev_[p] = krylov_diag(mv, site_[p].p, (long)dl * d * dr);

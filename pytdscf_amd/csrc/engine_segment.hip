@@ -96,8 +96,8 @@ void Engine::heff_apply_center(const double* in, double* out, int* flags) {
   DevBuf x = pool_get(n), y = pool_get(n);
   if (in) copy_in(x.p, in, n);
   else HIP_CHECK(hipMemcpyAsync(x.p, site_[p].p, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
-  trim_r_ = trim_identity_ && dr >= 256 && w.mr > 1 && right_block_is_identity(Rb, dr, w.mr);
-  trim_l_ = trim_identity_ && dl >= 256 && w.ml > 1 && left_block_is_identity(Lb, dl, w.ml);
+  identity_blocks(trim_identity_ && dl >= 256 && w.ml > 1 ? Lb : nullptr, dl, w.ml,
+                  trim_identity_ && dr >= 256 && w.mr > 1 ? Rb : nullptr, dr, w.mr, &trim_l_, &trim_r_);
   struct Reset { bool& f; bool& g; ~Reset() { f = false; g = false; } } reset{trim_r_, trim_l_};
   SmallChain sc;
   const bool small = small_ok() && chain_heff(sc, Lb, w, Rb, dl, d, dr, false);
