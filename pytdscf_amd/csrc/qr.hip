@@ -783,7 +783,7 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
                      reinterpret_cast<unsigned long long*>(sy->slots), sy->words + 2, sy->words + 3,
                      (sy->launches & 0xFFFFFu) << 12};
       const size_t dyn = (size_t)gpan * 64 * sizeof(double);
-      PersistentLaunch chain(st);
+      PersistentLaunch chain(st, gpan);
       if (rb == 32) hipLaunchKernelGGL(k_qr_panel<2>, dim3(gpan), dim3(512), dyn, st, pa);
       else if (rb == 64) hipLaunchKernelGGL(k_qr_panel<4>, dim3(gpan), dim3(512), dyn, st, pa);
       else if (rb == 128) hipLaunchKernelGGL(k_qr_panel<8>, dim3(gpan), dim3(512), dyn, st, pa);

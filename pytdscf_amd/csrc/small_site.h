@@ -53,13 +53,14 @@ size_t small_chain_lds(const SmallChain& c, bool exp_mode);
 // choose nsc / cs for a chain whose other fields are set; false when the chain does not qualify
 bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu);
 
-// Persistent launches (kernels whose workgroups exchange data inside the launch and must all be resident) of several
-// engines on one GPU are chained through a per-device event while more than one engine uses them: construct around
-// the launch.  persistent_register(+1 / -1): an engine starts / stops using the family on the current device.
+// Persistent launches (kernels whose workgroups exchange data inside the launch and must all be resident, one per
+// compute unit) of several engines on one GPU are admitted against a per-device budget of compute units while more
+// than one engine uses them (small_site.hip): construct around the launch with the launch's grid size.
+// persistent_register(+1 / -1): an engine starts / stops using the family on the current device.
 void persistent_register(int delta);
 class PersistentLaunch {
  public:
-  explicit PersistentLaunch(hipStream_t st);
+  PersistentLaunch(hipStream_t st, int grid);
   ~PersistentLaunch();
   PersistentLaunch(const PersistentLaunch&) = delete;
   PersistentLaunch& operator=(const PersistentLaunch&) = delete;
@@ -67,6 +68,7 @@ class PersistentLaunch {
  private:
   hipStream_t st_;
   int slot_;
+  int grid_;
   bool chained_ = false;
 };
 

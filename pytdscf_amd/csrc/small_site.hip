@@ -34,7 +34,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <vector>
 
 #include "../../include/mitdvp.h"
 
@@ -794,15 +796,23 @@ bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
 // k_small_site / k_qr_panel exchange data BETWEEN their workgroups inside one launch, so all workgroups of a launch
 // must be resident together.  Two such grids from two engines (an ensemble of trajectories on one GPU, host threads)
 // could each get part of the chip and wait for the rest of themselves until the 2 s timeout.  Per device, process
-// wide: while more than one engine uses the family, every persistent launch first waits (on the device, no host
-// synchronisation) for the event the previous persistent launch recorded, whatever engine and stream issued it.
+// wide, while more than one engine uses the family: every persistent launch is entered in a list with an event and
+// its grid size (one workgroup per compute unit: each takes more than half a CU's LDS), and a new launch is issued only
+// once "grids of other engines that may run beside it + its own grid <= compute units" holds (the launching host thread
+// waits for the oldest foreign launch otherwise).  Launches that fit beside
+// each other still overlap (two C2 local exponentials use 64-128 of the 256 compute units each); any set of launches
+// that can be running at the same time fits the chip as a whole, so none can starve another.
 namespace {
+struct PEvent {  // one recorded launch; shared so that a waiter keeps it alive while it is being retired elsewhere
+  hipEvent_t ev = nullptr;
+  ~PEvent() { if (ev) (void)hipEventDestroy(ev); }
+};
 struct PersistentChain {
   std::mutex mu;
-  hipEvent_t ev = nullptr;
-  bool recorded = false;
-  hipStream_t last = nullptr;
+  struct InFlight { std::shared_ptr<PEvent> e; int grid; hipStream_t st; };
+  std::vector<InFlight> fl;
   int users = 0;
+  int n_cu = 0;
 };
 PersistentChain g_pchain[64];
 inline int current_device_slot() {
@@ -817,20 +827,45 @@ void persistent_register(int delta) {
   std::lock_guard<std::mutex> lk(c.mu);
   c.users += delta;
   if (delta > 0 && c.users == 2) {
-    // the engine that was alone so far recorded nothing: let its launches drain once, from now on the chain orders them
+    // the engine that was alone so far recorded nothing: let its launches drain once, from now on the list orders them
     HIP_CHECK(hipDeviceSynchronize());
-    c.recorded = false;
   }
 }
 
-PersistentLaunch::PersistentLaunch(hipStream_t st) : st_(st), slot_(current_device_slot()) {
+// Admission on the HOST: the launching thread waits (hipEventSynchronize, lock released) for the oldest foreign launch
+// still in flight until its own grid fits beside the rest.  (Making the STREAM wait instead -- hipStreamWaitEvent on the
+// other engine's event -- was measured first: 8 engines fell from ~370 to 43 sweeps/s in aggregate, a cross-stream
+// dependency costs far more than the 20-140 us kernels it orders.)
+PersistentLaunch::PersistentLaunch(hipStream_t st, int grid) : st_(st), slot_(current_device_slot()), grid_(grid) {
   PersistentChain& c = g_pchain[slot_];
   c.mu.lock();
   chained_ = c.users > 1;
   if (!chained_) return;
   try {
-    if (!c.ev) HIP_CHECK(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
-    if (c.recorded && c.last != st) HIP_CHECK(hipStreamWaitEvent(st, c.ev, 0));
+    if (!c.n_cu) {
+      int dev = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      HIP_CHECK(hipDeviceGetAttribute(&c.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    for (;;) {
+      size_t keep = 0;  // forget what has completed
+      for (size_t k = 0; k < c.fl.size(); ++k)
+        if (hipEventQuery(c.fl[k].e->ev) != hipSuccess) c.fl[keep++] = c.fl[k];
+      c.fl.resize(keep);
+      (void)hipGetLastError();  // hipEventQuery reports "not ready" through the error state
+      int beside = 0;
+      std::shared_ptr<PEvent> oldest;
+      for (const auto& f : c.fl)
+        if (f.st != st) {  // stream order already puts this stream's own launches before the new one
+          beside += f.grid;
+          if (!oldest) oldest = f.e;
+        }
+      if (beside + grid <= c.n_cu || !oldest) break;
+      c.mu.unlock();
+      const hipError_t rc = hipEventSynchronize(oldest->ev);
+      c.mu.lock();
+      if (rc != hipSuccess) throw HipError("persistent launch admission: hipEventSynchronize failed");
+    }
   } catch (...) {
     c.mu.unlock();
     throw;
@@ -839,9 +874,10 @@ PersistentLaunch::PersistentLaunch(hipStream_t st) : st_(st), slot_(current_devi
 
 PersistentLaunch::~PersistentLaunch() {
   PersistentChain& c = g_pchain[slot_];
-  if (chained_ && c.ev && hipEventRecord(c.ev, st_) == hipSuccess) {
-    c.recorded = true;
-    c.last = st_;
+  if (chained_) {
+    auto e = std::make_shared<PEvent>();
+    if (hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(e->ev, st_) == hipSuccess)
+      c.fl.push_back({e, grid_, st_});
   }
   c.mu.unlock();
 }
@@ -911,7 +947,7 @@ static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
   g.trace = tracing ? trace_buf : nullptr;
   if (tracing) HIP_CHECK(hipMemsetAsync(trace_buf, 0, 1024 * sizeof(long long), st));
   {
-    PersistentLaunch chain(st);  // ordered after the previous persistent launch of ANY engine on this GPU
+    PersistentLaunch chain(st, c.na * c.nsc);  // admitted only when it fits beside the persistent launches in flight
     hipLaunchKernelGGL(k_small_site, dim3(c.na * c.nsc), dim3(SS_THREADS), lds, st, g);
   }
   HIP_CHECK(hipGetLastError());

@@ -283,9 +283,9 @@ def test_concurrent_engines_from_host_threads():
 
 def test_persistent_launches_of_eight_engines_from_eight_host_threads():
     """8 engines x 200 time steps from 8 host threads on one GPU, every local exponential a persistent one-launch
-    kernel (k_small_site needs all its workgroups resident together): the per-device event chain (small_site.hip,
-    PersistentLaunch) orders the persistent launches of ALL engines, so no two partially resident grids can wait for
-    each other until the exchange time-out.  Results are bit-identical to the same engines run one after the other."""
+    kernel (k_small_site needs all its workgroups resident together): persistent launches of ALL engines are admitted
+    against a per-device budget of compute units (small_site.hip, PersistentLaunch), so the grids in flight always fit
+    the chip together and no two partially resident grids can wait for each other until the exchange time-out.  Results are bit-identical to the same engines run one after the other."""
     import threading
 
     from oracle import tdvp_oracle as orc
