@@ -32,6 +32,28 @@ def test_engine_fails_loudly_without_gpu():
         TDVPEngine(4)
 
 
+def test_site_shard_fails_loudly_without_gpu_and_checks_its_arguments():
+    """The native site shard (mitdvp_shard_*, csrc/shard.hip) has no CPU fallback either; bad rank / block arguments
+    are refused before anything touches a device."""
+    import ctypes as C
+
+    import torch
+
+    from pytdscf_amd import _lib
+
+    lib = _lib.load()
+    cfg = _lib.Config()
+    cfg.nsite, cfg.device, cfg.integrator, cfg.conserve_norm, cfg.thresh, cfg.max_krylov = 4, 0, 0, 1, 1e-9, 20
+    h = C.c_void_p()
+    for rank, world, n, dr in ((2, 2, 4, 8), (0, 2, 1, 8), (0, 2, 4, 0)):  # rank out of range; one-site block; dr_next missing
+        assert lib.mitdvp_shard_create(C.byref(cfg), rank, world, n, dr, C.byref(h)) == _lib.EINVAL
+        assert not h.value and lib.mitdvp_shard_last_error(None)
+    assert lib.mitdvp_shard_step(None, 0.1) == _lib.EINVAL  # null handle
+    if not torch.cuda.is_available():
+        assert lib.mitdvp_shard_create(C.byref(cfg), 0, 2, 4, 8, C.byref(h)) == _lib.EHIP
+        assert not h.value
+
+
 def test_merge_terms_is_exact_sum():
     rng = np.random.default_rng(0)
     dims = [3, 2, 4, 2]
