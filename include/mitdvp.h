@@ -236,7 +236,7 @@ typedef struct mitdvp_shard mitdvp_shard;
 int mitdvp_shard_create(const mitdvp_config* cfg, int rank, int world, int nsite_block, int dr_next, mitdvp_shard** out);
 void mitdvp_shard_destroy(mitdvp_shard* h);
 const char* mitdvp_shard_last_error(const mitdvp_shard* h); /* h may be NULL */
-int mitdvp_shard_engine(mitdvp_shard* h, int which /* 0 block, 1 junction engine */, mitdvp_engine** out);
+int mitdvp_shard_engine(mitdvp_shard* h, int which /* 0 block, 1 junction engine, 2 left junction engine (pair mode) */, mitdvp_engine** out);
 /* the reference's treatment of small singular values at a junction: regularize != 0 lifts singular values below
  * SQRT_EPSRHO = 1e-4 to s + eps exp(-s / eps) -- in the (D_l D_r x d) unfolding of the left junction site before its
  * QR (SiteCoef.gauge_trf(regularize=True), _site_cls.py:207-246) and in the new joint matrix; p_svd >= 0 replaces
@@ -244,6 +244,15 @@ int mitdvp_shard_engine(mitdvp_shard* h, int which /* 0 block, 1 junction engine
  * the cut values, A <- A U, B <- Vh B, blocks rebuilt).  The reference runs with both (regularize = 1, p_svd =
  * const.p_svd, default 1e-7; _mps_parallel.py:369, :437-444); defaults here: 0, -1 (off). */
 int mitdvp_shard_set_options(mitdvp_shard* h, int regularize, double p_svd);
+/* Pair mode (call on EVERY rank before the first step, after the transport is attached): both ranks of a junction run
+ * its update on identical copies of the two facing sites, bond-sharded over the pair -- every apply and environment
+ * update of the two-site engine contracts half of the bra-side bond index on each GPU (the engine's exact tensor
+ * parallelism), combined by two-rank all-gathers / all-reduces over the same point-to-point transport -- instead of
+ * the right rank waiting while the left one works (in the reference the partner of propagate_joint_two_sites sits in
+ * comm.recv, _mps_parallel.py:196-203).  A rank > 0 gets a second two-site engine for the junction to its LEFT
+ * (mitdvp_shard_engine(h, 2, ...): give it the MPO cores of sites (first - 1, first)); dl_prev = left bond dimension of
+ * the left neighbour's last site (ignored on rank 0).  Same results as the default mode to rounding. */
+int mitdvp_shard_enable_pair(mitdvp_shard* h, int dl_prev);
 int mitdvp_shard_set_joint(mitdvp_shard* h, const double* reim, int dim);       /* host, (dim, dim) */
 int mitdvp_shard_get_joint(mitdvp_shard* h, double* reim_out, int* dim);        /* reim_out may be NULL */
 /* Transport.  Production: every rank calls mitdvp_shard_attach_rccl with the 128-byte id one rank got from

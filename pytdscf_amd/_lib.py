@@ -184,6 +184,7 @@ def load() -> C.CDLL:
         "mitdvp_shard_last_error": (C.c_char_p, [vp]),
         "mitdvp_shard_engine": (i, [vp, i, C.POINTER(vp)]),
         "mitdvp_shard_set_options": (i, [vp, i, d]),
+        "mitdvp_shard_enable_pair": (i, [vp, i]),
         "mitdvp_shard_set_joint": (i, [vp, dp, i]),
         "mitdvp_shard_get_joint": (i, [vp, dp, ip]),
         "mitdvp_shard_set_transport": (i, [vp, P2P_FN, vp]),

@@ -35,6 +35,18 @@ class SiteShard {
   // the junction to the right (nullptr on the last rank); dr_next = right bond of the right neighbour's first site
   SiteShard(Engine* block, Engine* joint, int rank, int world, int nsite_block, int dr_next)
       : rank_(rank), world_(world), n_(nsite_block), block_(block), joint_(joint), dr_next_(dr_next) {}
+  // Pair mode: BOTH ranks of a junction run its update, bond-sharded over the pair (the engine's exact tensor
+  // parallelism, DESIGN 7.2, with the two-rank all-gather / all-reduce carried by the shard's own point-to-point
+  // transport): the partner rank works instead of waiting.  jleft = this rank's copy of the two-site engine of the
+  // junction to its LEFT (nullptr on rank 0); dl_prev = left bond of the left neighbour's last site.
+  void enable_pair(Engine* jleft, int dl_prev) {
+    if (rank_ > 0 && (!jleft || dl_prev < 1)) throw ArgError("shard: pair mode needs the left junction engine and dl_prev");
+    jleft_ = jleft;
+    dl_prev_ = dl_prev;
+    pair_ = true;
+  }
+  bool pair_mode() const { return pair_; }
+  int rank() const { return rank_; }
   ~SiteShard() {
     if (comm_) (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(comm_));
   }
@@ -96,8 +108,15 @@ class SiteShard {
   }
 
   void junctions(double dt, int parity) {
-    if (rank_ % 2 == parity && rank_ < world_ - 1) junction_left(dt);
-    else if (rank_ % 2 != parity && rank_ > 0) junction_right();
+    const bool left = rank_ % 2 == parity && rank_ < world_ - 1, right = rank_ % 2 != parity && rank_ > 0;
+    if (pair_) {
+      if (left) junction_pair(dt, true);
+      else if (right) junction_pair(dt, false);
+    } else if (left) {
+      junction_left(dt);
+    } else if (right) {
+      junction_right();
+    }
   }
 
   // neighbour ping over every junction (both directions); returns the number of mismatching values
@@ -163,6 +182,11 @@ class SiteShard {
   int rank_, world_, n_;
   Engine* block_;
   Engine* joint_;
+  Engine* jleft_ = nullptr;  // pair mode: two-site engine of the junction to the LEFT
+  int dl_prev_ = 0;          // pair mode: left bond dimension of the left neighbour's last site
+  bool pair_ = false;
+  int pair_peer_ = -1;       // the rank at the other end of the junction being updated (collective callback)
+  DevBuf psi_l_, env_l_, xl_, coll_tmp_;  // (xl_: the LEFT junction's joint matrix on its right rank; X_ is the right junction's)
   int dr_next_ = 0;  // right bond dimension of the right neighbour's first site
   DevBuf X_, psi_r_, env_r_, xin_, tmpa_, tmpb_;
   int xdim_ = 0;
@@ -179,7 +203,8 @@ class SiteShard {
   // ---- transport ------------------------------------------------------------------------------------------
   void xfer_begin() {
     HIP_CHECK(hipStreamSynchronize(block_->st_));
-    if (joint_) HIP_CHECK(hipStreamSynchronize(joint_->st_));  // operands may come from either engine
+    if (joint_) HIP_CHECK(hipStreamSynchronize(joint_->st_));  // operands may come from any of the engines
+    if (jleft_) HIP_CHECK(hipStreamSynchronize(jleft_->st_));
     if (!fn_) {
       if (!comm_) throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)");
       rccl_check(RcclApi::get().group_start(), "ncclGroupStart");
@@ -377,6 +402,137 @@ class SiteShard {
     b.absorb_bond(false);
   }
 
+  // ---- pair mode ------------------------------------------------------------------------------------------
+  // two-rank all-gather / all-reduce of the bond-sharded junction engine over the point-to-point transport
+  static int pair_collective(void* user, int op, void* dev_ptr, size_t nbytes) {
+    try {
+      static_cast<SiteShard*>(user)->pair_coll(op, static_cast<zc*>(dev_ptr), nbytes / sizeof(zc));
+      return 0;
+    } catch (...) {
+      return 1;
+    }
+  }
+  void pair_coll(int op, zc* p, size_t elems) {
+    const int peer = pair_peer_, me = rank_ < peer ? 0 : 1;
+    if (op == COLL_ALLGATHER) {  // my half is in place; the halves swap
+      const size_t half = elems / 2;
+      exchange(p + (size_t)me * half, half, p + (size_t)(1 - me) * half, half, peer);
+    } else {  // sum: each rank sends its partial block whole and adds the partner's
+      coll_tmp_.reserve(elems);
+      exchange(p, elems, coll_tmp_.p, elems, peer);
+      Engine& J = me == 0 ? *joint_ : *jleft_;
+      vec_axpby(J.st_, p, coll_tmp_.p, (long)elems, make_double2(1.0, 0.0), make_double2(1.0, 0.0));
+      HIP_CHECK(hipStreamSynchronize(J.st_));
+    }
+  }
+  // send a buffer to `peer` and receive one from it: one group with RCCL; with the blocking callback transport the
+  // lower rank sends first
+  void exchange(const zc* snd, size_t ns, zc* rcv, size_t nr, int peer) {
+    xfer_begin();
+    if (fn_ && rank_ > peer) { recv_dev(rcv, nr, peer); send_dev(snd, ns, peer); }
+    else { send_dev(snd, ns, peer); recv_dev(rcv, nr, peer); }
+    xfer_end();
+  }
+
+  // propagate_joint_two_sites (_mps_parallel.py:270-470) run by BOTH ranks of the junction on identical copies of the
+  // two facing sites and the two boundary blocks: every apply and environment update of the two-site engine contracts
+  // half of the bra-side bond on each GPU, the Krylov algebra, the QRs and the small SVDs are replicated (identical
+  // data, identical decisions).  Each rank keeps what it needs at the end (left: A, X', the block right of A; right: B,
+  // X', the block left of B): nothing is sent back.
+  void junction_pair(double dt, bool is_left) {
+    Engine& b = *block_;
+    Engine& J = is_left ? *joint_ : *jleft_;
+    const int peer = is_left ? rank_ + 1 : rank_ - 1;
+    const MpoSite& w0 = J.mpo(0, 0);
+    const MpoSite& w1 = J.mpo(0, 1);
+    int dl, d0, D, d1, Dr;
+    DevBuf kbuf;
+    kbuf.reserve(1);
+    hzc kmsg(0.0, 0.0);
+    if (is_left) {
+      const int pl = n_ - 1;
+      dl = b.dl_[pl]; d0 = b.dd_[pl]; D = b.dr_[pl]; d1 = w1.d; Dr = dr_next_;
+      if (xdim_ != D) throw ArgError("shard: joint matrix and block bond dimension differ");
+      if (!b.envL_ok_[pl]) throw ArgError("shard: the block's left environment at its last site is missing");
+      psi_r_.reserve((size_t)D * d1 * Dr);
+      env_r_.reserve((size_t)Dr * w1.mr * Dr);
+      kmsg = hzc((double)b.kprev_get(n_ - 2), 0.0);
+      HIP_CHECK(hipMemcpy(kbuf.p, &kmsg, sizeof(zc), hipMemcpyHostToDevice));
+      xfer_begin();  // (blocking callbacks: the left rank sends first, the right rank receives first)
+      send_dev(b.site_[pl].p, (size_t)dl * d0 * D, peer);
+      send_dev(b.envL_[pl].p, (size_t)dl * w0.ml * dl, peer);
+      send_dev(X_.p, (size_t)D * D, peer);
+      send_dev(kbuf.p, 1, peer);
+      recv_dev(psi_r_.p, (size_t)D * d1 * Dr, peer);
+      recv_dev(env_r_.p, (size_t)Dr * w1.mr * Dr, peer);
+      xfer_end();
+    } else {
+      D = b.dl_[0]; d1 = b.dd_[0]; Dr = b.dr_[0]; d0 = w0.d; dl = dl_prev_;
+      if (b.center_ != 0) throw ArgError("shard: the block's first site must be the centre before a junction update");
+      if (!b.envR_ok_[1]) throw ArgError("shard: the block's right environment at its first site is missing");
+      psi_l_.reserve((size_t)dl * d0 * D);
+      env_l_.reserve((size_t)dl * w0.ml * dl);
+      xl_.reserve((size_t)D * D);
+      xfer_begin();
+      recv_dev(psi_l_.p, (size_t)dl * d0 * D, peer);
+      recv_dev(env_l_.p, (size_t)dl * w0.ml * dl, peer);
+      recv_dev(xl_.p, (size_t)D * D, peer);
+      recv_dev(kbuf.p, 1, peer);
+      send_dev(b.site_[0].p, (size_t)D * d1 * Dr, peer);
+      send_dev(b.envR_[1].p, (size_t)Dr * w1.mr * Dr, peer);
+      xfer_end();
+      HIP_CHECK(hipMemcpy(&kmsg, kbuf.p, sizeof(zc), hipMemcpyDeviceToHost));
+    }
+    const zc* psi_l = is_left ? b.site_[n_ - 1].p : psi_l_.p;
+    const zc* env_l = is_left ? b.envL_[n_ - 1].p : env_l_.p;
+    const zc* psi_r = is_left ? psi_r_.p : b.site_[0].p;
+    const zc* env_r = is_left ? env_r_.p : b.envR_[1].p;
+    DeviceMode mj(J), mb(b);
+    J.set_parallel(1, 0, nullptr, nullptr);  // set-up copies are local
+    J.set_site(0, dp(psi_l), dl, d0, D, MITDVP_GAUGE_C);
+    J.set_site(1, dp(psi_r), D, d1, Dr, MITDVP_GAUGE_C);
+    J.set_boundary_env(0, dp(env_l), dl, w0.ml);
+    J.set_boundary_env(1, dp(env_r), Dr, w1.mr);
+    J.require_ready();
+    J.kprev_set(0, (int)kmsg.real());
+    xin_.reserve((size_t)D * D);
+    zc* Xj = is_left ? X_.p : xl_.p;  // this junction's joint matrix
+    pinv_dev(J, Xj, D, xin_.p);
+    pair_peer_ = peer;
+    J.set_parallel(2, is_left ? 0 : 1, &SiteShard::pair_collective, this);
+    struct Unshare { Engine& e; ~Unshare() { e.set_parallel(1, 0, nullptr, nullptr); } } unshare{J};
+    J.set_bond(1, dp(xin_.p), D);  // psi_L X^+
+    J.absorb_bond(false);
+    J.replace_site(1, dp(psi_r), MITDVP_GAUGE_PSI);
+    J.split_center(false);
+    J.absorb_bond(false);
+    J.site_exp(dt);
+    if (regularize_) regularize_center(J);
+    J.split_center(true);
+    J.bond_exp(dt);
+    J.kprev_set(1, J.kprev_get(0));
+    J.absorb_bond(true);
+    J.site_exp(dt);
+    J.split_center(false);
+    J.bond_exp(dt);
+    if (p_svd_ >= 0.0) truncate_joint(J);
+    HIP_CHECK(hipStreamSynchronize(J.st_));
+    HIP_CHECK(hipMemcpyAsync(Xj, J.sig_.p, (size_t)D * D * sizeof(zc), hipMemcpyDeviceToDevice, b.st_));
+    HIP_CHECK(hipStreamSynchronize(b.st_));
+    if (is_left) {
+      b.kprev_set(n_ - 2, J.kprev_get(1));
+      b.replace_site(n_ - 1, dp(J.site_[0].p), MITDVP_GAUGE_A);
+      b.set_boundary_env(1, dp(J.envR_[1].p), D, w0.mr);
+      b.set_bond(n_, dp(X_.p), D);
+      b.absorb_bond(false);
+    } else {
+      b.replace_site(0, dp(J.site_[1].p), MITDVP_GAUGE_B);
+      b.set_boundary_env(0, dp(J.envL_[1].p), D, w1.ml);
+      b.set_bond(0, dp(xl_.p), D);
+      b.absorb_bond(true);
+    }
+  }
+
   // The right rank: sends its centre tensor and the block right of it, takes B, X' and the block left of B.
   void junction_right() {
     Engine& b = *block_;
@@ -409,7 +565,7 @@ class SiteShard {
 
 // --------------------------------------------------------------------------------------------------- C ABI
 struct mitdvp_shard {
-  mitdvp_engine block, joint;  // handed out by mitdvp_shard_engine; they live exactly as long as the shard
+  mitdvp_engine block, joint, jleft;  // handed out by mitdvp_shard_engine; they live exactly as long as the shard
   std::unique_ptr<mitdvp::SiteShard> s;
   std::string err;
   int device = 0;
@@ -477,9 +633,21 @@ const char* mitdvp_shard_last_error(const mitdvp_shard* h) { return h ? h->err.c
 int mitdvp_shard_engine(mitdvp_shard* h, int which, mitdvp_engine** out) {
   SH_CALL(h, {
     SH_NEED(out);
-    if (which != 0 && which != 1) throw mitdvp::ArgError("shard_engine: 0 = block, 1 = junction engine");
+    if (which < 0 || which > 2) throw mitdvp::ArgError("shard_engine: 0 = block, 1 = junction engine, 2 = left junction engine (pair mode)");
     if (which == 1 && !h->joint.e) throw mitdvp::ArgError("shard_engine: the last rank has no junction engine");
-    *out = which == 0 ? &h->block : &h->joint;
+    if (which == 2 && !h->jleft.e) throw mitdvp::ArgError("shard_engine: no left junction engine (mitdvp_shard_enable_pair on a rank > 0)");
+    *out = which == 0 ? &h->block : (which == 1 ? &h->joint : &h->jleft);
+  });
+}
+int mitdvp_shard_enable_pair(mitdvp_shard* h, int dl_prev) {
+  SH_CALL(h, {
+    if (h->s->rank() > 0 && !h->jleft.e) {
+      mitdvp_config c = h->block.e->cfg;
+      c.nsite = 2;
+      h->jleft.device = h->device;
+      h->jleft.e.reset(new mitdvp::Engine(c));
+    }
+    h->s->enable_pair(h->jleft.e.get(), dl_prev);
   });
 }
 int mitdvp_shard_set_options(mitdvp_shard* h, int regularize, double p_svd) { SH_CALL(h, h->s->set_options(regularize, p_svd)); }

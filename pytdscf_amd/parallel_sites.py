@@ -129,10 +129,12 @@ class SiteShardedTDVP:
     ``split``: explicit ranges [(first, last), ...] as the reference's ``parallel_split_indices``; default: contiguous
     near-equal ranges.  ``regularize`` / ``p_svd``: the reference's junction regularisation (module docstring).
     ``transport``: "rccl" (library-native, default with one rank per GPU), "callback" (torch.distributed carries the
-    messages; default when ranks share a GPU)."""
+    messages; default when ranks share a GPU).  ``junction``: "pair" (default) = both ranks of a junction run its
+    update, bond-sharded over the pair, so that the partner works instead of waiting; "single" = the left rank alone,
+    like the reference (``MITDVP_JUNCTION`` overrides); same results to rounding."""
 
     def __init__(self, comm, mpo, *, cores=None, dims=None, bond_dim=None, seed=1, integrator="lanczos", thresh=1e-9,
-                 conserve_norm=True, device=None, split=None, regularize=False, p_svd=None, transport=None):
+                 conserve_norm=True, device=None, split=None, regularize=False, p_svd=None, transport=None, junction=None):
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
         self.device = comm.gpu if device is None else device
@@ -159,6 +161,9 @@ class SiteShardedTDVP:
         self.transport = transport or os.environ.get("MITDVP_HALO_TRANSPORT") or ("callback" if shared else "rccl")
         if self.transport not in ("rccl", "callback"):
             raise ValueError("transport must be 'rccl' or 'callback'")
+        self.junction = junction or os.environ.get("MITDVP_JUNCTION") or "pair"
+        if self.junction not in ("pair", "single"):
+            raise ValueError("junction must be 'pair' or 'single'")
         self._h = None
         self._cb = None
         self._setup(cores, dims, bond_dim, seed, shared)
@@ -222,10 +227,19 @@ class SiteShardedTDVP:
             self._ck(lib.mitdvp_shard_engine(h, 1, C.byref(jh)))
             self.joint = TDVPEngine.borrow(jh, 2, self.device)
             self.joint.set_mpo([self.mpo[hi - 1], self.mpo[hi]])
+        self.joint_left = None
+        if N > 1 and self.junction == "pair":
+            self._ck(lib.mitdvp_shard_enable_pair(h, self.shapes[lo - 1][0] if r > 0 else 0))
+            if r > 0:
+                lh = C.c_void_p()
+                self._ck(lib.mitdvp_shard_engine(h, 2, C.byref(lh)))
+                self.joint_left = TDVPEngine.borrow(lh, 2, self.device)
+                self.joint_left.set_mpo([self.mpo[lo - 1], self.mpo[lo]])
         if shared:
             b.set_small_kernels(False)
-            if self.joint is not None:
-                self.joint.set_small_kernels(False)
+            for j in (self.joint, self.joint_left):
+                if j is not None:
+                    j.set_small_kernels(False)
         b.set_mpo(self.mpo[lo:hi])
         if even:
             for i, c in enumerate(bcores):
@@ -562,7 +576,8 @@ class SiteShardedTDVP:
     def close(self):
         if self._h is not None:
             self.block.close()
-            if self.joint is not None:
-                self.joint.close()
+            for j in (self.joint, getattr(self, "joint_left", None)):
+                if j is not None:
+                    j.close()
             self._lib.mitdvp_shard_destroy(self._h)
             self._h = None

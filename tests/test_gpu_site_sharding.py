@@ -72,10 +72,10 @@ from oracle import tdvp_parallel_oracle as par
 from pytdscf_amd.dist import Comm
 from pytdscf_amd.parallel_sites import SiteShardedTDVP
 comm = Comm()
-L, d, M, D, dt, nstep = {L}, 3, 4, 8, 0.2, 2
+L, d, M, D, dt, nstep = {L}, {d}, 4, {D}, 0.2, 2
 mpo = orc.synthetic_mpo(L, d, M, seed=0)
 mps = orc.synthetic_mps([d] * L, D, seed=1)
-eng = SiteShardedTDVP(comm, mpo, cores=mps, integrator={integ!r}, conserve_norm={cn})
+eng = SiteShardedTDVP(comm, mpo, cores=mps, integrator={integ!r}, conserve_norm={cn}, junction={junction!r})
 assert eng.selftest()
 g0 = eng.gather()
 for _ in range(nstep):
@@ -126,7 +126,7 @@ if comm.rank == 0:
                vs_oracle=abs(abs(orc.overlap(go, g)) / (nrm * ref.norm()) - 1),
                norm_gap=abs(nrm - ref.norm()),
                vs_serial=abs(abs(orc.overlap(ser.cores, g)) / nrm - 1), norm=nrm, obs_gap=obs_gap,
-               energy=obs["energy"].real, transport=eng.transport,
+               energy=obs["energy"].real, transport=eng.transport, collectives=(eng.joint.counters()["n_collectives"] if eng.joint is not None else 0),
                bytes=eng.traffic()[0], messages=eng.traffic()[1])
     print("RESULT " + json.dumps(out), flush=True)
 comm.barrier()
@@ -144,9 +144,9 @@ def _launch(script, world, timeout=300):
     return json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
 
 
-def _run(world, tmp_path, L=8, integ="lanczos", cn=True):
+def _run(world, tmp_path, L=8, integ="lanczos", cn=True, d=3, D=8, junction="single"):
     script = tmp_path / f"ss{world}.py"
-    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, L=L, integ=integ, cn=cn)))
+    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, L=L, integ=integ, cn=cn, d=d, D=D, junction=junction)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                MITDVP_DIST_BACKEND="gloo")
     rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
@@ -182,8 +182,8 @@ mpo = [g[f"mpo{{i}}"] for i in range(n)]
 start = [g[f"start{{i}}"] for i in range(n)]
 dt = float(g["dt_au"])
 eng = SiteShardedTDVP(comm, mpo, cores=start, split=[tuple(int(x) for x in r) for r in g["split"]],
-                      regularize=True, p_svd=float(g["p_svd"]))
-assert eng.selftest()
+                      regularize=True, p_svd=float(g["p_svd"]), junction={junction!r})
+assert eng.selftest() and eng.junction == {junction!r}
 worst = dict(fid=0.0, norm=0.0, auto=0.0, sv=0.0, norm_folded=0.0)
 for k in range(int(g["nstep"]) + 1):
     mine = eng.gather()
@@ -217,17 +217,19 @@ comm.close()
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("junction", ["pair", "single"])
 @pytest.mark.parametrize(
     "name, world", [("parallel_chain_r2.npz", 2), ("parallel_chain_r3.npz", 3), ("parallel_chain_graded.npz", 2)]
 )
-def test_site_sharded_reproduces_the_reference_parallel_tdvp(name, world, tmp_path):
+def test_site_sharded_reproduces_the_reference_parallel_tdvp(name, world, junction, tmp_path):
     """MPSCoefParallel.propagate (_mps_parallel.py:106-470) run by the REFERENCE on 2 / 3 ranks
     (tests/golden/make_golden_parallel.py): the state after every step, <Psi|Psi>, <Psi*|Psi>, the spectrum of every
-    joint matrix and every rank's Krylov counts.  ``graded``: Schmidt values down to 1e-6 at the junction, p_svd = 1e-5 --
+    joint matrix and every rank's Krylov counts -- with the junction update on the left rank alone ("single", the
+    reference's arrangement) and bond-sharded over both ranks of the junction ("pair", the default).  ``graded``: Schmidt values down to 1e-6 at the junction, p_svd = 1e-5 --
     the lifting of small singular values and the truncation of the joint matrix act (the reference's <Psi|Psi> falls to
     0.39 after one step); entries of X^+ reach 1e6 there, hence the looser bar."""
     script = tmp_path / "ref.py"
-    script.write_text(textwrap.dedent(REF_WORKER.format(root=ROOT, name=name)))
+    script.write_text(textwrap.dedent(REF_WORKER.format(root=ROOT, name=name, junction=junction)))
     r = _launch(script, world)
     tol = 1e-6 if "graded" in name else 1e-8
     assert r["transport"] == "callback"            # ranks share the GPU: gloo carries the library's messages
@@ -318,6 +320,20 @@ def test_library_rccl_point_to_point_on_a_one_rank_communicator():
             assert bad.value == 0
     finally:
         lib.mitdvp_shard_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_junction_update_bond_sharded_over_the_pair(world, tmp_path):
+    """Pair mode at a bond dimension the engine's tensor parallelism shards (D = 16: rows 0-7 on the left rank of a
+    junction, 8-15 on the right one): all-gathers / all-reduces of the two-site engine over the point-to-point transport
+    must actually run, the state must equal the oracle's and the left-rank-only mode's."""
+    L = 9 if world == 3 else 8
+    r = _run(world, tmp_path, L=L, d=4, D=16, junction="pair")
+    s = _run(world, tmp_path, L=L, d=4, D=16, junction="single")
+    assert r["collectives"] > 20 and s["collectives"] == 0   # rank 0's junction engine: sharded applies in pair mode only
+    assert r["init"] < 1e-12 and r["vs_oracle"] < 1e-8 and r["norm_gap"] < 1e-8 and r["obs_gap"] < 1e-10
+    assert abs(r["energy"] - s["energy"]) < 1e-12 and abs(r["norm"] - s["norm"]) < 1e-12
 
 
 @pytest.mark.gpu
