@@ -291,6 +291,7 @@ class Engine {
   bool chain_env(SmallChain& c, const zc* T, const zc* w2e, int din, int min_, int d, int dout, int mout) const;
   zc* ss_partials(const SmallChain& c);
   SmallSync* qr_sync();          // exchange state for the persistent QR panel kernel (nullptr: per-column launches)
+  QrHistory* qr_hist_ = nullptr; // this engine's memory of the shapes whose fast panels keep failing (qr.h)
   void ss_refresh_plan();
   void ss_check();               // raises what the small-site kernels recorded (not converged / timed out)
   void ss_pull_kprev();

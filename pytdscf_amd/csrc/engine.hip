@@ -34,6 +34,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   HIP_CHECK(hipSetDevice(c.device));
   HIP_CHECK(hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, c.device));
   HIP_CHECK(hipStreamCreate(&st_));
+  qr_hist_ = qr_history_new();
   dl_.assign(L_, 0); dd_.assign(L_, 0); dr_.assign(L_, 0); gauge_.assign(L_, -1);
   site_.resize(L_);
   envL_.resize(L_ + 1); envR_.resize(L_ + 1);
@@ -54,6 +55,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
 Engine::~Engine() {
   if (st_) (void)hipStreamSynchronize(st_);
   small_sync_free(ss_);
+  qr_history_free(qr_hist_);
   if (rccl_comm_) (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(rccl_comm_));
   for (auto& t : pending_) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& e : evpool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -633,7 +635,7 @@ void Engine::gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* 
   HIP_CHECK(hipMemcpyAsync(tmp1_.p, psi, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
   timer_begin(3);
   long nl = 0;
-  qr_householder(st_, tmp1_.p, dl * d, dr, A_out, sigma_out, qrwork_.p, &nl, 0, qr_sync());
+  qr_householder(st_, tmp1_.p, dl * d, dr, A_out, sigma_out, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
   timer_end();
   cnt_.n_launch += nl;
   cnt_.n_qr += 1;
@@ -645,7 +647,7 @@ void Engine::gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc*
   timer_begin(3);
   long nl = 0;
   transpose_rev3(st_, psi, tmp1_.p, dl, d, dr);  // (dr, d, dl)
-  qr_householder(st_, tmp1_.p, dr * d, dl, Bt_out, sig2_.p, qrwork_.p, &nl, 0, qr_sync());
+  qr_householder(st_, tmp1_.p, dr * d, dl, Bt_out, sig2_.p, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
   transpose_batched(st_, sig2_.p, sigma_out, dl, dl, dl, dl, 1, 0, 0);  // sigma = R^T
   if (B_out) transpose_rev3(st_, Bt_out, B_out, dr, d, dl);             // (dl, d, dr)
   timer_end();
@@ -846,7 +848,7 @@ void Engine::sweep(double dt, bool forward) {
       // Psi2Asigma: site[p] (destroyed) -> A in spare, sigma in sig_
       timer_begin(3);
       long nl = 0;
-      qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync());
+      qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
       timer_end();
       cnt_.n_launch += nl; cnt_.n_qr += 1;
       cnt_.qr_flops += 4.0 * (4.0 * (double)dl * d * dr * dr - 4.0 * (double)dr * dr * dr / 3.0);

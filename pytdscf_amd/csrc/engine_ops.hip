@@ -241,7 +241,7 @@ void Engine::thin_to_full_A(const zc* A, int l, int c, int r, int e, zc* out) {
   HIP_CHECK(hipMemcpyAsync(tmp1_.p, A, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
   long nl = 0;
   timer_begin(3);
-  qr_householder(st_, tmp1_.p, l * c, r, out, nullptr, qrwork_.p, &nl, e, qr_sync());
+  qr_householder(st_, tmp1_.p, l * c, r, out, nullptr, qrwork_.p, &nl, e, qr_sync(), qr_hist_);
   timer_end();
   // sign alignment (_site_cls.py:321-335): the leading columns equal the input
   copy2d(st_, out, r + e, A, r, (long)l * c, r, 0, make_double2(1.0, 0.0), false);
@@ -257,7 +257,7 @@ void Engine::thin_to_full_B(const zc* B, int l, int c, int r, int e, zc* out) {
     transpose_batched(st_, B, tmp1_.p, l, m, m, l, 1, 0, 0);  // mat = B.reshape(l, c r).T, _site_cls.py:357
     long nl = 0;
     timer_begin(3);
-    qr_householder(st_, tmp1_.p, m, l, tmp2_.p, nullptr, qrwork_.p, &nl, e, qr_sync());
+    qr_householder(st_, tmp1_.p, m, l, tmp2_.p, nullptr, qrwork_.p, &nl, e, qr_sync(), qr_hist_);
     timer_end();
     transpose_batched(st_, tmp2_.p, out, m, l + e, l + e, m, 1, 0, 0);
     cnt_.n_launch += nl + 2;
@@ -403,7 +403,7 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
     pool_put(std::move(env_bra));
     // from here on the plain step at the new rank
     timer_begin(3);
-    qr_householder(st_, site_[p].p, l * c, newD, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync());
+    qr_householder(st_, site_[p].p, l * c, newD, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
     timer_end();
     cnt_.n_launch += nl; cnt_.n_qr += 1;
     cnt_.qr_flops += 4.0 * (4.0 * (double)l * c * newD * newD - 4.0 * (double)newD * newD * newD / 3.0);

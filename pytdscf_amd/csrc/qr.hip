@@ -654,7 +654,9 @@ int qr_get_fast() { return qr_fast_enabled() ? 1 : 0; }
 // shapes whose panels keep failing the conditioning checks (rank-deficient / strongly graded tensors) skip the fast
 // attempt for a while: 2, 4, ... 64 factorisations after each consecutive failure
 struct QrBackoff { int fails = 0, skip = 0; };
-static thread_local std::map<long, QrBackoff> g_qr_backoff;
+struct QrHistory { std::map<long, QrBackoff> by_shape; };
+QrHistory* qr_history_new() { return new QrHistory(); }
+void qr_history_free(QrHistory* h) { delete h; }
 
 size_t qr_work_elems(int m, int n, int next) {
   const int nblk = (m + 31) / 32;  // upper bound over all row-block sizes
@@ -671,13 +673,16 @@ size_t qr_work_elems(int m, int n, int next) {
   return e;
 }
 
-static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast);
+static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast,
+                    QrHistory* hist);
 
-void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy) {
-  qr_impl(st, A, m, n, Q, R, work, nlaunch, next, sy, qr_fast_enabled());
+void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy,
+                    QrHistory* hist) {
+  qr_impl(st, A, m, n, Q, R, work, nlaunch, next, sy, qr_fast_enabled(), hist);
 }
 
-static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast) {
+static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast,
+                    QrHistory* hist) {
   if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
   if (next < 0 || n + next > m) throw ArgError("qr: more orthogonal-complement columns requested than exist");
   if (n <= 0) return;
@@ -734,8 +739,10 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
   };
   const long bkey = (long)m * 100003L + n;
   if (fast && m >= 2 * QR_NB) {
-    QrBackoff& bo = g_qr_backoff[bkey];
-    if (bo.skip > 0) { bo.skip -= 1; fast = false; }
+    if (hist) {
+      QrBackoff& bo = hist->by_shape[bkey];
+      if (bo.skip > 0) { bo.skip -= 1; fast = false; }
+    }
   } else {
     fast = false;
   }
@@ -825,16 +832,18 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     int bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, fflag, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    QrBackoff& bo = g_qr_backoff[bkey];
     if (bad) {
-      bo.fails = std::min(bo.fails + 1, 6);
-      bo.skip = 1 << bo.fails;
+      if (hist) {
+        QrBackoff& bo = hist->by_shape[bkey];
+        bo.fails = std::min(bo.fails + 1, 6);
+        bo.skip = 1 << bo.fails;
+      }
       HIP_CHECK(hipMemcpyAsync(A, backup, (size_t)m * n * sizeof(zc), hipMemcpyDeviceToDevice, st));
       if (nlaunch) *nlaunch += nl;
-      qr_impl(st, A, m, n, Q, R, work, nlaunch, next, sy, false);
+      qr_impl(st, A, m, n, Q, R, work, nlaunch, next, sy, false, nullptr);
       return;
     }
-    bo.fails = 0;
+    if (hist) hist->by_shape[bkey].fails = 0;
   }
   // R
   if (R) {
