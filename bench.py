@@ -480,8 +480,9 @@ def main():
                 "parallelism": {"single": "single GPU", "replicas": f"{args.gpus} independent replicas",
                                 "tp": f"bond-sharded over {args.gpus} GPUs (all-gather / all-reduce via {collectives})",
                                 "sites": f"site ranges over {args.gpus} GPUs (L/N sites per rank, one library call per time step: "
-                                         "half-sweeps + joint two-site update through pinv(X) + neighbour halo "
-                                         f"[{ss.transport if ss is not None else None}]); control plane torch.distributed/{comm.backend}; "
+                                         "half-sweeps + joint two-site update through pinv(X) "
+                                         f"[{(ss.junction + ': both ranks of a junction, bond-sharded') if ss is not None and ss.junction == 'pair' else 'left rank of a junction'}] "
+                                         f"+ neighbour halo [{ss.transport if ss is not None else None}]); control plane torch.distributed/{comm.backend}; "
                                          "roofline / breakdown are rank 0's block"}[mode],
                 "halo_GB": halo[0] / 1e9,
                 "halo_messages": halo[1],

@@ -75,7 +75,7 @@ comm = Comm()
 L, d, M, D, dt, nstep = {L}, {d}, 4, {D}, 0.2, 2
 mpo = orc.synthetic_mpo(L, d, M, seed=0)
 mps = orc.synthetic_mps([d] * L, D, seed=1)
-eng = SiteShardedTDVP(comm, mpo, cores=mps, integrator={integ!r}, conserve_norm={cn}, junction={junction!r})
+eng = SiteShardedTDVP(comm, mpo, cores=mps, integrator={integ!r}, conserve_norm={cn}, junction={junction!r}, **{opts!r})
 assert eng.selftest()
 g0 = eng.gather()
 for _ in range(nstep):
@@ -114,7 +114,7 @@ if comm.rank == 0:
     rdm_gap = max([rdm_gap] + [np.abs(rd_multi[k] - orc.reduced_density(gcan, [k.count(p) for p in range(L)])).max() for k in rd_multi])
     obs_gap = max(rdm_gap, abs(obs["norm"] - np.sqrt(sandwich(gc, g).real)), abs(obs["auto"] - sandwich(g, g)),
                   abs(obs["energy"] - sandwich(gc, g, mpo)), abs(obs["op2"] - sandwich(gc, g, op2)))
-    ref = par.ParallelOracle([c.copy() for c in mps], mpo, comm.world, integrator={integ!r}, conserve_norm={cn})
+    ref = par.ParallelOracle([c.copy() for c in mps], mpo, comm.world, integrator={integ!r}, conserve_norm={cn}, **{opts!r})
     ser = orc.OracleMPS([c.copy() for c in mps], mpo, integrator={integ!r}, conserve_norm={cn})
     ser.build_right_envs()
     for _ in range(nstep):
@@ -144,9 +144,9 @@ def _launch(script, world, timeout=300):
     return json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
 
 
-def _run(world, tmp_path, L=8, integ="lanczos", cn=True, d=3, D=8, junction="single"):
+def _run(world, tmp_path, L=8, integ="lanczos", cn=True, d=3, D=8, junction="single", opts=None):
     script = tmp_path / f"ss{world}.py"
-    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, L=L, integ=integ, cn=cn, d=d, D=D, junction=junction)))
+    script.write_text(textwrap.dedent(WORKER.format(root=ROOT, L=L, integ=integ, cn=cn, d=d, D=D, junction=junction, opts=opts or {})))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                MITDVP_DIST_BACKEND="gloo")
     rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
@@ -334,6 +334,12 @@ def test_junction_update_bond_sharded_over_the_pair(world, tmp_path):
     assert r["collectives"] > 20 and s["collectives"] == 0   # rank 0's junction engine: sharded applies in pair mode only
     assert r["init"] < 1e-12 and r["vs_oracle"] < 1e-8 and r["norm_gap"] < 1e-8 and r["obs_gap"] < 1e-10
     assert abs(r["energy"] - s["energy"]) < 1e-12 and abs(r["norm"] - s["norm"]) < 1e-12
+    if world == 2:  # the reference's regularisation + truncation of the joint matrix inside the sharded junction engine
+        opts = dict(regularize=True, p_svd=1e-8)
+        r = _run(world, tmp_path, L=L, d=4, D=16, junction="pair", opts=opts)
+        s = _run(world, tmp_path, L=L, d=4, D=16, junction="single", opts=opts)
+        assert r["vs_oracle"] < 1e-8 and r["norm_gap"] < 1e-8
+        assert abs(r["energy"] - s["energy"]) < 1e-12 and abs(r["norm"] - s["norm"]) < 1e-12
 
 
 @pytest.mark.gpu
