@@ -396,17 +396,19 @@ int qr_fast_panel(hipStream_t st, zc* A, long lda, int m, int j0, int nbp, zc* V
   // round 1
   hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, P, lda, mp, nbp, part, rpb);
   hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R1inv, (const zc*)nullptr, R1, 0, flag);
-  hipLaunchKernelGGL(k_fq_apply, dim3(nblk), dim3(256), 0, st, P, lda, mp, nbp, R1inv, Q1, (long)NB, (zc*)nullptr, 0L, 0, rpb);
+  // (the applies have no partial results to keep few: 32 rows per workgroup, four 8-row passes each)
+  const int arows = 32, ablk = (mp + arows - 1) / arows;
+  hipLaunchKernelGGL(k_fq_apply, dim3(ablk), dim3(256), 0, st, P, lda, mp, nbp, R1inv, Q1, (long)NB, (zc*)nullptr, 0L, 0, arows);
   // round 2
   hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, part, rpb);
   hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R2inv, R1, Rtot, 1, flag);
-  hipLaunchKernelGGL(k_fq_apply, dim3(nblk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, R2inv, Q2, (long)NB, (zc*)nullptr, 0L, 0, rpb);
+  hipLaunchKernelGGL(k_fq_apply, dim3(ablk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, R2inv, Q2, (long)NB, (zc*)nullptr, 0L, 0, arows);
   // Householder reconstruction: top block, then V2 = Q2[nbp:] U^-1 into the panel and into Vp
   hipLaunchKernelGGL(k_fq_reconstruct, dim3(1), dim3(1024 / FQ_NQ), 0, st, Q2, (long)NB, Rtot, nbp, P, lda, Vp, Tp, tau + j0, Uinv, flag);
   int nl = 7;
   if (mp > nbp) {
-    const int nb2 = (mp - nbp + rpb - 1) / rpb;
-    hipLaunchKernelGGL(k_fq_apply, dim3(nb2), dim3(256), 0, st, Q2, (long)NB, mp, nbp, Uinv, P, lda, Vp, (long)nbp, nbp, rpb);
+    const int nb2 = (mp - nbp + arows - 1) / arows;
+    hipLaunchKernelGGL(k_fq_apply, dim3(nb2), dim3(256), 0, st, Q2, (long)NB, mp, nbp, Uinv, P, lda, Vp, (long)nbp, nbp, arows);
     ++nl;
   }
   HIP_CHECK(hipGetLastError());
