@@ -186,7 +186,7 @@ class SiteShard {
   int dl_prev_ = 0;          // pair mode: left bond dimension of the left neighbour's last site
   bool pair_ = false;
   int pair_peer_ = -1;       // the rank at the other end of the junction being updated (collective callback)
-  DevBuf psi_l_, env_l_, xl_, coll_tmp_;  // (xl_: the LEFT junction's joint matrix on its right rank; X_ is the right junction's)
+  DevBuf psi_l_, env_l_, xl_, coll_tmp_, kbuf_;  // (xl_: the LEFT junction's joint matrix on its right rank; X_ is the right junction's)
   int dr_next_ = 0;  // right bond dimension of the right neighbour's first site
   DevBuf X_, psi_r_, env_r_, xin_, tmpa_, tmpb_;
   int xdim_ = 0;
@@ -220,7 +220,7 @@ class SiteShard {
       if (fn_(user_, 0, peer, stage_.data(), elems * sizeof(zc)) != 0) throw HipError("shard: the send callback failed");
       return;
     }
-    rccl_check(RcclApi::get().send(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclSend");
+    group_check(RcclApi::get().send(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclSend");
   }
   void recv_dev(zc* p, size_t elems, int peer) {
     if (fn_) {
@@ -229,7 +229,13 @@ class SiteShard {
       HIP_CHECK(hipMemcpy(p, stage_.data(), elems * sizeof(zc), hipMemcpyHostToDevice));
       return;
     }
-    rccl_check(RcclApi::get().recv(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclRecv");
+    group_check(RcclApi::get().recv(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclRecv");
+  }
+  // an error inside an open group closes the group before it is raised (a group left open would swallow every later call)
+  void group_check(ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return;
+    if (in_group_) { in_group_ = false; (void)RcclApi::get().group_end(); }
+    rccl_check(r, what);
   }
   void xfer_end() {
     if (in_group_) {
@@ -446,7 +452,7 @@ class SiteShard {
     const MpoSite& w0 = J.mpo(0, 0);
     const MpoSite& w1 = J.mpo(0, 1);
     int dl, d0, D, d1, Dr;
-    DevBuf kbuf;
+    DevBuf& kbuf = kbuf_;
     kbuf.reserve(1);
     hzc kmsg(0.0, 0.0);
     if (is_left) {
