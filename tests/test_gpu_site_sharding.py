@@ -346,6 +346,8 @@ def test_junction_update_bond_sharded_over_the_pair(world, tmp_path):
 def test_site_sharded_arnoldi_without_renormalisation(tmp_path):
     r = _run(2, tmp_path, integ="arnoldi", cn=False)
     assert r["vs_oracle"] < 1e-8 and r["vs_serial"] < 1e-6
+    p = _run(2, tmp_path, integ="arnoldi", cn=False, d=4, D=16, junction="pair")  # sharded Hessenberg solves in the junction engine
+    assert p["collectives"] > 20 and p["vs_oracle"] < 1e-8 and p["vs_serial"] < 1e-6
 
 
 @pytest.mark.gpu
