@@ -438,6 +438,47 @@ class WFunc:
         return complex(row[0])
 
 
+def _add_scalar_to_mpo(mpo, c):
+    """MPO of H + c: one more bond route carrying c on the first site and identities after it."""
+    out = []
+    n = len(mpo)
+    for i, w in enumerate(mpo):
+        ml, d, _, mr = w.shape
+        a, b = (ml if i == 0 else ml + 1), (mr if i == n - 1 else mr + 1)
+        z = np.zeros((a, d, d, b), dtype=np.complex128)
+        z[:ml, :, :, :mr] = w
+        eye = np.eye(d, dtype=np.complex128) * (c if i == 0 else 1.0)
+        z[a - 1, :, :, b - 1] += eye
+        out.append(z)
+    return out
+
+
+class _ShardedEngine:
+    """What the property loop of ``Simulator.propagate`` asks of an engine, answered by one rank of the site-sharded
+    sweep; every call is collective over the ranks."""
+
+    def __init__(self, sh, ops, ham):
+        self.sh, self.ops, self.ham, self.rank = sh, ops, ham, sh.rank
+
+    def autocorr(self):
+        return self.sh.autocorr()
+
+    def norm(self):
+        return self.sh.norm()
+
+    def expectation(self, k):
+        return self.sh.expectation(None if k == 0 else self.ops[k])
+
+    def reduced_density(self, legs):
+        return self.sh.reduced_density([i for i, n in enumerate(legs) for _ in range(n)])
+
+    def propagate(self, dt):
+        self.sh.step(dt)
+
+    def close(self):
+        self.sh.close()
+
+
 class Simulator:
     """``Simulator(jobname, model, ci_type="MPS", backend="hip", ...)`` --
     simulator_cls.py:58-94; ``propagate`` follows :160-285 and the loop of
@@ -464,6 +505,9 @@ class Simulator:
 
     def save_wavefunction(self, wf, ext=""):
         from . import checkpoint
+
+        if wf is None:  # not the writing rank of a sharded run (simulator_cls.py:584)
+            return
 
         checkpoint.save(self._wf_path(ext), wf.engine, self.model.space, self.model.nstate)
 
@@ -550,10 +594,9 @@ class Simulator:
                   energy_per_step=1, norm_per_step=1, populations_per_step=1, parallel_split_indices=None,
                   adaptive=False, adaptive_Dmax=20, adaptive_dD=5, adaptive_p_proj=1.0e-04, adaptive_p_svd=1.0e-07,
                   integrator="lanczos", display_time_unit="fs", conserve_norm=True):
-        if parallel_split_indices is not None:
-            raise NotImplementedError("MPI site sharding (approximate real-space parallel TDVP) is not part of the engine; see DESIGN.md section 7")
         if integrator not in ("lanczos", "arnoldi"):
             raise ValueError(f"Invalid integrator: {integrator}")
+        sharded = parallel_split_indices is not None
         dt_fs = Δt if Δt is not None else stepsize
         dt_au = dt_fs / units.au_in_fs
         liou = self.model.space == "liouville"
@@ -564,18 +607,28 @@ class Simulator:
                 raise NotImplementedError("Liouville space: pass energy=False (the Hamiltonian entry is the super-operator), like tests/test_mixedstate.py:434")
             if autocorr:
                 autocorr = False
-        eng, ids = self._engine(integrator, conserve_norm, thresh_sil, restart_ext=loadfile_ext if restart else None)
         multi = self.model.nstate > 1
         if multi and (adaptive or reduced_density is not None or not self.t2_trick):
             raise NotImplementedError("several electronic states: adaptive bonds, reduced densities and t2_trick=False are not implemented")
+        lead = True  # the rank that writes the files (const.mpi_rank == 0 in the reference)
+        if sharded:
+            # const.mpi_size > 1 (simulator_cls.py:364-370, :526-531): one site range per rank, each on its own GPU
+            if multi or liou or adaptive or restart or not self.t2_trick or self.model.one_gate_to_apply is not None or self.model.kraus_op:
+                raise NotImplementedError("parallel_split_indices: one electronic state in Hilbert space with t2_trick, "
+                                          "without adaptive bonds, restart, gates or Kraus operators")
+            eng, ids = self._sharded_engine(parallel_split_indices, integrator, conserve_norm, thresh_sil, adaptive_p_svd)
+            lead = eng.rank == 0
+        else:
+            eng, ids = self._engine(integrator, conserve_norm, thresh_sil, restart_ext=loadfile_ext if restart else None)
         if adaptive:  # const.adaptive / Dmax / dD / p_proj (_const_cls.py:212-216); p_svd is unused there too (:968-983)
             eng.set_adaptive(True, Dmax=adaptive_Dmax, dD=adaptive_dD, p_proj=adaptive_p_proj)
-        wf = self._wfunc(eng, ids)
+        wf = None if sharded else self._wfunc(eng, ids)
         outdir = f"{self.jobname}_prop"
-        os.makedirs(outdir, exist_ok=True)
+        if lead:
+            os.makedirs(outdir, exist_ok=True)
         tconv = {"fs": units.au_in_fs, "ps": units.au_in_fs * 1e-3, "au": 1.0}[display_time_unit]
         names = ("autocorr", "populations", "expectations") + (("bonddim",) if adaptive else ())
-        files = {k: open(os.path.join(outdir, f"{k}.dat"), "w") for k in names}
+        files = {k: open(os.path.join(outdir, f"{k}.dat") if lead else os.devnull, "w") for k in names}
         self.rdm_trace = []
         ener = None
         try:
@@ -620,10 +673,13 @@ class Simulator:
                         rec[tuple(key)] = eng.partial_trace(legs) if liou else eng.reduced_density(legs)
                     self.rdm_trace.append((t, rec))
                 if istep % backup_interval == backup_interval - 1:
-                    self.save_wavefunction(wf, savefile_ext)
+                    self.save_wavefunction(self._gathered_wfunc(eng, integrator, conserve_norm, thresh_sil) if sharded else wf,
+                                           savefile_ext)
                 eng.propagate(dt_au)
+            if sharded:
+                wf = self._gathered_wfunc(eng, integrator, conserve_norm, thresh_sil)
             self.save_wavefunction(wf, savefile_ext)
-            if reduced_density is not None and self.rdm_trace:
+            if lead and reduced_density is not None and self.rdm_trace:
                 # reduced_density.nc in the reference's layout (properties.py:156-209): time(step) and
                 # rho_{key}_{istate}(step, Q.., Q..); NETCDF4 compound type with netCDF4, NetCDF-3 + (re, im) axis without
                 from .util.nc_writer import write_reduced_density_nc
@@ -633,7 +689,47 @@ class Simulator:
         finally:
             for f in files.values():
                 f.close()
+            if sharded:
+                eng.close()
         return ener, wf
+
+    def _sharded_engine(self, split, integrator, conserve_norm, thresh, p_svd):
+        """The engine of ``propagate(parallel_split_indices=...)``: this rank's site range of the real-space parallel
+        sweep (MPSCoefParallel, _mps_parallel.py), with the reference's junction regularisation and ``adaptive_p_svd``
+        truncation always on as there.  Ranks come from RANK / WORLD_SIZE / MASTER_* (torchrun), one GPU each."""
+        from .dist import world_comm
+        from .parallel_sites import SiteShardedTDVP
+
+        m = self.model
+        comm = world_comm()
+        if len(split) != comm.world:  # _const_cls.py:237
+            raise ValueError(f"parallel_split_indices has {len(split)} ranges but the job has {comm.world} rank(s)")
+        ids = {"hamiltonian": 0}
+        ids.update({name: k for k, name in enumerate(m.observables, start=1)})
+        box = [None]
+        if comm.rank == 0:  # the operators may live on rank 0 alone, as in the reference's MPI test
+            ops = {0: m.hamiltonian.as_mpo(m.dims)}
+            ops.update({ids[name]: op.as_mpo(m.dims) for name, op in m.observables.items()})
+            box = [(ops, m.hamiltonian.coupleJ[0][0])]
+        if comm.world > 1:  # TensorHamiltonian.distribute_mpo_cores (simulator_cls.py:364-370)
+            comm.dist.broadcast_object_list(box, src=0)
+        ops, shift = box[0]
+        mpo = [np.array(w, dtype=np.complex128) for w in ops[0]]
+        if shift:  # the scalar term of the Hamiltonian rides on the first core's identity route
+            mpo = _add_scalar_to_mpo(mpo, shift)
+        sh = SiteShardedTDVP(comm, mpo, cores=m.initial_cores(), integrator=integrator, thresh=thresh,
+                             conserve_norm=conserve_norm, split=[tuple(r) for r in split], regularize=True, p_svd=p_svd)
+        return _ShardedEngine(sh, ops, mpo), ids
+
+    def _gathered_wfunc(self, eng, integrator, conserve_norm, thresh):
+        """MPSCoefParallel.to_MPSCoefMPO (simulator_cls.py:578-583): the whole chain on rank 0 as an ordinary wave
+        function (site-0-centred canonical form, norm kept); None on the other ranks.  Collective."""
+        cores = eng.sh.gather()
+        if eng.rank != 0:
+            return None
+        full, ids = self._engine(integrator, conserve_norm, thresh)
+        full.set_mps(cores, canonicalize=True, scale=None)
+        return self._wfunc(full, ids)
 
     def relax(self, stepsize=0.1, maxstep=20, improved=True, restart=False, savefile_ext="_gs", loadfile_ext="",
               backup_interval=10, norm=True, populations=True, observables=False, integrator="lanczos",

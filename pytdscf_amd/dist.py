@@ -108,6 +108,17 @@ class Comm:
             self.dist = None
 
 
+_WORLD = None
+
+
+def world_comm() -> Comm:
+    """The process-wide rendezvous (torch.distributed can be initialised once): what the shell API uses."""
+    global _WORLD
+    if _WORLD is None or (_WORLD.world > 1 and _WORLD.dist is None):
+        _WORLD = Comm()
+    return _WORLD
+
+
 def replica_throughput(comm: Comm, units_this_rank: float, elapsed_this_rank: float) -> tuple[float, float]:
     """Whole-job throughput of independent replicas: (sum of units over ranks) /
     (max elapsed over ranks).  Returns (throughput, max_elapsed)."""

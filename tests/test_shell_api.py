@@ -67,6 +67,19 @@ def test_unsupported_combinations_raise():
         Simulator("j", m, ci_type="MCTDH")
 
 
+def test_parallel_split_indices_must_match_the_ranks(golden, monkeypatch):
+    """_const_cls.py:237 -- one site range per rank; unsupported combinations are refused before any rendezvous."""
+    from pytdscf_amd import Simulator
+
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    sim = Simulator("j", _exciton_model(golden("exciton.npz")), backend="hip")
+    with pytest.raises(ValueError, match="2 ranges but the job has 1 rank"):
+        sim.propagate(maxstep=1, parallel_split_indices=[(0, 1), (2, 3)])
+    with pytest.raises(NotImplementedError):
+        sim.propagate(maxstep=1, parallel_split_indices=[(0, 1), (2, 3)], adaptive=True)
+
+
 @pytest.mark.gpu
 def test_exciton_script_on_gpu(golden, tmp_path, monkeypatch):
     """tests/test_exiciton_propagate.py of the reference, through the shell."""
