@@ -50,7 +50,7 @@ __device__ __forceinline__ int cd_row(int mode, int lk, int r) {
 }
 
 template <int WM, int WN, int BK, bool TA, bool TB, bool M3, bool SP = false>
-__global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
+__global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
   constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
   constexpr int LDAS = TA ? BM : (BK + 1);  // LDS row stride (complex elements)
   constexpr int LDBS = TB ? (BK + 1) : BN;
@@ -113,30 +113,47 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
   const int wm = w >> 1, wn = w & 1;
   const int li = lane & 15, lk = lane >> 4;
 
-  zc ra[A_PT], rb[B_PT];
+  // MITDVP_ZG_SETS (compile time): 1 = one register set per operand (the loads of tile k+2 are issued after the LDS
+  // stores of tile k+1 freed it: ~0.7 tile between a load and its use), 2 = two sets alternating by tile parity (loads of
+  // tile k+2 go out FIRST in tile k, into the set tile k's data left; 1.25 tiles between a load and its use)
+#ifndef MITDVP_ZG_SETS
+#define MITDVP_ZG_SETS 2
+#endif
+  constexpr int NSET = MITDVP_ZG_SETS;
+#ifndef MITDVP_ZG_STSLOT
+#define MITDVP_ZG_STSLOT 2
+#endif
+  typedef double v2d __attribute__((ext_vector_type(2)));  // one complex element as a register pair (plain loads / stores)
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  v2d ra[NSET][A_PT], rb[NSET][B_PT];
 
-  // Per-thread load pointers, advanced by one K tile per load.  Rows / columns
-  // beyond M / N are clamped to the last valid one (their products land in
-  // output elements that are never stored); elements beyond K are read from
-  // element 0 of the operand (valid memory) and zeroed when written to LDS.
-  const zc* pa[A_PT];
-  const zc* pb[B_PT];
-  int la[A_PT], lb[B_PT];  // LDS element offsets inside a stage
+  // Load addresses = uniform base of the tile (scalar registers; one K tile further per tile) + a per-thread byte
+  // offset that never changes (32 bits: a tile's rows span BM * lda elements, checked on the host).  Rows / columns
+  // beyond M / N are clamped to the last valid one (their products land in output elements that are never stored);
+  // elements beyond K are buffer loads with an out-of-range offset, which return zero: LDS stores need no mask.
+  unsigned oa[A_PT], ob[B_PT];
   // k index inside the tile: base (per thread) + compile-time offset per element
   const int kbA = TA ? t / BM : t % BK;
   const int kbB = TB ? t % BK : t / BN;
   constexpr int KSA = TA ? 256 / BM : 0;
   constexpr int KSB = TB ? 0 : 256 / BN;
   static_assert(256 % BK == 0 && 256 % BM == 0 && 256 % BN == 0, "thread/tile mapping");
+  // LDS element offsets inside a stage: affine in the element number p
+  const int la0 = TA ? (t / BM) * LDAS + t % BM : (t / BK) * LDAS + t % BK;
+  const int lb0 = A_SZ + (TB ? (t / BK) * LDBS + t % BK : (t / BN) * LDBS + t % BN);
+  constexpr int LSA = TA ? (256 / BM) * LDAS : (256 / BK) * LDAS;
+  constexpr int LSB = TB ? (256 / BK) * LDBS : (256 / BN) * LDBS;
+  // stored row of A's row m (the identity-block shortcut skips one stored row in every arow_skip)
+  auto arow = [&](int gm) { return (!TA && d.arow_skip > 1) ? (long)gm + gm / (d.arow_skip - 1) + 1 : (long)gm; };
+  const char* const baseA = reinterpret_cast<const char*>(A + (TA ? (long)m0 : arow(m0) * lda));
+  const char* const baseB = reinterpret_cast<const char*>(B + (TB ? (long)n0 * ldb : (long)n0));
 #pragma unroll
   for (int p = 0; p < A_PT; ++p) {
     const int e = t + p * 256;
     int m, k;
     if (TA) { k = e / BM; m = e % BM; } else { m = e / BK; k = e % BK; }
     const int gm = min(m0 + m, M - 1);
-    const long ga = (!TA && d.arow_skip > 1) ? (long)gm + gm / (d.arow_skip - 1) + 1 : (long)gm;  // stored row of A
-    pa[p] = A + (TA ? (long)k * lda + gm : ga * lda + k);
-    la[p] = TA ? k * LDAS + m : m * LDAS + k;
+    oa[p] = (unsigned)((TA ? (long)k * lda + (gm - m0) : (arow(gm) - arow(m0)) * lda + k) * (long)sizeof(zc));
   }
 #pragma unroll
   for (int p = 0; p < B_PT; ++p) {
@@ -144,11 +161,10 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
     int n, k;
     if (TB) { n = e / BK; k = e % BK; } else { k = e / BN; n = e % BN; }
     const int gn = min(n0 + n, N - 1);
-    pb[p] = B + (TB ? (long)gn * ldb + k : (long)k * ldb + gn);
-    lb[p] = A_SZ + (TB ? n * LDBS + k : k * LDBS + n);
+    ob[p] = (unsigned)((TB ? (long)(gn - n0) * ldb + k : (long)k * ldb + (gn - n0)) * (long)sizeof(zc));
   }
-  const long stepA = TA ? (long)BK * lda : BK;
-  const long stepB = TB ? BK : (long)BK * ldb;
+  const long stepA = (TA ? (long)BK * lda : (long)BK) * (long)sizeof(zc);  // bytes per K tile
+  const long stepB = (TB ? (long)BK : (long)BK * ldb) * (long)sizeof(zc);
 
   // side work of the pipeline, one element at a time so that it can be spread
   // between the MFMAs of a tile: item < NP stores element `item` of the tile held
@@ -171,45 +187,36 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
 #define MITDVP_ABLATE 0
 #endif
   constexpr bool abl_nobar = (MITDVP_ABLATE & 8) != 0, abl_noload = (MITDVP_ABLATE & 16) != 0, abl_nostore = (MITDVP_ABLATE & 32) != 0;
-  auto side = [&](int item, zc* stage, int kv, int kv2, int ord = 0) {
+  // ss = register set stored from, sl = register set loaded into
+  auto side = [&](int item, zc* stage, int kv, int kv2, int ord, auto SS, auto SL, auto FULL) __attribute__((always_inline)) {
+    constexpr int ss = decltype(SS)::value, sl = decltype(SL)::value;
+    constexpr bool full = decltype(FULL)::value;
     if (item < NP && abl_nostore && stage != smem) return;
     if (item >= NP && abl_noload && ord >= 2) return;
     if (item < A_PT) {
-      const int p = item;
-      const bool ok = kbA + p * KSA < kv;
-      zc v = ra[p];
-      v.x = ok ? v.x : 0.0;
-      v.y = ok ? v.y : 0.0;
-      stage[la[p]] = v;
+      *reinterpret_cast<v2d*>(&stage[la0 + item * LSA]) = ra[ss][item];
     } else if (item < NP) {
-      const int p = item - A_PT;
-      const bool ok = kbB + p * KSB < kv;
-      zc v = rb[p];
-      v.x = ok ? v.x : 0.0;
-      v.y = ok ? v.y : 0.0;
-      stage[lb[p]] = v;
-    } else if (item < NP + A_PT) {
-      const int p = item - NP;
-      if (SP) {
-        const bool ok = ord < nlist;
-        ra[p] = *(ok ? pa[p] + (long)kl[ok ? ord : 0] * stepA : A);
-      } else {
-        const bool ok = kbA + p * KSA < kv2;
-        ra[p] = *(ok ? pa[p] : A);
-        pa[p] += stepA;
-      }
+      *reinterpret_cast<v2d*>(&stage[lb0 + (item - A_PT) * LSB]) = rb[ss][item - A_PT];
     } else if (item < 2 * NP) {
-      const int p = item - NP - A_PT;
-      if (SP) {
-        const bool ok = ord < nlist;
-        rb[p] = *(ok ? pb[p] + (long)kl[ok ? ord : 0] * stepB : B);
-      } else {
-        const bool ok = kbB + p * KSB < kv2;
-        rb[p] = *(ok ? pb[p] : B);
-        pb[p] += stepB;
-      }
+      // buffer loads: scalar descriptor of the tile (base = uniform tile origin, rebuilt per tile in scalar registers)
+      // + the thread's constant 32-bit offset; an offset beyond the descriptor's range returns ZERO without touching
+      // memory, which is how elements beyond K are filled (general form: one select per load; FULL: none)
+      const bool isA = item < NP + A_PT;
+      const int p = isA ? item - NP : item - NP - A_PT;
+      const bool any = full || (SP ? ord < nlist : kv2 > 0);
+      const long tk = SP ? (long)kl[any ? ord : 0] : (long)ord;
+      const bool ok = full || (SP ? any : (isA ? kbA + p * KSA : kbB + p * KSB) < kv2);
+      const char* base = isA ? baseA + tk * stepA : baseB + tk * stepB;
+      const unsigned off = isA ? oa[p] : ob[p];
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xFFFFFFF0u, 0x00020000);
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : 0xFFFFFFFFu, 0, 0);
+      if (isA) ra[sl][p] = __builtin_bit_cast(v2d, v);
+      else rb[sl][p] = __builtin_bit_cast(v2d, v);
     }
   };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, NSET - 1>;
+  using GEN = std::false_type;  // loads that may reach beyond K (prologue, last tiles)
 
   // Accumulators are born as MFMA results (0*0 + 0) so that they live in the
   // AGPR half of the register file for the whole K loop: with a plain constant
@@ -231,14 +238,18 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
 
   const unsigned sa_mask = d.conjA ? 0x80000000u : 0u;
   const unsigned sb_mask = d.conjB ? 0x80000000u : 0u;
+  const double sgnA = d.conjA ? -1.0 : 1.0, sgnB = d.conjB ? -1.0 : 1.0;
   constexpr int NK4 = BK / 4;
   constexpr int SLOTS = NK4 * WM;                       // MFMA groups per tile
   // side items after each MFMA group: front-loaded (twice the even share) so that
   // the global loads of tile k+2 are in flight for most of tile k
   constexpr int PER_SLOT = 2 * ((2 * NP + SLOTS - 1) / SLOTS);
+  // two register sets: first MFMA group after which the LDS stores start (the loads take NP / PER_SLOT groups)
+  constexpr int ST_SLOT = (MITDVP_ZG_STSLOT * PER_SLOT >= NP && MITDVP_ZG_STSLOT * PER_SLOT + NP <= SLOTS * PER_SLOT)
+                              ? MITDVP_ZG_STSLOT : (NP + PER_SLOT - 1) / PER_SLOT;
 
   // LDS -> register fragments of k-step k4 of a stage
-  auto ldfrag = [&](const zc* st, int k4, zc (&a)[WM], zc (&bb)[WN]) {
+  auto ldfrag = [&](const zc* st, int k4, zc (&a)[WM], zc (&bb)[WN]) __attribute__((always_inline)) {
     const int kk = k4 * 4 + lk;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
@@ -253,16 +264,20 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
   };
 
   const int nkt = SP ? nlist : (K + BK - 1) / BK;
-  // prologue: tile 0 -> LDS stage 0, tile 1 -> registers
+  // prologue: tile 0 -> LDS stage 0, tile 1 -> registers (set 1 of two)
 #pragma unroll
-  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K, 0);
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K, 0, I0{}, I0{}, GEN{});
 #pragma unroll
-  for (int it = 0; it < NP; ++it) side(it, smem, SP ? (nlist > 0 ? BK : 0) : K, 0);
+  for (int it = 0; it < NP; ++it) side(it, smem, 0, 0, 0, I0{}, I0{}, GEN{});
 #pragma unroll
-  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K - BK, 1);
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K - BK, 1, I0{}, I1{}, GEN{});
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  // one K tile; PAR = parity of kt when two register sets alternate (compile-time register indices)
+  auto tile = [&](int kt, auto PAR, auto FULL) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value;
+    using SL = std::integral_constant<int, NSET == 2 ? par : 0>;        // free set: tile kt+2 is loaded into it
+    using SS = std::integral_constant<int, NSET == 2 ? 1 - par : 0>;    // holds tile kt+1: stored to the other stage
     const zc* st = smem + (kt & 1) * STAGE;
     zc* nst = smem + ((kt + 1) & 1) * STAGE;
     // valid k of the tile in registers (<= 0: no such tile) / of the tile to load now
@@ -276,16 +291,20 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
       zc a[WM], bb[WN];
       // conjugation = flip the sign bit of the imaginary part (one 32-bit xor
       // instead of an f64 multiply on the VALU port the MFMAs share)
+      // (every vector instruction between the MFMAs takes matrix-pipe issue time on this chip: 4M flips the sign
+      // bit of the imaginary parts -- one 32-bit xor each; 3M needs no flip at all: with sA, sB = -1 for a conjugated
+      // operand the products are P1 = Ar Br, P2 = Ai Bi (unsigned), P3 = (Ar + sA Ai)(Br + sB Bi), and
+      // Re = P1 - sA sB P2, Im = P3 - P1 - sA sB P2 -- the signs ride on the fused multiply-add that forms the sums)
 #pragma unroll
-      for (int i = 0; i < WM; ++i) { a[i] = fa[k4 & 1][i]; a[i].y = flip_sign(a[i].y, sa_mask); }
+      for (int i = 0; i < WM; ++i) { a[i] = fa[k4 & 1][i]; if (!M3) a[i].y = flip_sign(a[i].y, sa_mask); }
 #pragma unroll
-      for (int j = 0; j < WN; ++j) { bb[j] = fb[k4 & 1][j]; bb[j].y = flip_sign(bb[j].y, sb_mask); }
+      for (int j = 0; j < WN; ++j) { bb[j] = fb[k4 & 1][j]; if (!M3) bb[j].y = flip_sign(bb[j].y, sb_mask); }
       double as[WM], bs[WN];
       if (M3) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) as[i] = a[i].x + a[i].y;
+        for (int i = 0; i < WM; ++i) as[i] = __builtin_fma(sgnA, a[i].y, a[i].x);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) bs[j] = bb[j].x + bb[j].y;
+        for (int j = 0; j < WN; ++j) bs[j] = __builtin_fma(sgnB, bb[j].y, bb[j].x);
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
@@ -314,18 +333,43 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
           for (int j = 0; j < WN; ++j)
             acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, bb[j].x, acc[1][i][j], 0, 0, 0);
         }
-        // side work spread over the MFMA groups: first all LDS stores of tile
-        // kt+1 (the other stage), then the global loads of tile kt+2
-        // (sched_barrier pins this order: left alone, hipcc clusters all memory
-        // operations at the top of the tile, where nothing overlaps them)
+        // side work spread over the MFMA groups (sched_barrier pins the order: left alone, hipcc clusters all
+        // memory operations at the top of the tile, where nothing overlaps them).  One register set: first all
+        // LDS stores of tile kt+1 (the other stage), then the global loads of tile kt+2 into the registers they
+        // freed.  Two sets: the loads of tile kt+2 first, into the free set, then the stores of tile kt+1.
         const int slot = k4 * WM + i;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < PER_SLOT; ++q) side(slot * PER_SLOT + q, nst, kv1, kv2, kt + 2);
+        for (int q = 0; q < PER_SLOT; ++q) {
+          int item = slot * PER_SLOT + q;
+          if (NSET == 2) {  // loads in the first slots, stores from slot ST_SLOT on
+            constexpr int S0 = ST_SLOT * PER_SLOT;
+            item = item < NP ? item + NP : (item >= S0 && item < S0 + NP ? item - S0 : 2 * NP);
+          }
+          side(item, nst, kv1, kv2, kt + 2, SS{}, SL{}, FULL);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (!abl_nobar) __syncthreads();
+  };
+  // tiles kt whose prefetch target kt+2 lies inside K as a whole run the FULL form, the last ones the general one
+  const int nfull = max((SP ? nlist : K / BK) - 2, 0);
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int kt = 0;
+  if (NSET == 2) {
+    for (; kt + 1 < nfull; kt += 2) {
+      tile(kt, P0{}, std::true_type{});
+      tile(kt + 1, P1{}, std::true_type{});
+    }
+    for (; kt < nkt; kt += 2) {  // kt is even here: register-set parity stays a compile-time constant
+      tile(kt, P0{}, GEN{});
+      if (kt + 1 < nkt) tile(kt + 1, P1{}, GEN{});
+    }
+  } else {
+    for (; kt < nfull; ++kt) tile(kt, P0{}, std::true_type{});
+    for (; kt < nkt; ++kt) tile(kt, P0{}, GEN{});
   }
 
   // ---- epilogue: C = alpha*acc + beta*C -----------------------------------
@@ -343,7 +387,7 @@ __global__ __launch_bounds__(256) void zgemm_kernel(ZgemmDesc d, int ntm, int nt
         if (row < M && col < N) {
           zc v;
           if (M3) {
-            const double p1 = acc[0][i][j][r], p2 = acc[1][i][j][r], p3 = acc[NACC - 1][i][j][r];
+            const double p1 = acc[0][i][j][r], p2 = sgnA * sgnB * acc[1][i][j][r], p3 = acc[NACC - 1][i][j][r];
             v = make_double2(p1 - p2, p3 - p1 - p2);
           } else {
             v = make_double2(acc[0][i][j][r], acc[1][i][j][r]);
@@ -623,6 +667,7 @@ void zgemm(hipStream_t st, const ZgemmDesc& d0) {
   if (d.K < 0) throw ArgError("zgemm: negative K");
   if (d.arow_skip && (d.transA || d.arow_skip < 2 || d.klist)) throw ArgError("zgemm: arow_skip needs a plain, untransposed A");
   if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
+  if (d.lda >= (1L << 20) || d.ldb >= (1L << 20)) throw ArgError("zgemm: row stride >= 2^20 elements (per-thread tile offsets are 32-bit)");
   (void)zgemm_cd_mode(st);
   int cfg = d.tile_cfg;
   const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
