@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     kl += 1;
   }
   // MITDVP_ABLATE (compile time, TIMING EXPERIMENTS ONLY -- the product is wrong with any bit set): 8 no barrier in the
-  // K loop, 16 no global loads in the K loop, 32 no LDS stores in the K loop.  A second library built with
+  // K loop, 16 no global loads in the K loop, 32 no LDS stores in the K loop, 64 no 3M sums (P3 = Ar Br).  A second library built with
   // -DMITDVP_ABLATE=n (make ABLATE=n) and loaded through MITDVP_LIB; never the shipped one.
 #ifndef MITDVP_ABLATE
 #define MITDVP_ABLATE 0
@@ -302,9 +302,9 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
       double as[WM], bs[WN];
       if (M3) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) as[i] = __builtin_fma(sgnA, a[i].y, a[i].x);
+        for (int i = 0; i < WM; ++i) as[i] = (MITDVP_ABLATE & 64) ? a[i].x : __builtin_fma(sgnA, a[i].y, a[i].x);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) bs[j] = __builtin_fma(sgnB, bb[j].y, bb[j].x);
+        for (int j = 0; j < WN; ++j) bs[j] = (MITDVP_ABLATE & 64) ? bb[j].x : __builtin_fma(sgnB, bb[j].y, bb[j].x);
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
