@@ -681,6 +681,9 @@ void zgemm(hipStream_t st, const ZgemmDesc& d0) {
     // 64x64 tile WITH split-K (below): 512x512x8192 runs at 53 vs 42 TFLOP/s, 256x256x4096 at 47 vs 35.
     const long t64 = tiles(64, 64);
     cfg = (t64 >= 256 || (t64 >= 16 && d.K >= 1024 && d.batch == 1)) ? 1 : 2;
+    // MITDVP_ZGEMM_BIGTILE=1 (experiments): the 128-row tile, one workgroup per CU, for outputs of >= 1024 such tiles
+    static const int big_env = [] { const char* e = std::getenv("MITDVP_ZGEMM_BIGTILE"); return e ? std::atoi(e) : 0; }();
+    if (big_env && cfg == 1 && tiles(128, 64) >= 1024) cfg = 0;
   }
   // split-K for skinny outputs with a long contraction (QR block reflectors,
   // K_eff second stage): too few tiles to fill 256 CUs otherwise
