@@ -173,10 +173,14 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
   constexpr int NP = A_PT + B_PT;
   // SP: the K tiles to visit come from a list (block-sparse A); `ord` = position in that list of the tile being
   // loaded.  K % BK == 0 there, so a listed tile is valid as a whole and an unlisted position loads nothing.
-  const int* kl = nullptr;
+  // (read through the constant address space: the list is written by the host before the launch, and a uniform load
+  // from there is a SCALAR load -- the tile number lands in a scalar register and the buffer descriptor built from it
+  // stays uniform; through a plain global pointer hipcc loads it per lane and wraps every staging load in a waterfall loop)
+  typedef __attribute__((address_space(4))) const int cint4;
+  const cint4* kl = nullptr;
   int nlist = 0;
   if (SP) {
-    kl = d.klist + (long)tm * d.klist_stride;
+    kl = (const cint4*)(unsigned long)(d.klist + (long)tm * d.klist_stride);
     nlist = kl[0];
     kl += 1;
   }
