@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     } else if (item < 2 * NP) {
       // buffer loads: scalar descriptor of the tile (base = uniform tile origin, rebuilt per tile in scalar registers)
       // + the thread's constant 32-bit offset; an offset beyond the descriptor's range returns ZERO without touching
-      // memory, which is how elements beyond K are filled (general form: one select per load; FULL: none)
+      // memory, which is how elements beyond K are filled (general form: one select per load; FULL: none); the
+      // out-of-range offset equals the record count, so that offset + 15 cannot wrap around 32 bits
       const bool isA = item < NP + A_PT;
       const int p = isA ? item - NP : item - NP - A_PT;
       const bool any = full || (SP ? ord < nlist : kv2 > 0);
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
       const char* base = isA ? baseA + tk * stepA : baseB + tk * stepB;
       const unsigned off = isA ? oa[p] : ob[p];
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xFFFFFFF0u, 0x00020000);
-      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : 0xFFFFFFFFu, 0, 0);
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : 0xFFFFFFF0u, 0, 0);
       if (isA) ra[sl][p] = __builtin_bit_cast(v2d, v);
       else rb[sl][p] = __builtin_bit_cast(v2d, v);
     }
