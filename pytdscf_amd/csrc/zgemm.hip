@@ -5,21 +5,23 @@
 // row-major complex GEMM, so this kernel is the dominant kernel of the engine.
 //
 // Design (gfx950):
-//   * v_mfma_f64_16x16x4_f64, one real MFMA per (re,im) x (re,im) product:
-//       Cre += Are*Bre - Aim*Bim ;  Cim += Are*Bim + Aim*Bre     ("4M" form)
-//     complex MAC = 4 real MFMA-MACs = 8 flop, which is exactly the flop count
-//     SURVEY 8(d) uses, so MFMA utilisation = algorithmic flops / peak.
-//   * operands stay interleaved (re,im) in HBM and LDS: one lane's A (or B)
-//     operand for the 4 MFMAs is ONE 16-byte element = one ds_read_b128, so
-//     transposed / conjugated operand forms cost nothing extra.
-//   * 256-thread workgroups, 2x2 waves, each wave owns WMxWN 16x16 blocks with
-//     (re,im) accumulators in registers (WM=WN=4: 256 accumulator VGPRs, one
-//     wave per SIMD -- the f64 MFMA is 16 passes long, LDS/global traffic per
-//     MFMA is tiny, so occupancy is not what hides latency here).
-//   * register-staged global->LDS prefetch of the next K tile while the MFMAs of
-//     the current tile issue.
-//   * XCD-aware block remap + grouped tile order so that the blocks sharing an
-//     L2 walk neighbouring tiles.
+//   * v_mfma_f64_16x16x4_f64.  Complex product either "4M" (Cre += Are*Bre - Aim*Bim ; Cim += Are*Bim + Aim*Bre:
+//     4 real MFMAs per tile step = the 8 flop per complex MAC SURVEY 8(d) counts) or, by default, "3M" (Karatsuba:
+//     P1 = Ar Br, P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi); Re = P1 - P2, Im = P3 - P1 - P2: three accumulator sets,
+//     25 % less matrix-core work).
+//   * operands stay interleaved (re,im) in HBM and LDS: one lane's A (or B) operand of a tile step is ONE 16-byte
+//     element = one ds_read_b128, so transposed / conjugated operand forms cost nothing extra.
+//   * 256-thread workgroups, 2x2 waves, each wave owns WMxWN 16x16 blocks.  Default tile 64x64 (WM = WN = 2, 96
+//     accumulator registers in 3M) with TWO workgroups per CU -- two waves per SIMD fill each other's barrier and
+//     latency bubbles; a 128-row tile (one wave per SIMD) and a 32x32 tile for small outputs exist beside it.
+//   * the K loop holds nothing but MFMAs, the 3M sums and memory instructions: FP64 MFMA and FP64 VALU share the
+//     datapath on this chip, so every other vector instruction between two MFMAs is matrix time lost.  Staging loads
+//     are BUFFER loads (scalar descriptor = tile origin, advanced per K tile on the scalar unit; constant 32-bit
+//     per-thread offsets; out-of-range offsets return zero, which fills the K tail), LDS offsets are one base +
+//     compile-time strides, conjugation rides on the fused multiply-add of the 3M sums.
+//   * register-staged global->LDS prefetch, two staging register sets alternating by tile parity: the loads of tile
+//     k+2 are issued first in tile k, the LDS stores of tile k+1 after them, one barrier per tile, two LDS stages.
+//   * XCD-aware block remap + grouped tile order so that the blocks sharing an L2 walk neighbouring tiles.
 #include <algorithm>
 #include <cstdlib>
 
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
 #endif
   constexpr bool abl_nobar = (MITDVP_ABLATE & 8) != 0, abl_noload = (MITDVP_ABLATE & 16) != 0, abl_nostore = (MITDVP_ABLATE & 32) != 0;
   // ss = register set stored from, sl = register set loaded into
-  auto side = [&](int item, zc* stage, int kv, int kv2, int ord, auto SS, auto SL, auto FULL) __attribute__((always_inline)) {
+  auto side = [&](int item, zc* stage, int kv2, int ord, auto SS, auto SL, auto FULL) __attribute__((always_inline)) {
     constexpr int ss = decltype(SS)::value, sl = decltype(SL)::value;
     constexpr bool full = decltype(FULL)::value;
     if (item < NP && abl_nostore && stage != smem) return;
@@ -271,11 +273,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
   const int nkt = SP ? nlist : (K + BK - 1) / BK;
   // prologue: tile 0 -> LDS stage 0, tile 1 -> registers (set 1 of two)
 #pragma unroll
-  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K, 0, I0{}, I0{}, GEN{});
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, K, 0, I0{}, I0{}, GEN{});
 #pragma unroll
-  for (int it = 0; it < NP; ++it) side(it, smem, 0, 0, 0, I0{}, I0{}, GEN{});
+  for (int it = 0; it < NP; ++it) side(it, smem, 0, 0, I0{}, I0{}, GEN{});
 #pragma unroll
-  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, 0, K - BK, 1, I0{}, I1{}, GEN{});
+  for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, K - BK, 1, I0{}, I1{}, GEN{});
   __syncthreads();
 
   // one K tile; PAR = parity of kt when two register sets alternate (compile-time register indices)
@@ -285,9 +287,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     using SS = std::integral_constant<int, NSET == 2 ? 1 - par : 0>;    // holds tile kt+1: stored to the other stage
     const zc* st = smem + (kt & 1) * STAGE;
     zc* nst = smem + ((kt + 1) & 1) * STAGE;
-    // valid k of the tile in registers (<= 0: no such tile) / of the tile to load now
-    const int kv1 = SP ? (kt + 1 < nlist ? BK : 0) : K - (kt + 1) * BK;
-    const int kv2 = SP ? 0 : kv1 - BK;
+    // valid k of the tile to load now (<= 0: no such tile)
+    const int kv2 = SP ? 0 : K - (kt + 2) * BK;
     zc fa[2][WM], fb[2][WN];
     ldfrag(st, 0, fa[0], fb[0]);
 #pragma unroll
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
             constexpr int S0 = ST_SLOT * PER_SLOT;
             item = item < NP ? item + NP : (item >= S0 && item < S0 + NP ? item - S0 : 2 * NP);
           }
-          side(item, nst, kv1, kv2, kt + 2, SS{}, SL{}, FULL);
+          side(item, nst, kv2, kt + 2, SS{}, SL{}, FULL);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
