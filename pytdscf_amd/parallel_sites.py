@@ -161,6 +161,7 @@ class SiteShardedTDVP:
         self.transport = transport or os.environ.get("MITDVP_HALO_TRANSPORT") or ("callback" if shared else "rccl")
         if self.transport not in ("rccl", "callback"):
             raise ValueError("transport must be 'rccl' or 'callback'")
+        self._junction_explicit = bool(junction or os.environ.get("MITDVP_JUNCTION"))
         self.junction = junction or os.environ.get("MITDVP_JUNCTION") or "pair"
         if self.junction not in ("pair", "single"):
             raise ValueError("junction must be 'pair' or 'single'")
@@ -218,6 +219,12 @@ class SiteShardedTDVP:
         _lib.check(lib.mitdvp_shard_create(C.byref(cfg), r, N, n, dr_next, C.byref(h)), None, shard=True)
         self._h, self._lib = h, lib
         self._ck(lib.mitdvp_shard_set_options(h, int(self.regularize), -1.0 if self.p_svd is None else float(self.p_svd)))
+        if N > 1:
+            self._attach_transport()
+            if self.transport == "callback" and not shared and self.junction == "pair" and not self._junction_explicit:
+                # host-staged messages between different GPUs: the pair mode's 6x larger halo (both ranks need both
+                # halves of the junction) would cost more than the partner's idle time it saves
+                self.junction = "single"
         eh = C.c_void_p()
         self._ck(lib.mitdvp_shard_engine(h, 0, C.byref(eh)))
         b = TDVPEngine.borrow(eh, n, self.device)
@@ -264,8 +271,6 @@ class SiteShardedTDVP:
         if r < N - 1:  # joint matrix of the junction to the right (held by the left rank of every junction)
             x = np.ascontiguousarray(X_right, dtype=np.complex128)
             self._ck(lib.mitdvp_shard_set_joint(h, x.ctypes.data_as(C.POINTER(C.c_double)), x.shape[0]))
-        if N > 1:
-            self._attach_transport()
 
     def _attach_transport(self):
         """library-native RCCL between chain neighbours, or torch.distributed through the callback transport; all
