@@ -564,10 +564,24 @@ class SiteShardedTDVP:
         if self.world == 1:
             return True
         bad = C.c_int(-1)
-        try:
-            self._ck(self._lib.mitdvp_shard_selftest(self._h, C.byref(bad)))
-        except Exception as exc:  # noqa: BLE001 -- shared below
-            print(f"[site sharding] rank {self.rank}: transport self-test raised {exc}", flush=True)
+
+        def ping():
+            try:
+                self._ck(self._lib.mitdvp_shard_selftest(self._h, C.byref(bad)))
+            except Exception as exc:  # noqa: BLE001 -- shared below
+                print(f"[site sharding] rank {self.rank}: transport self-test raised {exc}", flush=True)
+
+        # with a deadline: a point-to-point transfer whose peer never arrives blocks for ever in the stream, and a run that
+        # hangs measures nothing.  A rank that times out leaves the handle behind (its stream is stuck: close() would block)
+        import threading
+
+        th = threading.Thread(target=ping, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("MITDVP_SELFTEST_TIMEOUT", "180")))
+        if th.is_alive():
+            print(f"[site sharding] rank {self.rank}: transport self-test did not return in time", flush=True)
+            self._wedged = True
+            return self.comm.min_over_ranks(0.0) >= 1.0
         return self.comm.min_over_ranks(1.0 if bad.value == 0 else 0.0) >= 1.0
 
     def traffic(self):
@@ -579,6 +593,9 @@ class SiteShardedTDVP:
         return (int(b.value), int(m.value))
 
     def close(self):
+        if getattr(self, "_wedged", False):  # a transfer still blocks the shard's stream: leak it rather than hang
+            self._h = None
+            return
         if self._h is not None:
             self.block.close()
             for j in (self.joint, getattr(self, "joint_left", None)):
