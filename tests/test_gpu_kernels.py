@@ -24,6 +24,34 @@ def test_mfma_layout_and_peak():
     assert tf > 20.0
 
 
+@pytest.mark.parametrize("k", [1, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65, 81])
+def test_zgemm_short_and_ragged_contractions(k):
+    """The K loop is peeled: tiles whose prefetch target lies inside K run a form without selects, the last two a general
+    one whose out-of-range elements are buffer loads that return zero, the tile loop is unrolled by the staging-register
+    parity.  Every count of K tiles from one to six, with and without a tail, in the four operand forms and both complex
+    products, against NumPy."""
+    from pytdscf_amd import engine as E
+
+    rng = np.random.default_rng(1000 + k)
+    m, n = 130, 70
+    for tA, tB, cA, cB in [(0, 0, 0, 0), (0, 1, 0, 1), (1, 0, 1, 0), (1, 1, 0, 0)]:
+        A = crandn(rng, *((k, m) if tA else (m, k)))
+        B = crandn(rng, *((n, k) if tB else (k, n)))
+        opA = (A.T if tA else A)
+        opB = (B.T if tB else B)
+        opA = opA.conj() if cA else opA
+        opB = opB.conj() if cB else opB
+        ref = opA @ opB
+        for mode in ("3m", "4m"):
+            E.set_gemm_mode(mode)
+            try:
+                for tile in (1, 2):
+                    out = E.zgemm(A, B, None, bool(tA), bool(cA), bool(tB), bool(cB), tile_cfg=tile)
+                    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-13, (k, tA, tB, mode, tile)
+            finally:
+                E.set_gemm_mode("3m")
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize(
     "tA,cA,tB,cB", [(0, 0, 0, 0), (0, 0, 1, 0), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 1, 1), (1, 1, 1, 1), (0, 1, 0, 1)]
