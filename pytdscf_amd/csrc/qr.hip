@@ -300,6 +300,30 @@ __global__ __launch_bounds__(256) void k_qr_build_t(const zc* __restrict__ G, co
   for (int e = threadIdx.x; e < nbp * nbp; e += 256) T[e] = Ts[e / nbp][e % nbp];
 }
 
+// V of the whole factorisation as one m x n matrix (zero above each column's diagonal element, which is 1): panel ip is
+// stored as an (m - 32 ip) x 32 unit-lower trapezoid starting at vall + ((ip m - 32 ip (ip - 1) / 2) 32)
+__global__ __launch_bounds__(256) void k_qr_assemble_v(const zc* __restrict__ vall, int m, int n, zc* __restrict__ V) {
+  const long tot = (long)m * n;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / n), c = (int)(e % n);
+    const int ip = c / QR_NB, j0 = ip * QR_NB;
+    zc v = make_double2(0.0, 0.0);
+    if (r >= j0) v = vall[((size_t)ip * m - (size_t)QR_NB * ip * (ip - 1) / 2) * QR_NB + (size_t)(r - j0) * QR_NB + (c - j0)];
+    V[e] = v;
+  }
+}
+
+// T (n x n, zero) <- the panels' 32 x 32 factors on the diagonal
+__global__ __launch_bounds__(256) void k_qr_place_t(const zc* __restrict__ Tp, int n, zc* __restrict__ T) {
+  const long tot = (long)n * n;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / n), c = (int)(e % n);
+    zc v = make_double2(0.0, 0.0);
+    if (r / QR_NB == c / QR_NB) v = Tp[(size_t)(r / QR_NB) * QR_NB * QR_NB + (size_t)(r % QR_NB) * QR_NB + (c % QR_NB)];
+    T[e] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, long lda, int n, zc* __restrict__ R) {
   const long tot = (long)n * n;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
@@ -670,6 +694,7 @@ size_t qr_work_elems(int m, int n, int next) {
   e += 2 * (size_t)nblk * QR_NB;   // partial y, double buffered
   e += 2 * QR_NB;                  // exported row, double buffered
   e += qr_fast_work_elems(m, n);   // CholeskyQR2 panels: input copy, panel buffers, flag
+  e += (size_t)m * n + 3 * (size_t)n * n + (size_t)n * (n + next);  // Q through the global compact-WY factor: V, G, T, scratch, X
   return e;
 }
 
@@ -850,10 +875,55 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     hipLaunchKernelGGL(k_qr_extract_r, dim3(vec_blocks((long)n * n)), dim3(256), 0, st, A, lda, n, R);
     ++nl;
   }
-  // Q = H_1 ... H_k I[:, :n+next]  (zungqr, block reflectors applied in reverse); columns
-  // n.. are the leading columns of the orthogonal complement in LAPACK's "full" Q
+  // Q = H_1 ... H_k I[:, :n+next]; columns n.. are the leading columns of the orthogonal complement in LAPACK's "full" Q
   set_identity(st, Q, m, nqt, nqt);
   ++nl;
+  // Fast panels keep every V: the product of the block reflectors is ONE block reflector I - V T V^H with the n x n
+  // factor T whose diagonal blocks are the panels' and T12 = -T11 (V1^H V2) T22 for every split into a left and a
+  // right half (Schreiber & Van Loan) -- built by doubling (log2(panels) levels of two batched GEMMs on blocks of
+  // G = V^H V), after which Q = E - V (T (V[:n+next, :])^H) is three large GEMMs instead of three small ones per panel
+  // applied in reverse order (zungqr): 15 launches instead of 3 per panel + split-K combines, ~0.15 against ~0.55 ms at
+  // 2048 x 512.  Panel counts that are not a power of two keep the reverse loop.  MITDVP_QR_GLOBALT=0: off.
+  static const bool globalt_on = !(std::getenv("MITDVP_QR_GLOBALT") && std::atoi(std::getenv("MITDVP_QR_GLOBALT")) == 0);
+  if (fast && globalt_on && n % QR_NB == 0 && npan >= 2 && (npan & (npan - 1)) == 0) {
+    zc* Vf = backup + qr_fast_work_elems(m, n);
+    zc* Gm = Vf + (size_t)m * n;
+    zc* Tb = Gm + (size_t)n * n;
+    zc* Sc = Tb + (size_t)n * n;
+    zc* Xm = Sc + (size_t)n * n;
+    hipLaunchKernelGGL(k_qr_assemble_v, dim3(vec_blocks((long)m * n)), dim3(256), 0, st, vall, m, n, Vf);
+    hipLaunchKernelGGL(k_qr_place_t, dim3(vec_blocks((long)n * n)), dim3(256), 0, st, T, n, Tb);
+    {
+      ZgemmDesc g = zgemm_desc(Vf, Vf, Gm, n, n, m);  // G = V^H V
+      g.transA = 1; g.conjA = 1; g.lda = n; g.ldb = n; g.ldc = n;
+      zgemm(st, g);
+    }
+    nl += 3;
+    for (int b = QR_NB; b < n; b *= 2) {
+      const int pairs = n / (2 * b);
+      const long stride = 2L * b * (n + 1);
+      ZgemmDesc t1 = zgemm_desc(Gm + b, Tb + (long)b * (n + 1), Sc + b, b, b, b);  // S12 = G12 T22
+      t1.lda = n; t1.ldb = n; t1.ldc = n; t1.batch = pairs; t1.strideA = t1.strideB = t1.strideC = stride;
+      zgemm(st, t1);
+      ZgemmDesc t2 = zgemm_desc(Tb, Sc + b, Tb + b, b, b, b);  // T12 = -T11 S12
+      t2.lda = n; t2.ldb = n; t2.ldc = n; t2.batch = pairs; t2.strideA = t2.strideB = t2.strideC = stride;
+      t2.alpha = mone;
+      zgemm(st, t2);
+      nl += 2;
+    }
+    {
+      ZgemmDesc x = zgemm_desc(Tb, Vf, Xm, n, nqt, n);  // X = T (V[:nqt, :])^H
+      x.transB = 1; x.conjB = 1; x.ldb = n;
+      zgemm(st, x);
+      ZgemmDesc q = zgemm_desc(Vf, Xm, Q, m, nqt, n);  // Q = E - V X
+      q.alpha = mone; q.beta = one;
+      zgemm(st, q);
+      nl += 2;
+    }
+    HIP_CHECK(hipGetLastError());
+    if (nlaunch) *nlaunch += nl;
+    return;
+  }
   for (int ip = npan - 1; ip >= 0; --ip) {
     const int j0 = ip * QR_NB, j1 = min(n, j0 + QR_NB), nbp = j1 - j0, mp = m - j0;
     const int nq = nqt - j0;
