@@ -261,7 +261,11 @@ class Engine {
   // workspaces
   DevBuf X_, Y_, V_, Vdiag_, tmp1_, tmp2_, sig_, sig2_, qrwork_, red_;
   int max_diag_krylov_ = 64;
-  zc* h_red_ = nullptr;  // pinned host mirror of red_
+  zc* h_red_ = nullptr;  // pinned host mirror of red_ (host-coherent, mapped into the device: h_red_dev_)
+  zc* h_red_dev_ = nullptr;
+  unsigned* h_seq_ = nullptr;      // sequence word the publish kernel bumps and read_partials spins on
+  unsigned* h_seq_dev_ = nullptr;
+  unsigned seq_tag_ = 0;
   size_t red_elems_ = 0;
   std::vector<int> kprev_;
 

@@ -42,7 +42,16 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   kprev_.assign(L_, 0);
   red_.reserve(RED_TOTAL);
   red_elems_ = RED_TOTAL;
-  HIP_CHECK(hipHostMalloc((void**)&h_red_, RED_TOTAL * sizeof(zc)));
+  HIP_CHECK(hipHostMalloc((void**)&h_red_, RED_TOTAL * sizeof(zc), hipHostMallocMapped | hipHostMallocCoherent));
+  HIP_CHECK(hipHostMalloc((void**)&h_seq_, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  *h_seq_ = 0;
+  {
+    void* dp = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&dp, h_red_, 0));
+    h_red_dev_ = static_cast<zc*>(dp);
+    HIP_CHECK(hipHostGetDevicePointer(&dp, h_seq_, 0));
+    h_seq_dev_ = static_cast<unsigned*>(dp);
+  }
   // trivial boundary blocks, construct_op_zerosite (_mps_mpo.py:364-419)
   const zc one = make_double2(1.0, 0.0);
   envL_[0].reserve(1); envR_[L_].reserve(1);
@@ -60,6 +69,7 @@ Engine::~Engine() {
   for (auto& t : pending_) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& e : evpool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h_red_) (void)hipHostFree(h_red_);
+  if (h_seq_) (void)hipHostFree(h_seq_);
   if (st_) { zgemm_release_stream(st_); (void)hipStreamDestroy(st_); }
 }
 
@@ -135,7 +145,34 @@ void Engine::counters_reset() {
   std::memset(&cnt_, 0, sizeof(cnt_));
 }
 
+// A Krylov iteration's scalars on their way to the host.  hipMemcpyAsync + hipStreamSynchronize costs ~15 us per round
+// trip on this stack; a one-workgroup kernel that copies the values into the (host-coherent, device-mapped) pinned buffer
+// and then bumps a sequence word the host spins on costs ~7 us (tools/probes/sync_latency.hip).  Local exponentials of the
+// mid-size regime wait for three or four such round trips each.  MITDVP_SPIN_SYNC=0: the copy + synchronise form.
+__global__ __launch_bounds__(256) void k_publish(const zc* __restrict__ src, zc* __restrict__ dst, size_t count,
+                                                 volatile unsigned* seq, unsigned tag) {
+  for (size_t e = threadIdx.x; e < count; e += 256) dst[e] = src[e];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *seq = tag;
+}
+
 void Engine::read_partials(size_t off, size_t count) {
+  static const bool spin = !(std::getenv("MITDVP_SPIN_SYNC") && std::atoi(std::getenv("MITDVP_SPIN_SYNC")) == 0);
+  if (spin && h_seq_ && count <= 16384) {
+    const unsigned tag = ++seq_tag_;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st_, red_.p + off, h_red_dev_ + off, count, h_seq_dev_, tag);
+    HIP_CHECK(hipGetLastError());
+    volatile unsigned* w = h_seq_;
+    for (long spins = 0; *w != tag; ++spins) {
+      if ((spins & 0xFFFFF) == 0xFFFFF && hipStreamQuery(st_) != hipErrorNotReady) {
+        // the stream is idle (or failed) and the word never arrived: surface the error / fall through after a sync
+        HIP_CHECK(hipStreamSynchronize(st_));
+        if (*w != tag) throw HipError("read_partials: the publish kernel did not deliver");
+      }
+    }
+    return;
+  }
   HIP_CHECK(hipMemcpyAsync(h_red_ + off, red_.p + off, count * sizeof(zc), hipMemcpyDeviceToHost, st_));
   HIP_CHECK(hipStreamSynchronize(st_));
 }
