@@ -370,6 +370,17 @@ int mitdvp_svd(int device, const double* A, int r, int c, double* U, double* S, 
 int mitdvp_set_trace_op_core(mitdvp_engine* h, int op_id, int isite, const double* reim, int ml, int n, int mr);
 int mitdvp_expect_trace(mitdvp_engine* h, int op_id, double out[2]);
 int mitdvp_partial_trace(mitdvp_engine* h, const int* remain_nleg, int nlen, double* reim_out, size_t* n_out);
+/* Subspace projection of a Liouville-space site (Model(subspace_inds={site: P_inds}), model_cls.py:110-118,
+ * MPSCoefMPO.project_subspace / define_reshape_mat, _mps_mpo.py:135-220): the site's physical leg holds the entries
+ * inds[0..ninds) of the n*n vectorised density matrix.  The caller hands over MPO cores and site tensors with the
+ * shorter leg (TensorHamiltonian.project_subspace, hamiltonian_cls.py:852-880); this call tells the trace
+ * observables how to embed the leg back into n x n.  Call it BEFORE mitdvp_set_trace_op_core for that site
+ * (those cores are gathered on arrival); ninds = 0 removes the projection. */
+int mitdvp_set_subspace(mitdvp_engine* h, int isite, int n, const int* inds, int ninds);
+/* MPSCoef.hermitise (_mps_cls.py:2289-2312, svd_conj_mpdo :2516-2562): rho <- (rho + rho^dagger) / 2 of a
+ * Liouville-space chain as a direct sum, re-truncated bond by bond to the old bond dimensions by two-site SVDs,
+ * left in the site-0-centred canonical form with its normalisation untouched. */
+int mitdvp_hermitise(mitdvp_engine* h);
 int mitdvp_krylov_stats(mitdvp_engine* h, int* per_site);            /* _Debug.niter_krylov, _helper.py:29 */
 
 /* -- counters: _ElpTime / _NFlops equivalents (_helper.py:33-101) ------- */

@@ -1189,29 +1189,43 @@ def reduced_density(cores: list[np.ndarray], remain_nleg) -> np.ndarray:
     return dens[0, 0, ...]
 
 
-def liouville_expectation(cores: list[np.ndarray], op: list[np.ndarray]) -> complex:
+def _liouville_4d(cores, subspace=None):
+    """``reshape_mat`` (``define_reshape_mat``, _mps_mpo.py:135-194): (i, j, k) -> (i, n, n, k); a site with a subspace
+    projection holds only the entries ``P_inds`` of its n*n leg and is embedded back with zeros elsewhere.
+    ``subspace`` = {site: (n, P_inds)}."""
+    out = []
+    for q, c in enumerate(cores):
+        i, j, k = c.shape
+        if subspace and q in subspace:
+            n, inds = subspace[q]
+            full = np.zeros((i, n * n, k), dtype=np.complex128)
+            full[:, list(inds), :] = c
+            out.append(full.reshape(i, n, n, k))
+        else:
+            n = math.isqrt(j)
+            out.append(c.reshape(i, n, n, k))
+    return out
+
+
+def liouville_expectation(cores: list[np.ndarray], op: list[np.ndarray], subspace=None) -> complex:
     """Tr(O rho) for a vectorised density matrix (site dims n^2, index j = row*n + col)
     and a full-chain MPO ``op`` with n-dimensional physical legs
-    (``_exp_liouville``, _mps_cls.py:3769-3838: "ab,bcde,adcf->fe")."""
+    (``_exp_liouville``, _mps_cls.py:3769-3838: "ab,bcde,adcf->fe").  With ``subspace`` the projected sites are
+    embedded first (the reference's ``_exp_liouville`` takes isqrt of the projected leg and cannot run there;
+    this is Tr(O rho) of the density its own partial traces describe)."""
     left = np.ones((1, 1), dtype=np.complex128)
-    for c, w in zip(cores, op):
-        i, j, k = c.shape
-        n = math.isqrt(j)
-        left = np.einsum("ab,bcde,adcf->fe", left, c.reshape(i, n, n, k), w)
+    for c4, w in zip(_liouville_4d(cores, subspace), op):
+        left = np.einsum("ab,bcde,adcf->fe", left, c4, w)
     return complex(left[0, 0])
 
 
-def liouville_partial_trace(cores: list[np.ndarray], remain_nleg) -> np.ndarray:
+def liouville_partial_trace(cores: list[np.ndarray], remain_nleg, subspace=None) -> np.ndarray:
     """``get_partial_trace`` (_mps_cls.py:1438-1510): trace out sites with 0 legs, keep
     the diagonal (1 leg) or both legs (2) of the others; the right-most kept site always
-    keeps both legs."""
+    keeps both legs.  ``subspace``: see ``_liouville_4d``."""
     legs = list(remain_nleg)
     center = max(i for i, n in enumerate(legs) if n)
-    resh = []
-    for c in cores:
-        i, j, k = c.shape
-        n = math.isqrt(j)
-        resh.append(c.reshape(i, n, n, k))
+    resh = _liouville_4d(cores, subspace)
     left = np.array([1.0 + 0.0j])
     for q in range(center):
         d = resh[q]
@@ -1221,6 +1235,62 @@ def liouville_partial_trace(cores: list[np.ndarray], remain_nleg) -> np.ndarray:
     for q in range(len(cores) - 1, center, -1):
         right = np.einsum("ijjl->il", resh[q]) @ right
     return np.tensordot(left, np.tensordot(resh[center], right, axes=(-1, 0)), axes=(-1, 0))
+
+
+def project_subspace_mpo(mpo: list[np.ndarray], inds: dict) -> list[np.ndarray]:
+    """``TensorHamiltonian.project_subspace`` (hamiltonian_cls.py:852-880): bra and ket legs of the named sites
+    restricted to the kept indices (4-leg cores ``[:, ix_(P, P), :]``, diagonal 3-leg cores ``[:, P, :]``)."""
+    out = []
+    for q, w in enumerate(mpo):
+        if q in inds:
+            P = list(inds[q])
+            w = w[:, P, :] if w.ndim == 3 else w[:, np.ix_(P, P)[0], np.ix_(P, P)[1], :]
+        out.append(np.ascontiguousarray(w))
+    return out
+
+
+def project_subspace_cores(cores: list[np.ndarray], inds: dict, m_aux_max: int) -> list[np.ndarray]:
+    """``MPSCoefMPO.project_subspace`` (_mps_mpo.py:196-220): the physical leg of the (already canonicalised) cores
+    sliced to the kept indices, then every bond trimmed to the caps of the projected lattice.  No re-orthogonalisation
+    follows in the reference: the sliced "B" tensors are used as they are."""
+    out = [c[:, list(inds[q]), :] if q in inds else c for q, c in enumerate(cores)]
+    caps = bond_dims([c.shape[1] for c in out], m_aux_max)
+    return [np.ascontiguousarray(c[:dl, :, :dr]) for c, (dl, dr) in zip(out, caps)]
+
+
+def hermitise(cores: list[np.ndarray]) -> list[np.ndarray]:
+    """``MPSCoef.hermitise`` (_mps_cls.py:2289-2312) / ``svd_conj_mpdo`` (:2516-2562): rho <- (rho + rho^dagger) / 2.
+
+    Every core becomes the direct sum of itself and its dagger (conjugate, physical legs swapped; first site: both
+    side by side with the factor 1/2, last site: stacked), then left to right the two-site matrix is SVD-truncated
+    to the OLD bond dimension (rho_L = U[:, :chi], rho_R = (S Vh)[:chi]) and the chain is canonicalised to site 0
+    without renormalisation (``canonicalize(..., orthogonal_center=0, incremental=False)``, :3519-3524)."""
+    L = len(cores)
+    four = [c.reshape(c.shape[0], math.isqrt(c.shape[1]), math.isqrt(c.shape[1]), c.shape[2]) for c in cores]
+    dag = [np.conj(c).transpose(0, 2, 1, 3) for c in four]
+    if L == 1:
+        return [(0.5 * (four[0] + dag[0])).reshape(cores[0].shape)]
+    chi = [c.shape[2] for c in cores[:-1]]
+    dbl = []
+    for q, (c, cd) in enumerate(zip(four, dag)):
+        a, b, _, d = c.shape
+        if q == 0:
+            t = 0.5 * np.concatenate((c, cd), axis=3)
+        elif q == L - 1:
+            t = np.concatenate((c, cd), axis=0)
+        else:
+            t = np.zeros((2 * a, b, b, 2 * d), dtype=np.complex128)
+            t[:a, ..., :d] = c
+            t[a:, ..., d:] = cd
+        dbl.append(t.reshape(t.shape[0], b * b, t.shape[3]))
+    for q in range(L - 1):
+        B = np.tensordot(dbl[q], dbl[q + 1], axes=(2, 0))
+        i, j, l, m = B.shape
+        U, S, Vh = scipy.linalg.svd(B.reshape(i * j, l * m), full_matrices=False)
+        k = min(chi[q], len(S))
+        dbl[q] = U[:, :k].reshape(i, j, k)
+        dbl[q + 1] = (S[:k, None] * Vh[:k]).reshape(k, l, m)
+    return canonicalize_site0(dbl, scale=None)
 
 
 # --------------------------------------------------------------------------

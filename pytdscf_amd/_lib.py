@@ -162,6 +162,8 @@ def load() -> C.CDLL:
         "mitdvp_set_trace_op_core": (i, [vp, i, i, dp, i, i, i]),
         "mitdvp_expect_trace": (i, [vp, i, dp]),
         "mitdvp_partial_trace": (i, [vp, ip, i, dp, C.POINTER(C.c_size_t)]),
+        "mitdvp_set_subspace": (i, [vp, i, i, ip, i]),
+        "mitdvp_hermitise": (i, [vp]),
         "mitdvp_krylov_stats": (i, [vp, ip]),
         "mitdvp_counters_get": (i, [vp, C.POINTER(Counters)]),
         "mitdvp_counters_reset": (i, [vp]),

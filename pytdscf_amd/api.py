@@ -18,7 +18,7 @@ import numpy as np
 
 from . import units
 from .engine import MultiStateEngine, TDVPEngine
-from .mps import product_state_cores
+from .mps import bond_dims, product_state_cores
 from .operators import compress_mpo, merge_operator_terms
 
 
@@ -258,8 +258,6 @@ class Model:
         self.basinfo = basinfo if isinstance(basinfo, BasInfo) else BasInfo(basinfo)
         if space.lower() not in ("hilbert", "liouville"):
             raise ValueError(f"space must be 'hilbert' or 'liouville' but got {space}")
-        if subspace_inds is not None:
-            raise NotImplementedError("subspace projection of Liouville-space sites (subspace_inds) is not implemented (DESIGN.md section 9)")
         if build_td_hamiltonian is not None:
             raise NotImplementedError("time-dependent Hamiltonians (const.doTDHamil is never enabled by the reference either)")
         if kraus_op is not None and not isinstance(kraus_op, dict):
@@ -303,6 +301,20 @@ class Model:
                 raise ValueError(f"operator {name} has {op.nstate} electronic state(s), the basis {self.nstate}")
         self.m_aux_max = bond_dim
         self.use_mpo = True
+        # subspace projection of Liouville-space sites (model_cls.py:110-120): ignored in Hilbert space, as there
+        self.subspace_inds = None
+        if self.space == "liouville" and subspace_inds is not None:
+            if not isinstance(subspace_inds, dict):
+                raise TypeError("subspace_inds must be a dict {site: tuple of kept physical indices}")
+            sub = {}
+            for site, inds in subspace_inds.items():
+                inds = tuple(int(x) for x in inds)
+                if not 0 <= int(site) < len(self.dims) or not inds or len(set(inds)) != len(inds) or min(inds) < 0 or max(inds) >= self.dims[int(site)]:
+                    raise ValueError(f"subspace_inds[{site}] = {inds} does not select distinct entries of the site's {self.dims[int(site)]} physical indices")
+                sub[int(site)] = inds
+            self.subspace_inds = sub
+            if self.nstate > 1:
+                raise NotImplementedError("Only one state is supported")  # _mps_mpo.py:139, hamiltonian_cls.py:853
         self.init_HartreeProduct = None
         self.init_weight_VIBSTATE = None
         self.init_weight_ESTATE = None  # _get_initial_condition, _mps_cls.py:150-167
@@ -324,6 +336,24 @@ class Model:
 
     def get_ndof(self):
         return len(self.dims)
+
+    def projected_dims(self):
+        """Site dimensions after the subspace projection (LatticeInfo.dim_of_sites, _mps_mpo.py:212-213)."""
+        sub = self.subspace_inds or {}
+        return [len(sub[i]) if i in sub else d for i, d in enumerate(self.dims)]
+
+    def project_mpo(self, cores):
+        """``TensorHamiltonian.project_subspace`` (hamiltonian_cls.py:852-880) on the merged MPO: bra and ket legs of
+        the named sites restricted to the kept indices (slicing commutes with the direct sum of the terms)."""
+        sub = self.subspace_inds or {}
+        out = []
+        for i, w in enumerate(cores):
+            w = np.asarray(w)
+            if i in sub:
+                ket, bra = np.ix_(sub[i], sub[i])
+                w = w[:, ket, bra, :] if w.ndim == 4 else w[:, list(sub[i]), :]
+            out.append(np.ascontiguousarray(w))
+        return out
 
     def initial_cores(self, istate=0):
         D = self.m_aux_max if self.m_aux_max is not None else 10**9  # _get_initial_condition, _mps_cls.py:147-148
@@ -367,6 +397,13 @@ class WFunc:
     def bonddim(self):
         """Bond dimensions of the MPS (wavefunction.py:151-167)."""
         return self.engine.bond_dims()
+
+    def hermitise(self):
+        """``wf.ci_coef.hermitise()`` (MPSCoef.hermitise, _mps_cls.py:2289-2312): rho <- (rho + rho^dagger) / 2 of
+        the matrix-product density operator, on the device (two-site SVDs back to the old bond dimensions)."""
+        if self.space != "liouville":
+            raise ValueError("hermitise needs space='liouville'")
+        self.engine.hermitise()
 
     def apply_one_gate(self, matOp, reorth_center: int = 0):
         """``WFunc.apply_one_gate`` (wavefunction.py:588-598): one-site operators applied
@@ -561,7 +598,10 @@ class Simulator:
         liou = m.space == "liouville"
         eng = TDVPEngine(len(m.dims), integrator=integrator, conserve_norm=conserve_norm, thresh=thresh, relax=relax)
         ids = {"hamiltonian": 0}
-        eng.set_mpo(m.hamiltonian.as_mpo(m.dims), 0, shift=m.hamiltonian.coupleJ[0][0])
+        sub = m.subspace_inds or {}
+        eng.set_mpo(m.project_mpo(m.hamiltonian.as_mpo(m.dims)), 0, shift=m.hamiltonian.coupleJ[0][0])
+        for site, inds in sub.items():  # before the trace observables: their cores are gathered on arrival
+            eng.set_subspace(site, int(round(m.dims[site] ** 0.5)), inds)
         for k, (name, op) in enumerate(m.observables.items(), start=1):
             if liou:  # observables act on the n-dimensional Hilbert-space legs, site dim = n*n
                 eng.set_trace_op(op.as_mpo([int(round(d ** 0.5)) for d in m.dims]), k)
@@ -569,7 +609,17 @@ class Simulator:
                 eng.set_mpo(op.as_mpo(m.dims), k)
             ids[name] = k
         # Liouville space keeps the (trace) normalisation of the initial state (_mps_cls.py:2695-2699)
-        if restart_ext is None:
+        if restart_ext is None and sub:
+            # MPSCoefMPO.project_subspace (_mps_mpo.py:196-220) slices the ALREADY canonicalised cores and trims the
+            # bonds to the projected lattice's caps; nothing is re-orthogonalised afterwards, and neither is it here
+            full = TDVPEngine(len(m.dims))
+            full.set_mps(m.initial_cores(), canonicalize=True, scale=None)
+            cores = [c[:, list(sub[i]), :] if i in sub else c for i, c in enumerate(full.get_mps())]
+            full.close()
+            caps = bond_dims(m.projected_dims(), m.m_aux_max if m.m_aux_max is not None else 10**9)
+            for i, (c, (dl_, dr_)) in enumerate(zip(cores, caps)):
+                eng.set_site(i, np.ascontiguousarray(c[:dl_, :, :dr_]), "Psi" if i == 0 else "B")
+        elif restart_ext is None:
             eng.set_mps(m.initial_cores(), canonicalize=True, scale=None if liou else 1.0)
         else:  # const.doRestart: continue from the saved state, gauges as saved
             cores, gauges = self._load_cores(restart_ext)
@@ -578,7 +628,12 @@ class Simulator:
             for i, (c, g_) in enumerate(zip(cores, gauges)):
                 eng.set_site(i, c, g_)
         if m.one_gate_to_apply is not None:  # applied between the half-sweeps of every step (_mps_cls.py:489-490)
-            eng.set_gates(m.one_gate_to_apply.one_site_gates(m.dims))
+            gates = m.one_gate_to_apply.one_site_gates(m.dims)
+            for site, inds in sub.items():  # project_subspace of the gate operator, model_cls.py:117-118
+                if site in gates:
+                    U = np.asarray(gates[site])
+                    gates[site] = U[list(inds)] if U.ndim == 1 else U[np.ix_(inds, inds)]
+            eng.set_gates(gates)
         if m.kraus_op:  # after the gates, _mps_cls.py:491-492
             eng.set_kraus(m.kraus_op)
         return eng, ids

@@ -349,7 +349,8 @@ int mitdvp_partial_trace(mitdvp_engine* h, const int* remain_nleg, int nlen, dou
       for (int p = 0; p <= center; ++p) {
         int l = 0, d = 0, r = 0, g = 0;
         h->e->get_site_shape(p, &l, &d, &r, &g);
-        const size_t nn = (size_t)std::lround(std::sqrt((double)d));
+        (void)d;
+        const size_t nn = (size_t)h->e->liouville_n(p);
         const int k = p == center ? 2 : remain_nleg[p];
         for (int q = 0; q < k; ++q) n *= nn;
       }
@@ -363,6 +364,10 @@ int mitdvp_partial_trace(mitdvp_engine* h, const int* remain_nleg, int nlen, dou
     *n_out = v.size();
   });
 }
+int mitdvp_set_subspace(mitdvp_engine* h, int isite, int n, const int* inds, int ninds) {
+  ENG_CALL(h, h->e->set_subspace(isite, n, inds, ninds));
+}
+int mitdvp_hermitise(mitdvp_engine* h) { ENG_CALL(h, h->e->hermitise()); }
 int mitdvp_krylov_stats(mitdvp_engine* h, int* per_site) { ENG_CALL(h, { NEED(per_site); h->e->krylov_stats(per_site); }); }
 int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out) { ENG_CALL(h, { NEED(out); h->e->counters_get(out); }); }
 int mitdvp_counters_reset(mitdvp_engine* h) { ENG_CALL(h, h->e->counters_reset()); }

@@ -72,6 +72,7 @@ struct MpoSite {
   DevBuf w2er;  // small-site environment update, <- direction: [(c,j)][(i,t)] = W[c,i,j,t]
   DevBuf wtr;  // Liouville trace operator: O2[f][(a,c,d)] = O[a,d,c,f], n = sqrt(site dim)
   int ntr = 0, mltr = 0, mrtr = 0;
+  int dtr = 0;  // physical entries per (a, f) of wtr: n*n, or the size of the site's subspace when it was set
   bool set = false;
 };
 struct Operator {
@@ -128,6 +129,12 @@ class Engine {
   void set_trace_op_core(int op_id, int isite, const double* reim, int ml, int n, int mr);
   hzc expect_trace(int op_id);
   void partial_trace(const int* legs, int nlen, std::vector<hzc>& out);
+  // subspace projection of a Liouville-space site (Model(subspace_inds=...), _mps_mpo.py:135-220): the site's
+  // physical index runs over the listed entries of the n*n vectorised density matrix only
+  void set_subspace(int isite, int n, const int* inds, int ninds);
+  int liouville_n(int isite) const;  // Hilbert-space dimension n of a Liouville-space site
+  // rho <- (rho + rho^dagger) / 2 as a direct sum re-truncated to the old bonds (MPSCoef.hermitise, _mps_cls.py:2289-2312)
+  void hermitise();
   void krylov_stats(int* per_site);
 
   void counters_get(mitdvp_counters* out);
@@ -243,6 +250,8 @@ class Engine {
   hipStream_t st_ = nullptr;
   std::vector<int> dl_, dd_, dr_, gauge_;
   std::vector<DevBuf> site_;
+  std::vector<std::vector<int>> sub_;  // per site: kept entries of the n*n physical index (empty: all)
+  std::vector<int> subn_;
   std::map<int, Operator> ops_;
   int center_ = -1;
   // segment mode: outer bonds wider than 1, boundary blocks supplied by the neighbours; pending bond matrix in sig_

@@ -37,6 +37,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   qr_hist_ = qr_history_new();
   dl_.assign(L_, 0); dd_.assign(L_, 0); dr_.assign(L_, 0); gauge_.assign(L_, -1);
   site_.resize(L_);
+  sub_.assign(L_, {}); subn_.assign(L_, 0);
   envL_.resize(L_ + 1); envR_.resize(L_ + 1);
   envL_ok_.assign(L_ + 1, 0); envR_ok_.assign(L_ + 1, 0);
   kprev_.assign(L_, 0);

@@ -2,6 +2,8 @@
 // values, autocorrelation, reduced densities, SVD bond truncation, Liouville-space traces.
 #include "engine_internal.h"
 
+#include <climits>
+
 namespace mitdvp {
 
 // ---------------------------------------------------------------------------
@@ -320,18 +322,68 @@ int Engine::truncate_bond(double p, int max_dim, std::vector<double>& svals) {
 void Engine::set_trace_op_core(int op_id, int isite, const double* reim, int ml, int n, int mr) {
   if (isite < 0 || isite >= L_) throw ArgError("set_trace_op_core: bad site index");
   if (ml < 1 || mr < 1 || n < 1) throw ArgError("set_trace_op_core: bad shape");
+  const std::vector<int>& sub = sub_[isite];
+  if (!sub.empty() && subn_[isite] != n) throw ArgError("set_trace_op_core: n differs from the site's subspace definition");
   const hzc* O = reinterpret_cast<const hzc*>(reim);  // O[a][d][c][f]  (bond, out, in, bond)
-  std::vector<hzc> o2((size_t)mr * ml * n * n);
+  // physical entries kept per (a, f): all n*n (index c*n + d), or the site's subspace (set_subspace comes first)
+  const int dk = sub.empty() ? n * n : (int)sub.size();
+  std::vector<hzc> o2((size_t)mr * ml * dk);
   for (int a = 0; a < ml; ++a)
-    for (int dd = 0; dd < n; ++dd)
-      for (int c = 0; c < n; ++c)
-        for (int f = 0; f < mr; ++f)
-          o2[(size_t)f * ml * n * n + ((size_t)a * n + c) * n + dd] = O[(((size_t)a * n + dd) * n + c) * mr + f];
+    for (int k = 0; k < dk; ++k) {
+      const int j = sub.empty() ? k : sub[k];
+      const int c = j / n, dd = j % n;
+      for (int f = 0; f < mr; ++f) o2[(size_t)f * ml * dk + (size_t)a * dk + k] = O[(((size_t)a * n + dd) * n + c) * mr + f];
+    }
   MpoSite& s = op(op_id).sites[isite];
   s.wtr.reserve(o2.size());
   HIP_CHECK(hipMemcpyAsync(s.wtr.p, o2.data(), o2.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
   HIP_CHECK(hipStreamSynchronize(st_));
-  s.ntr = n; s.mltr = ml; s.mrtr = mr;
+  s.ntr = n; s.mltr = ml; s.mrtr = mr; s.dtr = dk;
+}
+
+// ---------------------------------------------------------------------------
+// subspace projection (Model(space="liouville", subspace_inds={site: P_inds}), model_cls.py:110-118): the site's
+// physical index keeps the entries P_inds of the n*n vectorised density matrix.  The sweep never looks at this (the
+// MPO cores and the tensors simply arrive with the shorter leg, hamiltonian_cls.py:852-880, _mps_mpo.py:196-220);
+// the trace observables do: they embed the kept entries back into n x n (reshape_mat, _mps_mpo.py:135-194).
+// ---------------------------------------------------------------------------
+void Engine::set_subspace(int isite, int n, const int* inds, int ninds) {
+  if (isite < 0 || isite >= L_) throw ArgError("set_subspace: bad site index");
+  if (ninds == 0) { sub_[isite].clear(); subn_[isite] = 0; return; }
+  if (n < 1 || ninds < 0 || ninds > n * n || !inds) throw ArgError("set_subspace: bad arguments");
+  std::vector<char> seen((size_t)n * n, 0);
+  for (int k = 0; k < ninds; ++k) {
+    if (inds[k] < 0 || inds[k] >= n * n) throw ArgError("set_subspace: index outside the n*n physical leg");
+    if (seen[inds[k]]) throw ArgError("set_subspace: repeated index");
+    seen[inds[k]] = 1;
+  }
+  sub_[isite].assign(inds, inds + ninds);
+  subn_[isite] = n;
+  for (auto& kv : ops_) kv.second.sites[isite].ntr = 0;  // trace-operator cores of this site must be set again
+}
+
+int Engine::liouville_n(int p) const {
+  if (p < 0 || p >= L_) throw ArgError("bad site index");
+  if (!sub_[p].empty()) {
+    if ((int)sub_[p].size() != dd_[p]) throw ArgError("Liouville space: site dimension differs from the size of its subspace");
+    return subn_[p];
+  }
+  const int n = (int)std::lround(std::sqrt((double)dd_[p]));
+  if (n * n != dd_[p]) throw ArgError("Liouville space: site dimension is not n*n");
+  return n;
+}
+
+// out[l][j][r] = in[l][inv[j]][r] for the kept entries j of the full physical leg, 0 elsewhere
+__global__ __launch_bounds__(256) void k_embed_phys(const zc* __restrict__ in, zc* __restrict__ out, int dl, int dsub, int dfull,
+                                                   int dr, const int* __restrict__ inv) {
+  const long total = (long)dl * dfull * dr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int r = (int)(idx % dr);
+    const long t = idx / dr;
+    const int j = (int)(t % dfull), l = (int)(t / dfull);
+    const int k = inv[j];
+    out[idx] = k >= 0 ? in[((size_t)l * dsub + k) * dr + r] : make_double2(0.0, 0.0);
+  }
 }
 
 // Tr(O rho): left[f][e] = sum left[a][b] rho[b][c][d][e] O[a][d][c][f]   (_exp_liouville)
@@ -344,7 +396,8 @@ hzc Engine::expect_trace(int op_id) {
   for (int p = 0; p < L_; ++p) {
     const MpoSite& w = it->second.sites[p];
     if (!w.ntr) throw ArgError("trace operator core not set for this site");
-    if (w.ntr * w.ntr != dd_[p]) throw ArgError("trace operator: site dimension is not n*n");
+    if (w.dtr != dd_[p] || (int)(sub_[p].empty() ? w.ntr * w.ntr : sub_[p].size()) != dd_[p])
+      throw ArgError("trace operator: site dimension is not n*n (or the size of the site's subspace)");
     mx = std::max(mx, (size_t)std::max(w.mltr, w.mrtr) * dd_[p] * std::max(dl_[p], dr_[p]));
   }
   DevBuf left = pool_get(mx), nxt = pool_get(mx), U = pool_get(mx);
@@ -381,17 +434,32 @@ void Engine::partial_trace(const int* legs, int nlen, std::vector<hzc>& out) {
   if (center < 0) throw ArgError("No site with 2 legs found in remain_nleg");
   std::vector<int> nn(L_);
   size_t maxd = 1;
+  std::vector<DevBuf> emb(L_);     // projected sites embedded back into the full n*n leg
+  std::vector<const zc*> core(L_);
   for (int p = 0; p < L_; ++p) {
-    nn[p] = (int)std::lround(std::sqrt((double)dd_[p]));
-    if (nn[p] * nn[p] != dd_[p]) throw ArgError("partial_trace: site dimension is not n*n");
+    nn[p] = liouville_n(p);
     maxd = std::max(maxd, (size_t)std::max(dl_[p], dr_[p]));
+    core[p] = site_[p].p;
+    if (!sub_[p].empty()) {
+      const int dfull = nn[p] * nn[p];
+      std::vector<int> inv(dfull, -1);
+      for (size_t k = 0; k < sub_[p].size(); ++k) inv[sub_[p][k]] = (int)k;
+      const size_t e = (size_t)dl_[p] * dfull * dr_[p];
+      emb[p] = pool_get(e + (dfull + 1) / 2 + 1);  // the index map rides behind the tensor
+      int* inv_dev = reinterpret_cast<int*>(emb[p].p + e);
+      HIP_CHECK(hipMemcpyAsync(inv_dev, inv.data(), dfull * sizeof(int), hipMemcpyHostToDevice, st_));
+      HIP_CHECK(hipStreamSynchronize(st_));  // inv goes out of scope
+      const int nb = (int)std::min<size_t>(1024, (e + 255) / 256);
+      hipLaunchKernelGGL(k_embed_phys, dim3(nb), dim3(256), 0, st_, site_[p].p, emb[p].p, dl_[p], dd_[p], dfull, dr_[p], inv_dev);
+      core[p] = emb[p].p;
+    }
   }
   const zc one = make_double2(1.0, 0.0);
   // right environment vector: sites right of the centre are traced out
   DevBuf right = pool_get(maxd), rnext = pool_get(maxd), tq = pool_get(maxd * maxd * 0 + (size_t)maxd * maxd);
   HIP_CHECK(hipMemcpyAsync(right.p, &one, sizeof(zc), hipMemcpyHostToDevice, st_));
   for (int q = L_ - 1; q > center; --q) {
-    phys_diag(st_, site_[q].p, tq.p, dl_[q], nn[q], dr_[q], true);
+    phys_diag(st_, core[q], tq.p, dl_[q], nn[q], dr_[q], true);
     ZgemmDesc g = zgemm_desc(tq.p, right.p, rnext.p, dl_[q], 1, dr_[q]);
     zgemm(st_, g);
     std::swap(right, rnext);
@@ -406,11 +474,11 @@ void Engine::partial_trace(const int* legs, int nlen, std::vector<hzc>& out) {
     DevBuf tmp;
     long cols;
     if (legs[q] == 2) {
-      M = site_[q].p;
+      M = core[q];
       cols = (long)n * n * dr;
     } else {
       tmp = pool_get((size_t)dl * n * dr);
-      phys_diag(st_, site_[q].p, tmp.p, dl, n, dr, legs[q] == 0);
+      phys_diag(st_, core[q], tmp.p, dl, n, dr, legs[q] == 0);
       M = tmp.p;
       cols = (legs[q] == 0 ? 1L : (long)n) * dr;
     }
@@ -425,7 +493,7 @@ void Engine::partial_trace(const int* legs, int nlen, std::vector<hzc>& out) {
   {
     const int dl = dl_[center], dr = dr_[center], n = nn[center];
     DevBuf wv = pool_get((size_t)dl * n * n), dm = pool_get((size_t)no * n * n);
-    ZgemmDesc g1 = zgemm_desc(site_[center].p, right.p, wv.p, dl * n * n, 1, dr);  // C (x) right
+    ZgemmDesc g1 = zgemm_desc(core[center], right.p, wv.p, dl * n * n, 1, dr);  // C (x) right
     zgemm(st_, g1);
     ZgemmDesc g2 = zgemm_desc(left.p, wv.p, dm.p, (int)no, n * n, dl);
     zgemm(st_, g2);
@@ -435,6 +503,118 @@ void Engine::partial_trace(const int* legs, int nlen, std::vector<hzc>& out) {
     pool_put(std::move(wv)); pool_put(std::move(dm));
   }
   pool_put(std::move(left)); pool_put(std::move(right)); pool_put(std::move(rnext)); pool_put(std::move(tq));
+  for (auto& b : emb)
+    if (b.p) pool_put(std::move(b));
+}
+
+// ---------------------------------------------------------------------------
+// MPSCoef.hermitise (_mps_cls.py:2289-2312) = svd_conj_mpdo (:2516-2562): rho <- (rho + rho^dagger) / 2.
+// Every core is doubled into the direct sum of itself and its conjugate with the two physical legs swapped
+// (first site: both blocks side by side along the right bond with the factor 1/2, last site: stacked along
+// the left bond), then the chain is swept left to right: two-site matrix B = rho_L rho_R, SVD, the leading
+// chi = old bond dimension singular vectors stay (rho_L <- U[:, :chi], rho_R <- (S Vh)[:chi] = rho_L^H B), and
+// finally the chain is brought to the site-0-centred canonical form without touching its normalisation.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hermit_double(const zc* __restrict__ in, zc* __restrict__ out, int dl, int n, int dr,
+                                                      int dbl_row, int dbl_col, double scale) {
+  const int l2 = dbl_row ? 2 * dl : dl, r2 = dbl_col ? 2 * dr : dr;
+  const long total = (long)l2 * n * n * r2;
+  const bool sym = !dbl_row && !dbl_col;  // one-site chain: the plain average
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int d2 = (int)(idx % r2);
+    long t = idx / r2;
+    const int c = (int)(t % n);
+    t /= n;
+    const int b = (int)(t % n), a2 = (int)(t / n);
+    const bool lowa = dbl_row && a2 >= dl, lowd = dbl_col && d2 >= dr;
+    const int a = lowa ? a2 - dl : a2, d = lowd ? d2 - dr : d2;
+    const zc v = in[(((size_t)a * n + b) * n + c) * dr + d];
+    const zc w = in[(((size_t)a * n + c) * n + b) * dr + d];  // dagger block: conj of the swapped legs
+    zc o;
+    if (sym) o = make_double2(v.x + w.x, v.y - w.y);
+    else if (dbl_row && dbl_col && lowa != lowd) o = make_double2(0.0, 0.0);
+    else if (lowa || lowd) o = make_double2(w.x, -w.y);
+    else o = v;
+    out[idx] = make_double2(scale * o.x, scale * o.y);
+  }
+}
+
+void Engine::hermitise() {
+  require_ready();
+  std::vector<int> nn(L_);
+  for (int p = 0; p < L_; ++p) {
+    if (!sub_[p].empty()) throw ArgError("hermitise: sites with a subspace projection are not supported");
+    nn[p] = liouville_n(p);
+  }
+  auto dbl = [&](int p, zc* out, bool row, bool col, double scale) {
+    const size_t e = (size_t)(row ? 2 : 1) * dl_[p] * dd_[p] * (col ? 2 : 1) * dr_[p];
+    const int nb = (int)std::min<size_t>(1024, (e + 255) / 256);
+    hipLaunchKernelGGL(k_hermit_double, dim3(nb), dim3(256), 0, st_, site_[p].p, out, dl_[p], nn[p], dr_[p], row ? 1 : 0,
+                       col ? 1 : 0, scale);
+  };
+  if (L_ == 1) {
+    DevBuf t = pool_get(site_[0].n);
+    dbl(0, t.p, false, false, 0.5);
+    std::swap(site_[0], t);
+    pool_put(std::move(t));
+    invalidate_env();
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  // cur = the left factor of the next two-site matrix: (rows x k)
+  long rows = (long)dl_[0] * dd_[0];
+  int k = 2 * dr_[0];
+  DevBuf cur = pool_get((size_t)rows * k);
+  dbl(0, cur.p, false, true, 0.5);
+  for (int p = 0; p + 1 < L_; ++p) {
+    const bool last = p + 1 == L_ - 1;
+    const int chi_old = dr_[p];
+    const int dn = dd_[p + 1], rn = last ? dr_[p + 1] : 2 * dr_[p + 1];
+    const long cols = (long)dn * rn;
+    if (rows > INT_MAX / 2 || cols > INT_MAX / 2) throw ArgError("hermitise: two-site matrix too large");
+    DevBuf R = pool_get((size_t)k * cols);
+    dbl(p + 1, R.p, true, !last, 1.0);
+    DevBuf B = pool_get((size_t)rows * cols);
+    {
+      ZgemmDesc g = zgemm_desc(cur.p, R.p, B.p, (int)rows, (int)cols, k);
+      zgemm(st_, g);
+    }
+    const int kk = (int)std::min(rows, cols), chi = std::min(chi_old, kk);
+    DevBuf U = pool_get((size_t)rows * kk), Vh = pool_get((size_t)kk * cols), work = pool_get(svd_work_elems((int)rows, (int)cols));
+    std::vector<double> sv(kk);
+    int sweeps = 0;
+    svd_jacobi(st_, B.p, (int)rows, (int)cols, U.p, sv.data(), Vh.p, work.p, &sweeps);
+    DevBuf newl = pool_get(std::max(site_[p].n, (size_t)rows * chi));
+    copy2d(st_, newl.p, chi, U.p, kk, rows, chi, chi, make_double2(1.0, 0.0), false);  // U[:, :chi]
+    DevBuf nxt = pool_get((size_t)chi * cols);
+    {
+      ZgemmDesc g = zgemm_desc(newl.p, B.p, nxt.p, chi, (int)cols, (int)rows);  // (S Vh)[:chi] = U[:, :chi]^H B
+      g.transA = 1; g.conjA = 1; g.lda = chi;
+      zgemm(st_, g);
+    }
+    HIP_CHECK(hipStreamSynchronize(st_));
+    std::swap(site_[p], newl);
+    dr_[p] = chi;
+    dl_[p + 1] = chi;
+    gauge_[p] = MITDVP_GAUGE_C;
+    pool_put(std::move(newl)); pool_put(std::move(R)); pool_put(std::move(B)); pool_put(std::move(U)); pool_put(std::move(Vh));
+    pool_put(std::move(work)); pool_put(std::move(cur));
+    cur = std::move(nxt);
+    rows = (long)chi * dn;
+    k = rn;
+  }
+  {
+    const size_t e = (size_t)dl_[L_ - 1] * dd_[L_ - 1] * dr_[L_ - 1];
+    site_[L_ - 1].reserve(e);
+    HIP_CHECK(hipMemcpyAsync(site_[L_ - 1].p, cur.p, e * sizeof(zc), hipMemcpyDeviceToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    gauge_[L_ - 1] = MITDVP_GAUGE_C;
+    pool_put(std::move(cur));
+  }
+  HIP_CHECK(hipGetLastError());
+  center_ = -1;
+  invalidate_env();
+  canonicalize(-1.0);  // canonicalize(superblock, orthogonal_center=0, incremental=False): the norm is kept
 }
 
 void Engine::krylov_stats(int* per_site) {

@@ -414,6 +414,24 @@ class TDVPEngine:
                 raise ValueError("trace operator core must be (M_l, n, n, M_r)")
             self._ck(self._lib.mitdvp_set_trace_op_core(self._h, op_id, i, _dp(a), a.shape[0], a.shape[1], a.shape[3]))
 
+    def set_subspace(self, isite: int, n: int, inds):
+        """Subspace projection of a Liouville-space site (``Model(subspace_inds=...)``, _mps_mpo.py:135-220): the
+        physical leg of ``isite`` holds the entries ``inds`` of the n*n vectorised density matrix.  Before
+        ``set_trace_op`` for that site; the sweep itself only sees the shorter leg."""
+        inds = [int(x) for x in inds]
+        arr = (C.c_int * max(1, len(inds)))(*inds)
+        self._ck(self._lib.mitdvp_set_subspace(self._h, int(isite), int(n), arr, len(inds)))
+        self._sub_n = dict(getattr(self, "_sub_n", {}))
+        if inds:
+            self._sub_n[int(isite)] = int(n)
+        else:
+            self._sub_n.pop(int(isite), None)
+
+    def hermitise(self):
+        """``MPSCoef.hermitise`` (_mps_cls.py:2289-2312): rho <- (rho + rho^dagger) / 2, bonds re-truncated to their
+        old dimensions, site-0-centred canonical form."""
+        self._ck(self._lib.mitdvp_hermitise(self._h))
+
     def expect_trace(self, op_id: int) -> complex:
         out = np.zeros(2)
         self._ck(self._lib.mitdvp_expect_trace(self._h, op_id, _dp(out)))
@@ -429,7 +447,7 @@ class TDVPEngine:
         center = max(i for i, k in enumerate(legs) if k)
         shape = []
         for p in range(center + 1):
-            nn = int(round(self.get_site_shape(p)[1] ** 0.5))
+            nn = getattr(self, "_sub_n", {}).get(p) or int(round(self.get_site_shape(p)[1] ** 0.5))
             shape += [nn] * (2 if p == center else legs[p])
         return out.reshape(shape)
 

@@ -161,6 +161,63 @@ def test_liouville_space(golden):
             np.testing.assert_allclose(orc.liouville_partial_trace(st.cores, legs), g[f"n{ns}_{tag}"], atol=1e-11)
 
 
+def _subspace_setup(g):
+    from pytdscf_amd.mps import product_state_cores
+
+    n, D = int(g["nsite"]), int(g["bond_dim"])
+    mpo = [g[f"mpo{i}"] for i in range(n)]
+    inds = {int(q): tuple(int(x) for x in g[f"sub{int(q)}"]) for q in g["sub_sites"]}
+    init = product_state_cores([g[f"rho{i}"] for i in range(n)], D, space="liouville")
+    keys = {"pt2": (0, 0, 2), "pt1": (0, 2), "pt13": (0, 2, 0, 1), "pt3": (0, 0, 0, 2), "pt04": (2, 0, 0, 0, 2)}
+    return n, D, mpo, inds, init, keys
+
+
+def test_liouville_subspace_projection(golden):
+    """``Model(space="liouville", subspace_inds=...)``: operator and (canonicalised) state sliced to the kept
+    physical indices, bonds trimmed, no re-orthogonalisation (model_cls.py:110-118, hamiltonian_cls.py:852-880,
+    _mps_mpo.py:196-220); partial traces embed the kept entries back (reshape_mat)."""
+    g = golden("liouville_subspace.npz")
+    n, D, mpo, inds, init, keys = _subspace_setup(g)
+    sub = {q: (2, inds[q]) for q in inds}
+    cores = orc.project_subspace_cores(orc.canonicalize_site0(init, scale=None), inds, D)
+    pm = orc.project_subspace_mpo(mpo, inds)
+    dt = float(g["dt_au"])
+    for ns in (1, 3):
+        st = orc.OracleMPS([c.copy() for c in cores], pm, integrator="arnoldi", conserve_norm=False)
+        for _ in range(ns):
+            st.propagate(dt)
+        assert [c.shape for c in st.cores] == [g[f"n{ns}_final{i}"].shape for i in range(n)]
+        assert list(g[f"n{ns}_krylov"]) == [st.kprev[i] for i in range(n)]
+        np.testing.assert_allclose(st.norm(), float(g[f"n{ns}_norm"]), rtol=1e-10)
+        for tag, legs in keys.items():
+            np.testing.assert_allclose(orc.liouville_partial_trace(st.cores, legs, sub), g[f"n{ns}_{tag}"], atol=1e-11)
+        # Tr(O rho) with the embedding is consistent with the partial trace of the same state
+        sz = np.diag([1.0, -1.0]).astype(np.complex128)
+        op = [np.eye(2, dtype=np.complex128).reshape(1, 2, 2, 1) for _ in range(n)]
+        op[1] = sz.reshape(1, 2, 2, 1)
+        np.testing.assert_allclose(orc.liouville_expectation(st.cores, op, sub),
+                                   np.trace(sz @ orc.liouville_partial_trace(st.cores, (0, 2), sub)), atol=1e-12)
+
+
+def _contract_chain(cores):
+    t = cores[0]
+    for c in cores[1:]:
+        t = np.tensordot(t, c, axes=(-1, 0))
+    return t
+
+
+def test_hermitise(golden):
+    """``MPSCoef.hermitise`` / ``svd_conj_mpdo`` (_mps_cls.py:2289-2312, :2516-2562) against the reference's output:
+    same bond dimensions, same matrix-product density operator."""
+    g = golden("hermitise.npz")
+    for tag in "abc":
+        L = int(g[f"{tag}_nsite"])
+        out = orc.hermitise([g[f"{tag}_in{i}"] for i in range(L)])
+        ref = [g[f"{tag}_out{i}"] for i in range(L)]
+        assert [o.shape for o in out] == [r.shape for r in ref]
+        np.testing.assert_allclose(_contract_chain(out), _contract_chain(ref), atol=1e-12)
+
+
 def _adaptive_kw(g):
     return dict(adaptive=True, Dmax=int(g["Dmax"]), dD=int(g["dD"]), p_proj=float(g["p_proj"]))
 

@@ -56,8 +56,10 @@ def test_unsupported_combinations_raise():
     from pytdscf_amd import Exciton, Model, Simulator
 
     core = np.zeros((1, 2, 2, 1))
-    with pytest.raises(NotImplementedError):
-        Model([Exciton(4)], [np.zeros((1, 4, 4, 1))], bond_dim=2, space="liouville", subspace_inds={0: (0, 3)})
+    m_sub = Model([Exciton(4)], [np.zeros((1, 4, 4, 1))], bond_dim=2, space="liouville", subspace_inds={0: (0, 3)})
+    assert m_sub.projected_dims() == [2] and m_sub.project_mpo([np.zeros((1, 4, 4, 1))])[0].shape == (1, 2, 2, 1)
+    with pytest.raises(ValueError):  # index outside the site's 4 physical entries
+        Model([Exciton(4)], [np.zeros((1, 4, 4, 1))], bond_dim=2, space="liouville", subspace_inds={0: (0, 4)})
     with pytest.raises(ValueError):
         Model([Exciton(2)], [core], bond_dim=2, space="fock")
     with pytest.raises(ValueError):
