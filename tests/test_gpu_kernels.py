@@ -2,6 +2,8 @@
 against NumPy (complex128).  Tolerances: rounding-level (1e-12 relative to the
 operand norms) -- these are the same arithmetic in a different summation order."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -249,7 +251,7 @@ def test_qr_fast_panels_fall_back_on_rank_deficient_and_graded_input():
     np.testing.assert_allclose(s, sr, atol=1e-11)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 7), (33, 33), (64, 20), (20, 64), (128, 128), (257, 257)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (7, 7), (33, 33), (64, 20), (20, 64), (128, 128), (257, 257), (140, 300), (300, 140)])
 def test_jacobi_svd_vs_lapack(shape):
     """One-sided Jacobi SVD: singular values to working precision (small ones as
     well), orthonormal factors, exact reconstruction."""
@@ -267,6 +269,47 @@ def test_jacobi_svd_vs_lapack(shape):
     assert np.abs(Vh @ Vh.conj().T - np.eye(k)).max() < 1e-13 * k
     assert np.abs((U * S) @ Vh - A).max() < 1e-13 * np.abs(A).max() * k
     assert sweeps <= 20
+
+
+@pytest.mark.parametrize("precond", ["1", "0"])
+def test_jacobi_svd_graded_and_rank_deficient(precond):
+    """The QR-preconditioned path (from 128 rows on; MITDVP_SVD_PRECOND=0 in a child process = the plain path): a
+    spectrum graded over twelve decades (singular values to the absolute accuracy eps * sigma_max of the input) needs few
+    sweeps; a rank-deficient matrix (48 exact zeros) reconstructs, its non-zero part is orthonormal."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import numpy as np
+        from pytdscf_amd import engine as E
+        rng = np.random.default_rng(11)
+        n = 256
+        A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        u, _, vh = np.linalg.svd(A)
+        sv = np.logspace(0, -12, n)
+        B = (u * sv) @ vh
+        U, S, Vh, sweeps = E.svd(B)
+        assert np.max(np.abs(S - sv) / sv) < %(tol)s, np.max(np.abs(S - sv) / sv)
+        assert np.linalg.norm((U * S) @ Vh - B) < 1e-12
+        assert np.abs(U.conj().T @ U - np.eye(n)).max() < 1e-11 and np.abs(Vh @ Vh.conj().T - np.eye(n)).max() < 1e-11
+        assert sweeps <= %(sw)d, sweeps
+        sv0 = np.linspace(1.0, 0.1, n); sv0[-48:] = 0.0
+        C = (u * sv0) @ vh
+        U, S, Vh, sweeps = E.svd(C)
+        assert np.abs(S - sv0).max() < 1e-13 and np.linalg.norm((U * S) @ Vh - C) < 1e-12
+        k = n - 48
+        assert np.abs(U[:, :k].conj().T @ U[:, :k] - np.eye(k)).max() < 1e-11
+        assert np.abs(Vh[:k] @ Vh[:k].conj().T - np.eye(k)).max() < 1e-11
+        D = C[:, :180]                      # rectangular and rank-deficient
+        U, S, Vh, sweeps = E.svd(D)
+        assert np.abs(S - np.linalg.svd(D, compute_uv=False)).max() < 1e-13 and np.linalg.norm((U * S) @ Vh - D) < 1e-12
+        print("ok", sweeps)
+    """) % dict(tol="1e-3", sw=20 if precond == "1" else 60)
+    env = dict(os.environ, MITDVP_SVD_PRECOND=precond)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_concurrent_engines_from_host_threads():
