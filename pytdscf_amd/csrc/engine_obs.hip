@@ -574,31 +574,72 @@ void Engine::hermitise() {
     if (rows > INT_MAX / 2 || cols > INT_MAX / 2) throw ArgError("hermitise: two-site matrix too large");
     DevBuf R = pool_get((size_t)k * cols);
     dbl(p + 1, R.p, true, !last, 1.0);
-    DevBuf B = pool_get((size_t)rows * cols);
-    {
-      ZgemmDesc g = zgemm_desc(cur.p, R.p, B.p, (int)rows, (int)cols, k);
-      zgemm(st_, g);
-    }
     const int kk = (int)std::min(rows, cols), chi = std::min(chi_old, kk);
-    DevBuf U = pool_get((size_t)rows * kk), Vh = pool_get((size_t)kk * cols), work = pool_get(svd_work_elems((int)rows, (int)cols));
-    std::vector<double> sv(kk);
-    int sweeps = 0;
-    svd_jacobi(st_, B.p, (int)rows, (int)cols, U.p, sv.data(), Vh.p, work.p, &sweeps);
     DevBuf newl = pool_get(std::max(site_[p].n, (size_t)rows * chi));
-    copy2d(st_, newl.p, chi, U.p, kk, rows, chi, chi, make_double2(1.0, 0.0), false);  // U[:, :chi]
     DevBuf nxt = pool_get((size_t)chi * cols);
-    {
-      ZgemmDesc g = zgemm_desc(newl.p, B.p, nxt.p, chi, (int)cols, (int)rows);  // (S Vh)[:chi] = U[:, :chi]^H B
-      g.transA = 1; g.conjA = 1; g.lda = chi;
-      zgemm(st_, g);
+    std::vector<double> sv;
+    int sweeps = 0;
+    if (rows >= k && cols >= k) {
+      // B = cur R is never formed: cur = Qc Rc, R^T = Q2 R2  =>  B = Qc (Rc R2^T) Q2^T, and the SVD is that of the
+      // k x k matrix in the middle (k = the doubled bond) instead of the (rows x cols) two-site matrix
+      DevBuf Qc = pool_get((size_t)rows * k), Rc = pool_get((size_t)k * k), Rt = pool_get((size_t)cols * k),
+             Q2 = pool_get((size_t)cols * k), R2 = pool_get((size_t)k * k), S = pool_get((size_t)k * k),
+             Us = pool_get((size_t)k * k), Vsh = pool_get((size_t)k * k), T = pool_get((size_t)chi * k),
+             qw = pool_get(qr_work_elems((int)std::max(rows, cols), k)), work = pool_get(svd_work_elems(k, k));
+      long nl = 0;
+      qr_householder(st_, cur.p, (int)rows, k, Qc.p, Rc.p, qw.p, &nl);
+      transpose_batched(st_, R.p, Rt.p, k, (int)cols, cols, k, 1, 0, 0);
+      qr_householder(st_, Rt.p, (int)cols, k, Q2.p, R2.p, qw.p, &nl);
+      {
+        ZgemmDesc g = zgemm_desc(Rc.p, R2.p, S.p, k, k, k);  // Rc R2^T
+        g.transB = 1; g.ldb = k;
+        zgemm(st_, g);
+      }
+      sv.resize(k);
+      svd_jacobi(st_, S.p, k, k, Us.p, sv.data(), Vsh.p, work.p, &sweeps);
+      {
+        ZgemmDesc g = zgemm_desc(Qc.p, Us.p, newl.p, (int)rows, chi, k);  // rho_L = Qc Us[:, :chi]
+        g.ldb = k;
+        zgemm(st_, g);
+      }
+      {
+        ZgemmDesc g = zgemm_desc(Us.p, S.p, T.p, chi, k, k);  // (Sigma Vs^H)[:chi] = Us[:, :chi]^H (Rc R2^T)
+        g.transA = 1; g.conjA = 1; g.lda = k;
+        zgemm(st_, g);
+      }
+      {
+        ZgemmDesc g = zgemm_desc(T.p, Q2.p, nxt.p, chi, (int)cols, k);  // rho_R = that times Q2^T
+        g.transB = 1; g.ldb = k;
+        zgemm(st_, g);
+      }
+      HIP_CHECK(hipStreamSynchronize(st_));
+      pool_put(std::move(Qc)); pool_put(std::move(Rc)); pool_put(std::move(Rt)); pool_put(std::move(Q2)); pool_put(std::move(R2));
+      pool_put(std::move(S)); pool_put(std::move(Us)); pool_put(std::move(Vsh)); pool_put(std::move(T)); pool_put(std::move(qw));
+      pool_put(std::move(work));
+    } else {
+      // a short side (first and last bond: rows or cols = the physical dimension): the two-site matrix itself is small
+      DevBuf B = pool_get((size_t)rows * cols);
+      {
+        ZgemmDesc g = zgemm_desc(cur.p, R.p, B.p, (int)rows, (int)cols, k);
+        zgemm(st_, g);
+      }
+      DevBuf U = pool_get((size_t)rows * kk), Vh = pool_get((size_t)kk * cols), work = pool_get(svd_work_elems((int)rows, (int)cols));
+      sv.resize(kk);
+      svd_jacobi(st_, B.p, (int)rows, (int)cols, U.p, sv.data(), Vh.p, work.p, &sweeps);
+      copy2d(st_, newl.p, chi, U.p, kk, rows, chi, chi, make_double2(1.0, 0.0), false);  // U[:, :chi]
+      {
+        ZgemmDesc g = zgemm_desc(newl.p, B.p, nxt.p, chi, (int)cols, (int)rows);  // (S Vh)[:chi] = U[:, :chi]^H B
+        g.transA = 1; g.conjA = 1; g.lda = chi;
+        zgemm(st_, g);
+      }
+      HIP_CHECK(hipStreamSynchronize(st_));
+      pool_put(std::move(B)); pool_put(std::move(U)); pool_put(std::move(Vh)); pool_put(std::move(work));
     }
-    HIP_CHECK(hipStreamSynchronize(st_));
     std::swap(site_[p], newl);
     dr_[p] = chi;
     dl_[p + 1] = chi;
     gauge_[p] = MITDVP_GAUGE_C;
-    pool_put(std::move(newl)); pool_put(std::move(R)); pool_put(std::move(B)); pool_put(std::move(U)); pool_put(std::move(Vh));
-    pool_put(std::move(work)); pool_put(std::move(cur));
+    pool_put(std::move(newl)); pool_put(std::move(R)); pool_put(std::move(cur));
     cur = std::move(nxt);
     rows = (long)chi * dn;
     k = rn;

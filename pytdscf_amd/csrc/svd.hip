@@ -23,6 +23,7 @@
 #include <numeric>
 #include <vector>
 
+#include "grid_exchange.h"
 #include "qr.h"
 #include "vecops.h"
 
@@ -154,14 +155,23 @@ __device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, int rn
   else { d = make_double2(cs * er, cs * ei); o = make_double2(sn, 0.0); }
 }
 
+// Column split (round 3): a pairing occupies nblk / 2 workgroups -- 64 of the 256 compute units at 1024 rows -- and each of
+// them pulls its 16 rows (256 KB) through one compute unit's memory pipeline, which is what the Gram stage waits for
+// (18 of the kernel's 31.6 us).  With gridDim.y = NS > 1 the columns of a pair are split over NS workgroups: each
+// writes its partial Gram matrix with agent-scope stores, drains them, takes a ticket from the pair's counter, and the
+// workgroup that draws the LAST ticket sums the partials in part order (the result does not depend on who was last)
+// and runs the sweep; the others leave.  Nobody waits for anybody, so no co-residency is assumed.
 template <int GU>
 __global__ __launch_bounds__(JT) void k_jacobi_block_rot(const zc* __restrict__ M, int nrow, int ncol, int nblk, int round,
                                                          unsigned long long* __restrict__ offmax, double tiny2, int cd_mode,
-                                                         zc* __restrict__ Vg, int* __restrict__ flags) {
+                                                         zc* __restrict__ Vg, int* __restrict__ flags, zc* __restrict__ Gpart,
+                                                         unsigned* __restrict__ tickets) {
   __shared__ double Gp[JW][2][J2][J2 + 1];
   __shared__ zc G[2][J2][J2 + 1];
   __shared__ zc V[2][J2][J2 + 1];
   __shared__ unsigned long long relmax_sh;
+  __shared__ unsigned ticket_sh;
+  const int NS = gridDim.y, part = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int P, Q;
   jblock_pair(blockIdx.x, nblk, round, P, Q);
@@ -174,11 +184,12 @@ __global__ __launch_bounds__(JT) void k_jacobi_block_rot(const zc* __restrict__ 
     const bool rv = r < nrow;
     jd4 arr = {0, 0, 0, 0}, aii = {0, 0, 0, 0}, air = {0, 0, 0, 0}, ari = {0, 0, 0, 0};
     const int ngrp = (ncol + 3) / 4;
-    for (int g0 = wv; g0 < ngrp; g0 += JW * GU) {
+    const int gstep = JW * NS;
+    for (int g0 = part * JW + wv; g0 < ngrp; g0 += gstep * GU) {
       zc x[GU];  // all loads of the pass in flight before the first MFMA
 #pragma unroll
       for (int u = 0; u < GU; ++u) {
-        const int g = g0 + JW * u, c = g * 4 + lk;
+        const int g = g0 + gstep * u, c = g * 4 + lk;
         x[u] = (rv && g < ngrp && c < ncol) ? xr[c] : make_double2(0.0, 0.0);
       }
 #pragma unroll
@@ -199,10 +210,33 @@ __global__ __launch_bounds__(JT) void k_jacobi_block_rot(const zc* __restrict__ 
   __syncthreads();
   const bool eig = tid < J2 * J2;
   const int ti = (tid >> 4) & 15, tj = tid & 15;
+  double gr = 0, gi = 0;
   if (eig) {
-    double gr = 0, gi = 0;
 #pragma unroll
     for (int u = 0; u < JW; ++u) { gr += Gp[u][0][ti][tj]; gi += Gp[u][1][ti][tj]; }
+  }
+  if (NS > 1) {
+    zc* mine = Gpart + ((size_t)blockIdx.x * NS + part) * (J2 * J2);
+    if (eig) gx_stz(mine + ti * J2 + tj, make_double2(gr, gi));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its agent-scope stores have landed
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (unsigned)NS - 1u) __hip_atomic_store(tickets + blockIdx.x, 0u, GX_RLX);  // ready for the next launch
+      ticket_sh = t;
+    }
+    __syncthreads();
+    if (ticket_sh != (unsigned)NS - 1u) return;  // uniform: another workgroup of this pair finishes the job
+    if (eig) {
+      gr = 0; gi = 0;
+      const zc* all = Gpart + (size_t)blockIdx.x * NS * (J2 * J2) + ti * J2 + tj;
+      for (int q = 0; q < NS; ++q) {
+        const zc v = gx_ldz(all + (size_t)q * (J2 * J2));
+        gr += v.x; gi += v.y;
+      }
+    }
+  }
+  if (eig) {
     G[0][ti][tj] = make_double2(gr, gi);
     V[0][ti][tj] = make_double2(ti == tj ? 1.0 : 0.0, 0.0);
   }
@@ -347,20 +381,34 @@ static int jacobi_rows(hipStream_t st, zc* M, zc* W, int nr, int nc, unsigned lo
     ~Scratch() { if (p) (void)hipFree(p); }
   } vg;
   int* flags = nullptr;
+  // column split of the Gram stage: up to four workgroups per pair while the launch stays within ~two waves of the chip
+  // and every part keeps at least one full pass of eight column groups per wave (MITDVP_SVD_SPLIT=1: off)
+  static const int split_max = [] { const char* e = std::getenv("MITDVP_SVD_SPLIT"); return e ? std::max(1, std::atoi(e)) : 4; }();
+  int ns = 1;
+  while (blk && ns * 2 <= split_max && (nblk / 2) * ns * 2 <= 512 && (nc + 3) / 4 >= JW * ns * 2 * 8) ns *= 2;
+  zc* gpart = nullptr;
+  unsigned* tickets = nullptr;
   if (blk) {
-    HIP_CHECK(hipMalloc((void**)&vg.p, (size_t)(nblk / 2) * (J2 * J2 + 1) * sizeof(zc)));
-    flags = reinterpret_cast<int*>(vg.p + (size_t)(nblk / 2) * J2 * J2);
+    const size_t npair = (size_t)(nblk / 2);
+    HIP_CHECK(hipMalloc((void**)&vg.p, (npair * (J2 * J2 + 1) + npair * ns * (J2 * J2) + npair) * sizeof(zc)));
+    flags = reinterpret_cast<int*>(vg.p + npair * J2 * J2);
+    gpart = vg.p + npair * (J2 * J2 + 1);
+    tickets = reinterpret_cast<unsigned*>(gpart + npair * ns * (J2 * J2));
+    HIP_CHECK(hipMemsetAsync(tickets, 0, npair * sizeof(unsigned), st));
   }
   for (; sweeps < 60; ++sweeps) {
     HIP_CHECK(hipMemsetAsync(off_dev, 0, sizeof(unsigned long long), st));
     if (blk) {
       for (int round = 0; round < nblk - 1; ++round) {
-        if (nc > JW * 16 * 4)
+        if (ns > 1)
+          hipLaunchKernelGGL(k_jacobi_block_rot<8>, dim3(nblk / 2, ns), dim3(JT), 0, st, M, nr, nc, nblk, round, off_dev, tiny2,
+                             cd_mode, vg.p, flags, gpart, tickets);
+        else if (nc > JW * 16 * 4)
           hipLaunchKernelGGL(k_jacobi_block_rot<32>, dim3(nblk / 2), dim3(JT), 0, st, M, nr, nc, nblk, round, off_dev, tiny2,
-                             cd_mode, vg.p, flags);
+                             cd_mode, vg.p, flags, gpart, tickets);
         else
           hipLaunchKernelGGL(k_jacobi_block_rot<16>, dim3(nblk / 2), dim3(JT), 0, st, M, nr, nc, nblk, round, off_dev, tiny2,
-                             cd_mode, vg.p, flags);
+                             cd_mode, vg.p, flags, gpart, tickets);
         hipLaunchKernelGGL(k_jacobi_block_apply, dim3(nblk / 2, JAPPLY_Y), dim3(256), 0, st, M, W, nr, nc, nblk, round, cd_mode,
                            vg.p, flags);
       }
