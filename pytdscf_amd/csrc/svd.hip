@@ -455,10 +455,13 @@ void svd_rows_us(hipStream_t st, zc* M, int nr, int nc, double* S_host, int* idx
 // spectrum graded over twelve decades (profiles/r03_svd_precond_ab.txt; the QR is 4.3 ms of 72).  M^T rather than M^H so that no conjugation pass is needed:
 //   R1 = W^H S Vq  (row Jacobi, W accumulated)   =>   M = R1^T Q1^T = Vq^T S (conj(W) Q1^T).
 // MITDVP_SVD_PRECOND=0 switches it off; it is used from 128 rows on (below that the QR costs more than it saves).
-static int svd_precond_rows() {
+// MITDVP_SVD_PRECOND=2 takes a second LR step (R1^T = Q2 R2, sweeps on R2): graded spectra 12 -> 8 sweeps, random ones
+// unchanged, for a second QR worth 0.8 sweeps at 1024^2 -- not the default.
+static int svd_precond_steps() {
   static const int v = [] { const char* e = std::getenv("MITDVP_SVD_PRECOND"); return e ? std::atoi(e) : 1; }();
-  return v ? 128 : INT_MAX;
+  return v;
 }
+static int svd_precond_rows() { return svd_precond_steps() ? 128 : INT_MAX; }
 
 size_t svd_work_elems(int r, int c) {
   const int nr = std::min(r, c), nc = std::max(r, c);
@@ -503,6 +506,31 @@ void svd_jacobi(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host
     long nl = 0;
     qr_householder(st, P, nc, nr, Q1, X, qrw, &nl);
     set_identity(st, W, nr, nr, nr);
+    if (svd_precond_steps() >= 2) {
+      // a second LR step: R1^T = Q2 R2, sweeps on the rows of R2:  W R2 = S Vq  =>  M = R1^T Q1^T = (Q2 W^H) S (Vq Q1^T)
+      zc* Q2 = Cw;
+      zc* X2 = G2;
+      transpose_batched(st, X, M, nr, nr, nr, nr, 1, 0, 0);
+      qr_householder(st, M, nr, nr, Q2, X2, qrw, &nl);
+      const int sweeps = jacobi_rows(st, X2, W, nr, nr, off_dev, s_dev);
+      sorted(X2, nr, idx);
+      zc* Vq = M;    // (nr x nr)
+      zc* Wh = Ut;   // (nr x nr) W^H with its columns in sorted order
+      hipLaunchKernelGGL(k_svd_gather, dim3(nr), dim3(256), 0, st, X2, W, idx_dev, s_dev, nr, nr, Wh, Vq);
+      ZgemmDesc gu = zgemm_desc(Q2, Wh, tr ? W : U, nr, nr, nr);          // Q2 W^H
+      zgemm(st, gu);
+      ZgemmDesc gv = zgemm_desc(Vq, Q1, tr ? G2 : Vh, nr, nc, nr);        // Vq Q1^T
+      gv.transB = 1; gv.ldb = nr;
+      zgemm(st, gv);
+      if (tr) {  // A = M^T = (Vq Q1^T)^T S (Q2 W^H)^T
+        transpose_batched(st, G2, U, nr, nc, nc, nr, 1, 0, 0);
+        transpose_batched(st, W, Vh, nr, nr, nr, nr, 1, 0, 0);
+      }
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (sweeps_out) *sweeps_out = sweeps;
+      return;
+    }
     const int sweeps = jacobi_rows(st, X, W, nr, nr, off_dev, s_dev);
     sorted(X, nr, idx);
     zc* Vq = M;  // (nr x nr): the reflectors are no longer needed

@@ -271,9 +271,9 @@ def test_jacobi_svd_vs_lapack(shape):
     assert sweeps <= 20
 
 
-@pytest.mark.parametrize("precond", ["1", "0"])
+@pytest.mark.parametrize("precond", ["1", "0", "2"])
 def test_jacobi_svd_graded_and_rank_deficient(precond):
-    """The QR-preconditioned path (from 128 rows on; MITDVP_SVD_PRECOND=0 in a child process = the plain path): a
+    """The QR-preconditioned path (from 128 rows on; MITDVP_SVD_PRECOND=0 in a child process = the plain path, 2 = two LR steps): a
     spectrum graded over twelve decades (singular values to the absolute accuracy eps * sigma_max of the input) needs few
     sweeps; a rank-deficient matrix (48 exact zeros) reconstructs, its non-zero part is orthonormal."""
     import subprocess
@@ -305,7 +305,7 @@ def test_jacobi_svd_graded_and_rank_deficient(precond):
         U, S, Vh, sweeps = E.svd(D)
         assert np.abs(S - np.linalg.svd(D, compute_uv=False)).max() < 1e-13 and np.linalg.norm((U * S) @ Vh - D) < 1e-12
         print("ok", sweeps)
-    """) % dict(tol="1e-3", sw=20 if precond == "1" else 60)
+    """) % dict(tol="1e-3", sw=60 if precond == "0" else 20)
     env = dict(os.environ, MITDVP_SVD_PRECOND=precond)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
