@@ -566,7 +566,7 @@ class Simulator:
                 states = [[(z[f"site{i}"], names[int(g)]) for i, g in zip(range(int(z["nsite"])), z["gauges"])]]
         else:
             raise FileNotFoundError(f"restart=True but {path} does not exist")
-        if len(states) != self.model.nstate or any(len(st) != n or [c.shape[1] for c, _ in st] != list(self.model.dims) for st in states):
+        if len(states) != self.model.nstate or any(len(st) != n or [c.shape[1] for c, _ in st] != list(self.model.projected_dims()) for st in states):
             raise ValueError(f"{path} does not match the model's sites / states")
         return states
 

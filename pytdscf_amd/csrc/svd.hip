@@ -455,11 +455,22 @@ void svd_rows_us(hipStream_t st, zc* M, int nr, int nc, double* S_host, int* idx
 // spectrum graded over twelve decades (profiles/r03_svd_precond_ab.txt; the QR is 4.3 ms of 72).  M^T rather than M^H so that no conjugation pass is needed:
 //   R1 = W^H S Vq  (row Jacobi, W accumulated)   =>   M = R1^T Q1^T = Vq^T S (conj(W) Q1^T).
 // MITDVP_SVD_PRECOND=0 switches it off; it is used from 128 rows on (below that the QR costs more than it saves).
-// MITDVP_SVD_PRECOND=2 takes a second LR step (R1^T = Q2 R2, sweeps on R2): graded spectra 12 -> 8 sweeps, random ones
-// unchanged, for a second QR worth 0.8 sweeps at 1024^2 -- not the default.
+// A second LR step (R1^T = Q2 R2, sweeps on R2) takes graded spectra from 12 to 8 sweeps and leaves random ones where they
+// are, for a second QR worth 0.8 sweeps at 1024^2: taken when R1's diagonal is graded (default), always (=2) or never (=1).
+// -1 (default): one step, and a second one when the diagonal of R1 says the spectrum is graded or rank-deficient
+// (max |r_ii| > 1e3 min |r_ii|; a Gaussian matrix of 1024 rows stays below 1e2).  Bond matrices, junction matrices and
+// doubled density operators are graded; the random matrices of a benchmark are not.
 static int svd_precond_steps() {
-  static const int v = [] { const char* e = std::getenv("MITDVP_SVD_PRECOND"); return e ? std::atoi(e) : 1; }();
+  static const int v = [] { const char* e = std::getenv("MITDVP_SVD_PRECOND"); return e ? std::atoi(e) : -1; }();
   return v;
+}
+
+__global__ void k_diag_abs2(const zc* __restrict__ X, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const zc v = X[(size_t)i * n + i];
+    out[i] = v.x * v.x + v.y * v.y;
+  }
 }
 static int svd_precond_rows() { return svd_precond_steps() ? 128 : INT_MAX; }
 
@@ -506,7 +517,17 @@ void svd_jacobi(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host
     long nl = 0;
     qr_householder(st, P, nc, nr, Q1, X, qrw, &nl);
     set_identity(st, W, nr, nr, nr);
-    if (svd_precond_steps() >= 2) {
+    bool second = svd_precond_steps() >= 2;
+    if (svd_precond_steps() < 0) {
+      hipLaunchKernelGGL(k_diag_abs2, dim3((nr + 255) / 256), dim3(256), 0, st, X, nr, s_dev);
+      std::vector<double> dg(nr);
+      HIP_CHECK(hipMemcpyAsync(dg.data(), s_dev, nr * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      double mx = 0.0, mn = HUGE_VAL;
+      for (double v : dg) { mx = std::max(mx, v); mn = std::min(mn, v); }
+      second = !(mn > 1e-6 * mx);  // squared moduli: a ratio of 1e3 between the diagonal entries
+    }
+    if (second) {
       // a second LR step: R1^T = Q2 R2, sweeps on the rows of R2:  W R2 = S Vq  =>  M = R1^T Q1^T = (Q2 W^H) S (Vq Q1^T)
       zc* Q2 = Cw;
       zc* X2 = G2;

@@ -271,9 +271,9 @@ def test_jacobi_svd_vs_lapack(shape):
     assert sweeps <= 20
 
 
-@pytest.mark.parametrize("precond", ["1", "0", "2"])
+@pytest.mark.parametrize("precond", ["-1", "1", "0", "2"])
 def test_jacobi_svd_graded_and_rank_deficient(precond):
-    """The QR-preconditioned path (from 128 rows on; MITDVP_SVD_PRECOND=0 in a child process = the plain path, 2 = two LR steps): a
+    """The QR-preconditioned path (from 128 rows on; MITDVP_SVD_PRECOND in a child process: -1 = the default, a second LR step when R's diagonal is graded; 1 / 2 = one / two steps always; 0 = the plain path): a
     spectrum graded over twelve decades (singular values to the absolute accuracy eps * sigma_max of the input) needs few
     sweeps; a rank-deficient matrix (48 exact zeros) reconstructs, its non-zero part is orthonormal."""
     import subprocess
