@@ -123,10 +123,10 @@ __device__ __forceinline__ void jblock_pair(int k, int nblk, int round, int& P, 
   else { P = (round + k) % (nblk - 1); Q = (round - k + (nblk - 1)) % (nblk - 1); }
 }
 
-// rotation of the pair index i belongs to in step rnd of the 16-player tournament, as the row map
+// rotation of the pair index i belongs to, as the row map
 // x_i' = d x_i + o x_partner;  rel = |G_pq|^2 / (G_pp G_qq) before the rotation (0 when the pair is skipped)
-__device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, int rnd, double tiny2, int& partner, zc& d, zc& o,
-                                           double& rel) {
+// pairing of index i in step rnd of the 16-player tournament: partner | is_p << 7 (is_p: i is the first of the pair)
+__device__ __forceinline__ unsigned jblock_pairing(int i, int rnd) {
   int p, q;
   bool is_p;
   if (i == J2 - 1) { p = i; q = rnd; is_p = true; }
@@ -136,7 +136,14 @@ __device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, int rn
     if (kk <= JB - 1) { p = i; q = (rnd - kk + (J2 - 1)) % (J2 - 1); is_p = true; }
     else { const int k2 = (J2 - 1) - kk; p = (rnd + k2) % (J2 - 1); q = i; is_p = false; }
   }
-  partner = is_p ? q : p;
+  return (unsigned)(is_p ? q : p) | (is_p ? 128u : 0u);
+}
+
+__device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, unsigned pairing, double tiny2, int& partner, zc& d, zc& o,
+                                           double& rel) {
+  partner = (int)(pairing & 31u);
+  const bool is_p = (pairing & 128u) != 0u;
+  const int p = is_p ? i : partner, q = is_p ? partner : i;
   d = make_double2(1.0, 0.0); o = make_double2(0.0, 0.0); rel = 0.0;
   const double a = Gc[p][p].x, b = Gc[q][q].x;
   const zc g = Gc[p][q];
@@ -147,6 +154,11 @@ __device__ __forceinline__ void jblock_rot(const zc (*Gc)[J2 + 1], int i, int rn
   const double ig = fast_rsqrt(g2);
   const double er = g.x * ig, ei = g.y * ig;  // e^{i phi}
   const double zeta = 0.5 * (b - a) * ig;
+  // t = sign / (|zeta| + sqrt(1 + zeta^2)), cos = 1 / sqrt(1 + t^2), sin = t cos: for the small angles of the late sweeps
+  // cos comes out as exactly 1 and the rotation is unitary to O(t^2).  Measured and dropped (round 3): the half-angle
+  // form cos^2 = (1 + |zeta| / h) / 2, sin = sign / (2 h cos) saves a dependent root but carries a rounding error of
+  // one ulp in cos at EVERY small angle; over the ~2e4 rotations a row sees that is 2.5e-13 in the singular values
+  // and the reconstruction instead of 9e-14.
   const double z1 = 1.0 + zeta * zeta;
   const double t = (zeta >= 0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + z1 * fast_rsqrt(z1));
   const double cs = fast_rsqrt(1.0 + t * t), sn = cs * t;
@@ -171,12 +183,14 @@ __global__ __launch_bounds__(JT) void k_jacobi_block_rot(const zc* __restrict__ 
   __shared__ zc V[2][J2][J2 + 1];
   __shared__ unsigned long long relmax_sh;
   __shared__ unsigned ticket_sh;
+  __shared__ unsigned char ptab[J2 - 1][J2];  // pairings of the inner tournament (integer modulo chains out of the steps)
   const int NS = gridDim.y, part = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int P, Q;
   jblock_pair(blockIdx.x, nblk, round, P, Q);
   auto rowidx = [&](int i) { return i < JB ? P * JB + i : Q * JB + (i - JB); };
   if (tid == 0) relmax_sh = 0ull;
+  if (tid < (J2 - 1) * J2) ptab[tid >> 4][tid & 15] = (unsigned char)jblock_pairing(tid & 15, tid >> 4);
   {
     const int li = lane & 15, lk = lane >> 4;
     const int r = rowidx(li);
@@ -248,8 +262,8 @@ __global__ __launch_bounds__(JT) void k_jacobi_block_rot(const zc* __restrict__ 
       int pi, pj;
       zc di, oi, dj, oj;
       double ri, rj;
-      jblock_rot(G[cur], ti, rnd, tiny2, pi, di, oi, ri);
-      jblock_rot(G[cur], tj, rnd, tiny2, pj, dj, oj, rj);
+      jblock_rot(G[cur], ti, ptab[rnd][ti], tiny2, pi, di, oi, ri);
+      jblock_rot(G[cur], tj, ptab[rnd][tj], tiny2, pj, dj, oj, rj);
       relmax = fmax(relmax, ri);
       dj = zconj(dj); oj = zconj(oj);
       // (J G)_{i l} for l = j and l = partner(j), then times J^H
