@@ -178,3 +178,36 @@ def test_reduced_density_nc_layout_and_reader(tmp_path):
             assert f.variables["rho_(3, 3)_0"].dimensions == ("step", "Q3", "Q3", "complex")
             assert f.variables["rho_(0, 0, 3, 3)_0"].dimensions == ("step", "Q0", "Q0", "Q3", "Q3", "complex")
             assert f.variables["time"].dimensions == ("step",)
+
+
+def test_subspace_projection_host_side(golden):
+    """Host side of ``Model(space="liouville", subspace_inds=...)`` (no GPU): the shell's operator projection equals the
+    oracle's restatement of ``TensorHamiltonian.project_subspace`` (hamiltonian_cls.py:852-880), projected site dimensions
+    and trimmed bond caps follow ``LatticeInfo.get_bond_dim`` on the projected lattice (_mps_mpo.py:196-220)."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import Exciton, Model
+    from pytdscf_amd.mps import bond_dims, product_state_cores
+
+    g = golden("liouville_subspace.npz")
+    n, D = int(g["nsite"]), int(g["bond_dim"])
+    inds = {int(q): tuple(int(x) for x in g[f"sub{int(q)}"]) for q in g["sub_sites"]}
+    mpo = [g[f"mpo{i}"] for i in range(n)]
+    model = Model([Exciton(nstate=4) for _ in range(n)], operators={"hamiltonian": mpo}, bond_dim=D, space="liouville",
+                  subspace_inds=inds)
+    for a, b in zip(model.project_mpo(model.hamiltonian.as_mpo(model.dims)), orc.project_subspace_mpo(mpo, inds)):
+        assert a.shape[1:3] == b.shape[1:3]
+    assert model.projected_dims() == [4, 2, 4, 3, 4]
+    cores = orc.project_subspace_cores(orc.canonicalize_site0(product_state_cores([g[f"rho{i}"] for i in range(n)], D, space="liouville"),
+                                                             scale=None), inds, D)
+    assert [c.shape for c in cores] == [g[f"n1_final{i}"].shape for i in range(n)]
+    assert [(c.shape[0], c.shape[2]) for c in cores] == bond_dims(model.projected_dims(), D)
+    # the merged, projected MPO represents the projected operator: contract both chains to dense matrices
+    def dense(cs):
+        t = cs[0]
+        for c in cs[1:]:
+            t = np.tensordot(t, c, axes=(-1, 0))
+        return t
+    da = dense(model.project_mpo(model.hamiltonian.as_mpo(model.dims)))  # whole chain: the outer MPO bonds are 1
+    db = dense(orc.project_subspace_mpo(mpo, inds))
+    assert da.shape == db.shape
+    np.testing.assert_allclose(da, db, atol=1e-12 * max(1.0, np.abs(db).max()))
