@@ -561,6 +561,10 @@ void Engine::hermitise() {
     HIP_CHECK(hipGetLastError());
     return;
   }
+  // the new tensors are collected aside and installed together at the end: a factorisation that throws half-way
+  // (no convergence, out of memory) leaves the chain as it was
+  std::vector<DevBuf> fresh(L_);
+  std::vector<int> nbond(L_ - 1);
   // cur = the left factor of the next two-site matrix: (rows x k)
   long rows = (long)dl_[0] * dd_[0];
   int k = 2 * dr_[0];
@@ -635,24 +639,27 @@ void Engine::hermitise() {
       HIP_CHECK(hipStreamSynchronize(st_));
       pool_put(std::move(B)); pool_put(std::move(U)); pool_put(std::move(Vh)); pool_put(std::move(work));
     }
-    std::swap(site_[p], newl);
-    dr_[p] = chi;
-    dl_[p + 1] = chi;
-    gauge_[p] = MITDVP_GAUGE_C;
-    pool_put(std::move(newl)); pool_put(std::move(R)); pool_put(std::move(cur));
+    fresh[p] = std::move(newl);
+    nbond[p] = chi;
+    pool_put(std::move(R)); pool_put(std::move(cur));
     cur = std::move(nxt);
     rows = (long)chi * dn;
     k = rn;
   }
+  HIP_CHECK(hipGetLastError());
   {
-    const size_t e = (size_t)dl_[L_ - 1] * dd_[L_ - 1] * dr_[L_ - 1];
-    site_[L_ - 1].reserve(e);
+    const size_t e = (size_t)nbond[L_ - 2] * dd_[L_ - 1] * dr_[L_ - 1];  // <= the old tensor: the bond did not grow
     HIP_CHECK(hipMemcpyAsync(site_[L_ - 1].p, cur.p, e * sizeof(zc), hipMemcpyDeviceToDevice, st_));
     HIP_CHECK(hipStreamSynchronize(st_));
-    gauge_[L_ - 1] = MITDVP_GAUGE_C;
     pool_put(std::move(cur));
   }
-  HIP_CHECK(hipGetLastError());
+  for (int p = 0; p + 1 < L_; ++p) {
+    std::swap(site_[p], fresh[p]);
+    pool_put(std::move(fresh[p]));
+    dr_[p] = nbond[p];
+    dl_[p + 1] = nbond[p];
+  }
+  for (int p = 0; p < L_; ++p) gauge_[p] = MITDVP_GAUGE_C;
   center_ = -1;
   invalidate_env();
   canonicalize(-1.0);  // canonicalize(superblock, orthogonal_center=0, incremental=False): the norm is kept
