@@ -398,7 +398,8 @@ typedef struct {
   double n_collectives;    /* collectives issued (bond-sharded mode)                   */
   double collective_bytes; /* sum of the collective buffer sizes                       */
   double heff_flops_skipped; /* part of heff_flops NOT executed: zero blocks of W skipped by the block-sparse W stage */
-  double reserved[2];
+  double n_host_waits;     /* device->host records the host waited for inside local exponentials (multi-launch regime) */
+  double reserved[1];
 } mitdvp_counters;
 int mitdvp_counters_get(mitdvp_engine* h, mitdvp_counters* out);
 int mitdvp_counters_reset(mitdvp_engine* h);

@@ -61,7 +61,8 @@ class Counters(C.Structure):
         ("n_collectives", C.c_double),
         ("collective_bytes", C.c_double),
         ("heff_flops_skipped", C.c_double),
-        ("reserved", C.c_double * 2),
+        ("n_host_waits", C.c_double),
+        ("reserved", C.c_double * 1),
     ]
 
     def as_dict(self):

@@ -756,7 +756,7 @@ class Simulator:
         from .parallel_sites import SiteShardedTDVP
 
         m = self.model
-        comm = world_comm()
+        comm = world_comm(site_sharding=True)
         if len(split) != comm.world:  # _const_cls.py:237
             raise ValueError(f"parallel_split_indices has {len(split)} ranges but the job has {comm.world} rank(s)")
         ids = {"hamiltonian": 0}

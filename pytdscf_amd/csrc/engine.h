@@ -7,6 +7,7 @@
 
 #include "../../include/mitdvp.h"
 #include "common.h"
+#include "krylov_dev.h"
 #include "qr.h"
 #include "small_site.h"
 #include "svd.h"
@@ -166,6 +167,10 @@ class Engine {
   // x <- exp(scale * Op) x ; returns Krylov dimension used
   template <class MV>
   int krylov_exp(hzc scale, MV&& matvec, zc* x, long n, int k_prev, long nsize = -1);
+  // the same with the Ritz step and the convergence test on the device (krylov_dev.h): what krylov_exp runs unless
+  // MITDVP_DEVICE_RITZ=0
+  template <class MV>
+  int krylov_exp_dev(hzc scale, MV&& matvec, zc* x, long n, int k_prev, long nsize);
   // x <- lowest eigenvector of Op (improved relaxation); returns Krylov dimension used
   template <class MV>
   int krylov_diag(MV&& matvec, zc* x, long n);
@@ -275,6 +280,13 @@ class Engine {
   unsigned* h_seq_ = nullptr;      // sequence word the publish kernel bumps and read_partials spins on
   unsigned* h_seq_dev_ = nullptr;
   unsigned seq_tag_ = 0;
+  // device-resident convergence logic of the multi-launch Krylov loop (krylov_dev.h)
+  bool device_ritz_ = true;      // MITDVP_DEVICE_RITZ=0: Ritz step and test on the host (two round trips per checked iteration)
+  KryDev* kst_ = nullptr;
+  KryPub* h_kpub_ = nullptr;     // host-coherent, mapped into the device: h_kpub_dev_
+  KryPub* h_kpub_dev_ = nullptr;
+  unsigned kry_tag_ = 0;
+  void wait_pub(unsigned tag);   // spins until the record with this tag has been published
   size_t red_elems_ = 0;
   std::vector<int> kprev_;
 

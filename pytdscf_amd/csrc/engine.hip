@@ -27,6 +27,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (const char* e = std::getenv("MITDVP_SMALL_KERNELS")) small_kernels_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_SPARSE_W")) sparse_w_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_TRIM_IDENTITY")) trim_identity_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MITDVP_DEVICE_RITZ")) device_ritz_ = std::atoi(e) != 0;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -53,6 +54,15 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
     HIP_CHECK(hipHostGetDevicePointer(&dp, h_seq_, 0));
     h_seq_dev_ = static_cast<unsigned*>(dp);
   }
+  HIP_CHECK(hipMalloc((void**)&kst_, sizeof(KryDev)));
+  HIP_CHECK(hipMemsetAsync(kst_, 0, sizeof(KryDev), st_));
+  HIP_CHECK(hipHostMalloc((void**)&h_kpub_, sizeof(KryPub), hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(h_kpub_, 0, sizeof(KryPub));
+  {
+    void* dp = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&dp, h_kpub_, 0));
+    h_kpub_dev_ = static_cast<KryPub*>(dp);
+  }
   // trivial boundary blocks, construct_op_zerosite (_mps_mpo.py:364-419)
   const zc one = make_double2(1.0, 0.0);
   envL_[0].reserve(1); envR_[L_].reserve(1);
@@ -71,6 +81,8 @@ Engine::~Engine() {
   for (auto& e : evpool_) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h_red_) (void)hipHostFree(h_red_);
   if (h_seq_) (void)hipHostFree(h_seq_);
+  if (h_kpub_) (void)hipHostFree(h_kpub_);
+  if (kst_) (void)hipFree(kst_);
   if (st_) { zgemm_release_stream(st_); (void)hipStreamDestroy(st_); }
 }
 
@@ -159,6 +171,7 @@ __global__ __launch_bounds__(256) void k_publish(const zc* __restrict__ src, zc*
 }
 
 void Engine::read_partials(size_t off, size_t count) {
+  cnt_.n_host_waits += 1;
   static const bool spin = !(std::getenv("MITDVP_SPIN_SYNC") && std::atoi(std::getenv("MITDVP_SPIN_SYNC")) == 0);
   if (spin && h_seq_ && count <= 16384) {
     const unsigned tag = ++seq_tag_;
@@ -166,16 +179,28 @@ void Engine::read_partials(size_t off, size_t count) {
     HIP_CHECK(hipGetLastError());
     volatile unsigned* w = h_seq_;
     for (long spins = 0; *w != tag; ++spins) {
-      if ((spins & 0xFFFFF) == 0xFFFFF && hipStreamQuery(st_) != hipErrorNotReady) {
+      if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(st_) != hipErrorNotReady) {
         // the stream is idle (or failed) and the word never arrived: surface the error / fall through after a sync
         HIP_CHECK(hipStreamSynchronize(st_));
         if (*w != tag) throw HipError("read_partials: the publish kernel did not deliver");
       }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the values behind the word are read with plain loads
     return;
   }
   HIP_CHECK(hipMemcpyAsync(h_red_ + off, red_.p + off, count * sizeof(zc), hipMemcpyDeviceToHost, st_));
   HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+void Engine::wait_pub(unsigned tag) {
+  volatile unsigned* w = &h_kpub_->seq;
+  for (long spins = 0; *w != tag; ++spins) {
+    if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(st_) != hipErrorNotReady) {
+      HIP_CHECK(hipStreamSynchronize(st_));
+      if (*w != tag) throw HipError("wait_pub: the Krylov record was not published");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
 // ---------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 // (RCCL over xGMI: one link per neighbour pair, no collective anywhere on the data path).  Ranks that share a GPU
 // (the one-GPU test box: RCCL refuses two ranks on one device) plug in a host callback instead
 // (mitdvp_shard_set_transport); the junction code is the same.
+#include <atomic>
 #include <mutex>
 
 #include "capi_internal.h"
@@ -48,19 +49,19 @@ class SiteShard {
   bool pair_mode() const { return pair_; }
   int rank() const { return rank_; }
   ~SiteShard() {
-    if (comm_) (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(comm_));
+    if (comm_.load()) (void)RcclApi::get().comm_destroy(static_cast<ncclComm_t>(comm_.load()));
   }
 
   void set_options(int regularize, double p_svd) { regularize_ = regularize != 0; p_svd_ = p_svd; }
   void set_transport(P2PFn fn, void* user) { fn_ = fn; user_ = user; }
   void attach_rccl(const char id_bytes[128]) {
     const RcclApi& r = RcclApi::get();
-    if (comm_) { (void)r.comm_destroy(static_cast<ncclComm_t>(comm_)); comm_ = nullptr; }
+    if (void* old = comm_.exchange(nullptr)) (void)r.comm_destroy(static_cast<ncclComm_t>(old));
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id) < 128 ? sizeof(id) : 128);
     ncclComm_t comm = nullptr;
     rccl_check(r.comm_init_rank(&comm, world_, id, rank_), "ncclCommInitRank");
-    comm_ = comm;
+    comm_.store(comm);
   }
 
   // the joint matrix of the junction to the right (joint_sigvec_not_pinv of the left rank)
@@ -159,7 +160,7 @@ class SiteShard {
   // a grouped ncclSend / ncclRecv of `elems` complex numbers from this rank to itself: the RCCL point-to-point path
   // on a one-rank communicator (what the one-GPU test box can exercise)
   int self_sendrecv(size_t elems) {
-    if (!comm_) throw ArgError("shard: no RCCL communicator (mitdvp_shard_attach_rccl)");
+    if (!comm_.load()) throw ArgError("shard: no RCCL communicator (mitdvp_shard_attach_rccl)");
     DevBuf a, b;
     a.reserve(elems); b.reserve(elems);
     hipStream_t st = block_->st_;
@@ -176,7 +177,7 @@ class SiteShard {
   }
 
   void traffic(double* bytes, long* messages) const { *bytes = bytes_; *messages = messages_; }
-  bool native_transport() const { return comm_ != nullptr && fn_ == nullptr; }
+  bool native_transport() const { return comm_.load() != nullptr && fn_ == nullptr; }
 
  private:
   int rank_, world_, n_;
@@ -194,7 +195,8 @@ class SiteShard {
   double p_svd_ = -1.0;  // < 0: the joint matrix is not truncated
   P2PFn fn_ = nullptr;
   void* user_ = nullptr;
-  void* comm_ = nullptr;
+  // written by the attach (which the host side runs on a helper thread with a deadline) and read by the sweep
+  std::atomic<void*> comm_{nullptr};
   bool in_group_ = false;
   std::vector<char> stage_;
   double bytes_ = 0;
@@ -206,7 +208,7 @@ class SiteShard {
     if (joint_) HIP_CHECK(hipStreamSynchronize(joint_->st_));  // operands may come from any of the engines
     if (jleft_) HIP_CHECK(hipStreamSynchronize(jleft_->st_));
     if (!fn_) {
-      if (!comm_) throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)");
+      if (!comm_.load()) throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)");
       rccl_check(RcclApi::get().group_start(), "ncclGroupStart");
       in_group_ = true;
     }
@@ -220,7 +222,7 @@ class SiteShard {
       if (fn_(user_, 0, peer, stage_.data(), elems * sizeof(zc)) != 0) throw HipError("shard: the send callback failed");
       return;
     }
-    group_check(RcclApi::get().send(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclSend");
+    group_check(RcclApi::get().send(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_.load()), block_->st_), "ncclSend");
   }
   void recv_dev(zc* p, size_t elems, int peer) {
     if (fn_) {
@@ -229,7 +231,7 @@ class SiteShard {
       HIP_CHECK(hipMemcpy(p, stage_.data(), elems * sizeof(zc), hipMemcpyHostToDevice));
       return;
     }
-    group_check(RcclApi::get().recv(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_), block_->st_), "ncclRecv");
+    group_check(RcclApi::get().recv(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_.load()), block_->st_), "ncclRecv");
   }
   // an error inside an open group closes the group before it is raised (a group left open would swallow every later call)
   void group_check(ncclResult_t r, const char* what) {
@@ -308,7 +310,10 @@ class SiteShard {
     svd_jacobi(J.st_, J.sig_.p, D, D, U.p, s.data(), Vh.p, work.p, &sweeps);
     double tot = 0, cum = 0;
     for (double v : s) tot += v;
-    int idx = D;
+    // a zero or non-finite spectrum: refuse before any tensor is overwritten (the reference would divide by zero and
+    // carry NaN into both neighbours)
+    if (!(tot > 0.0) || !std::isfinite(tot)) throw NotConverged("shard: the joint bond matrix has a zero or non-finite spectrum");
+    int idx = 1;  // argmax of an all-False array is 0 (numpy), hence idx = 1 when no cumulative weight reaches 1 - p
     for (int k = 0; k < D; ++k) {  // idx = argmax(cumsum / total >= 1 - p) + 1
       cum += s[k];
       if (cum / tot >= 1.0 - p_svd_) { idx = k + 1; break; }
@@ -319,6 +324,7 @@ class SiteShard {
       thin[k] = (regularize_ && D > 1) ? lift(s[k]) : s[k];
       nrm2 += thin[k] * thin[k];
     }
+    if (!(nrm2 > 0.0) || !std::isfinite(nrm2)) throw NotConverged("shard: the kept singular values of the joint bond matrix have zero norm");
     std::vector<hzc> xn((size_t)D * D, hzc(0, 0));
     for (int k = 0; k < idx; ++k) xn[(size_t)k * D + k] = hzc(thin[k] / std::sqrt(nrm2), 0);
     DevBuf a2 = J.pool_get(J.site_[0].n), b2 = J.pool_get(J.site_[1].n);

@@ -31,6 +31,7 @@
 // hanging.  Reductions are summed in a fixed order: all workgroups obtain bit-identical scalars and take
 // identical branches.
 #include "small_site.h"
+#include "krylov_dev.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -312,6 +313,120 @@ __device__ void ss_expm_col0(zc* Tm, zc* M2, zc* M3, zc* M4, zc* Pm, zc* Qm, int
   }
   if (tid < k) coef[tid] = Pm[tid * k];
   __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// krylov_dev.h: the Ritz step of the MULTI-launch Krylov loop on the device (one workgroup).  Reference semantics:
+// _iter_info warm-up (_integrator.py:178-186) is applied by the host (it decides WHICH iterations are inspected, a
+// function of k_prev only); here: the scalars of iterations [q0, l], exhaustion (:569 / :392), the projected exponential
+// (:581-637 / :397-409; real alpha -> the symmetric tridiagonal T, :617-621), and the bookkeeping of the previous Ritz
+// coefficients for the convergence test (:638-651) that kry_diff finishes.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double kr_sum256(const double* __restrict__ p, int stride, int lane) {
+  // one wave: fixed-order sum of NPART = 256 partials (stride in doubles between consecutive partials)
+  const double v = (p[(size_t)lane * stride] + p[(size_t)(lane + 64) * stride]) +
+                   (p[(size_t)(lane + 128) * stride] + p[(size_t)(lane + 192) * stride]);
+  return wave_sum64(v);  // lane 0
+}
+
+__global__ __launch_bounds__(SS_THREADS) void k_kry_ritz(KryRitzArgs a) {
+  static_assert(NPART == 256, "kr_sum256 is written for 256 partials");
+  __shared__ zc mats[6 * MAXK * MAXK];
+  __shared__ zc coef_s[MAXK];
+  __shared__ double wsh[SS_WAVES * SS_PAYMAX];
+  __shared__ int ctl[4];
+  KryDev* st = a.st;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (!a.first && st->state != KRY_RUNNING) return;  // closed by an earlier check: the host has queued one iteration too many
+  for (int q = a.q0; q <= a.l; ++q) {
+    const int nz = a.lanczos ? 1 : q + 1;
+    for (int j = w; j <= nz; j += SS_WAVES) {
+      if (j < nz) {
+        const double* p = reinterpret_cast<const double*>(a.lanczos ? a.alpha_p + (size_t)q * NPART
+                                                                   : a.h_p + ((size_t)q * MAXK + j) * NPART);
+        const double re = kr_sum256(p, 2, lane), im = kr_sum256(p + 1, 2, lane);
+        if (lane == 0) {
+          if (a.lanczos) st->alpha[q] = make_double2(re, im);
+          else st->hess[j * MAXK + q] = make_double2(re, im);
+        }
+      } else {
+        const double s = kr_sum256(a.nrm_p + (size_t)q * NPART, 1, lane);
+        if (lane == 0) st->beta[q] = sqrt(s);
+      }
+    }
+  }
+  if (a.first && w == SS_WAVES - 1) {
+    const double s = a.beta0_p ? kr_sum256(a.beta0_p, 1, lane) : 1.0;
+    if (lane == 0) st->beta0 = a.beta0_p ? sqrt(s) : 1.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    int ld = a.l, exhausted = 0;
+    for (int q = a.q0; q <= a.l; ++q) {
+      const double b = st->beta[q];
+      if (!a.lanczos && b > a.eps) st->hess[(q + 1) * MAXK + q] = make_double2(b, 0.0);
+      if (b < a.eps || q + 1 == a.nsize) { ld = q; exhausted = 1; break; }
+    }
+    int real_alpha = 1;
+    if (a.lanczos)
+      for (int q = 0; q <= ld; ++q)
+        if (fabs(st->alpha[q].y) > 1e-10) real_alpha = 0;
+    ctl[0] = ld + 1;
+    ctl[1] = exhausted;
+    ctl[2] = real_alpha;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int k = ctl[0];
+  const bool exhausted = ctl[1] != 0, real_alpha = ctl[2] != 0;
+  zc* Tm = mats;
+  zc* M2 = Tm + MAXK * MAXK;
+  zc* M3 = M2 + MAXK * MAXK;
+  zc* M4 = M3 + MAXK * MAXK;
+  zc* Pm = M4 + MAXK * MAXK;
+  zc* Qm = Pm + MAXK * MAXK;
+  for (int t = tid; t < k * k; t += SS_THREADS) {
+    const int i = t / k, j = t - i * k;
+    zc z = make_double2(0.0, 0.0);
+    if (a.lanczos) {
+      if (i == j) { z = st->alpha[i]; if (real_alpha) z.y = 0.0; }
+      else if (i == j + 1) z = make_double2(st->beta[j], 0.0);
+      else if (j == i + 1) z = make_double2(st->beta[i], 0.0);
+    } else {
+      if (i <= j + 1) z = st->hess[i * MAXK + j];
+    }
+    Tm[t] = make_double2(a.scale.x * z.x - a.scale.y * z.y, a.scale.x * z.y + a.scale.y * z.x);
+  }
+  __syncthreads();
+  ss_expm_col0(Tm, M2, M3, M4, Pm, Qm, k, coef_s, wsh);
+  const int have_prev = a.first ? 0 : st->have_prev;
+  const int prev_len = a.first ? 0 : st->prev_len;
+  if (tid < k) {
+    const zc c = coef_s[tid];
+    st->coef[tid] = c;
+    if (!exhausted) {
+      if (have_prev) {
+        zc d = c;
+        if (tid < prev_len) { const zc o = st->cprev[tid]; d.x -= o.x; d.y -= o.y; }
+        st->dcoef[tid] = d;
+      } else {
+        st->cprev[tid] = c;
+      }
+    }
+  }
+  if (tid == 0) {
+    st->k = k;
+    if (a.first) { st->ticket = 0u; st->err = -1.0; }
+    if (exhausted) {
+      st->state = KRY_EXHAUSTED;
+      st->need_diff = 0;
+    } else {
+      st->state = KRY_RUNNING;
+      st->need_diff = have_prev ? 1 : 0;
+      if (!have_prev) { st->have_prev = 1; st->prev_len = k; }
+    }
+  }
 }
 
 // LDS carve (units: zc unless noted); the same arithmetic runs on the host in small_chain_lds
@@ -764,6 +879,11 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
 }
 
 }  // namespace
+
+void kry_ritz(hipStream_t st, const KryRitzArgs& a) {
+  hipLaunchKernelGGL(k_kry_ritz, dim3(1), dim3(SS_THREADS), 0, st, a);
+  HIP_CHECK(hipGetLastError());
+}
 
 // ---------------------------------------------------------------------------
 // host side

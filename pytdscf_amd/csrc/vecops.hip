@@ -7,6 +7,7 @@
 // the kernels of one Krylov iteration (the reference syncs twice per iteration,
 // _integrator.py:553-554).
 #include "vecops.h"
+#include "krylov_dev.h"
 
 #include <algorithm>
 
@@ -188,6 +189,73 @@ __global__ __launch_bounds__(256) void k_lincomb(zc* __restrict__ out, const zc*
   if (nrm) {
     s = block_sum(s, sh);
     if (threadIdx.x == 0) nrm[blockIdx.x] = s;
+  }
+}
+
+// krylov_dev.h: || sum_j dcoef_j V_j || against the threshold (_integrator.py:638-651), decided on the device.
+// Every workgroup leaves its partial with an agent-scope store and takes an arrival ticket; the one whose ticket is the
+// last sums the partials in a fixed order (thread i <- partial i, then the block tree: the same bits whichever
+// workgroup it is), closes the exponential or rolls coef_prev, and publishes the record the host spins on.
+// (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms: sc1 stores drained before ONE agent-scope add per
+// workgroup to one counter; the last arriver, told by the value its add returned, reads with sc1 loads.)
+__device__ __forceinline__ void kry_publish(const KryDev* st, KryPub* pub, unsigned tag) {
+  const int k = st->k;
+  for (int j = 0; j < k; ++j) pub->coef[j] = st->coef[j];
+  pub->beta0 = st->beta0;
+  pub->err = st->err;
+  pub->state = st->state;
+  pub->k = k;
+  __threadfence_system();
+  *reinterpret_cast<volatile unsigned*>(&pub->seq) = tag;
+}
+__global__ __launch_bounds__(256) void k_kry_diff(KryDev* st, const zc* __restrict__ V, long ldv, long n, double thresh,
+                                                  KryPub* pub, unsigned tag) {
+  __shared__ double sh[5];
+  __shared__ zc dc[MAXK];
+  __shared__ unsigned last_s;
+  if (!st->need_diff) {  // first Ritz vector of this exponential, or closed already: nothing to compare
+    if (blockIdx.x == 0 && threadIdx.x == 0) kry_publish(st, pub, tag);
+    return;
+  }
+  const int k = st->k;
+  if (threadIdx.x < k) dc[threadIdx.x] = st->dcoef[threadIdx.x];
+  __syncthreads();
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double re = 0, im = 0;
+    for (int j = 0; j < k; ++j) {
+      const zc a = V[(long)j * ldv + i];
+      const zc c = dc[j];
+      re += c.x * a.x - c.y * a.y;
+      im += c.x * a.y + c.y * a.x;
+    }
+    s += re * re + im * im;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&st->part[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  double v = (int)threadIdx.x < (int)gridDim.x
+                 ? __hip_atomic_load(&st->part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                 : 0.0;
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) {
+    const double err = sqrt(v);
+    st->err = err;
+    if (err < thresh) {
+      st->state = KRY_CONVERGED;
+    } else {
+      for (int j = 0; j < k; ++j) st->cprev[j] = st->coef[j];
+      st->prev_len = k;
+    }
+    st->need_diff = 0;
+    __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    kry_publish(st, pub, tag);
   }
 }
 
@@ -524,6 +592,9 @@ void vec_arnoldi_update(hipStream_t st, zc* v, const zc* V, long ldv, int k, lon
 void vec_lincomb(hipStream_t st, zc* out, const zc* V, long ldv, int k, const Coefs& c, long n, double* nrm_p) {
   if (k > MAXK) throw ArgError("vec_lincomb: k > MAXK");
   LAUNCH(k_lincomb, NPART, st, out, V, ldv, k, c, n, nrm_p);
+}
+void kry_diff(hipStream_t st, KryDev* kst, const zc* V, long ldv, long n, double thresh, KryPub* pub_dev, unsigned tag) {
+  LAUNCH(k_kry_diff, NPART, st, kst, V, ldv, n, thresh, pub_dev, tag);
 }
 void vec_axpby(hipStream_t st, zc* y, const zc* x, long n, zc a, zc b) { LAUNCH(k_axpby, vec_blocks(n), st, y, x, n, a, b); }
 void vec_scale(hipStream_t st, zc* y, long n, zc a) { LAUNCH(k_scale, vec_blocks(n), st, y, n, a); }

@@ -24,6 +24,7 @@ class Comm:
         self.dist = None
         self.device = None
         self.backend = None
+        self._owns_group = True
         torch = None
         if self.world > 1:
             # dmabuf IPC is the only form this driver stack supports; without it RCCL's cross-process
@@ -52,7 +53,13 @@ class Comm:
             backend = os.environ.get("MITDVP_DIST_BACKEND") or ("nccl" if n_devices > 0 and not self.shared_gpu else "gloo")
             if n_devices > 0:
                 torch.cuda.set_device(self.gpu)
-            if backend == "nccl":
+            if dist.is_initialized():
+                # the user's script (or an earlier Comm) has set the process group up: reuse it, never a second
+                # init_process_group; its backend decides where the scalars of the control plane live
+                backend = str(dist.get_backend()).lower()
+                self.device = torch.device("cuda", self.gpu) if "nccl" in backend and n_devices > 0 else torch.device("cpu")
+                self._owns_group = False
+            elif backend == "nccl":
                 self.device = torch.device("cuda", self.gpu)
                 dist.init_process_group("nccl", device_id=self.device)
             else:  # gloo: CPU-only hosts, or several test ranks sharing one GPU
@@ -104,17 +111,25 @@ class Comm:
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
-            self.dist.destroy_process_group()
+            if self._owns_group:
+                self.dist.destroy_process_group()
             self.dist = None
 
 
 _WORLD = None
 
 
-def world_comm() -> Comm:
-    """The process-wide rendezvous (torch.distributed can be initialised once): what the shell API uses."""
+def world_comm(site_sharding: bool = False) -> Comm:
+    """The process-wide rendezvous (torch.distributed can be initialised once): what the shell API uses.
+
+    ``site_sharding``: the caller moves its halo with the library's own RCCL communicator
+    (``mitdvp_shard_attach_rccl``); torch.distributed is then the control plane only and runs over gloo unless the
+    user chose otherwise, so that the process holds ONE RCCL instance on its GPU -- the configuration bench.py and
+    every test of the sharded sweep run."""
     global _WORLD
     if _WORLD is None or (_WORLD.world > 1 and _WORLD.dist is None):
+        if site_sharding:
+            os.environ.setdefault("MITDVP_DIST_BACKEND", "gloo")
         _WORLD = Comm()
     return _WORLD
 

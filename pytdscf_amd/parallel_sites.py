@@ -304,6 +304,9 @@ class SiteShardedTDVP:
                 th.join(float(os.environ.get("MITDVP_RCCL_ATTACH_TIMEOUT", "120")))
                 if th.is_alive():
                     state["err"] = TimeoutError("ncclCommInitRank did not return in time")
+                    # the helper is still inside mitdvp_shard_attach_rccl(h): the handle must outlive it, so close()
+                    # leaks the shard instead of destroying it under the helper's feet (as after a wedged transfer)
+                    self._wedged = True
             except Exception as exc:  # noqa: BLE001 -- all ranks fall back together below
                 state["err"] = exc
             if state["err"] is not None or not state["ok"]:
