@@ -185,7 +185,8 @@ int mitdvp_site_exp(mitdvp_engine* h, double dt_au);      /* exp_superH_propagat
  * exactly as the local exponential issues its applies: identity blocks of the environments short-circuited when the
  * numerical check finds them (the reference's eye shortcut, _mps_mpo.py:510-523), zero blocks of the MPO core skipped.
  * reim_in NULL: x = the centre tensor.  *flags (may be NULL): bit 0 first stage trimmed, bit 1 third stage trimmed,
- * bit 2 block-sparse W stage, bit 3 the one-launch small-bond kernel.  For parity tests of the kernels a sweep runs. */
+ * bit 2 block-sparse W stage, bit 3 the one-launch small-bond kernel, bit 4 the two-product form of an edge-structured
+ * core (reducing epilogue, no intermediates; then bits 0-2 are clear).  For parity tests of the kernels a sweep runs. */
 int mitdvp_heff_apply_center(mitdvp_engine* h, const double* reim_in, double* reim_out, int* flags);
 /* trans_next_psite_AsigmaB (:1798-1850): centre -> A sigma (forward) or sigma B; the block through the site is built,
  * sigma stays in the engine as the pending bond matrix */

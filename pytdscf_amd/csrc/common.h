@@ -92,6 +92,14 @@ struct ZgemmDesc {
   int arow_skip;
   // scheduling experiments of the MFMA kernel (MITDVP_ZGEMM_TUNE; 0 = the tuned default), see zgemm.hip
   int tune;
+  // Reducing epilogue (zgemm_reduce; the "edge" form of an H_eff apply, engine.hip::heff_apply_edge): the product is
+  // never stored.  Rows are pairs m = (u, x), x in [0, epi_xm), columns pairs n = (v, y), y in [0, epi_yn); a 64 x 64
+  // tile holds epi_tu = 64 / epi_xm values of u and epi_tv = 64 / epi_yn values of v whole, and the kernel stores
+  //   C[u * epi_su + v * epi_sv + i * epi_si] (+)= sum_{x, y} epi_w[i * epi_ldw + x * epi_yn + y] * T[(u, x)][(v, y)],  i < epi_di
+  // (a 16 x (tu * tv) x (xm * yn) product on the matrix cores out of the tile kept in LDS).  M = nu * xm, N = nv * yn.
+  const zc* epi_w;
+  long epi_ldw, epi_su, epi_sv, epi_si;
+  int epi_xm, epi_yn, epi_di, epi_acc;
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
 void zgemm(hipStream_t st, const ZgemmDesc& d);
@@ -106,8 +114,13 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.klist = nullptr; d.klist_stride = 0; d.rowmap_p = 0; d.rowmap_s1 = 0; d.rowmap_s2 = 0; d.rowmap_r0 = 0;
   d.arow_skip = 0;
   d.tune = -1;
+  d.epi_w = nullptr; d.epi_ldw = d.epi_su = d.epi_sv = d.epi_si = 0; d.epi_xm = d.epi_yn = d.epi_di = d.epi_acc = 0;
   return d;
 }
+// the product with the reducing epilogue described at ZgemmDesc::epi_w (NN or NT operands, no batch); false when the
+// shape does not qualify (the caller takes another path)
+bool zgemm_reduce_ok(int xm, int yn, int di);
+void zgemm_reduce(hipStream_t st, const ZgemmDesc& d);
 int zgemm_default_mode();
 void zgemm_set_default_mode(int m);
 double mfma_peak_probe(hipStream_t st);

@@ -71,6 +71,21 @@ struct MpoSite {
   std::vector<SpSeg> seg_l, seg_r;
   DevBuf w2el;  // small-site environment update, -> direction: [(t,j)][(i,c)] = W[c,i,j,t]
   DevBuf w2er;  // small-site environment update, <- direction: [(c,j)][(i,t)] = W[c,i,j,t]
+  // "edge" form of an apply (Engine::heff_apply_edge): with S = the MPO-bond states c whose left block L[:, c, :] is a
+  // multiple lam_c of the identity and E = the states t whose right block R[:, t, :] is a multiple mu_t of the identity
+  // (a canonical chain under a finite-state-machine MPO, or a direct sum of such: the "nothing applied yet" / "all
+  // applied" states; a sign or weight of a summand may ride on them), and every non-zero (c, t) block of W in a row of S
+  // or a column of E, the apply is two products with a reducing epilogue and no intermediate in memory.  The reduced
+  // cores depend on (S, E, lam, mu), found numerically per site, and are cached:
+  //   w_edge_r[i][(j, t)] = sum_{c in S} lam_c W[c, i, j, t]
+  //   w_edge_l[i][(c, j)] = sum_{t in E} mu_t W[c, i, j, t] for c not in S, else 0
+  std::vector<hzc> whost;           // the core as uploaded (ml, d, d, mr); empty when a bond exceeds 64 states
+  std::vector<char> nzblk;          // [c * mr + t]: block (c, t) holds a non-zero
+  mutable bool edge_valid = false;  // w_edge_l / w_edge_r correspond to (edge_s, edge_e)
+  mutable unsigned long long edge_s = 0, edge_e = 0;
+  mutable std::vector<hzc> edge_lam, edge_mu;
+  mutable bool edge_has_l = false, edge_has_r = false;
+  mutable DevBuf w_edge_l, w_edge_r;
   DevBuf wtr;  // Liouville trace operator: O2[f][(a,c,d)] = O[a,d,c,f], n = sqrt(site dim)
   int ntr = 0, mltr = 0, mrtr = 0;
   int dtr = 0;  // physical entries per (a, f) of wtr: n*n, or the size of the site's subspace when it was set
@@ -156,6 +171,12 @@ class Engine {
   // rectangular blocks (bra bond != ket bond), no shift term: the adaptive-rank applies
   void heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dlo, int dli, int d,
                        int dro, int dri);
+  // edge-structured MPO core between canonical environments: sigma = sum_t W[0,:,:,t] (psi R_t^T) + sum_{c>=1} W[c,:,:,mr-1] (L_c psi),
+  // each a GEMM whose 64 x 64 tiles are contracted with W in the epilogue (zgemm_reduce): X / Y never exist
+  void heff_apply_edge(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr);
+  // which forms the H_eff applies of the site between these blocks take (sets trim_l_, trim_r_, edge_; one host
+  // synchronisation for the numerical identity checks); the caller resets them when the local solve is over
+  void choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, int dl, int d, int dr);
   void keff_apply_rect(const zc* L, const zc* R, const zc* sig, zc* out, int dlo, int dli, int dro, int dri, int m);
   void env_update_rect(const zc* env_in, const zc* Tk, const zc* Tb, const zc* w2, zc* env_out, int dbi, int dki,
                        int min_, int d, int dbo, int dko, int mout, const MpoSite* sp = nullptr, int sp_side = 0);
@@ -249,6 +270,8 @@ class Engine {
   bool trim_l_ = false;  // the same for the FIRST MPO-bond block of the left environment (stage S1: rows (a, c = 0) of X = psi)
   bool left_block_is_identity(const zc* L, int dl, int m);
   bool trim_identity_ = true;  // MITDVP_TRIM_IDENTITY=0 switches the shortcut off
+  bool edge_ = false;          // the current local exponential's applies take heff_apply_edge
+  int edge_mode_ = -1;         // MITDVP_EDGE_APPLY: 0 never, 1 wherever valid, -1 (default) the size rule of choose_apply_forms
   bool right_block_is_identity(const zc* R, int dr, int m);
   void identity_blocks(const zc* L, int dl, int ml, const zc* R, int dr, int mr, bool* left, bool* right);
   int L_;

@@ -28,6 +28,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (const char* e = std::getenv("MITDVP_SPARSE_W")) sparse_w_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_TRIM_IDENTITY")) trim_identity_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_DEVICE_RITZ")) device_ritz_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MITDVP_EDGE_APPLY")) edge_mode_ = std::atoi(e);
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -322,6 +323,17 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
   };
   sparse_form(w2l, mr, ml, s.w2lt, s.kl_l, s.kl_stride_l, s.sp_frac_l, s.seg_l);
   sparse_form(w2r, ml, mr, s.w2rt, s.kl_r, s.kl_stride_r, s.sp_frac_r, s.seg_r);
+  // what the edge form of an apply needs (heff_apply_edge): the core itself and the map of its non-zero blocks
+  s.whost.clear(); s.nzblk.clear(); s.edge_valid = false;
+  if (ml <= 64 && mr <= 64) {
+    s.whost.assign(W, W + (size_t)ml * d * d * mr);
+    s.nzblk.assign((size_t)ml * mr, 0);
+    for (int c = 0; c < ml; ++c)
+      for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+          for (int t = 0; t < mr; ++t)
+            if (W[(((size_t)c * d + i) * d + j) * mr + t] != hzc(0.0, 0.0)) s.nzblk[(size_t)c * mr + t] = 1;
+  }
   s.w2el.reserve(w2el.size());
   s.w2er.reserve(w2er.size());
   HIP_CHECK(hipMemcpyAsync(s.w2el.p, w2el.data(), w2el.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
@@ -590,6 +602,121 @@ void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const z
   cnt_.heff_flops_skipped += 8.0 * (1.0 - s2_frac) * ((double)na * dri * ml * mr * d * d);
 }
 
+// The apply for an edge-structured core between canonical environments (MpoSite::edge; L[:, 0, :] = R[:, mr-1, :] = 1,
+// verified numerically by choose_apply_forms).  All terms with c = 0 see X_0 = psi, all terms with t = mr - 1 see the
+// identity on the right, and there are no others:
+//   sigma[a,i,r] = sum_{j,t} W[0,i,j,t] T[(a,j)][(r,t)],        T = psi[(a,j)][s] R[(r,t)][s]^T        ("R side")
+//                + sum_{c>=1,j} W[c,i,j,mr-1] X[(a,c)][(r,j)],  X = L[(a,c)][b] psiT[b][(r,j)]        ("L side")
+// Both are GEMMs of the size of stages S1 / S3 whose 64 x 64 tiles hold whole (j, t) / (c, j) groups and are contracted
+// with the d x (d M) reduced core in the epilogue (zgemm_reduce): the M-fold intermediates X and Y of the three-stage
+// chain ("must be tiled / fused") are never written.  psiT = psi with its last two indices swapped.
+void Engine::heff_apply_edge(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr) {
+  const int ml = w.ml, mr = w.mr;
+  bool first = true;
+  double exe = 0.0;
+  if (w.edge_has_r) {  // R side: rows (a, j), columns (r, t)
+    timer_begin(12);
+    ZgemmDesc g = zgemm_desc(psi, R, out, dl * d, dr * mr, dr);
+    g.transB = 1; g.ldb = dr;
+    g.epi_w = w.w_edge_r.p; g.epi_ldw = (long)d * mr; g.epi_xm = d; g.epi_yn = mr; g.epi_di = d;
+    g.epi_su = (long)d * dr; g.epi_sv = 1; g.epi_si = dr; g.epi_acc = 0;
+    zgemm_reduce(st_, g);
+    timer_end();
+    first = false;
+    cnt_.n_launch += 1;
+    exe += 8.0 * ((double)dl * d * dr * mr * dr + (double)dl * dr * d * d * mr);
+  }
+  if (w.edge_has_l) {
+    timer_begin(11);
+    transpose_batched(st_, psi, X_.p, d, dr, dr, d, dl, (long)d * dr, (long)d * dr);  // psiT[b][s][j]
+    timer_end();
+    timer_begin(10);
+    // L side: rows (a, c), columns (s, j)
+    ZgemmDesc g = zgemm_desc(L, X_.p, out, dl * ml, dr * d, dl);
+    g.epi_w = w.w_edge_l.p; g.epi_ldw = (long)ml * d; g.epi_xm = ml; g.epi_yn = d; g.epi_di = d;
+    g.epi_su = (long)d * dr; g.epi_sv = 1; g.epi_si = dr; g.epi_acc = first ? 0 : 1;
+    zgemm_reduce(st_, g);
+    timer_end();
+    first = false;
+    cnt_.n_launch += 2;
+    exe += 8.0 * ((double)dl * ml * dl * d * dr + (double)dl * dr * d * ml * d);
+  }
+  if (first) HIP_CHECK(hipMemsetAsync(out, 0, (size_t)dl * d * dr * sizeof(zc), st_));  // a zero core
+  cnt_.n_heff += 1;
+  const double alg = 8.0 * ((double)dl * dl * ml * d * dr + (double)dl * dr * ml * mr * d * d + (double)dl * dr * dr * mr * d);
+  cnt_.heff_flops += alg;
+  cnt_.heff_flops_skipped += alg - exe;
+}
+
+// Which forms the applies of the local solve between these blocks take.  The three-stage chain may trim the identity
+// blocks L[:, 0, :] and R[:, mr-1, :] (checked from D = 256 on, where one check per site buys 1 / M of stages S1 / S3 in
+// every apply); the edge form needs the identity states of both bonds (all blocks checked: two launches, one copy).
+void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, int dl, int d, int dr) {
+  trim_l_ = trim_r_ = edge_ = false;
+  int a0, a1;
+  const bool sharded = shard_range(dl, a0, a1);
+  const int ml = w.ml, mr = w.mr;
+  const bool edge_cand = edge_mode_ != 0 && trim_identity_ && !w.whost.empty() && !sharded && dl >= 32 && dr >= 32 &&
+                         zgemm_reduce_ok(d, mr, d) && zgemm_reduce_ok(ml, d, d) && (long)d * dr < (1L << 20) &&
+                         (edge_mode_ > 0 || (long)dl * dr <= 512L * 512L);
+  if (!edge_cand) {
+    identity_blocks(trim_identity_ && dl >= 256 && ml > 1 ? Lb : nullptr, dl, ml,
+                    trim_identity_ && dr >= 256 && mr > 1 ? Rb : nullptr, dr, mr, &trim_l_, &trim_r_);
+    return;
+  }
+  double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
+  zc* lam_dev = red_.p + RED_MISC + 64;  // behind the 128 deviations
+  struct { double dev[128]; hzc lam[128]; } h;
+  static_assert(sizeof(h) == 128 * 8 + 128 * 16, "layout of the identity-check record");
+  ident_deviation_multi(st_, Lb, ml, dl, (long)ml * dl, dl, dev, lam_dev);
+  ident_deviation_multi(st_, Rb, mr, dr, (long)mr * dr, dr, dev + 64, lam_dev + 64);
+  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  cnt_.n_launch += 2;
+  unsigned long long S = 0, E = 0;
+  std::vector<hzc> lam(ml), mu(mr);
+  for (int c = 0; c < ml; ++c) { lam[c] = h.lam[c]; if (h.dev[c] < 1e-13) S |= 1ull << c; }
+  for (int t = 0; t < mr; ++t) { mu[t] = h.lam[64 + t]; if (h.dev[64 + t] < 1e-13) E |= 1ull << t; }
+  // the trimmed three-stage chain wants the plain identity in state 0 / mr - 1
+  trim_l_ = ml > 1 && (S & 1ull) && std::abs(lam[0] - 1.0) < 1e-13;
+  trim_r_ = mr > 1 && ((E >> (mr - 1)) & 1ull) && std::abs(mu[mr - 1] - 1.0) < 1e-13;
+  for (int c = 0; c < ml; ++c)
+    for (int t = 0; t < mr; ++t)
+      if (w.nzblk[(size_t)c * mr + t] && !((S >> c) & 1ull) && !((E >> t) & 1ull)) return;  // a block between general states
+  bool same = w.edge_valid && w.edge_s == S && w.edge_e == E;
+  if (same) {  // the multiples are compared exactly: they are +-1 or weights that do not change along a run
+    for (int c = 0; c < ml && same; ++c) if (((S >> c) & 1ull) && w.edge_lam[c] != lam[c]) same = false;
+    for (int t = 0; t < mr && same; ++t) if (((E >> t) & 1ull) && w.edge_mu[t] != mu[t]) same = false;
+  }
+  if (!same) {
+    const hzc* W = w.whost.data();
+    std::vector<hzc> wl((size_t)d * ml * d, hzc(0, 0)), wr((size_t)d * d * mr, hzc(0, 0));
+    bool has_l = false, has_r = false;
+    for (int c = 0; c < ml; ++c)
+      for (int t = 0; t < mr; ++t) {
+        if (!w.nzblk[(size_t)c * mr + t]) continue;
+        const bool in_s = (S >> c) & 1ull;
+        const hzc f = in_s ? lam[c] : mu[t];
+        if (f == hzc(0.0, 0.0)) continue;  // a zero block of the environment: the term vanishes
+        for (int i = 0; i < d; ++i)
+          for (int j = 0; j < d; ++j) {
+            const hzc v = f * W[(((size_t)c * d + i) * d + j) * mr + t];
+            if (in_s) wr[(size_t)i * d * mr + (size_t)j * mr + t] += v;
+            else wl[(size_t)i * ml * d + (size_t)c * d + j] += v;
+          }
+        (in_s ? has_r : has_l) = true;
+      }
+    w.w_edge_l.reserve(wl.size());
+    w.w_edge_r.reserve(wr.size());
+    HIP_CHECK(hipMemcpyAsync(w.w_edge_l.p, wl.data(), wl.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(w.w_edge_r.p, wr.data(), wr.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    w.edge_s = S; w.edge_e = E; w.edge_lam = lam; w.edge_mu = mu;
+    w.edge_has_l = has_l; w.edge_has_r = has_r; w.edge_valid = true;
+  }
+  edge_ = true;
+}
+
 void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* psi, zc* out, int dl, int d, int dr,
                         hzc shift) {
   SmallChain sc;
@@ -602,7 +729,8 @@ void Engine::heff_apply(const zc* L, const MpoSite& w, const zc* R, const zc* ps
     cnt_.heff_flops += 8.0 * ((double)dl * dl * w.ml * d * dr + (double)dl * dr * w.ml * w.mr * d * d + (double)dl * dr * dr * w.mr * d);
     return;
   }
-  heff_apply_rect(L, w, R, psi, out, dl, dl, d, dr, dr);
+  if (edge_) heff_apply_edge(L, w, R, psi, out, dl, d, dr);
+  else heff_apply_rect(L, w, R, psi, out, dl, dl, d, dr, dr);
   if (shift != hzc(0.0, 0.0))
     vec_axpby(st_, out, psi, (long)dl * d * dr, make_double2(shift.real(), shift.imag()), make_double2(1.0, 0.0));
 }
@@ -872,9 +1000,8 @@ void Engine::local_site_exp(int p, double dt) {
   const hzc shift = op(0).shift;
   auto mv = [&](const zc* in, zc* out) { heff_apply(Lb, w, Rb, in, out, dl, d, dr, shift); };
   // large bonds: one check per site (two tiny launches and a synchronisation) buys 1 / M_r of stage S3 in every apply
-  identity_blocks(trim_identity_ && dl >= 256 && w.ml > 1 ? Lb : nullptr, dl, w.ml,
-                  trim_identity_ && dr >= 256 && w.mr > 1 ? Rb : nullptr, dr, w.mr, &trim_l_, &trim_r_);
-  struct Reset { bool& f; bool& g; ~Reset() { f = false; g = false; } } reset{trim_r_, trim_l_};
+  choose_apply_forms(Lb, w, Rb, dl, d, dr);
+  struct Reset { bool& f; bool& g; bool& e; ~Reset() { f = false; g = false; e = false; } } reset{trim_r_, trim_l_, edge_};
   if (cfg.relax == 2)  // improved relaxation, _mps_cls.py:1078-1084
     kprev_[p] = krylov_diag(mv, site_[p].p, (long)dl * d * dr);
   else

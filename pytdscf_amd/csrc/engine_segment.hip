@@ -96,13 +96,15 @@ void Engine::heff_apply_center(const double* in, double* out, int* flags) {
   DevBuf x = pool_get(n), y = pool_get(n);
   if (in) copy_in(x.p, in, n);
   else HIP_CHECK(hipMemcpyAsync(x.p, site_[p].p, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
-  identity_blocks(trim_identity_ && dl >= 256 && w.ml > 1 ? Lb : nullptr, dl, w.ml,
-                  trim_identity_ && dr >= 256 && w.mr > 1 ? Rb : nullptr, dr, w.mr, &trim_l_, &trim_r_);
-  struct Reset { bool& f; bool& g; ~Reset() { f = false; g = false; } } reset{trim_r_, trim_l_};
+  choose_apply_forms(Lb, w, Rb, dl, d, dr);
+  struct Reset { bool& f; bool& g; bool& e; ~Reset() { f = false; g = false; e = false; } } reset{trim_r_, trim_l_, edge_};
   SmallChain sc;
   const bool small = small_ok() && chain_heff(sc, Lb, w, Rb, dl, d, dr, false);
-  const bool sparse = !small && sparse_w_ && dr >= 64 && w.kl_l.p && w.sp_frac_l <= 0.6;
-  if (flags) *flags = (trim_l_ && !small ? 1 : 0) | (trim_r_ && !small ? 2 : 0) | (sparse ? 4 : 0) | (small ? 8 : 0);
+  const bool edge = edge_ && !small;
+  const bool sparse = !small && !edge && sparse_w_ && dr >= 64 && w.kl_l.p && w.sp_frac_l <= 0.6;
+  if (flags)
+    *flags = (trim_l_ && !small && !edge ? 1 : 0) | (trim_r_ && !small && !edge ? 2 : 0) | (sparse ? 4 : 0) | (small ? 8 : 0) |
+             (edge ? 16 : 0);
   heff_apply(Lb, w, Rb, x.p, y.p, dl, d, dr, op(0).shift);
   copy_out(out, y.p, n);
   pool_put(std::move(x)); pool_put(std::move(y));

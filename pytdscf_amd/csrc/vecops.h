@@ -38,6 +38,10 @@ void set_identity(hipStream_t st, zc* out, int rows, int cols, long ld);
 void vec_copy_raw(hipStream_t st, zc* dst, const zc* src, size_t n);
 // max |blk[r][s] - delta_rs| over an n x n block with leading dimension ld -> *out_dev (one double, overwritten)
 void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_dev);
+// nblk blocks at once (block c at base + c * blk_stride, same ld and n), against multiples of the identity:
+// lam_dev[c] = the block's first diagonal element, out_dev[c] = max |block - lam 1|
+void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_stride, long ld, int n, double* out_dev,
+                           zc* lam_dev);
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
             bool accumulate);
 // norm profiles for the adaptive-rank functional (plain device arrays, no partials)

@@ -704,6 +704,34 @@ __global__ __launch_bounds__(256) void k_ident_dev(const zc* __restrict__ blk, l
   // non-negative doubles order like their bit patterns
   if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
 }
+// nblk blocks at once, against MULTIPLES of the identity: block c starts at base + c * blk_stride; lam[c] = its first
+// diagonal element, out[c] = max |blk - lam * 1|
+__global__ __launch_bounds__(256) void k_ident_dev_multi(const zc* __restrict__ base, long blk_stride, long ld, int n,
+                                                         unsigned long long* __restrict__ out, zc* __restrict__ lam) {
+  const zc* blk = base + (long)blockIdx.y * blk_stride;
+  const zc l = blk[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) lam[blockIdx.y] = l;
+  double m = 0.0;
+  const long tot = (long)n * n;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / n), c = (int)(e % n);
+    const zc v = blk[(long)r * ld + c];
+    m = fmax(m, r == c ? fmax(fabs(v.x - l.x), fabs(v.y - l.y)) : fmax(fabs(v.x), fabs(v.y)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out + blockIdx.y, (unsigned long long)__double_as_longlong(m));
+}
+void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_stride, long ld, int n, double* out_dev,
+                           zc* lam_dev) {
+  if (nblk < 1) return;
+  HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)nblk * sizeof(double), st));
+  const long tot = (long)n * n;
+  const int nb = (int)std::min<long>((tot + 255) / 256, 256);
+  hipLaunchKernelGGL(k_ident_dev_multi, dim3(nb, nblk), dim3(256), 0, st, base, blk_stride, ld, n,
+                     reinterpret_cast<unsigned long long*>(out_dev), lam_dev);
+  HIP_CHECK(hipGetLastError());
+}
 void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_dev) {
   HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(double), st));
   const long tot = (long)n * n;

@@ -51,7 +51,11 @@ __device__ __forceinline__ int cd_row(int mode, int lk, int r) {
   return mode == 0 ? (lk + 4 * r) : (4 * lk + r);
 }
 
-template <int WM, int WN, int BK, bool TA, bool TB, bool M3, bool SP = false>
+// The reducing epilogue of zgemm_reduce for RB x CB blocks of 16 x 16 outputs (declared here, defined below the kernel)
+template <int RB, int CB>
+__device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
+
+template <int WM, int WN, int BK, bool TA, bool TB, bool M3, bool SP = false, bool EPI = false>
 __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
   constexpr int BM = 2 * WM * 16, BN = 2 * WN * 16;
   constexpr int LDAS = TA ? BM : (BK + 1);  // LDS row stride (complex elements)
@@ -79,7 +83,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
   const int rem = bid - group * per_group;
   const int tm = first_m + rem % gsz;
   const int tn = rem / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  // EPI: a tile holds whole (u, x) / (v, y) groups only, i.e. 64 / xm * xm rows and 64 / yn * yn columns of it are used
+  const int m0 = EPI ? tm * ((BM / d.epi_xm) * d.epi_xm) : tm * BM, n0 = EPI ? tn * ((BN / d.epi_yn) * d.epi_yn) : tn * BN;
   const int b = blockIdx.y;
 
   const long lda = d.lda, ldb = d.ldb;
@@ -378,6 +383,45 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     for (; kt < nkt; ++kt) tile(kt, P0{}, GEN{});
   }
 
+  if constexpr (EPI) {
+    // ---- reducing epilogue: the tile goes to LDS (the K loop's stages are free: its last tile ended with a barrier),
+    // then out[u][v][i] = sum_{x,y} w[i][(x,y)] T[(u,x)][(v,y)] on the matrix cores (reduce_epilogue)
+    static_assert(BM == 64 && BN == 64, "the reducing epilogue is written for 64 x 64 tiles");
+    constexpr int LDT = BN + 1;
+    static_assert((size_t)BM * LDT <= 2 * (size_t)STAGE, "tile does not fit the K loop's LDS");
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (wm * WM + i) * 16 + cd_row(cd_mode, lk, r);
+          const int col = (wn * WN + j) * 16 + li;
+          zc v;
+          if (M3) {
+            const double p1 = acc[0][i][j][r], p2 = sgnA * sgnB * acc[1][i][j][r], p3 = acc[NACC - 1][i][j][r];
+            v = make_double2(p1 - p2, p3 - p1 - p2);
+          } else {
+            v = make_double2(acc[0][i][j][r], acc[1][i][j][r]);
+          }
+          smem[row * LDT + col] = v;
+        }
+    __syncthreads();
+    const int rbn = (d.epi_di + 15) / 16;
+    const int cbn = ((BM / d.epi_xm) * (BN / d.epi_yn) + 15) / 16;
+    if (cbn == 1) {
+      if (rbn == 1) reduce_epilogue<1, 1>(d, smem, tm, tn, cd_mode);
+      else if (rbn == 2) reduce_epilogue<2, 1>(d, smem, tm, tn, cd_mode);
+      else reduce_epilogue<4, 1>(d, smem, tm, tn, cd_mode);
+    } else if (cbn == 2) {
+      if (rbn == 1) reduce_epilogue<1, 2>(d, smem, tm, tn, cd_mode);
+      else reduce_epilogue<2, 2>(d, smem, tm, tn, cd_mode);
+    } else {
+      reduce_epilogue<1, 4>(d, smem, tm, tn, cd_mode);
+    }
+    return;
+  }
+
   // ---- epilogue: C = alpha*acc + beta*C -----------------------------------
   const zc alpha = d.alpha, beta = d.beta;
   const bool has_beta = (beta.x != 0.0 || beta.y != 0.0);
@@ -406,6 +450,122 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
           *p = o;
         }
       }
+}
+
+// The reducing epilogue (ZgemmDesc::epi_w).  T = the 64 x 64 tile in LDS (row stride 65).  The contraction index
+// k' = (x, y) is split over the four waves; every wave forms RB x CB partial blocks of 16 (i) x 16 (pairs (u, v)) with
+// the 4M complex product; the partials meet in LDS (over T, once every wave has read it) and are summed in a fixed
+// order.  The fragments of w come from global memory (L2: the matrix is d x (xm yn), shared by all tiles) four k-steps
+// ahead of their use.
+template <int RB, int CB>
+__device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode) {
+  constexpr int LDT = 65;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 15, lk = lane >> 4;
+  const int XM = d.epi_xm, YN = d.epi_yn, KP = XM * YN, DI = d.epi_di;
+  const int TU = 64 / XM, TV = 64 / YN, npair = TU * TV;
+  const int nk4 = (KP + 3) / 4, per = (nk4 + 3) / 4;
+  const int k4a = w * per, k4b = min(nk4, k4a + per);
+  const zc* __restrict__ Wm = d.epi_w;
+  const long ldw = d.epi_ldw;
+  double zin = 0.0;
+  asm volatile("" : "+v"(zin));
+  d4 zr[RB * CB], zi[RB * CB];
+#pragma unroll
+  for (int q = 0; q < RB * CB; ++q) {
+    zr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+    zi[q] = zr[q];
+  }
+  // LDS offsets of this lane's pairs (one per column block)
+  int toff[CB];
+  bool tval[CB];
+#pragma unroll
+  for (int jb = 0; jb < CB; ++jb) {
+    const int pr = jb * 16 + li;
+    tval[jb] = pr < npair;
+    const int prc = tval[jb] ? pr : 0;
+    const int ul = prc / TV, vl = prc - ul * TV;
+    toff[jb] = ul * XM * LDT + vl * YN;
+  }
+  const zc zero = make_double2(0.0, 0.0);
+  constexpr int CH = 4;  // k-steps per chunk of w fragments
+  zc wv[2][CH][RB];
+  auto load_w = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int kk = (k4s + c) * 4 + lk;
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) {
+        const int i = ib * 16 + li;
+        const bool ok = (k4s + c) < k4b && kk < KP && i < DI;
+        wv[buf][c][ib] = ok ? Wm[(long)i * ldw + kk] : zero;
+      }
+    }
+  };
+  auto chunk = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k4 = k4s + c;
+      if (k4 < k4b) {
+        const int kk = k4 * 4 + lk;
+        const bool kv = kk < KP;
+        const int kc = kv ? kk : 0;
+        const int x = kc / YN, y = kc - x * YN;
+        zc tv[CB];
+#pragma unroll
+        for (int jb = 0; jb < CB; ++jb) tv[jb] = (kv && tval[jb]) ? smem[toff[jb] + x * LDT + y] : zero;
+#pragma unroll
+        for (int ib = 0; ib < RB; ++ib) {
+          const zc a = wv[buf][c][ib];
+          const double nai = -a.y;
+#pragma unroll
+          for (int jb = 0; jb < CB; ++jb) {
+            const int q = ib * CB + jb;
+            zr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, tv[jb].x, zr[q], 0, 0, 0);
+            zi[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, tv[jb].y, zi[q], 0, 0, 0);
+            zr[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, tv[jb].y, zr[q], 0, 0, 0);
+            zi[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, tv[jb].x, zi[q], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  load_w(0, k4a);
+  for (int k4s = k4a; k4s < k4b; k4s += 2 * CH) {
+    load_w(1, k4s + CH);
+    chunk(0, k4s);
+    load_w(0, k4s + 2 * CH);
+    chunk(1, k4s + CH);
+  }
+  __syncthreads();  // every wave has read its part of T
+  // partials: [wave][block][reg * 64 + lane]
+#pragma unroll
+  for (int q = 0; q < RB * CB; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) smem[(w * (RB * CB) + q) * 256 + r * 64 + lane] = make_double2(zr[q][r], zi[q][r]);
+  __syncthreads();
+  const int el = t & 63, er = t >> 6;  // thread t owns (lane el, register er) of every block
+  const int row_b = cd_row(cd_mode, el >> 4, er), col_b = el & 15;
+#pragma unroll
+  for (int q = 0; q < RB * CB; ++q) {
+    const int ib = q / CB, jb = q - ib * CB;
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const zc v = smem[(ww * (RB * CB) + q) * 256 + t];
+      re += v.x;
+      im += v.y;
+    }
+    const int i = ib * 16 + row_b, pr = jb * 16 + col_b;
+    if (i < DI && pr < npair) {
+      const int ul = pr / TV, vl = pr - ul * TV;
+      const long u = (long)tm * TU + ul, v = (long)tn * TV + vl;
+      if (u * XM < d.M && v * YN < d.N) {
+        zc* p = d.C + u * d.epi_su + v * d.epi_sv + (long)i * d.epi_si;
+        if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
+        *p = make_double2(re, im);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -654,16 +814,66 @@ static void launch_sparse(hipStream_t st, const ZgemmDesc& d, int m3) {
   HIP_CHECK(hipGetLastError());
 }
 
+static int zgemm_tune_default() {
+  static const int v = [] { const char* e = std::getenv("MITDVP_ZGEMM_TUNE"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
+int zgemm_cd_mode(hipStream_t st);
+
+bool zgemm_reduce_ok(int xm, int yn, int di) {
+  if (xm < 1 || yn < 1 || di < 1 || xm > 64 || yn > 64 || di > 64) return false;
+  const int rb = (di + 15) / 16, cb = ((64 / xm) * (64 / yn) + 15) / 16;
+  // the block shapes reduce_epilogue is instantiated for (3 row blocks run as 4, 3 column blocks as 4)
+  return (cb == 1) || (cb == 2 && rb <= 2) || (cb <= 4 && rb == 1);
+}
+
+void zgemm_reduce(hipStream_t st, const ZgemmDesc& d0) {
+  ZgemmDesc d = d0;
+  if (d.tune < 0) d.tune = zgemm_tune_default();
+  if (d.M <= 0 || d.N <= 0) return;
+  if (!zgemm_reduce_ok(d.epi_xm, d.epi_yn, d.epi_di) || !d.epi_w) throw ArgError("zgemm_reduce: shape outside the reducing epilogue's range");
+  if (d.transA || d.batch != 1 || d.ksplit || d.klist || d.arow_skip || d.rowmap_p || d.conjA || d.conjB)
+    throw ArgError("zgemm_reduce: plain NN / NT operands only");
+  if (d.M % d.epi_xm || d.N % d.epi_yn) throw ArgError("zgemm_reduce: M, N must be whole groups");
+  if (d.lda >= (1L << 20) || d.ldb >= (1L << 20)) throw ArgError("zgemm: row stride >= 2^20 elements (per-thread tile offsets are 32-bit)");
+  (void)zgemm_cd_mode(st);
+  const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
+  const int tu = 64 / d.epi_xm, tv = 64 / d.epi_yn;
+  const int nu = d.M / d.epi_xm, nv = d.N / d.epi_yn;
+  const int ntm = (nu + tu - 1) / tu, ntn = (nv + tv - 1) / tv;
+  dim3 grid(ntm * ntn, 1);
+  auto launch = [&](auto kern, size_t lds) {
+    if (lds > 65536) {  // per device and instantiation, as in launch_one
+      static std::mutex mu;
+      static std::map<std::pair<const void*, int>, bool> done;
+      int dev = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> lk(mu);
+      bool& f = done[{reinterpret_cast<const void*>(kern), dev}];
+      if (!f) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        f = true;
+      }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, ntm, ntn, g_cd_mode);
+  };
+  const size_t lds_nn = 2 * (size_t)(64 * 17 + 16 * 64) * sizeof(zc), lds_nt = 2 * (size_t)(64 * 17 + 64 * 17) * sizeof(zc);
+  if (!d.transB) {
+    if (m3) launch(zgemm_kernel<2, 2, 16, false, false, true, false, true>, lds_nn);
+    else launch(zgemm_kernel<2, 2, 16, false, false, false, false, true>, lds_nn);
+  } else {
+    if (m3) launch(zgemm_kernel<2, 2, 16, false, true, true, false, true>, lds_nt);
+    else launch(zgemm_kernel<2, 2, 16, false, true, false, false, true>, lds_nt);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 int zgemm_cd_mode(hipStream_t st) {
   // the accumulator lane map is a property of the gfx950 ISA, not of a device: once per process
   static std::once_flag probe_once;  // several engines may issue their first GEMM concurrently
   std::call_once(probe_once, [&] { if (g_cd_mode < 0) mfma_layout_probe(st, nullptr); });
   return g_cd_mode;
-}
-
-static int zgemm_tune_default() {
-  static const int v = [] { const char* e = std::getenv("MITDVP_ZGEMM_TUNE"); return e ? std::atoi(e) : 0; }();
-  return v;
 }
 
 void zgemm(hipStream_t st, const ZgemmDesc& d0) {
