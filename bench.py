@@ -13,7 +13,7 @@ resident in HBM before the timed region.
 
 Wall budget.  A C4 sweep takes about a minute, so the requested --steps /
 --warmup are an upper bound: after the first warm-up sweep the run knows the
-sweep time and fits `warmup + steps` into --max-seconds (default 420 s, env
+sweep time and fits `warmup + steps` into --max-seconds (default 400 s, env
 MITDVP_BENCH_BUDGET; the CPU-baseline leg and the start-up are counted).  The
 JSON line reports the sweeps actually run ("steps", "warmup") next to
 "steps_requested" / "warmup_requested"; at least one warm-up and one timed
@@ -91,15 +91,17 @@ def cpu_baseline_is_sampled(L, d, D, M):
     return sweep_flops_estimate(L, d, D, M) > 2e12
 
 
-def cpu_baseline_seconds_estimate(L, d, D, M):
+def cpu_baseline_seconds_estimate(L, d, D, M, short=False):
     """Wall time the cpu_baseline leg needs on the GPU box's host (reserved out of the budget)."""
+    if short and not cpu_baseline_is_sampled(L, d, D, M):
+        return 12.0
     if cpu_baseline_is_sampled(L, d, D, M):
         # one chunked H_eff apply + one K_eff apply + one QR at the interior shape: ~25 s at C4 on 64 BLAS threads
         return 10.0 + 3.0 * flops_heff(D, d, D, M, M) / 1e12
     return 20.0
 
 
-def cpu_baseline(L, d, D, M, kh, kk, n_threads, dt, budget_s=15.0):
+def cpu_baseline(L, d, D, M, kh, kk, n_threads, dt, budget_s=15.0, short=False):
     """Oracle (NumPy/OpenBLAS zgemm + LAPACK QR) timed on the host cores on a bounded
     sample: one H_eff apply, one K_eff apply and one QR gauge move at the interior
     site shape; extrapolated over the chain with per-site flop ratios and the
@@ -115,7 +117,8 @@ def cpu_baseline(L, d, D, M, kh, kk, n_threads, dt, budget_s=15.0):
         return rng.standard_normal(s) + 1j * rng.standard_normal(s)
 
     f_int = flops_heff(dl, d, dr, ml, mr)
-    if cpu_baseline_is_sampled(L, d, D, M):  # an end-to-end oracle sweep would take minutes to hours on the host
+    # (short: the secondary legs of the bench line have seconds, not tens of seconds: mid-size workloads are sampled too)
+    if cpu_baseline_is_sampled(L, d, D, M) or (short and sweep_flops_estimate(L, d, D, M) > 2e11):  # an end-to-end oracle sweep would take minutes to hours on the host
         # chunk the apply over the left bond so the intermediates stay ~1 GB
         Lb, Rb, psi = crandn(dl, ml, dl), crandn(dr, mr, dr), crandn(dl, d, dr)
         W = crandn(ml, d, d, mr)
@@ -145,8 +148,9 @@ def cpu_baseline(L, d, D, M, kh, kk, n_threads, dt, budget_s=15.0):
     mps = orc.synthetic_mps([d] * L, D, seed=1)
     st = orc.OracleMPS(mps, mpo)
     st.build_right_envs()
-    st.sweep(dt, True)
-    st.sweep(dt, False)
+    if not short:
+        st.sweep(dt, True)
+        st.sweep(dt, False)
     n = 0
     t0 = time.perf_counter()
     while True:
@@ -160,12 +164,12 @@ def cpu_baseline(L, d, D, M, kh, kk, n_threads, dt, budget_s=15.0):
 
 
 def committed_traffic(name, L, d, D, M):
-    """HBM-side bytes per H_eff apply from the committed PMC passes (separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per MI355X_MICROARCH.md), newest round first;
-    None for shapes that were not measured."""
-    cands = ["r03_%s_traffic.json" % name, "r02_%s_traffic.json" % name, "r01_%s_traffic.json" % name]
-    if name == "heff":  # per-shape files of the other large-bond workloads (round 3)
-        cands = ["r03_heff_traffic_D%d_d%d_M%d.json" % (D, d, M)] + cands
+    """(HBM-side bytes per H_eff apply, the committed file they come from) -- PMC passes run beside the bench, NOT a
+    measurement of this run (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per
+    MI355X_MICROARCH.md), newest round first; (None, None) for shapes that were not measured."""
+    cands = ["r%02d_%s_traffic.json" % (r, name) for r in (4, 3, 2, 1)]
+    if name == "heff":  # per-shape files of the other large-bond workloads
+        cands = ["r%02d_heff_traffic_D%d_d%d_M%d.json" % (r, D, d, M) for r in (4, 3)] + cands
     for fn in cands:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", fn)))
@@ -175,8 +179,186 @@ def committed_traffic(name, L, d, D, M):
                 or f"L={L} d={d} D={D} M={M}" in str(t.get("workload", ""))):
             for k in ("total_bytes", "bytes_per_heff_apply", "zgemm_NN_NT_bytes_per_heff_apply_upper_bound"):
                 if k in t:
-                    return t[k]
+                    return t[k], "profiles/" + fn
+    return None, None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
     return None
+
+
+def blas_threads():
+    nthr = os.cpu_count() or 1
+    try:  # the threads the BLAS behind NumPy actually runs (OpenBLAS caps at its build-time maximum)
+        import threadpoolctl
+
+        blas = [x["num_threads"] for x in threadpoolctl.threadpool_info() if x.get("user_api") == "blas"]
+        if blas:
+            nthr = max(blas)
+    except Exception:
+        pass
+    return nthr
+
+
+def roofline_report(cnt, L, d, D, M, gemm_mode, el_s, profile_in_timed, tp=False):
+    """(roofline, breakdown_ms, mean Krylov dimension of the site / bond exponentials) from the engine's counters."""
+    kh = cnt["n_heff"] / max(cnt["n_exp_site"], 1)
+    kk = cnt["n_keff"] / max(cnt["n_exp_bond"], 1)
+    alg = cnt["heff_flops"] / max(cnt["heff_ms"], 1e-9) / 1e9  # algorithmic TFLOP/s (8 flop per complex MAC)
+    # the 3M (Karatsuba) complex product executes 6 real flop per complex MAC, the 4M product all 8:
+    # the roofline fraction is what the matrix cores actually execute over their peak
+    # zero (c, t) blocks of W are skipped by the block-sparse W stage: those flops are not executed either
+    done_share = 1.0 - cnt.get("heff_flops_skipped", 0.0) / max(cnt["heff_flops"], 1.0)
+    executed = alg * done_share * (0.75 if gemm_mode == "3m" else 1.0)
+    # small-bond regime (SURVEY 8d: C2, D < 128): the apply is memory / latency bound, the
+    # roofline that applies is HBM: algorithmic bytes B_H per apply over the apply time
+    small = D < 128
+    bytes_apply = 16.0 * (2 * D * d * D + 2 * D * D * M + M * d * d * M)  # interior site, SURVEY 8d B_H
+    ach_gbs = bytes_apply * cnt["n_heff"] / max(cnt["heff_ms"], 1e-9) / 1e6  # GB/s
+    traffic, traffic_src = committed_traffic("c2" if small else "heff", L, d, D, M)
+    if small:
+        roof = {
+            "bound": "hbm",
+            "kernel": "k_small_site (one launch per local exponential: H_eff applies, Krylov algebra, k x k exponential, convergence test)",
+            "achieved": ach_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": ach_gbs / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "bytes_per_apply": bytes_apply,
+            "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
+            "n_apply": cnt["n_heff"],
+            "tflops": alg,
+            "note": ("latency bound: a site is a few hundred KB; achieved = algorithmic bytes B_H per H_eff apply x applies / HIP-event "
+                     "time of the site exponentials (which also holds their Krylov algebra and grid-wide exchanges)"),
+        }
+    else:
+        roof = {
+            "bound": "mfma",
+            "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)" + (" -- per GPU, this rank's bond shard" if tp else ""),
+            "achieved": executed,
+            "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": executed / FP64_MFMA_PEAK_TFLOPS,
+            "algorithmic_tflops": alg,
+            "achieved_algorithmic": alg,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "traffic_note": "bytes per apply from the committed PMC passes named in traffic_source, not measured in this run",
+            "flops_per_apply": cnt["heff_flops"] / max(cnt["n_heff"], 1),
+            "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
+            "stage_ms_per_apply": [x / max(cnt["n_heff"], 1) for x in cnt["heff_stage_ms"]],
+            "n_apply": cnt["n_heff"],
+            "complex_product": gemm_mode,
+            "executed_share_of_algorithmic": done_share * (0.75 if gemm_mode == "3m" else 1.0),
+            "w_stage": ("block-sparse: zero blocks of the finite-state-machine MPO skipped; identity blocks of the two "
+                        "environments short-circuited in stages S1 / S3" if done_share < 0.999 else "dense"),
+            "note": ("achieved / frac = flop the matrix cores EXECUTE per second: the 3M (Karatsuba) complex product "
+                     "runs 6 real flop per complex MAC, the W stage skips the zero blocks of the MPO and stages S1 / S3 the identity "
+                     "blocks of the environments; "
+                     "algorithmic_tflops counts the 8 flop of the textbook dense product (SURVEY 8d F_H) over the "
+                     "same HIP-event time") if gemm_mode == "3m"
+                    else "4M complex product: executed = algorithmic flops",
+        }
+    brk = {
+        "heff": cnt["heff_ms"], "env": cnt["env_ms"], "keff": cnt["keff_ms"], "qr": cnt["qr_ms"],
+        "krylov_vec": cnt["krylov_vec_ms"], "wall": 1e3 * el_s,
+        "phases_from": "the timed sweeps" if profile_in_timed else "a profiled repeat of the timed sweeps (event overhead kept out of the timed region)",
+        "env_tflops": cnt["env_flops"] / max(cnt["env_ms"], 1e-9) / 1e9,
+        "keff_tflops": cnt["keff_flops"] / max(cnt["keff_ms"], 1e-9) / 1e9,
+        "qr_tflops": cnt["qr_flops"] / max(cnt["qr_ms"], 1e-9) / 1e9,
+        "launches": cnt["n_launch"],
+        "host_waits": cnt.get("n_host_waits", 0.0),
+    }
+    return roof, brk, kh, kk
+
+
+# Per-phase HIP-event timing (roofline / breakdown) costs two event records per phase: nothing at C4 (0.01 %), a third
+# of the run in the launch-bound small-bond regime, a few per cent at D = 128.  Below this bond dimension the timed
+# region runs unprofiled and the same sweeps are repeated afterwards, profiled, only for the breakdown.
+PROFILE_IN_TIMED_MIN_D = 512
+
+
+def secondary_leg(name, device, gemm_mode, seconds, steps_req, with_cpu, note):
+    """One short single-GPU run of another BASELINE config after the headline one: the same measurement (warm-up, timed
+    sweeps between synchronisations, counters -> roofline / breakdown, the oracle on the host cores), a few seconds of
+    sweeps.  Returns the record for the `secondary` key of the JSON line."""
+    from pytdscf_amd import synthetic as syn
+    from pytdscf_amd import TDVPEngine
+
+    t_leg = time.perf_counter()
+    L, d, D, M, dt, integ, desc = WORKLOADS[name]
+    liouville = integ == "arnoldi"
+    mpo_cores = syn.synthetic_liouvillian_mpo(L, M, seed=0, gamma=0.002) if liouville else syn.synthetic_mpo(L, d, M, seed=0)
+    eng = TDVPEngine(L, device=device, integrator=integ, conserve_norm=not liouville)
+    try:
+        eng.set_mpo(mpo_cores)
+        eng.init_random([d] * L, D, seed=1)
+        e0 = eng.expectation().real
+        fwd = [True]
+
+        def sweep():
+            eng.sweep(dt, fwd[0])
+            fwd[0] = not fwd[0]
+
+        t1 = time.perf_counter()
+        sweep()
+        eng.norm()
+        t_first = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        sweep()
+        eng.norm()
+        t_sweep = time.perf_counter() - t1
+        warm = 2
+        profile_in_timed = D >= PROFILE_IN_TIMED_MIN_D
+        reserve = (cpu_baseline_seconds_estimate(L, d, D, M, short=True) if with_cpu else 0.0) + 2.0
+        left = seconds - (time.perf_counter() - t_leg) - reserve
+        afford = int(left / max(t_sweep, 1e-9) / (1 if profile_in_timed else 2))
+        steps = max(2, min(steps_req, (afford // 2) * 2))
+        eng.counters_reset()
+        eng.set_profiling(profile_in_timed)
+        eng.norm()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sweep()
+        nrm = eng.norm()
+        el = time.perf_counter() - t0
+        if not profile_in_timed:
+            eng.counters_reset()
+            eng.set_profiling(True)
+            for _ in range(steps):
+                sweep()
+            eng.norm()
+        cnt = eng.counters()
+        eng.set_profiling(False)
+        e1 = eng.expectation().real
+        roof, brk, kh, kk = roofline_report(cnt, L, d, D, M, gemm_mode, el, profile_in_timed)
+        rec = {
+            "workload": f"{name}: {desc}",
+            "value": steps / el, "unit": "sweeps/s", "steps": steps, "warmup": warm, "ms_per_step": 1e3 * el / steps,
+            "first_sweep_s": t_first,
+            "config": {"L": L, "d": d, "D": D, "M": M, "dt_au": dt, "thresh_sil": 1e-9, "integrator": integ,
+                       "mean_krylov_site": round(kh, 2), "mean_krylov_bond": round(kk, 2),
+                       "norm_after": nrm, "energy_before": e0, "energy_after": e1},
+            "roofline": roof,
+            "breakdown_ms": brk,
+        }
+    finally:
+        eng.close()
+    if with_cpu:
+        note(f"{name}: timing the CPU baseline (oracle on the host cores)")
+        rec["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, blas_threads(), dt, budget_s=6.0, short=True)
+        rec["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        rec["cpu_baseline"]["cpu_model"] = cpu_model()
+    rec["leg_s"] = time.perf_counter() - t_leg
+    return rec
 
 
 def plan_sweeps(budget_s, elapsed_s, t_sweep, warm_done, warm_req, steps_req, reserve_s):
@@ -236,9 +418,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("MITDVP_WORKLOAD", "C4"), choices=sorted(WORKLOADS))
     ap.add_argument("--dt", type=float, default=None, help="time step in a.u. (default per workload)")
-    ap.add_argument("--max-seconds", type=float, default=float(os.environ.get("MITDVP_BENCH_BUDGET", "420")),
+    ap.add_argument("--max-seconds", type=float, default=float(os.environ.get("MITDVP_BENCH_BUDGET", "400")),
                     help="wall budget for the whole run; steps / warmup are cut to fit (0 = no limit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", default=os.environ.get("MITDVP_BENCH_SECONDARY", "auto"),
+                    help="other BASELINE configs run as short single-GPU legs after the headline one and reported under "
+                         "the `secondary` key: auto (C2, C3, C5), none, or a comma list")
+    ap.add_argument("--secondary-seconds", type=float, default=float(os.environ.get("MITDVP_BENCH_SECONDARY_BUDGET", "100")),
+                    help="wall budget of all secondary legs together (beside --max-seconds)")
     ap.add_argument("--parallel", default=os.environ.get("MITDVP_PARALLEL", "auto"), choices=["auto", "sites", "tp", "replicas"])
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.gpus < 1:
@@ -403,11 +590,7 @@ def main():
              f"(requested {args.warmup} + {args.steps})")
     sync_norm()
     meas.counters_reset()
-    # Per-phase HIP-event timing (roofline / breakdown) costs two event records per phase:
-    # nothing at C4 (0.01 %), a third of the run in the launch-bound small-bond regime.  There
-    # the timed region runs unprofiled and the same number of sweeps is repeated afterwards,
-    # profiled, only for the breakdown.
-    profile_in_timed = D >= 128
+    profile_in_timed = D >= PROFILE_IN_TIMED_MIN_D  # below: an unprofiled timed region + a profiled repeat
     meas.set_profiling(profile_in_timed)
     barrier()
     t0 = time.perf_counter()
@@ -437,21 +620,13 @@ def main():
     if ss is not None:  # the sharded state's own norm and energy after the run (collective; not timed)
         nrm = ss.norm()
         e1 = ss.expectation().real
+    elif mode == "single":  # energy conservation of the run itself (a fresh chain of right blocks; not timed)
+        if not state["forward"]:  # an odd number of sweeps so far: the centre sits at the last site; bring it home
+            run_unit()
+        e1 = eng.expectation().real
 
     if rank == 0:
-        kh = cnt["n_heff"] / max(cnt["n_exp_site"], 1)
-        kk = cnt["n_keff"] / max(cnt["n_exp_bond"], 1)
-        alg = cnt["heff_flops"] / max(cnt["heff_ms"], 1e-9) / 1e9  # algorithmic TFLOP/s (8 flop per complex MAC)
-        # the 3M (Karatsuba) complex product executes 6 real flop per complex MAC, the 4M product all 8:
-        # the roofline fraction is what the matrix cores actually execute over their peak
-        # zero (c, t) blocks of W are skipped by the block-sparse W stage: those flops are not executed either
-        done_share = 1.0 - cnt.get("heff_flops_skipped", 0.0) / max(cnt["heff_flops"], 1.0)
-        executed = alg * done_share * (0.75 if gemm_mode == "3m" else 1.0)
-        # small-bond regime (C2, D < 128): the apply is memory / latency bound, the
-        # roofline that applies is HBM: algorithmic bytes B_H per apply over the apply time
-        small = D < 128
-        bytes_apply = 16.0 * (2 * D * d * D + 2 * D * D * M + M * d * d * M)  # interior site, SURVEY 8d B_H
-        ach_gbs = bytes_apply * cnt["n_heff"] / max(cnt["heff_ms"], 1e-9) / 1e6  # GB/s
+        roof, brk, kh, kk = roofline_report(cnt, L, d, D, M, gemm_mode, el, profile_in_timed, tp=(mode == "tp"))
         out = {
             "metric": "tdvp_sweeps_per_sec",
             "value": value,
@@ -498,68 +673,31 @@ def main():
                 "collective_GB": cnt["collective_bytes"] / 1e9,
                 "wall_budget_s": args.max_seconds,
             },
-            "roofline": ({
-                "bound": "hbm",
-                "kernel": "k_small_site (one launch per local exponential: H_eff applies, Krylov algebra, k x k exponential, convergence test)",
-                "achieved": ach_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": ach_gbs / HBM_PEAK_GBS,
-                "traffic": committed_traffic("c2", L, d, D, M),
-                "bytes_per_apply": bytes_apply,
-                "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
-                "n_apply": cnt["n_heff"],
-                "tflops": alg,
-                "note": ("latency bound: a site is a few hundred KB; achieved = algorithmic bytes B_H per H_eff apply x applies / HIP-event "
-                         "time of the site exponentials (which also holds their Krylov algebra and grid-wide exchanges)"),
-            } if small else {
-                "bound": "mfma",
-                "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)" + (" -- per GPU, this rank's bond shard" if mode == "tp" else ""),
-                "achieved": executed,
-                "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": executed / FP64_MFMA_PEAK_TFLOPS,
-                "algorithmic_tflops": alg,
-                "achieved_algorithmic": alg,
-                "traffic": committed_traffic("heff", L, d, D, M),
-                "flops_per_apply": cnt["heff_flops"] / max(cnt["n_heff"], 1),
-                "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
-                "stage_ms_per_apply": [x / max(cnt["n_heff"], 1) for x in cnt["heff_stage_ms"]],
-                "n_apply": cnt["n_heff"],
-                "complex_product": gemm_mode,
-                "executed_share_of_algorithmic": done_share * (0.75 if gemm_mode == "3m" else 1.0),
-                "w_stage": ("block-sparse: zero blocks of the finite-state-machine MPO skipped; identity blocks of the two "
-                            "environments short-circuited in stages S1 / S3" if done_share < 0.999 else "dense"),
-                "note": ("achieved / frac = flop the matrix cores EXECUTE per second: the 3M (Karatsuba) complex product "
-                         "runs 6 real flop per complex MAC, the W stage skips the zero blocks of the MPO and stages S1 / S3 the identity "
-                         "blocks of the environments; "
-                         "algorithmic_tflops counts the 8 flop of the textbook dense product (SURVEY 8d F_H) over the "
-                         "same HIP-event time") if gemm_mode == "3m"
-                        else "4M complex product: executed = algorithmic flops",
-            }),
-            "breakdown_ms": {
-                "heff": cnt["heff_ms"], "env": cnt["env_ms"], "keff": cnt["keff_ms"], "qr": cnt["qr_ms"],
-                "krylov_vec": cnt["krylov_vec_ms"], "wall": 1e3 * el,
-                "phases_from": "the timed sweeps" if profile_in_timed else "a profiled repeat of the timed sweeps (event overhead kept out of the timed region)",
-                "env_tflops": cnt["env_flops"] / max(cnt["env_ms"], 1e-9) / 1e9,
-                "keff_tflops": cnt["keff_flops"] / max(cnt["keff_ms"], 1e-9) / 1e9,
-                "qr_tflops": cnt["qr_flops"] / max(cnt["qr_ms"], 1e-9) / 1e9,
-                "launches": cnt["n_launch"],
-            },
+            "roofline": roof,
+            "breakdown_ms": brk,
         }
         if with_cpu:
-            nthr = os.cpu_count() or 1
-            try:  # the threads the BLAS behind NumPy actually runs (OpenBLAS caps at its build-time maximum)
-                import threadpoolctl
-
-                blas = [x["num_threads"] for x in threadpoolctl.threadpool_info() if x.get("user_api") == "blas"]
-                if blas:
-                    nthr = max(blas)
-            except Exception:
-                pass
             note("timing the CPU baseline (oracle on the host cores)")
-            out["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, nthr, dt)
+            out["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, blas_threads(), dt)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+            out["cpu_baseline"]["cpu_model"] = cpu_model()
+        # ---- the other BASELINE configs, driver-observed: short single-GPU legs after the headline run ----
+        if mode == "single" and args.secondary != "none":
+            names = [w for w in ("C2", "C3", "C5") if w != args.workload] if args.secondary == "auto" else \
+                    [w for w in args.secondary.split(",") if w in WORKLOADS and w != args.workload]
+            eng.close()
+            eng = None
+            out["secondary"] = {}
+            share = {"C2": 0.15, "C3": 0.25, "C5": 0.60}
+            tot_share = sum(share.get(w, 0.3) for w in names) or 1.0
+            for w in names:
+                secs = args.secondary_seconds * share.get(w, 0.3) / tot_share
+                note(f"secondary leg {w} ({secs:.0f}s)")
+                try:
+                    out["secondary"][w] = secondary_leg(w, comm.gpu, gemm_mode, secs, args.steps if w != "C2" else max(args.steps, 100),
+                                                        not args.no_cpu_baseline, note)
+                except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
+                    out["secondary"][w] = {"error": f"{type(e).__name__}: {e}"}
         out["wall_s"] = elapsed()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if eng is not None:

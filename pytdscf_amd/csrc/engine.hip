@@ -658,7 +658,9 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
   const int ml = w.ml, mr = w.mr;
   const bool edge_cand = edge_mode_ != 0 && trim_identity_ && !w.whost.empty() && !sharded && dl >= 32 && dr >= 32 &&
                          zgemm_reduce_ok(d, mr, d) && zgemm_reduce_ok(ml, d, d) && (long)d * dr < (1L << 20) &&
-                         (edge_mode_ > 0 || (long)dl * dr <= 512L * 512L);
+                         // the size rule: the epilogue streams the d x (d M) reduced core once per tile -- cheap beside a
+                         // tile's K loop only while d M is small (measured: profiles/r04_edge_apply_ab.txt)
+                         (edge_mode_ > 0 || ((long)d * std::max(ml, mr) <= 64 && (long)dl * dr <= 512L * 512L));
   if (!edge_cand) {
     identity_blocks(trim_identity_ && dl >= 256 && ml > 1 ? Lb : nullptr, dl, ml,
                     trim_identity_ && dr >= 256 && mr > 1 ? Rb : nullptr, dr, mr, &trim_l_, &trim_r_);

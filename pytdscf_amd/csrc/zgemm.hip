@@ -486,7 +486,6 @@ __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, in
     const int ul = prc / TV, vl = prc - ul * TV;
     toff[jb] = ul * XM * LDT + vl * YN;
   }
-  const zc zero = make_double2(0.0, 0.0);
   constexpr int CH = 4;  // k-steps per chunk of w fragments
   zc wv[2][CH][RB];
   auto load_w = [&](int buf, int k4s) __attribute__((always_inline)) {
@@ -497,7 +496,12 @@ __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, in
       for (int ib = 0; ib < RB; ++ib) {
         const int i = ib * 16 + li;
         const bool ok = (k4s + c) < k4b && kk < KP && i < DI;
-        wv[buf][c][ib] = ok ? Wm[(long)i * ldw + kk] : zero;
+        // (the index is clamped and the VALUE selected: a select between the load and a constant makes hipcc select
+        // between two addresses, the constant's in scratch)
+        zc v = Wm[ok ? (long)i * ldw + kk : 0];
+        v.x = ok ? v.x : 0.0;
+        v.y = ok ? v.y : 0.0;
+        wv[buf][c][ib] = v;
       }
     }
   };
@@ -512,7 +516,13 @@ __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, in
         const int x = kc / YN, y = kc - x * YN;
         zc tv[CB];
 #pragma unroll
-        for (int jb = 0; jb < CB; ++jb) tv[jb] = (kv && tval[jb]) ? smem[toff[jb] + x * LDT + y] : zero;
+        for (int jb = 0; jb < CB; ++jb) {
+          const bool ok = kv && tval[jb];
+          zc v = smem[ok ? toff[jb] + x * LDT + y : 0];
+          v.x = ok ? v.x : 0.0;
+          v.y = ok ? v.y : 0.0;
+          tv[jb] = v;
+        }
 #pragma unroll
         for (int ib = 0; ib < RB; ++ib) {
           const zc a = wv[buf][c][ib];

@@ -43,8 +43,27 @@ def _check_common(o):
     assert 1 <= o["steps"] <= o["steps_requested"] and 1 <= o["warmup"]
 
 
+def _check_secondary(rec, name):
+    """one short leg of another BASELINE config under the `secondary` key: value, ms_per_step, roofline, cpu_baseline"""
+    assert "error" not in rec, rec
+    assert rec["workload"].startswith(name) and rec["unit"] == "sweeps/s" and rec["steps"] >= 2
+    assert abs(rec["value"] - 1e3 / rec["ms_per_step"]) < 1e-6 * rec["value"]
+    r = rec["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] <= 1.0
+    assert "traffic_source" in r
+    c = rec["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["unit"] == "sweeps/s" and c["sample"] and "cpu_model" in c
+    cfg = rec["config"]
+    if cfg["integrator"] == "lanczos":  # unitary: the norm stays 1 and the energy where it was
+        assert abs(cfg["norm_after"] - 1) < 1e-10
+        assert abs(cfg["energy_after"] - cfg["energy_before"]) < 1e-7 * max(1.0, abs(cfg["energy_before"]))
+    b = rec["breakdown_ms"]
+    assert b["wall"] > 0 and b["launches"] > 0
+
+
 def test_bench_single_gpu_contract():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C2", "--steps", "4", "--warmup", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C2", "--steps", "4", "--warmup", "1",
+                        "--secondary", "C3", "--secondary-seconds", "40"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     o = _line(p.stdout)
@@ -52,7 +71,12 @@ def test_bench_single_gpu_contract():
     assert o["n_gpus"] == 1 and o["steps"] == 4 and o["warmup"] == 1
     c = o["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "sweeps/s" and c["sample"]
+    assert "cpu_model" in c
     assert abs(o["config"]["norm_after"] - 1) < 1e-10
+    # energy conservation of the run itself, on one GPU as well
+    assert abs(o["config"]["energy_after"] - o["config"]["energy_before"]) < 1e-7 * max(1.0, abs(o["config"]["energy_before"]))
+    assert list(o["secondary"]) == ["C3"]
+    _check_secondary(o["secondary"]["C3"], "C3")
 
 
 def test_bench_driver_command_line_fits_its_wall_budget():
@@ -62,7 +86,7 @@ def test_bench_driver_command_line_fits_its_wall_budget():
     (one warm-up + one timed sweep + the CPU sample) to keep the test short."""
     t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
-                       capture_output=True, text=True, timeout=560, cwd=ROOT, env=dict(os.environ, MITDVP_BENCH_BUDGET="150"))
+                       capture_output=True, text=True, timeout=660, cwd=ROOT, env=dict(os.environ, MITDVP_BENCH_BUDGET="150"))
     wall = time.time() - t0
     assert p.returncode == 0, p.stderr[-2000:]
     o = _line(p.stdout)
@@ -73,7 +97,13 @@ def test_bench_driver_command_line_fits_its_wall_budget():
     assert o["roofline"]["algorithmic_tflops"] >= o["roofline"]["achieved"]
     assert o["cpu_baseline"]["value"] > 0
     assert abs(o["config"]["norm_after"] - 1) < 1e-10
-    assert wall < 420, wall  # budget 150 s + at most one sweep + the CPU sample
+    assert abs(o["config"]["energy_after"] - o["config"]["energy_before"]) < 1e-7 * max(1.0, abs(o["config"]["energy_before"]))
+    assert o["roofline"]["traffic_source"] and o["roofline"]["traffic_source"].startswith("profiles/")
+    # the other BASELINE configs ride on the same line, driver-observed
+    assert sorted(o["secondary"]) == ["C2", "C3", "C5"]
+    for w in ("C2", "C3", "C5"):
+        _check_secondary(o["secondary"][w], w)
+    assert wall < 520, wall  # budget 150 s + at most one sweep + the CPU sample + the secondary legs (100 s)
 
 
 def test_bench_plain_multi_gpu_command_launches_its_own_ranks():

@@ -30,6 +30,25 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
+def _engine(L, edge="1", **kw):
+    """an engine with MITDVP_EDGE_APPLY set while it is created (the variable is read there): "1" = the form wherever it
+    is valid, "0" = never, None = the library's size rule"""
+    from pytdscf_amd import TDVPEngine
+
+    old = os.environ.get("MITDVP_EDGE_APPLY")
+    if edge is None:
+        os.environ.pop("MITDVP_EDGE_APPLY", None)
+    else:
+        os.environ["MITDVP_EDGE_APPLY"] = edge
+    try:
+        return TDVPEngine(L, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("MITDVP_EDGE_APPLY", None)
+        else:
+            os.environ["MITDVP_EDGE_APPLY"] = old
+
+
 def _to_site(eng, c):
     eng.build_envs(1)
     for _ in range(c):  # centre to site c: left-canonical sites and their blocks behind it
@@ -54,7 +73,6 @@ def test_c3_shape_interior_and_tapering_sites(mode):
     """BASELINE configs[2]'s chain (L=6, d=32, D=128, M=16; bonds 1,32,128,128,128,32,1): the two interior sites
     (128 x 32 x 128: two row blocks of the epilogue) and the tapering ones (32 x 32 x 128, 128 x 32 x 32)."""
     from oracle import tdvp_oracle as orc
-    from pytdscf_amd import TDVPEngine
     from pytdscf_amd import engine as E
     from pytdscf_amd import synthetic as syn
 
@@ -64,7 +82,7 @@ def test_c3_shape_interior_and_tapering_sites(mode):
     E.set_gemm_mode(mode)
     try:
         for c in (1, 2, 3, 4):
-            eng = TDVPEngine(L)
+            eng = _engine(L)
             eng.set_mpo(mpo)
             eng.init_random([d] * L, D, seed=1)
             _to_site(eng, c)
@@ -79,12 +97,11 @@ def test_c5_shape_direct_sum_generator():
     identity states on either bond and 64 (u, v) pairs per tile = four column blocks of the epilogue), D = 512 reached at
     reduced length."""
     from oracle import tdvp_oracle as orc
-    from pytdscf_amd import TDVPEngine
     from pytdscf_amd import synthetic as syn
 
     L, D = 14, 512
     mpo = syn.synthetic_liouvillian_mpo(L, 16, seed=0, gamma=0.002)
-    eng = TDVPEngine(L, integrator="arnoldi", conserve_norm=False)
+    eng = _engine(L, edge=None, integrator="arnoldi", conserve_norm=False)  # the size rule selects the form here
     eng.set_mpo(mpo)
     eng.init_random([4] * L, D, seed=3)
     c = L // 2
@@ -99,13 +116,12 @@ def test_ragged_groups_and_a_general_core():
     are no multiple of the tile); then the same chain under a core with a block between two general states: the edge
     form must not be chosen, the result stays right."""
     from oracle import tdvp_oracle as orc
-    from pytdscf_amd import TDVPEngine
     from pytdscf_amd import synthetic as syn
 
     L, d, D, M = 6, 12, 50, 10
     rng = np.random.default_rng(9)
     mpo = syn.synthetic_mpo(L, d, M, seed=2)
-    eng = TDVPEngine(L)
+    eng = _engine(L)
     eng.set_mpo(mpo)
     eng.init_random([d] * L, D, seed=4)
     assert eng.get_site_shape(2)[:3] == (D, d, D)
@@ -114,7 +130,7 @@ def test_ragged_groups_and_a_general_core():
     eng.close()
     general = [w.copy() for w in mpo]
     general[2][3, :, :, 4] = 0.01 * _crandn(rng, d, d)  # neither state 3 (left) nor state 4 (right) is an identity state
-    eng = TDVPEngine(L)
+    eng = _engine(L)
     eng.set_mpo(general)
     eng.init_random([d] * L, D, seed=4)
     _to_site(eng, 2)
@@ -123,25 +139,16 @@ def test_ragged_groups_and_a_general_core():
 
 
 def test_sweeps_with_and_without_the_edge_form_agree():
-    """A whole time step of the C3 chain with the form on (default at this size) and off (MITDVP_EDGE_APPLY=0, read when
-    the engine is created): same Krylov counts, energies and autocorrelation to 1e-10, states to fidelity 1e-10."""
+    """A whole time step of the C3 chain with the form on (MITDVP_EDGE_APPLY=1) and off (=0; read when the engine is
+    created): same Krylov counts, energies and autocorrelation to 1e-10, states to fidelity 1e-10."""
     from oracle import tdvp_oracle as orc
-    from pytdscf_amd import TDVPEngine
     from pytdscf_amd import synthetic as syn
 
     L, d, D, M, dt = 6, 32, 128, 16, 1.0
     mpo = syn.synthetic_mpo(L, d, M, seed=0)
     res = {}
     for on in ("1", "0"):
-        old = os.environ.get("MITDVP_EDGE_APPLY")
-        os.environ["MITDVP_EDGE_APPLY"] = on
-        try:
-            eng = TDVPEngine(L)
-        finally:
-            if old is None:
-                del os.environ["MITDVP_EDGE_APPLY"]
-            else:
-                os.environ["MITDVP_EDGE_APPLY"] = old
+        eng = _engine(L, edge=on)
         eng.set_mpo(mpo)
         eng.init_random([d] * L, D, seed=1)
         eng.propagate(dt)
@@ -159,20 +166,11 @@ def test_c4_shape_forced():
     """The C4 interior shape (1024 x 16 x 1024, M = 32) with the form forced on (the size rule keeps the trimmed
     three-stage chain there): whole output against the oracle."""
     from oracle import tdvp_oracle as orc
-    from pytdscf_amd import TDVPEngine
     from pytdscf_amd import synthetic as syn
 
     L, d, D, M = 7, 16, 1024, 32
     mpo = syn.synthetic_mpo(L, d, M, seed=0)
-    old = os.environ.get("MITDVP_EDGE_APPLY")
-    os.environ["MITDVP_EDGE_APPLY"] = "1"
-    try:
-        eng = TDVPEngine(L)
-    finally:
-        if old is None:
-            del os.environ["MITDVP_EDGE_APPLY"]
-        else:
-            os.environ["MITDVP_EDGE_APPLY"] = old
+    eng = _engine(L)
     eng.set_mpo(mpo)
     eng.init_random([d] * L, D, seed=1)
     c = 3

@@ -96,6 +96,38 @@ def test_c5_interior_site_against_oracle():
     _check_interior(orc, E, 512, 4, 16, full_env=True)
 
 
+def test_c2_exact_shape_three_steps_against_oracle():
+    """BASELINE configs[1] at its exact shape and time step as bench.py runs it (L=10, d=10, D=32, M=6, dt=2.0 a.u.): every
+    local exponential is ONE launch of k_small_site (csrc/small_site.hip) -- three time steps against OracleMPS
+    (short_iterative_lanczos semantics, _integrator.py:453-655, incl. the warm-up memory :178-186): equal Krylov counts
+    after every step, energy / autocorrelation to 1e-8 relative, fidelity to 1e-10, norm to 1e-12."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+
+    L, d, D, M, dt = 10, 10, 32, 6, 2.0
+    mpo = orc.synthetic_mpo(L, d, M, seed=0)
+    mps = orc.synthetic_mps([d] * L, D, seed=1)
+    eng = TDVPEngine(L)
+    eng.set_mpo(mpo)
+    eng.set_mps(mps)
+    ref = orc.OracleMPS([c.copy() for c in mps], mpo)
+    eng.counters_reset()
+    for step in range(3):
+        eng.propagate(dt)
+        ref.propagate(dt)
+        assert eng.krylov_stats() == [ref.kprev[i] for i in range(L)], step
+        eg, er = eng.expectation(), ref.expectation()
+        ag, ar = eng.autocorr(), ref.autocorr()
+        assert abs(eg - er) < 1e-8 * abs(er) and abs(ag - ar) < 1e-8 * abs(ar), step
+        assert abs(eng.norm() - 1) < 1e-12
+        assert abs(abs(orc.overlap(ref.cores, eng.get_mps())) - 1) < 1e-10, step
+    # the one-launch family really ran: 6 sweeps of 10 site + 9 bond exponentials, no multi-launch apply in between
+    cnt = eng.counters()
+    assert cnt["n_exp_site"] == 6 * L and cnt["n_exp_bond"] == 6 * (L - 1)
+    assert cnt["n_host_waits"] <= 6 * 4, cnt["n_host_waits"]  # norm / energy reads only: no wait inside a local exponential
+    eng.close()
+
+
 def test_c3_full_size_step_against_oracle():
     from oracle import tdvp_oracle as orc
     from pytdscf_amd import TDVPEngine
