@@ -64,10 +64,13 @@ struct MpoSite {
   DevBuf w2lt, w2rt, kl_l, kl_r;
   int kl_stride_l = 0, kl_stride_r = 0;
   double sp_frac_l = 1.0, sp_frac_r = 1.0;
-  // row-tile ranges [t0, t1) of the 64-row grid, each either dense (most K tiles needed: the plain kernel on that row
-  // range) or sparse (the list kernel) -- mixing both kinds in one launch lets the few heavy tiles crawl among the many
-  // light ones (23 ms instead of 6 at the C4 shape)
-  struct SpSeg { int t0, t1; bool dense; };
+  // row ranges [r0, r1) of the permuted matrix, whole bond states (d rows each), each either dense (most K tiles needed:
+  // the plain kernel on exactly those rows) or sparse (the list kernel; tile0 = index of the range's first 64-row tile in
+  // the list array: every sparse range has its own tile grid) -- mixing both kinds in one launch lets the few heavy tiles
+  // crawl among the many light ones (23 ms instead of 6 at the C4 shape), and a dense state that shares a 64-row tile
+  // with light ones would drag them through all K tiles (round 4: the "all applied" state of a finite-state-machine core
+  // is d rows, a quarter or half of a tile)
+  struct SpSeg { int r0, r1; bool dense; int tile0; };
   std::vector<SpSeg> seg_l, seg_r;
   DevBuf w2el;  // small-site environment update, -> direction: [(t,j)][(i,c)] = W[c,i,j,t]
   DevBuf w2er;  // small-site environment update, <- direction: [(c,j)][(i,t)] = W[c,i,j,t]

@@ -289,32 +289,50 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
     for (int i = 0; i < d; ++i)
       for (int q = 0; q < mo; ++q)
         std::memcpy(&p[((size_t)q * d + i) * K], &w2[((size_t)i * mo + q) * K], (size_t)K * sizeof(hzc));
-    const int ntm = (M + 63) / 64, nkt = K / 16;
+    const int nkt = K / 16;
     stride = nkt + 1;
-    std::vector<int> list((size_t)ntm * stride, 0);
-    long visited = 0;
-    for (int tm = 0; tm < ntm; ++tm) {
-      int cnt = 0;
+    // per bond state q (rows [q d, (q + 1) d)): the K tiles that hold a non-zero
+    std::vector<std::vector<char>> need(mo, std::vector<char>(nkt, 0));
+    std::vector<int> cntq(mo, 0);
+    for (int q = 0; q < mo; ++q) {
       for (int kt = 0; kt < nkt; ++kt) {
         bool nz = false;
-        for (int r = tm * 64; r < std::min(M, tm * 64 + 64) && !nz; ++r)
+        for (int r = q * d; r < (q + 1) * d && !nz; ++r)
           for (int k = kt * 16; k < kt * 16 + 16; ++k)
             if (p[(size_t)r * K + k] != hzc(0.0, 0.0)) { nz = true; break; }
-        if (nz) list[(size_t)tm * stride + 1 + cnt++] = kt;
+        need[q][kt] = nz;
+        cntq[q] += nz;
       }
-      list[(size_t)tm * stride] = cnt;
-      visited += cnt;
     }
-    // executed share: dense ranges run all their K tiles
-    long executed = 0;
-    for (int tm = 0; tm < ntm; ++tm) {
-      const bool dense = 2 * list[(size_t)tm * stride] > nkt;
-      executed += dense ? nkt : list[(size_t)tm * stride];
-      if (!segs.empty() && segs.back().dense == dense) segs.back().t1 = tm + 1;
-      else segs.push_back(MpoSite::SpSeg{tm, tm + 1, dense});
+    std::vector<int> list;
+    long executed = 0;  // in units of (row, K tile)
+    for (int q0 = 0; q0 < mo;) {
+      const bool dense = 2 * cntq[q0] > nkt;
+      int q1 = q0 + 1;
+      while (q1 < mo && (2 * cntq[q1] > nkt) == dense) ++q1;
+      MpoSite::SpSeg sg{q0 * d, q1 * d, dense, 0};
+      if (dense) {
+        executed += (long)(sg.r1 - sg.r0) * nkt;
+      } else {
+        sg.tile0 = (int)(list.size() / stride);
+        for (int r = sg.r0; r < sg.r1; r += 64) {  // this range's own grid of 64-row tiles
+          const size_t o = list.size();
+          list.resize(o + stride, 0);
+          int cnt = 0;
+          for (int kt = 0; kt < nkt; ++kt) {
+            bool nz = false;
+            for (int q = r / d; q <= (std::min(r + 64, sg.r1) - 1) / d && !nz; ++q) nz = need[q][kt];
+            if (nz) list[o + 1 + cnt++] = kt;
+          }
+          list[o] = cnt;
+          executed += (long)(std::min(r + 64, sg.r1) - r) * cnt;
+        }
+      }
+      segs.push_back(sg);
+      q0 = q1;
     }
-    (void)visited;
-    frac = (double)executed / ((double)ntm * nkt);
+    if (list.empty()) list.assign(stride, 0);
+    frac = (double)executed / ((double)M * nkt);
     wt.reserve(p.size());
     kl.reserve((list.size() * sizeof(int) + sizeof(zc) - 1) / sizeof(zc));
     HIP_CHECK(hipMemcpyAsync(wt.p, p.data(), p.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
@@ -525,18 +543,17 @@ double Engine::w_stage(const MpoSite* sp, int side, const zc* w2, int d, int mou
   const int* kl = reinterpret_cast<const int*>(side == 0 ? sp->kl_l.p : sp->kl_r.p);
   const int stride = side == 0 ? sp->kl_stride_l : sp->kl_stride_r;
   const auto& segs = side == 0 ? sp->seg_l : sp->seg_r;
-  const int M = d * mout, K = min_ * d;
+  const int K = min_ * d;
   // heavy ranges first: they are the long-running workgroups
   for (int pass = 0; pass < 2; ++pass)
     for (const auto& sgm : segs) {
       if (sgm.dense != (pass == 0)) continue;
-      const int r0 = sgm.t0 * 64, r1 = std::min(M, sgm.t1 * 64);
       ZgemmDesc h = g;
-      h.A = wt + (size_t)r0 * K;
-      h.M = r1 - r0;
-      h.rowmap_p = d; h.rowmap_s1 = (long)mout * ncol; h.rowmap_s2 = ncol; h.rowmap_r0 = r0;
-      if (!sgm.dense) { h.klist = kl + (size_t)sgm.t0 * stride; h.klist_stride = stride; }
-      h.tile_cfg = 1;
+      h.A = wt + (size_t)sgm.r0 * K;
+      h.M = sgm.r1 - sgm.r0;
+      h.rowmap_p = d; h.rowmap_s1 = (long)mout * ncol; h.rowmap_s2 = ncol; h.rowmap_r0 = sgm.r0;
+      if (!sgm.dense) { h.klist = kl + (size_t)sgm.tile0 * stride; h.klist_stride = stride; }
+      h.tile_cfg = (sgm.dense && h.M <= 32) ? 2 : 1;  // a dense state of <= 32 rows: the 32 x 32 tile, no rows wasted
       zgemm(st_, h);
       cnt_.n_launch += 1;
     }
