@@ -58,7 +58,12 @@ typedef struct {
                            1: orthodox alpha_l=<v_l|H|v_l>                  */
   int max_diag_krylov;  /* Krylov vectors kept by the improved-relaxation solver
                            (0 = default 64; the reference allows up to 3000)   */
-  int reserved[7];
+  int cu_first, cu_count; /* > 0: the engine's stream is confined to cu_count compute units starting at cu_first
+                             (hipExtStreamCreateWithCUMask; unit u = CU u / 8 of XCD u % 8, so a range of 8 k units is
+                             k CUs on every XCD): several engines of one process with DISJOINT ranges run side by side
+                             without ever competing for a compute unit -- an ensemble of trajectories in the small-bond
+                             regime (mitdvp_ensemble_step).  0 = the whole device.                                     */
+  int reserved[5];
 } mitdvp_config;
 
 /* -- lifetime ----------------------------------------------------------
@@ -72,6 +77,7 @@ const char* mitdvp_version(void);
 /* Number of HIP devices visible to this process (0 without a GPU; no engine needed).  Lets a launcher map
  * ranks to devices (rank % count) without importing a second GPU runtime. */
 int mitdvp_device_count(int* count);
+int mitdvp_device_cu_count(int device, int* count); /* compute units of a device (256 on MI355X): what cu_first / cu_count divide */
 /* hipDeviceSynchronize on `device`: the fence bench.py puts on both sides of its timed region (the engine's
  * stream is private, so a foreign runtime's "current stream" synchronise would not see its work). */
 int mitdvp_device_sync(int device);
@@ -104,6 +110,12 @@ int mitdvp_set_shift(mitdvp_engine* h, int op_id, double re, double im);
  * (_mps_cls.py:482-500).  First call builds all right environments
  * (:835-843); the cache is reused afterwards (:848-861). */
 int mitdvp_step(mitdvp_engine* h, double dt_au);
+/* nsteps time steps of n independent engines at once (independent trajectories / replicas of one model: SURVEY 7 step 6,
+ * 8e "fallback"; the reference averages trajectories in a Python loop, tests/test_mixedstate.py:269-308): every engine is
+ * driven by its own host thread inside this call.  Meant for engines created with disjoint cu_first / cu_count ranges (see
+ * mitdvp_config): their launches then overlap on the chip without any admission control.  Returns the first non-zero
+ * status (that engine's mitdvp_last_error holds the message); statuses[i] (may be NULL) receives each engine's own. */
+int mitdvp_ensemble_step(mitdvp_engine** hs, int n, double dt_au, int nsteps, int* statuses);
 /* propagate_along_sweep (_mps_cls.py:798-1014), one direction only. */
 int mitdvp_sweep(mitdvp_engine* h, double dt_au, int forward);
 /* op_sys_sites = None (_mps_cls.py:2311,2371,2417, wavefunction.py:64-65). */
@@ -450,6 +462,10 @@ int mitdvp_mfma_peak_probe(int device, double* tflops_out);
 /* shader-clock probe: out[0] = shader cycles, out[1] = 100 MHz reference ticks spent by a
  * single-wavefront dependent-FMA loop of `iters` iterations (clock in MHz = 100 * out[0] / out[1]). */
 int mitdvp_clock_probe(int device, long iters, double* cycles_ticks_out);
+/* Where the workgroups of a launch on a stream created with a CU mask run (hipExtStreamCreateWithCUMask; mask NULL: an
+ * ordinary stream): out[b] = XCC id (bits 3:0) | CU / shader-array / shader-engine id (bits 15:8) of workgroup b.  Every
+ * workgroup holds lds_bytes of LDS for spin_us microseconds.  Used to find the mask bits of one XCD (ensemble mode). */
+int mitdvp_cu_mask_probe(int device, const unsigned* mask, int nwords, int nblocks, size_t lds_bytes, int spin_us, int* out);
 int mitdvp_mfma_layout_probe(int device, int* out);
 
 #ifdef __cplusplus

@@ -35,7 +35,9 @@ class Config(C.Structure):
         ("max_krylov", C.c_int),
         ("lanczos_variant", C.c_int),
         ("max_diag_krylov", C.c_int),
-        ("reserved", C.c_int * 7),
+        ("cu_first", C.c_int),
+        ("cu_count", C.c_int),
+        ("reserved", C.c_int * 5),
     ]
 
 
@@ -205,6 +207,9 @@ def load() -> C.CDLL:
         "mitdvp_get_krylov_memory": (i, [vp, i, ip]),
         "mitdvp_set_krylov_memory": (i, [vp, i, i]),
         "mitdvp_set_small_kernels": (i, [vp, i]),
+        "mitdvp_ensemble_step": (i, [C.POINTER(vp), i, d, i, ip]),
+        "mitdvp_device_cu_count": (i, [i, ip]),
+        "mitdvp_cu_mask_probe": (i, [i, C.POINTER(C.c_uint), i, i, C.c_size_t, i, ip]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -1,5 +1,7 @@
 // capi.hip -- extern "C" surface declared in include/mitdvp.h.
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "capi_internal.h"
 #include "engine_internal.h"
@@ -76,6 +78,13 @@ int mitdvp_device_count(int* count) {
   return MITDVP_OK;
 }
 
+int mitdvp_device_cu_count(int device, int* count) {
+  return guard(nullptr, [&] {
+    if (!count) throw mitdvp::ArgError("null pointer argument");
+    HIP_CHECK(hipDeviceGetAttribute(count, hipDeviceAttributeMultiprocessorCount, device));
+  });
+}
+
 int mitdvp_device_sync(int device) {
   return guard(nullptr, [&] {
     HIP_CHECK(hipSetDevice(device));
@@ -129,6 +138,30 @@ int mitdvp_set_mpo_core(mitdvp_engine* h, int op_id, int isite, const double* re
 int mitdvp_set_shift(mitdvp_engine* h, int op_id, double re, double im) { ENG_CALL(h, h->e->set_shift(op_id, re, im)); }
 int mitdvp_step(mitdvp_engine* h, double dt) { ENG_CALL(h, h->e->step(dt)); }
 int mitdvp_sweep(mitdvp_engine* h, double dt, int forward) { ENG_CALL(h, h->e->sweep(dt, forward != 0)); }
+int mitdvp_ensemble_step(mitdvp_engine** hs, int n, double dt, int nsteps, int* statuses) {
+  if (!hs || n < 1 || nsteps < 0) { g_err = "mitdvp_ensemble_step: bad arguments"; return MITDVP_EINVAL; }
+  for (int i = 0; i < n; ++i)
+    if (!hs[i] || !hs[i]->e) { g_err = "mitdvp_ensemble_step: null engine"; return MITDVP_EINVAL; }
+  std::vector<int> rc((size_t)n, MITDVP_OK);
+  std::vector<std::thread> th;
+  th.reserve((size_t)n);
+  for (int i = 0; i < n; ++i)
+    th.emplace_back([&, i] {
+      mitdvp_engine* h = hs[i];
+      rc[(size_t)i] = guard(h, [&] {
+        for (int s = 0; s < nsteps; ++s) h->e->step(dt);
+        h->e->check_device_errors();
+        HIP_CHECK(hipStreamSynchronize(h->e->stream()));
+      });
+    });
+  for (auto& t : th) t.join();
+  int first = MITDVP_OK;
+  for (int i = 0; i < n; ++i) {
+    if (statuses) statuses[i] = rc[(size_t)i];
+    if (first == MITDVP_OK && rc[(size_t)i] != MITDVP_OK) first = rc[(size_t)i];
+  }
+  return first;
+}
 int mitdvp_invalidate_env(mitdvp_engine* h) { ENG_CALL(h, h->e->invalidate_env()); }
 int mitdvp_replace_site(mitdvp_engine* h, int isite, const double* reim, int gauge) {
   ENG_CALL(h, { NEED(reim); h->e->replace_site(isite, reim, gauge); });
@@ -679,6 +712,12 @@ int mitdvp_clock_probe(int device, long iters, double* cycles_ticks_out) {
     mitdvp::clock_probe(nullptr, iters, o);
     cycles_ticks_out[0] = o[0];
     cycles_ticks_out[1] = o[1];
+  });
+}
+int mitdvp_cu_mask_probe(int device, const unsigned* mask, int nwords, int nblocks, size_t lds_bytes, int spin_us, int* out) {
+  return guard(nullptr, [&] {
+    HIP_CHECK(hipSetDevice(device));
+    mitdvp::where_probe(mask, nwords, nblocks, lds_bytes, spin_us, out);
   });
 }
 int mitdvp_mfma_layout_probe(int device, int* out) {

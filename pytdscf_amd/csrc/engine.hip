@@ -35,7 +35,20 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (c.device < 0 || c.device >= ndev) throw ArgError("bad device ordinal");
   HIP_CHECK(hipSetDevice(c.device));
   HIP_CHECK(hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, c.device));
-  HIP_CHECK(hipStreamCreate(&st_));
+  if (c.cu_count > 0) {
+    // a stream confined to the compute units [cu_first, cu_first + cu_count): mask bit u = CU u / 8 of XCD u % 8 (measured,
+    // tools/cu_mask_probe.py); every XCD must keep at least one unit or the hardware falls back to units of its own choice
+    if (c.cu_first < 0 || c.cu_first + c.cu_count > n_cu_ || c.cu_count % 8 != 0 || c.cu_first % 8 != 0)
+      throw ArgError("cu_first / cu_count: a multiple of 8 compute units inside the device (8 k units = k CUs on every XCD)");
+    std::vector<uint32_t> mask((size_t)(n_cu_ + 31) / 32, 0u);
+    for (int u = c.cu_first; u < c.cu_first + c.cu_count; ++u) mask[(size_t)u / 32] |= 1u << (u % 32);
+    HIP_CHECK(hipExtStreamCreateWithCUMask(&st_, (uint32_t)mask.size(), mask.data()));
+    n_cu_ = c.cu_count;
+    ss_.max_grid = c.cu_count;
+    ss_.partitioned = true;
+  } else {
+    HIP_CHECK(hipStreamCreate(&st_));
+  }
   qr_hist_ = qr_history_new();
   dl_.assign(L_, 0); dd_.assign(L_, 0); dr_.assign(L_, 0); gauge_.assign(L_, -1);
   site_.resize(L_);

@@ -802,12 +802,13 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     // rows per workgroup: as few as the 64-workgroup exchange allows -- the column update of a step is spread
     // over (rows / rb) compute units, and that, not the exchange, is what a step waits for when rb is large
     int rb = 32;
-    while ((mp + rb - 1) / rb > GX_MAXG && rb < 256) rb *= 2;
+    const int gcap = (sy && sy->max_grid > 0) ? std::min(GX_MAXG, sy->max_grid) : GX_MAXG;
+    while ((mp + rb - 1) / rb > gcap && rb < 256) rb *= 2;
     if (const char* e = std::getenv("MITDVP_QR_RB")) rb = std::max(32, std::min(256, std::atoi(e)));
     const int gpan = (mp + rb - 1) / rb;
     if (fast) {
       nl += qr_fast_panel(st, A, lda, m, j0, nbp, Vp, Tp, tau, fws, fflag);
-    } else if (panel_on && sy && sy->slots && gpan <= GX_MAXG) {
+    } else if (panel_on && sy && sy->slots && gpan <= gcap) {
       // one persistent launch: column steps, T and the unit-lower copy of the panel
       sy->launches += 1;
       if ((sy->launches & 0xFFFFFu) == 0u) sy->launches += 1;  // tag 0 is the cleared state
@@ -815,7 +816,7 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
                      reinterpret_cast<unsigned long long*>(sy->slots), sy->words + 2, sy->words + 3,
                      (sy->launches & 0xFFFFFu) << 12};
       const size_t dyn = (size_t)gpan * 64 * sizeof(double);
-      PersistentLaunch chain(st, gpan);
+      PersistentLaunch chain(st, gpan, sy->partitioned);
       if (rb == 32) hipLaunchKernelGGL(k_qr_panel<2>, dim3(gpan), dim3(512), dyn, st, pa);
       else if (rb == 64) hipLaunchKernelGGL(k_qr_panel<4>, dim3(gpan), dim3(512), dyn, st, pa);
       else if (rb == 128) hipLaunchKernelGGL(k_qr_panel<8>, dim3(gpan), dim3(512), dyn, st, pa);

@@ -34,6 +34,8 @@ struct SmallSync {
   long long* stats = nullptr; // [0] applies inside site exponentials, [1] inside bond exponentials, [2], [3] their flops
   int* kprev = nullptr;       // per-site Krylov iteration memory (device copy)
   unsigned launches = 0;      // launch sequence number (exchange tags are unique per launch)
+  int max_grid = 0;           // compute units this engine may fill with one persistent launch (0: the device's)
+  bool partitioned = false;   // the engine's stream owns its compute units (CU mask): no admission control needed
 };
 
 struct SmallExp {
@@ -60,7 +62,7 @@ bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu);
 void persistent_register(int delta);
 class PersistentLaunch {
  public:
-  PersistentLaunch(hipStream_t st, int grid);
+  PersistentLaunch(hipStream_t st, int grid, bool partitioned = false);
   ~PersistentLaunch();
   PersistentLaunch(const PersistentLaunch&) = delete;
   PersistentLaunch& operator=(const PersistentLaunch&) = delete;

@@ -909,6 +909,16 @@ bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
     c.cs = cs;
     if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
   }
+  // fewer chunks than wanted: an engine confined to part of the chip (ensemble mode) has fewer compute units than the
+  // chain would like workgroups
+  for (int nsc = want / 2; nsc >= 1; nsc /= 2) {
+    if (c.na * nsc > gmax) continue;
+    const int cs = (c.ns + nsc - 1) / nsc;
+    if ((nsc - 1) * cs >= c.ns) continue;
+    c.nsc = nsc;
+    c.cs = cs;
+    if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
+  }
   return false;
 }
 
@@ -956,7 +966,9 @@ void persistent_register(int delta) {
 // still in flight until its own grid fits beside the rest.  (Making the STREAM wait instead -- hipStreamWaitEvent on the
 // other engine's event -- was measured first: 8 engines fell from ~370 to 43 sweeps/s in aggregate, a cross-stream
 // dependency costs far more than the 20-140 us kernels it orders.)
-PersistentLaunch::PersistentLaunch(hipStream_t st, int grid) : st_(st), slot_(current_device_slot()), grid_(grid) {
+PersistentLaunch::PersistentLaunch(hipStream_t st, int grid, bool partitioned)
+    : st_(st), slot_(partitioned ? -1 : current_device_slot()), grid_(grid) {
+  if (slot_ < 0) return;  // a stream confined to its own compute units: nobody to wait for
   PersistentChain& c = g_pchain[slot_];
   c.mu.lock();
   chained_ = c.users > 1;
@@ -993,6 +1005,7 @@ PersistentLaunch::PersistentLaunch(hipStream_t st, int grid) : st_(st), slot_(cu
 }
 
 PersistentLaunch::~PersistentLaunch() {
+  if (slot_ < 0) return;
   PersistentChain& c = g_pchain[slot_];
   if (chained_) {
     auto e = std::make_shared<PEvent>();
@@ -1067,7 +1080,7 @@ static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
   g.trace = tracing ? trace_buf : nullptr;
   if (tracing) HIP_CHECK(hipMemsetAsync(trace_buf, 0, 1024 * sizeof(long long), st));
   {
-    PersistentLaunch chain(st, c.na * c.nsc);  // admitted only when it fits beside the persistent launches in flight
+    PersistentLaunch chain(st, c.na * c.nsc, sy.partitioned);  // admitted only when it fits beside the persistent launches in flight
     hipLaunchKernelGGL(k_small_site, dim3(c.na * c.nsc), dim3(SS_THREADS), lds, st, g);
   }
   HIP_CHECK(hipGetLastError());

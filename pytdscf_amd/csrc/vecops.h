@@ -55,6 +55,8 @@ void phys_diag(hipStream_t st, const zc* C, zc* out, int dl, int n, int dr, bool
 // out[i0][i2][i1][i3] = in[i0][i1][i2][i3]
 void permute_0213(hipStream_t st, const zc* in, zc* out, long n0, int n1, int n2, int n3);
 void clock_probe(hipStream_t st, long iters, double* host_out3 /* shader cycles, 100 MHz ticks, dummy */);
+// XCC / CU ids of the workgroups of one launch on a stream created with this CU mask (nullptr: an ordinary stream)
+void where_probe(const uint32_t* mask, int nwords, int nblocks, size_t lds_bytes, int spin_us, int* host_out);
 // out (C order, dims[0..4]) = in gathered with in_strides; map2 (device, nullable) replaces index 2
 void permute5(hipStream_t st, const zc* in, zc* out, const int dims[5], const long in_strides[5], const int* map2);
 void scale_cols(hipStream_t st, zc* x, long rows, int cols, long ld, const double* sc_dev);

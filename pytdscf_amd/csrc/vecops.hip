@@ -628,6 +628,37 @@ void clock_probe(hipStream_t st, long iters, double* host_out3) {
   (void)hipFree(d);
 }
 
+// Where the workgroups of a launch on a CU-masked stream run: out[b] = XCC_ID (0-7) | CU id << 8 of workgroup b's wave 0
+// (HW_REG_XCC_ID; HW_REG_HW_ID: CU_ID bits 11:8, SH_ID bit 12, SE_ID bits 15:13).  Every workgroup takes `lds_bytes` of
+// LDS and waits `spin_us`, so that a grid larger than the mask's CUs shows up as a second round, not as sharing.
+__global__ void k_where(int* out, int spin_us) {
+  extern __shared__ char hold[];
+  if (threadIdx.x == 0) {
+    unsigned xcc = 0, hw = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    hold[0] = 1;
+    out[blockIdx.x] = (int)((xcc & 0xF) | (((hw >> 8) & 0xFF) << 8));
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)spin_us * 100ull) __builtin_amdgcn_s_sleep(8);
+  }
+}
+void where_probe(const uint32_t* mask, int nwords, int nblocks, size_t lds_bytes, int spin_us, int* host_out) {
+  hipStream_t st = nullptr;
+  if (mask && nwords > 0) HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask));
+  else HIP_CHECK(hipStreamCreate(&st));
+  int* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, (size_t)nblocks * sizeof(int)));
+  if (lds_bytes > 65536)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_where), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(k_where, dim3(nblocks), dim3(64), lds_bytes, st, d, spin_us);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(host_out, d, (size_t)nblocks * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  (void)hipFree(d);
+  (void)hipStreamDestroy(st);
+}
+
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
             bool accumulate) {
   const long n = rows * (long)std::max(cols, zero_to);

@@ -61,7 +61,10 @@ class TDVPEngine:
         thresh: float = 1e-9,
         max_krylov: int = 20,
         lanczos_variant: str = "reference",
+        cu_range: tuple[int, int] | None = None,
     ):
+        """``cu_range = (first, count)``: confine the engine to ``count`` compute units starting at ``first`` (multiples of 8:
+        8 k units are k CUs on every XCD); engines with disjoint ranges never compete for a compute unit (TDVPEnsemble)."""
         lib = _lib.load()
         cfg = _lib.Config()
         cfg.nsite = nsite
@@ -72,6 +75,8 @@ class TDVPEngine:
         cfg.thresh = thresh
         cfg.max_krylov = max_krylov
         cfg.lanczos_variant = {"reference": 0, "orthodox": 1}[lanczos_variant]
+        if cu_range is not None:
+            cfg.cu_first, cfg.cu_count = int(cu_range[0]), int(cu_range[1])
         self._lib = lib
         self._h = C.c_void_p()
         self.nsite = nsite
@@ -681,6 +686,62 @@ def heff_selfcheck(dl, d, dr, ml, mr, device=0) -> dict:
     out = np.zeros(4)
     _lib.check(_lib.load().mitdvp_heff_selfcheck(device, dl, d, dr, ml, mr, _dp(out)))
     return {"rel_3m_vs_4m": out[0], "linearity_defect": out[1], "norm_Hx": out[2], "ms": out[3]}
+
+
+class TDVPEnsemble:
+    """B independent trajectories (replicas) of one model on ONE GPU, each on its own slice of the chip.
+
+    The small-bond regime (C2) is latency bound: one trajectory's one-launch local exponentials keep 32-128
+    of the 256 compute units busy for tens of microseconds at a time.  Here every replica is an engine whose stream is
+    confined to ``n_cu / B`` compute units of its own (``mitdvp_config.cu_first / cu_count``), so the replicas' launches
+    overlap without admission control, and ``propagate`` is ONE library call (``mitdvp_ensemble_step``: a host thread
+    per replica inside the library).  The reference runs trajectories one after the other in a Python loop
+    (tests/test_mixedstate.py:269-308).  Results are those of the same engines stepped one at a time, bit for bit.
+    """
+
+    def __init__(self, n_replicas: int, nsite: int, *, device: int = 0, n_cu: int | None = None, **engine_kw):
+        if n_replicas < 1:
+            raise ValueError("n_replicas must be >= 1")
+        if n_cu is None:
+            n_cu = device_cu_count(device)
+        per = (n_cu // n_replicas) // 8 * 8
+        if per < 8:
+            raise ValueError(f"{n_replicas} replicas do not fit {n_cu} compute units (8 per replica at least)")
+        self.cu_per_replica = per
+        self.engines = [TDVPEngine(nsite, device=device, cu_range=(r * per, per), **engine_kw) for r in range(n_replicas)]
+        self._lib = _lib.load()
+
+    def __len__(self):
+        return len(self.engines)
+
+    def __getitem__(self, i):
+        return self.engines[i]
+
+    def set_mpo(self, cores, op_id: int = 0):
+        for e in self.engines:
+            e.set_mpo(cores, op_id)
+
+    def propagate(self, dt_au: float, nsteps: int = 1):
+        """``nsteps`` time steps of every replica, all replicas at once."""
+        n = len(self.engines)
+        hs = (C.c_void_p * n)(*[e._h for e in self.engines])
+        st = (C.c_int * n)()
+        rc = self._lib.mitdvp_ensemble_step(hs, n, float(dt_au), int(nsteps), st)
+        if rc != 0:
+            bad = next(i for i in range(n) if st[i] != 0)
+            _lib.check(st[bad], self.engines[bad]._h)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+
+def device_cu_count(device: int = 0) -> int:
+    """compute units of the device (256 on MI355X)"""
+    n = C.c_int()
+    _lib.check(_lib.load().mitdvp_device_cu_count(device, C.byref(n)))
+    return n.value
 
 
 def set_gemm_mode(mode: str):

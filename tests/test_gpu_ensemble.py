@@ -1,0 +1,81 @@
+"""GPU: ensemble mode of the small-bond regime (SURVEY 7 step 6, 8e "fallback": independent trajectories; the reference
+averages them in a Python loop, tests/test_mixedstate.py:269-308).  Two and eight replicas of BASELINE configs[1]'s shape, each an
+engine confined to 128 / 32 compute units of its own (mitdvp_config.cu_first / cu_count), all stepped by ONE library call
+(mitdvp_ensemble_step: a host thread per replica inside the library):
+
+  * bit-identical to the same engines stepped one after the other (the replicas share nothing but the MPO);
+  * equal to an engine on the whole chip to rounding (its contraction chains are chunked differently: 1e-10 fidelity, equal
+    Krylov counts);
+  * with 128 compute units per replica every local exponential is still one launch (no host wait inside a time step); with
+    32 the interior sites' chains (128 workgroups at this shape: DESIGN.md section 6) no longer fit a slice and run through
+    the multi-launch kernels -- slower, same results.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L, d, D, M, DT = 10, 10, 32, 6, 2.0
+
+
+def _setup(ens_or_engs, mpo):
+    for r, e in enumerate(ens_or_engs):
+        e.set_mpo(mpo)
+        e.init_random([d] * L, D, seed=11 + r)
+
+
+@pytest.mark.parametrize("B", [2, 8])
+def test_replicas_on_disjoint_compute_units(B):
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine, TDVPEnsemble
+    from pytdscf_amd import synthetic as syn
+
+    mpo = syn.synthetic_mpo(L, d, M, seed=0)
+    nsteps = 3
+    ens = TDVPEnsemble(B, L)
+    per = ens.cu_per_replica
+    assert per == 256 // B
+    _setup(ens.engines, mpo)
+    for e in ens.engines:
+        e.counters_reset()
+    ens.propagate(DT, nsteps)
+    got = [e.get_mps() for e in ens.engines]
+    ks = [e.krylov_stats() for e in ens.engines]
+    for e in ens.engines:
+        assert abs(e.norm() - 1) < 1e-12
+        c = e.counters()
+        assert c["n_exp_site"] == 2 * nsteps * L
+        if B == 2:
+            assert c["n_host_waits"] <= 2  # the one-launch family throughout: no wait inside a time step
+    ens.close()
+    # the same engines, one at a time
+    for r in range(B):
+        e = TDVPEngine(L, cu_range=(per * r, per))
+        e.set_mpo(mpo)
+        e.init_random([d] * L, D, seed=11 + r)
+        for _ in range(nsteps):
+            e.propagate(DT)
+        ser = e.get_mps()
+        assert e.krylov_stats() == ks[r]
+        for a, b in zip(got[r], ser):
+            assert np.array_equal(a, b), r
+        e.close()
+    # the first and the last replica against engines on the whole chip
+    for r in (0, B - 1):
+        e = TDVPEngine(L)
+        e.set_mpo(mpo)
+        e.init_random([d] * L, D, seed=11 + r)
+        for _ in range(nsteps):
+            e.propagate(DT)
+        assert e.krylov_stats() == ks[r]
+        assert abs(abs(orc.overlap(e.get_mps(), got[r])) - 1) < 1e-10
+        e.close()
+
+
+def test_bad_compute_unit_ranges_are_refused():
+    from pytdscf_amd import TDVPEngine
+
+    for rng in ((4, 32), (0, 12), (248, 16), (-8, 8)):
+        with pytest.raises(ValueError):
+            TDVPEngine(4, cu_range=rng)
