@@ -657,6 +657,19 @@ def main():
     cnt = meas.counters()
     meas.set_profiling(False)
     halo = ss.traffic() if ss is not None else (0, 0)
+    per_rank = None
+    if ss is not None:  # every rank's share of the time step: block half-sweeps vs junction updates (incl. waiting for them)
+        bm, jm, ns = ss.phase_times()
+        mine = [bm / max(ns, 1), jm / max(ns, 1), ss.setup_s]
+        if comm.dist is not None:
+            import torch
+
+            t = torch.tensor(mine, dtype=torch.float64, device=comm.device)
+            allr = [torch.zeros_like(t) for _ in range(world)]
+            comm.dist.all_gather(allr, t)
+            per_rank = [[float(x) for x in a.tolist()] for a in allr]
+        else:
+            per_rank = [mine]
     e1 = None
     if ss is not None:  # the sharded state's own norm and energy after the run (collective; not timed)
         nrm = ss.norm()
@@ -702,6 +715,9 @@ def main():
                                          "roofline / breakdown are rank 0's block"}[mode],
                 "halo_GB": halo[0] / 1e9,
                 "halo_messages": halo[1],
+                "per_rank_ms_per_step": ({"block_sweeps": [r[0] for r in per_rank], "junctions": [r[1] for r in per_rank]}
+                                         if per_rank else None),
+                "setup_s_per_rank": [r[2] for r in per_rank] if per_rank else None,
                 "halo_path": (("library RCCL: grouped ncclSend / ncclRecv of device buffers on the engine's stream"
                                if ss.transport == "rccl" else f"callback transport: torch.distributed/{comm.backend}, host-staged")
                               if ss is not None and world > 1 else None),

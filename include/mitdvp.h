@@ -285,6 +285,9 @@ int mitdvp_shard_step(mitdvp_shard* h, double dt_au);                           
 int mitdvp_shard_sweep(mitdvp_shard* h, double dt_au, int forward, int skip_end);
 int mitdvp_shard_junctions(mitdvp_shard* h, double dt_au, int parity);
 int mitdvp_shard_traffic(mitdvp_shard* h, double* bytes, long* messages);        /* halo traffic sent so far */
+/* host wall time this rank has spent in its block half-sweeps / in (and waiting for) the junction updates, over `steps`
+ * mitdvp_shard_step calls: the load balance of the site-sharded sweep */
+int mitdvp_shard_phase_times(mitdvp_shard* h, double* block_ms, double* junction_ms, long* steps);
 /* Panel factorisation of the QR gauge move (SiteCoef.gauge_trf, _site_cls.py:138-292 = LAPACK zgeqrf + zungqr):
  * 1 (default) = CholeskyQR2 of each 32-column panel + reconstruction of LAPACK's Householder vectors / T / tau / signs
  * of diag(R) from the orthonormal panel, falling back to 0 = one Householder step per launch (unconditionally stable)

@@ -200,6 +200,7 @@ def load() -> C.CDLL:
         "mitdvp_shard_sweep": (i, [vp, d, i, i]),
         "mitdvp_shard_junctions": (i, [vp, d, i]),
         "mitdvp_shard_traffic": (i, [vp, dp, C.POINTER(C.c_long)]),
+        "mitdvp_shard_phase_times": (i, [vp, dp, dp, C.POINTER(C.c_long)]),
         "mitdvp_heff_apply_center": (i, [vp, dp, dp, ip]),
         "mitdvp_set_qr_fast": (i, [i]),
         "mitdvp_get_qr_fast": (i, []),

@@ -13,6 +13,7 @@
 // (the one-GPU test box: RCCL refuses two ranks on one device) plug in a host callback instead
 // (mitdvp_shard_set_transport); the junction code is the same.
 #include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "capi_internal.h"
@@ -100,12 +101,31 @@ class SiteShard {
       sweep_block(dt, false, false);
       return;
     }
+    // host wall clock per phase (the block's stream is drained at the phase boundaries by the message groups anyway):
+    // what a rank spends sweeping its block, and what it spends in / waiting for the junction updates
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
     bool fwd = rank_ % 2 == 0;
+    auto t0 = now();
     sweep_block(dt, fwd, !((fwd && rank_ == world_ - 1) || (!fwd && rank_ == 0)));
+    HIP_CHECK(hipStreamSynchronize(block_->st_));
+    auto t1 = now();
     junctions(dt, 0);
+    auto t2 = now();
     fwd = !fwd;
     sweep_block(dt, fwd, !((fwd && rank_ == world_ - 1) || (!fwd && rank_ == 0)));
+    HIP_CHECK(hipStreamSynchronize(block_->st_));
+    auto t3 = now();
     junctions(dt, 1);
+    auto t4 = now();
+    ms_block_ += ms(t0, t1) + ms(t2, t3);
+    ms_junction_ += ms(t1, t2) + ms(t3, t4);
+    n_steps_ += 1;
+  }
+  void phase_times(double* block_ms, double* junction_ms, long* steps) const {
+    *block_ms = ms_block_; *junction_ms = ms_junction_; *steps = n_steps_;
   }
 
   void junctions(double dt, int parity) {
@@ -201,50 +221,80 @@ class SiteShard {
   std::vector<char> stage_;
   double bytes_ = 0;
   long messages_ = 0;
+  double ms_block_ = 0, ms_junction_ = 0;
+  long n_steps_ = 0;
 
   // ---- transport ------------------------------------------------------------------------------------------
+  // A message group = everything between xfer_begin and xfer_end, all with ONE neighbour.  Library RCCL: a grouped
+  // ncclSend / ncclRecv on the block engine's stream.  Callback transport (torch.distributed carries host-staged
+  // buffers; what the one-GPU multi-rank tests run): the SAME contract -- operations are only POSTED by send_dev /
+  // recv_dev and complete at xfer_end, so that code which touched a receive buffer before the group closed, or relied
+  // on the order of operations inside a group, fails in the tests exactly as it would over RCCL.  The blocking
+  // callbacks are then issued in an order that cannot deadlock: the lower rank of the pair sends all it posted, then
+  // receives; the higher rank receives first (per peer, RCCL too matches sends and receives in posting order).
+  struct PostedOp { bool send; const zc* src; zc* dst; size_t elems; int peer; };
+  std::vector<PostedOp> posted_;
+  bool open_ = false;
   void xfer_begin() {
+    if (open_) throw ArgError("shard: message groups do not nest");
     HIP_CHECK(hipStreamSynchronize(block_->st_));
     if (joint_) HIP_CHECK(hipStreamSynchronize(joint_->st_));  // operands may come from any of the engines
     if (jleft_) HIP_CHECK(hipStreamSynchronize(jleft_->st_));
+    open_ = true;
+    posted_.clear();
     if (!fn_) {
-      if (!comm_.load()) throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)");
+      if (!comm_.load()) { open_ = false; throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)"); }
       rccl_check(RcclApi::get().group_start(), "ncclGroupStart");
       in_group_ = true;
     }
   }
   void send_dev(const zc* p, size_t elems, int peer) {
+    if (!open_) throw ArgError("shard: send outside a message group");
     bytes_ += 16.0 * (double)elems;
     messages_ += 1;
-    if (fn_) {
-      stage_.resize(elems * sizeof(zc));
-      HIP_CHECK(hipMemcpy(stage_.data(), p, elems * sizeof(zc), hipMemcpyDeviceToHost));
-      if (fn_(user_, 0, peer, stage_.data(), elems * sizeof(zc)) != 0) throw HipError("shard: the send callback failed");
-      return;
-    }
+    if (fn_) { posted_.push_back({true, p, nullptr, elems, peer}); return; }
     group_check(RcclApi::get().send(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_.load()), block_->st_), "ncclSend");
   }
   void recv_dev(zc* p, size_t elems, int peer) {
-    if (fn_) {
-      stage_.resize(elems * sizeof(zc));
-      if (fn_(user_, 1, peer, stage_.data(), elems * sizeof(zc)) != 0) throw HipError("shard: the receive callback failed");
-      HIP_CHECK(hipMemcpy(p, stage_.data(), elems * sizeof(zc), hipMemcpyHostToDevice));
-      return;
-    }
+    if (!open_) throw ArgError("shard: receive outside a message group");
+    if (fn_) { posted_.push_back({false, nullptr, p, elems, peer}); return; }
     group_check(RcclApi::get().recv(p, 2 * elems, ncclDouble, peer, static_cast<ncclComm_t>(comm_.load()), block_->st_), "ncclRecv");
   }
   // an error inside an open group closes the group before it is raised (a group left open would swallow every later call)
   void group_check(ncclResult_t r, const char* what) {
     if (r == ncclSuccess) return;
     if (in_group_) { in_group_ = false; (void)RcclApi::get().group_end(); }
+    open_ = false;
     rccl_check(r, what);
   }
   void xfer_end() {
+    if (!open_) throw ArgError("shard: xfer_end without xfer_begin");
+    open_ = false;
     if (in_group_) {
       in_group_ = false;
       rccl_check(RcclApi::get().group_end(), "ncclGroupEnd");
       HIP_CHECK(hipStreamSynchronize(block_->st_));  // the joint engine reads the buffers from ITS stream next
+      return;
     }
+    if (posted_.empty()) return;
+    const int peer = posted_[0].peer;
+    for (const auto& o : posted_)
+      if (o.peer != peer) throw ArgError("shard: a message group talks to one neighbour");
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool sends = (pass == 0) == (rank_ < peer);  // lower rank: sends, then receives; higher rank: the reverse
+      for (const auto& o : posted_) {
+        if (o.send != sends) continue;
+        stage_.resize(o.elems * sizeof(zc));
+        if (o.send) {
+          HIP_CHECK(hipMemcpy(stage_.data(), o.src, o.elems * sizeof(zc), hipMemcpyDeviceToHost));
+          if (fn_(user_, 0, o.peer, stage_.data(), o.elems * sizeof(zc)) != 0) throw HipError("shard: the send callback failed");
+        } else {
+          if (fn_(user_, 1, o.peer, stage_.data(), o.elems * sizeof(zc)) != 0) throw HipError("shard: the receive callback failed");
+          HIP_CHECK(hipMemcpy(o.dst, stage_.data(), o.elems * sizeof(zc), hipMemcpyHostToDevice));
+        }
+      }
+    }
+    posted_.clear();
   }
 
   struct DeviceMode {  // the engines' tensor arguments are device pointers while the shard drives them
@@ -441,8 +491,8 @@ class SiteShard {
   // lower rank sends first
   void exchange(const zc* snd, size_t ns, zc* rcv, size_t nr, int peer) {
     xfer_begin();
-    if (fn_ && rank_ > peer) { recv_dev(rcv, nr, peer); send_dev(snd, ns, peer); }
-    else { send_dev(snd, ns, peer); recv_dev(rcv, nr, peer); }
+    send_dev(snd, ns, peer);
+    recv_dev(rcv, nr, peer);
     xfer_end();
   }
 
@@ -470,7 +520,7 @@ class SiteShard {
       env_r_.reserve((size_t)Dr * w1.mr * Dr);
       kmsg = hzc((double)b.kprev_get(n_ - 2), 0.0);
       HIP_CHECK(hipMemcpy(kbuf.p, &kmsg, sizeof(zc), hipMemcpyHostToDevice));
-      xfer_begin();  // (blocking callbacks: the left rank sends first, the right rank receives first)
+      xfer_begin();
       send_dev(b.site_[pl].p, (size_t)dl * d0 * D, peer);
       send_dev(b.envL_[pl].p, (size_t)dl * w0.ml * dl, peer);
       send_dev(X_.p, (size_t)D * D, peer);
@@ -674,6 +724,9 @@ int mitdvp_shard_self_sendrecv(mitdvp_shard* h, size_t elems, int* mismatches) {
 int mitdvp_shard_sweep(mitdvp_shard* h, double dt_au, int forward, int skip_end) { SH_CALL(h, h->s->sweep_block(dt_au, forward != 0, skip_end != 0)); }
 int mitdvp_shard_junctions(mitdvp_shard* h, double dt_au, int parity) { SH_CALL(h, h->s->junctions(dt_au, parity)); }
 int mitdvp_shard_step(mitdvp_shard* h, double dt_au) { SH_CALL(h, h->s->step(dt_au)); }
+int mitdvp_shard_phase_times(mitdvp_shard* h, double* block_ms, double* junction_ms, long* steps) {
+  SH_CALL(h, { SH_NEED(block_ms); SH_NEED(junction_ms); SH_NEED(steps); h->s->phase_times(block_ms, junction_ms, steps); });
+}
 int mitdvp_shard_traffic(mitdvp_shard* h, double* bytes, long* messages) {
   SH_CALL(h, { SH_NEED(bytes); SH_NEED(messages); h->s->traffic(bytes, messages); });
 }

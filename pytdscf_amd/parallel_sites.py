@@ -167,7 +167,11 @@ class SiteShardedTDVP:
             raise ValueError("junction must be 'pair' or 'single'")
         self._h = None
         self._cb = None
+        import time as _time
+
+        t0 = _time.perf_counter()
         self._setup(cores, dims, bond_dim, seed, shared)
+        self.setup_s = _time.perf_counter() - t0
 
     # ------------------------------------------------------------------ set-up (not timed)
     def _ck(self, rc):
@@ -594,6 +598,14 @@ class SiteShardedTDVP:
         b, m = C.c_double(), C.c_long()
         self._ck(self._lib.mitdvp_shard_traffic(self._h, C.byref(b), C.byref(m)))
         return (int(b.value), int(m.value))
+
+    def phase_times(self):
+        """(block_ms, junction_ms, steps): host wall time of this rank's block half-sweeps / junction updates so far"""
+        if self._h is None:
+            return (0.0, 0.0, 0)
+        b, j, n = C.c_double(), C.c_double(), C.c_long()
+        self._ck(self._lib.mitdvp_shard_phase_times(self._h, C.byref(b), C.byref(j), C.byref(n)))
+        return (b.value, j.value, int(n.value))
 
     def close(self):
         if getattr(self, "_wedged", False):  # a transfer still blocks the shard's stream: leak it rather than hang
