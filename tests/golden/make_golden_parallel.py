@@ -17,6 +17,9 @@ top of those.  No reference source is copied; the fixtures hold inputs and the r
     ``parallel_split_indices=[(0, 1), (2, 3)]``, product start, 20 steps of 0.05 fs, non-adaptive): energy /
     norm / autocorrelation per step and the final gathered state.  The generator asserts the reference-held
     pin (energy 0.01000, rel 1e-1, ``:220``).
+``parallel_adaptive_r2.npz``  the same model with ``adaptive=True`` (Dmax = dD = 60, p_proj = 1e-5, p_svd = 1e-6): bond
+    dimensions per step (the junction bond grows in the joint update, ``_mps_parallel.py:321-333``), norm / <Psi*|Psi> /
+    energy estimator, the assembled state and joint matrix after every step.
 ``parallel_chain_r2.npz`` / ``parallel_chain_r3.npz``  a synthetic Hermitian chain (L = 8, d = 3, M = 4, D = 6,
     full-rank random start) on 2 and 3 ranks: per-step norm / <Psi*|Psi> / the reference's energy estimator, the
     state after every step as ``MPSCoefParallel.ovlp`` reads it, joint matrices, Krylov counts.
@@ -297,6 +300,7 @@ def job_chain(rank, size, spec):
         maxstep=0,
         parallel_split_indices=split,
         adaptive_p_svd=spec.get("p_svd", 1e-8),
+        **spec.get("adaptive", {}),
     )
     ci = wf.ci_coef
     matH = model.hamiltonian
@@ -454,7 +458,38 @@ def main():
         np.savez_compressed(os.path.join(HERE, name), **kw)
         print("wrote", name, {k: np.shape(v) for k, v in kw.items()})
 
-    which = sys.argv[1:] or ["exciton", "chain2", "chain3", "graded"]
+    # ("chain_adaptive" is not in the default list: the reference itself fails there, see below)
+    which = sys.argv[1:] or ["exciton", "adaptive", "chain2", "chain3", "graded"]
+
+    if "adaptive" in which:
+        # the same model with const.adaptive on (Dmax = dD = 60, p_proj = 1e-5, p_svd = 1e-6, product start with every
+        # bond 1): the block sweeps AND the junction update grow the bonds (get_adaptive_rank_and_block at the junction,
+        # _mps_parallel.py:321-333, :371-374) -- 1,1,1 -> 8,7,2 within the first step
+        nstep = 6
+        res = run_world(2, stubs, job_exciton, nstep, True)
+        o = {}
+        dims = []
+        for k, snaps in enumerate(res["snap"]):
+            chain, joints = assemble(snaps, np)
+            dims.append([c.shape[2] for c in chain[:-1]])
+            o.update({f"step{k}_site{i}": c for i, c in enumerate(chain)})
+            o.update({f"step{k}_joint{i}": c for i, c in enumerate(joints)})
+        o.update({f"pot{i}": w for i, w in enumerate(res["pot_mpo"])})
+        o.update({f"kin{i}": w for i, w in enumerate(res["kin_mpo"])})
+        o.update({f"weight{i}": w for i, w in enumerate(res["weights"])})
+        save(
+            "parallel_adaptive_r2.npz",
+            nstep=np.array(nstep),
+            split=np.array([(0, 1), (2, 3)]),
+            Dmax=np.array(60), dD=np.array(60), p_proj=np.array(1e-5),
+            bond_dims=np.array(dims),
+            norm=np.array(res["norm"]),
+            autocorr=np.array(res["autocorr"]),
+            energy_ref=np.array(res["energy_ref"]),
+            dt_au=np.array(res["dt_au"]),
+            p_svd=np.array(res["p_svd"]),
+            **o,
+        )
 
     if "exciton" in which:
         nstep = 20
@@ -504,11 +539,26 @@ def main():
         ("chain3", "parallel_chain_r3.npz", [(0, 2), (3, 4), (5, 7)], start, 1e-8),
         ("graded", "parallel_chain_graded.npz", [(0, 3), (4, 7)], start_graded, 1e-5),
     )
+    # adaptive ranks across the junction from a FULL-RANK start of bond dimension 3 (Dmax = 6, dD = 3), where the widened
+    # directions would be determined (full-QR completions of full-rank tensors), unlike from the product start of the
+    # exciton model.  ATTEMPTED IN ROUND 4, NOT A FIXTURE: as soon as the junction bond grows (p_proj = 1e-9, dt = 0.05 or
+    # 0.1 fs) the reference's own junction update raises "Short Iterative Lanczos is not converged in 19 basis when
+    # maxsize=108" (_integrator.py:653 from propagate_joint_two_sites, _mps_parallel.py:353); with p_proj = 1e-4 it runs
+    # and no bond grows.  `python make_golden_parallel.py chain_adaptive` reproduces the failure.
+    bd3 = orc.bond_dims([d] * L, 3)
+    start3 = orc.canonicalize_site0([crandn(dl, d, dr) for (dl, dr) in bd3])
+    cases = cases + (("chain_adaptive", "parallel_chain_adaptive.npz", [(0, 3), (4, 7)], start3, 1e-8),)
     for tag, fname, split, start, p_svd in cases:
         if tag not in which:
             continue
         nstep = 3
         spec = dict(mpo=mpo, cores=start, start=start, D=D, dt_fs=0.02, nstep=nstep, split=split, p_svd=p_svd)
+        extra = {}
+        if tag == "chain_adaptive":
+            spec["D"] = 3
+            spec["dt_fs"] = 0.05
+            spec["adaptive"] = dict(adaptive=True, adaptive_Dmax=6, adaptive_dD=3, adaptive_p_proj=1e-9)
+            extra = dict(Dmax=np.array(6), dD=np.array(3), p_proj=np.array(1e-9), D0=np.array(3))
         res = run_world(len(split), stubs, job_chain, spec)
         o = {f"mpo{i}": w for i, w in enumerate(mpo)}
         o.update({f"start{i}": c for i, c in enumerate(start)})
@@ -529,6 +579,7 @@ def main():
             krylov=kry,
             dt_au=np.array(res["dt_au"]),
             p_svd=np.array(res["p_svd"]),
+            **extra,
             **o,
         )
 

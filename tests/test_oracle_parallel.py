@@ -193,3 +193,41 @@ def test_reference_mpi_exciton_run(golden):
             assert e == pytest.approx(float(g["energy_ref"][k].real), rel=2e-2)
         p.step(dt)
         s.propagate(dt)
+
+
+def test_reference_adaptive_parallel_run_fixture(golden):
+    """``parallel_adaptive_r2.npz``: the reference's MPSCoefParallel with ``adaptive=True`` (Dmax = dD = 60, p_proj = 1e-5,
+    p_svd = 1e-6) on the model of its own MPI test, 2 ranks, product start.  What the fixture pins about that branch
+    (``get_adaptive_rank_and_block`` at the junction, _mps_parallel.py:321-333, :371-374): every bond -- the junction's
+    too -- has grown to its final rank (8, 7, 2) after ONE time step and stays there; the chain the reference's ``ovlp``
+    reads is what the norm record says; norm and energy stay inside the reference's own acceptance (properties.py:367-369
+    accepts 1e-2 per step on the norm, tests/test_mpi_exiciton_propagate.py:220 rel 1e-1 on the energy); the serial
+    adaptive sweep from the same start reaches the same energy and, at the junction, a rank within one of it.  The HIP
+    path refuses adaptive ranks together with site sharding (the reference's own junction update does
+    not converge once the bond of a full-rank chain grows, see make_golden_parallel.py)."""
+    from pytdscf_amd import mps as M
+    from pytdscf_amd import operators as O
+
+    g = golden("parallel_adaptive_r2.npz")
+    n = int(g["nstep"])
+    assert [list(r) for r in g["bond_dims"]] == [[1, 1, 1]] + [[8, 7, 2]] * n
+    for k in range(n + 1):
+        ref = _ref_chain(g, k, 4)
+        assert abs(abs(orc.overlap(ref, ref)) - float(g["norm"][k])) < 1e-12
+        assert g[f"step{k}_joint0"].shape == (ref[1].shape[2],) * 2
+        assert abs(float(g["norm"][k]) - 1) < 3e-2
+        assert float(g["energy_ref"][k].real) == pytest.approx(0.01000, rel=1e-2)
+    # the serial adaptive sweep (pinned to the reference by the a1TDVP fixtures) from the same start
+    pot = [g[f"pot{i}"] for i in range(4)]
+    kin = [g[f"kin{i}"] for i in range(3)]
+    mpo = O.merge_operator_terms([(pot, [0, 1, 2, 3]), (kin, [0, 1, 2])], dims=[8, 8, 8, 2])
+    start = orc.canonicalize_site0(M.product_state_cores([g[f"weight{i}"] for i in range(4)], bond_dim=1))
+    s = orc.OracleMPS([c.copy() for c in start], mpo, adaptive=True, Dmax=int(g["Dmax"]), dD=int(g["dD"]), p_proj=float(g["p_proj"]))
+    for _ in range(n):
+        s.propagate(float(g["dt_au"]))
+    dims = [c.shape[2] for c in s.cores[:-1]]
+    assert dims[0] == 8 and dims[2] == 2 and abs(dims[1] - 7) <= 1
+    assert s.expectation().real == pytest.approx(float(g["energy_ref"][n].real), rel=1e-2)
+    ref = _ref_chain(g, n, 4)
+    fid = abs(orc.overlap(ref, s.cores)) / np.sqrt(abs(orc.overlap(ref, ref)) * abs(orc.overlap(s.cores, s.cores)))
+    assert fid > 1 - 2e-2  # parallel vs serial scheme: O(dt^2) per junction update, six steps
