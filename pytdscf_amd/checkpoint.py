@@ -68,3 +68,32 @@ def load(path: str) -> SavedWFunc:
     if not hasattr(wf, "ci_coef") or not hasattr(wf.ci_coef, "superblock_states"):
         raise ValueError(f"{path} is not a wavefunction checkpoint")
     return wf
+
+
+def to_reference_checkpoint(path_in: str, path_out: str, model) -> None:
+    """PyTDSCF side of the wire format (needs the reference package importable; nothing here runs on the GPU box).
+
+    The reference's restart does ``wf = dill.load(f); wf = WFunc(wf.ci_coef, wf.spf_coef, ints_prim)``
+    (simulator_cls.py:501-507): ``ci_coef`` has to be a genuine ``MPSCoefMPO`` with its methods, which only the reference
+    can construct.  This converter does that on the reference's side: an ``MPSCoefMPO`` allocated for ``model`` (the
+    reference ``Model`` of the run; ``alloc_random``, _mps_mpo.py:56-120) takes the saved tensors and gauge tags site by
+    site, is wrapped in a ``WFunc`` and written with dill where ``Simulator.propagate(restart=True, loadfile_ext=...)``
+    looks for it.  tests/golden/crosscheck_reference.py restarts the reference from such a file and compares the next
+    step with the oracle's (development container)."""
+    import dill
+    from pytdscf._mps_mpo import MPSCoefMPO  # the reference
+    from pytdscf._site_cls import SiteCoef
+    from pytdscf._spf_cls import SPFCoef
+    from pytdscf.wavefunction import WFunc
+
+    saved = load(path_in)
+    ci = MPSCoefMPO.alloc_random(model)
+    if len(ci.superblock_states) != saved.ci_coef.nstate or len(ci.superblock_states[0]) != saved.ci_coef.nsite:
+        raise ValueError("the model and the checkpoint disagree on the number of states / sites")
+    for istate, sites in enumerate(saved.ci_coef.superblock_states):
+        for isite, sc in enumerate(sites):
+            ci.superblock_states[istate][isite] = SiteCoef(np.array(sc.data, dtype=np.complex128), sc.gauge, isite)
+    ci.op_sys_sites = None  # environments are rebuilt from the tensors (_mps_cls.py:835-843)
+    with open(path_out, "wb") as f:
+        # the standard method carries trivial single-particle functions ("uniform (all 1.0)", simulator_cls.py:523-524)
+        dill.dump(WFunc(ci, SPFCoef.alloc_eye(model), None), f)

@@ -191,6 +191,29 @@ def main():
     report("two states, shared keys + off-diagonal coupleJ (cache off): energy, pops, tensors", abs(ener - e.real),
            np.abs(np.array(wf.pop_states()) - np.array(st.pop_states())).max(),
            max(np.abs(a - b).max() for x, y in zip(fin, st.cores) for a, b in zip(x, y)))
+    # wire format: a checkpoint written by pytdscf_amd (host-side snapshot classes), converted on the reference's side
+    # (pytdscf_amd.checkpoint.to_reference_checkpoint) and RESTARTED by the reference (simulator_cls.py:501-507): its next
+    # step against the oracle's
+    import dill
+
+    from pytdscf_amd import checkpoint as ck
+
+    st = orc.OracleMPS(orc.canonicalize_site0(init), mpo)
+    for _ in range(2):
+        st.propagate(dt)
+    snap = ck.SavedWFunc(ck.SavedMPSCoef([[ck.SavedSiteCoef(c, "Psi" if i == 0 else "B", i) for i, c in enumerate(st.cores)]], "hilbert"))
+    with open("wf_amd.pkl", "wb") as f:
+        dill.dump(snap, f)
+    m = Model(basis, operators={"hamiltonian": [w.copy() for w in mpo]}, bond_dim=6)
+    m.init_HartreeProduct = [[np.array(c) for c in init]]
+    sim = Simulator("x", m, backend="numpy", verbose=0)
+    ck.to_reference_checkpoint("wf_amd.pkl", "wf_x_amd.pkl", m)
+    ener, wf = sim.propagate(stepsize=0.05, maxstep=1, restart=True, loadfile_ext="_amd")
+    e = st.expectation()
+    st.propagate(dt)
+    ref = [np.array(s.data) for s in wf.ci_coef.superblock_states[0]]
+    report("restart of the reference from a pytdscf_amd checkpoint: energy, 1-|ovlp|, autocorr", abs(ener - e.real),
+           abs(abs(orc.overlap(ref, st.cores)) - 1), abs(wf._ints_wf_ovlp_mpssm(wf.ci_coef, conj=False) - st.autocorr()))
     print("all differences should be at rounding level (<= 1e-12)")
 
 

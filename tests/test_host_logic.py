@@ -211,3 +211,107 @@ def test_subspace_projection_host_side(golden):
     db = dense(orc.project_subspace_mpo(mpo, inds))
     assert da.shape == db.shape
     np.testing.assert_allclose(da, db, atol=1e-12 * max(1.0, np.abs(db).max()))
+
+
+def _parse_cdf2(buf):
+    """A NetCDF classic / 64-bit-offset header read BYTE BY BYTE from the format's definition (magic, numrecs, dimension /
+    attribute / variable lists with tags 0x0A / 0x0C / 0x0B, names and values padded to 4 bytes, big endian): independent of
+    scipy's reader and of pytdscf_amd.util.read_nc.  Returns (version, numrecs, dims [(name, size)], gatts {name: bytes},
+    vars [(name, dim ids, nc_type, vsize, begin)], record size)."""
+    import struct
+
+    pos = [0]
+
+    def take(n):
+        out = buf[pos[0] : pos[0] + n]
+        assert len(out) == n
+        pos[0] += n
+        return out
+
+    def u32():
+        return struct.unpack(">I", take(4))[0]
+
+    def name():
+        n = u32()
+        s = take(n).decode()
+        take((-n) % 4)
+        return s
+
+    def att_list():
+        tag, n = u32(), u32()
+        assert (tag, n) == (0, 0) or tag == 0x0C
+        out = {}
+        for _ in range(n):
+            k = name()
+            typ, cnt = u32(), u32()
+            size = {1: 1, 2: 1, 3: 2, 4: 4, 5: 4, 6: 8}[typ] * cnt
+            out[k] = take(size)
+            take((-size) % 4)
+        return out
+
+    assert take(3) == b"CDF"
+    version = take(1)[0]
+    numrecs = u32()
+    tag, ndim = u32(), u32()
+    assert tag == 0x0A
+    dims = []
+    for _ in range(ndim):
+        k = name()
+        dims.append((k, u32()))
+    gatts = att_list()
+    tag, nvar = u32(), u32()
+    assert tag == 0x0B
+    vs = []
+    for _ in range(nvar):
+        k = name()
+        ids = [u32() for _ in range(u32())]
+        att_list()
+        typ, vsize = u32(), u32()
+        begin = struct.unpack(">Q", take(8))[0] if version == 2 else u32()
+        vs.append((k, ids, typ, vsize, begin))
+    recsize = sum(v[3] for v in vs if v[1] and dims[v[1][0]][1] == 0)
+    return version, numrecs, dims, gatts, vs, recsize
+
+
+def test_reduced_density_nc_bytes_against_the_layout_written_out_by_hand(tmp_path):
+    """The NetCDF-3 form of reduced_density.nc, checked at the byte level against an expectation written out from the
+    reference's layout (Properties._create_nc_file, properties.py:156-209: dimensions step (record), state, then Q{idof} in
+    order of first appearance over the keys; variable time(step) f8; rho_{key}_{istate}(step, Q.., Q..) per key -- here
+    with the trailing (real, imag) dimension that stands in for the NETCDF4 compound type): header fields, variable
+    order, types, record layout, and the numbers themselves at the offsets the header promises."""
+    import struct
+
+    from pytdscf_amd.util.nc_writer import write_reduced_density_nc
+
+    rng = np.random.default_rng(4)
+    times = [0.0, 0.25]
+    recs = [{(0, 0): rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3)),
+             (0, 2): rng.standard_normal((3, 2)) + 1j * rng.standard_normal((3, 2))} for _ in times]
+    path = str(tmp_path / "reduced_density.nc")
+    assert write_reduced_density_nc(path, times, recs, fmt="NETCDF3") == "NETCDF3"
+    buf = open(path, "rb").read()
+    version, numrecs, dims, gatts, vs, recsize = _parse_cdf2(buf)
+    assert version == 2 and numrecs == len(times)  # 64-bit offsets; one record per saved step
+    assert dims == [("step", 0), ("state", 1), ("complex", 2), ("Q0", 3), ("Q2", 2)]  # size 0 = THE record dimension
+    assert b"trailing dimension 'complex'" in gatts["layout"]
+    NC_DOUBLE = 6
+    names = [v[0] for v in vs]
+    assert names == ["time", "rho_(0, 0)_0", "rho_(0, 2)_0"]  # the reference's names: f"rho_{key}_{istate}" with key a tuple
+    did = {n: i for i, (n, _) in enumerate(dims)}
+    want_dims = {"time": ["step"], "rho_(0, 0)_0": ["step", "Q0", "Q0", "complex"], "rho_(0, 2)_0": ["step", "Q0", "Q2", "complex"]}
+    want_vsize = {"time": 8, "rho_(0, 0)_0": 3 * 3 * 2 * 8, "rho_(0, 2)_0": 3 * 2 * 2 * 8}  # bytes of ONE record
+    for k, ids, typ, vsize, begin in vs:
+        assert ids == [did[d] for d in want_dims[k]] and typ == NC_DOUBLE and vsize == want_vsize[k], k
+    assert recsize == sum(want_vsize.values())
+    # records are interleaved: record r of a variable sits at begin + r * recsize
+    begins = {k: b for k, _, _, _, b in vs}
+    assert begins["rho_(0, 0)_0"] == begins["time"] + 8 and begins["rho_(0, 2)_0"] == begins["rho_(0, 0)_0"] + want_vsize["rho_(0, 0)_0"]
+    assert len(buf) == begins["time"] + numrecs * recsize
+    for r, (t, rec) in enumerate(zip(times, recs)):
+        assert struct.unpack(">d", buf[begins["time"] + r * recsize :][:8])[0] == t
+        for key in rec:
+            k = f"rho_{key}_0"
+            n = want_vsize[k] // 8
+            vals = np.frombuffer(buf, dtype=">f8", count=n, offset=begins[k] + r * recsize).reshape(rec[key].shape + (2,))
+            np.testing.assert_array_equal(vals[..., 0], rec[key].real)
+            np.testing.assert_array_equal(vals[..., 1], rec[key].imag)
