@@ -318,14 +318,16 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
       }
     }
     std::vector<int> list;
-    long executed = 0;  // in units of (row, K tile)
+    long executed = 0;  // in units of (row, K tile), padding rows of the tiles included: the flop the hardware runs
     for (int q0 = 0; q0 < mo;) {
       const bool dense = 2 * cntq[q0] > nkt;
       int q1 = q0 + 1;
       while (q1 < mo && (2 * cntq[q1] > nkt) == dense) ++q1;
       MpoSite::SpSeg sg{q0 * d, q1 * d, dense, 0};
       if (dense) {
-        executed += (long)(sg.r1 - sg.r0) * nkt;
+        // what the matrix cores execute: whole tiles (32 rows for a range of <= 32 rows, else 64: w_stage's choice)
+        const int rows = sg.r1 - sg.r0, tile = rows <= 32 ? 32 : 64;
+        executed += (long)((rows + tile - 1) / tile) * tile * nkt;
       } else {
         sg.tile0 = (int)(list.size() / stride);
         for (int r = sg.r0; r < sg.r1; r += 64) {  // this range's own grid of 64-row tiles
@@ -338,7 +340,7 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
             if (nz) list[o + 1 + cnt++] = kt;
           }
           list[o] = cnt;
-          executed += (long)(std::min(r + 64, sg.r1) - r) * cnt;
+          executed += 64L * cnt;  // a tile runs all its 64 rows through every listed K tile
         }
       }
       segs.push_back(sg);
