@@ -54,6 +54,8 @@ __device__ __forceinline__ int cd_row(int mode, int lk, int r) {
 // The reducing epilogue of zgemm_reduce for RB x CB blocks of 16 x 16 outputs (declared here, defined below the kernel)
 template <int RB, int CB>
 __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
+template <int RB, int CB>
+__device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
 
 template <int WM, int WN, int BK, bool TA, bool TB, bool M3, bool SP = false, bool EPI = false>
 __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
@@ -409,15 +411,17 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     __syncthreads();
     const int rbn = (d.epi_di + 15) / 16;
     const int cbn = ((BM / d.epi_xm) * (BN / d.epi_yn) + 15) / 16;
+    // four blocks of outputs: one block per wave over the whole contraction (no partials to exchange); fewer: the
+    // contraction split over the waves
     if (cbn == 1) {
       if (rbn == 1) reduce_epilogue<1, 1>(d, smem, tm, tn, cd_mode);
       else if (rbn == 2) reduce_epilogue<2, 1>(d, smem, tm, tn, cd_mode);
-      else reduce_epilogue<4, 1>(d, smem, tm, tn, cd_mode);
+      else reduce_epilogue_blocks<4, 1>(d, smem, tm, tn, cd_mode);
     } else if (cbn == 2) {
       if (rbn == 1) reduce_epilogue<1, 2>(d, smem, tm, tn, cd_mode);
-      else reduce_epilogue<2, 2>(d, smem, tm, tn, cd_mode);
+      else reduce_epilogue_blocks<2, 2>(d, smem, tm, tn, cd_mode);
     } else {
-      reduce_epilogue<1, 4>(d, smem, tm, tn, cd_mode);
+      reduce_epilogue_blocks<1, 4>(d, smem, tm, tn, cd_mode);
     }
     return;
   }
@@ -573,6 +577,88 @@ __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, in
         zc* p = d.C + u * d.epi_su + v * d.epi_sv + (long)i * d.epi_si;
         if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
         *p = make_double2(re, im);
+      }
+    }
+  }
+}
+
+// The same contraction when there are FOUR blocks of 16 x 16 outputs (RB * CB = 4: d = 4, M = 16 gives 64 (u, v) pairs per
+// tile = four column blocks): wave w owns block w over the whole contraction index, so nothing is exchanged between the
+// waves and each writes its own outputs -- two barriers and a 64 KB LDS round trip less than the split form.
+template <int RB, int CB>
+__device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode) {
+  static_assert(RB * CB == 4, "one block per wave");
+  constexpr int LDT = 65;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 15, lk = lane >> 4;
+  const int ib = w / CB, jb = w - ib * CB;
+  const int XM = d.epi_xm, YN = d.epi_yn, KP = XM * YN, DI = d.epi_di;
+  const int TU = 64 / XM, TV = 64 / YN, npair = TU * TV;
+  const int nk4 = (KP + 3) / 4;
+  const zc* __restrict__ Wm = d.epi_w;
+  const long ldw = d.epi_ldw;
+  double zin = 0.0;
+  asm volatile("" : "+v"(zin));
+  d4 zr = __builtin_amdgcn_mfma_f64_16x16x4f64(zin, zin, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0), zi = zr;
+  const int pr = jb * 16 + li;
+  const bool pval = pr < npair;
+  const int prc = pval ? pr : 0;
+  const int ul = prc / TV, vl = prc - ul * TV;
+  const int toff = ul * XM * LDT + vl * YN;
+  const int i = ib * 16 + li;
+  constexpr int CH = 4;
+  zc wv[2][CH];
+  auto load_w = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int kk = (k4s + c) * 4 + lk;
+      const bool ok = (k4s + c) < nk4 && kk < KP && i < DI;
+      zc v = Wm[ok ? (long)i * ldw + kk : 0];
+      v.x = ok ? v.x : 0.0;
+      v.y = ok ? v.y : 0.0;
+      wv[buf][c] = v;
+    }
+  };
+  auto chunk = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k4 = k4s + c;
+      if (k4 < nk4) {
+        const int kk = k4 * 4 + lk;
+        const bool ok = kk < KP && pval;
+        const int kc = kk < KP ? kk : 0;
+        const int x = kc / YN, y = kc - x * YN;
+        zc tv = smem[ok ? toff + x * LDT + y : 0];
+        tv.x = ok ? tv.x : 0.0;
+        tv.y = ok ? tv.y : 0.0;
+        const zc a = wv[buf][c];
+        const double nai = -a.y;
+        zr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, tv.x, zr, 0, 0, 0);
+        zi = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, tv.y, zi, 0, 0, 0);
+        zr = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, tv.y, zr, 0, 0, 0);
+        zi = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, tv.x, zi, 0, 0, 0);
+      }
+    }
+  };
+  load_w(0, 0);
+  for (int k4s = 0; k4s < nk4; k4s += 2 * CH) {
+    load_w(1, k4s + CH);
+    chunk(0, k4s);
+    load_w(0, k4s + 2 * CH);
+    chunk(1, k4s + CH);
+  }
+  // lane (li, lk) holds outputs (row cd_row(lk, r), column li) of its block, r = 0..3
+  if (pval) {
+    const long u = (long)tm * TU + ul, v = (long)tn * TV + vl;
+    if (u * XM < d.M && v * YN < d.N) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int io = ib * 16 + cd_row(cd_mode, lk, r);
+        if (io < DI) {
+          zc* p = d.C + u * d.epi_su + v * d.epi_sv + (long)io * d.epi_si;
+          double re = zr[r], im = zi[r];
+          if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
+          *p = make_double2(re, im);
+        }
       }
     }
   }
