@@ -281,9 +281,10 @@ def roofline_report(cnt, L, d, D, M, gemm_mode, el_s, profile_in_timed, tp=False
 
 
 # Per-phase HIP-event timing (roofline / breakdown) costs two event records per phase: nothing at C4 (0.01 %), a third
-# of the run in the launch-bound small-bond regime, a few per cent at D = 128.  Below this bond dimension the timed
-# region runs unprofiled and the same sweeps are repeated afterwards, profiled, only for the breakdown.
-PROFILE_IN_TIMED_MIN_D = 512
+# of the run in the launch-bound small-bond regime, 15 % at C3 (D = 128), 1.7 % at C5 (D = 512; 0.4614 vs 0.4691 sweeps/s).
+# Below this bond dimension the timed region runs unprofiled and the same sweeps are repeated afterwards, profiled, only
+# for the breakdown.
+PROFILE_IN_TIMED_MIN_D = int(os.environ.get("MITDVP_BENCH_PROFILE_MIN_D", "1024"))
 
 
 def ensemble_leg(name, device, n_steps):
