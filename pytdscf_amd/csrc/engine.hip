@@ -702,15 +702,24 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
   zc* lam_dev = red_.p + RED_MISC + 64;  // behind the 128 deviations
   struct { double dev[128]; hzc lam[128]; } h;
   static_assert(sizeof(h) == 128 * 8 + 128 * 16, "layout of the identity-check record");
-  ident_deviation_multi(st_, Lb, ml, dl, (long)ml * dl, dl, dev, lam_dev);
-  ident_deviation_multi(st_, Rb, mr, dr, (long)mr * dr, dr, dev + 64, lam_dev + 64);
-  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
-  cnt_.n_launch += 2;
+  // The identity states of a site do not change from sweep to sweep (they follow from the MPO's structure and the
+  // canonical form): first only the blocks that were identity multiples last time are looked at (3 of 16 at C5); all of
+  // them again when one of those has stopped being one, or when there is no previous answer.
   unsigned long long S = 0, E = 0;
   std::vector<hzc> lam(ml), mu(mr);
-  for (int c = 0; c < ml; ++c) { lam[c] = h.lam[c]; if (h.dev[c] < 1e-13) S |= 1ull << c; }
-  for (int t = 0; t < mr; ++t) { mu[t] = h.lam[64 + t]; if (h.dev[64 + t] < 1e-13) E |= 1ull << t; }
+  for (int attempt = (w.edge_valid ? 0 : 1); attempt < 2; ++attempt) {
+    const unsigned long long ms = attempt == 0 ? w.edge_s : ~0ull, me = attempt == 0 ? w.edge_e : ~0ull;
+    ident_deviation_multi(st_, Lb, ml, dl, (long)ml * dl, dl, dev, lam_dev, ms);
+    ident_deviation_multi(st_, Rb, mr, dr, (long)mr * dr, dr, dev + 64, lam_dev + 64, me);
+    HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    cnt_.n_launch += 2;
+    S = E = 0;
+    for (int c = 0; c < ml; ++c) { lam[c] = h.lam[c]; if (((ms >> c) & 1ull) && h.dev[c] < 1e-13) S |= 1ull << c; }
+    for (int t = 0; t < mr; ++t) { mu[t] = h.lam[64 + t]; if (((me >> t) & 1ull) && h.dev[64 + t] < 1e-13) E |= 1ull << t; }
+    if (attempt == 0 && (S != w.edge_s || E != w.edge_e)) continue;  // something changed: look at every block
+    break;
+  }
   // the trimmed three-stage chain wants the plain identity in state 0 / mr - 1
   trim_l_ = ml > 1 && (S & 1ull) && std::abs(lam[0] - 1.0) < 1e-13;
   trim_r_ = mr > 1 && ((E >> (mr - 1)) & 1ull) && std::abs(mu[mr - 1] - 1.0) < 1e-13;

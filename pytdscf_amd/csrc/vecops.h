@@ -40,8 +40,9 @@ void vec_copy_raw(hipStream_t st, zc* dst, const zc* src, size_t n);
 void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_dev);
 // nblk blocks at once (block c at base + c * blk_stride, same ld and n), against multiples of the identity:
 // lam_dev[c] = the block's first diagonal element, out_dev[c] = max |block - lam 1|
+// mask: bit c set = block c is looked at (the others' outputs are meaningless)
 void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_stride, long ld, int n, double* out_dev,
-                           zc* lam_dev);
+                           zc* lam_dev, unsigned long long mask = ~0ull);
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
             bool accumulate);
 // norm profiles for the adaptive-rank functional (plain device arrays, no partials)

@@ -738,7 +738,9 @@ __global__ __launch_bounds__(256) void k_ident_dev(const zc* __restrict__ blk, l
 // nblk blocks at once, against MULTIPLES of the identity: block c starts at base + c * blk_stride; lam[c] = its first
 // diagonal element, out[c] = max |blk - lam * 1|
 __global__ __launch_bounds__(256) void k_ident_dev_multi(const zc* __restrict__ base, long blk_stride, long ld, int n,
-                                                         unsigned long long* __restrict__ out, zc* __restrict__ lam) {
+                                                         unsigned long long* __restrict__ out, zc* __restrict__ lam,
+                                                         unsigned long long mask) {
+  if (!((mask >> blockIdx.y) & 1ull)) return;  // not asked for: out[c] keeps its 0, the caller ignores it
   const zc* blk = base + (long)blockIdx.y * blk_stride;
   const zc l = blk[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) lam[blockIdx.y] = l;
@@ -754,13 +756,13 @@ __global__ __launch_bounds__(256) void k_ident_dev_multi(const zc* __restrict__ 
   if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out + blockIdx.y, (unsigned long long)__double_as_longlong(m));
 }
 void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_stride, long ld, int n, double* out_dev,
-                           zc* lam_dev) {
+                           zc* lam_dev, unsigned long long mask) {
   if (nblk < 1) return;
   HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)nblk * sizeof(double), st));
   const long tot = (long)n * n;
   const int nb = (int)std::min<long>((tot + 255) / 256, 256);
   hipLaunchKernelGGL(k_ident_dev_multi, dim3(nb, nblk), dim3(256), 0, st, base, blk_stride, ld, n,
-                     reinterpret_cast<unsigned long long*>(out_dev), lam_dev);
+                     reinterpret_cast<unsigned long long*>(out_dev), lam_dev, mask);
   HIP_CHECK(hipGetLastError());
 }
 void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_dev) {
