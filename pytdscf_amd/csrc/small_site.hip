@@ -315,6 +315,71 @@ __device__ void ss_expm_col0(zc* Tm, zc* M2, zc* M3, zc* M4, zc* Pm, zc* Qm, int
   __syncthreads();
 }
 
+// coef = first column of exp(scale * T_k) for the TRIDIAGONAL T of a Lanczos recurrence (diagonal alpha, off-diagonal
+// beta), by ONE WAVE with the vector in registers: lane q holds row q of T / 2^s and entry q of the vector, a product
+// T p is two wave shifts and three complex multiply-adds, exp(T / 2^s) e_0 is the degree-20 Taylor sum (|T / 2^s|_1 <= 1:
+// remainder 1 / 21! = 2e-20) applied 2^s times.  No LDS, no barrier, no k x k products: 20 dependent steps of ~50 cycles
+// where ss_expm_col0 takes seven k x k products behind workgroup barriers (measured in k_small_site at C2: 14.2 us per
+// inspected iteration, two per local exponential).  Every wave of the workgroup may run it redundantly (same
+// instructions, same bits): all then know s, which decides uniformly whether this form is used (s <= SS_VEC_SMAX; for
+// larger norms the 2^s repetitions cost more than squaring the matrix).  Returns s; coef is written by the caller's wave 0.
+constexpr int SS_VEC_SMAX = 3;
+__device__ __forceinline__ double wave_shr1(double v) {  // lane q <- lane q - 1 (lane 0 <- 0)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_shl1(double v) {  // lane q <- lane q + 1 (lane 63 <- 0)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_expm_tridiag(const zc* alpha, const double* beta, zc scale, int k, bool real_alpha,
+                                                 zc& out) {
+  const int q = threadIdx.x & 63;
+  zc a = make_double2(0.0, 0.0), bl = a, bu = a;
+  if (q < k) {
+    zc al = alpha[q];
+    if (real_alpha) al.y = 0.0;
+    a = make_double2(scale.x * al.x - scale.y * al.y, scale.x * al.y + scale.y * al.x);
+    if (q + 1 < k) { const double b = beta[q]; bu = make_double2(scale.x * b, scale.y * b); }
+    if (q > 0) { const double b = beta[q - 1]; bl = make_double2(scale.x * b, scale.y * b); }
+  }
+  // column q of T: T[q][q] = a, T[q-1][q] = b_{q-1}, T[q+1][q] = b_q
+  double nrm = wave_max64(sqrt(a.x * a.x + a.y * a.y) + sqrt(bl.x * bl.x + bl.y * bl.y) + sqrt(bu.x * bu.x + bu.y * bu.y));
+  int s = 0;
+  while (nrm > 1.0 && s < 60) { nrm *= 0.5; ++s; }
+  if (s > SS_VEC_SMAX) return s;
+  const double sc = ldexp(1.0, -s);
+  a.x *= sc; a.y *= sc; bl.x *= sc; bl.y *= sc; bu.x *= sc; bu.y *= sc;
+  zc y = make_double2(q == 0 ? 1.0 : 0.0, 0.0);
+  for (int rep = 0; rep < (1 << s); ++rep) {
+    zc p = y, acc = y;
+#pragma unroll 4
+    for (int n = 1; n <= 20; ++n) {
+      const zc pm = make_double2(wave_shr1(p.x), wave_shr1(p.y));  // p_{q-1}
+      const zc pp = make_double2(wave_shl1(p.x), wave_shl1(p.y));  // p_{q+1}
+      // (T p)_q = T[q][q-1] p_{q-1} + T[q][q] p_q + T[q][q+1] p_{q+1}, T[q][q-1] = b_{q-1}, T[q][q+1] = b_q
+      double re = a.x * p.x - a.y * p.y, im = a.x * p.y + a.y * p.x;
+      re = fma(bl.x, pm.x, re); re = fma(-bl.y, pm.y, re);
+      im = fma(bl.x, pm.y, im); im = fma(bl.y, pm.x, im);
+      re = fma(bu.x, pp.x, re); re = fma(-bu.y, pp.y, re);
+      im = fma(bu.x, pp.y, im); im = fma(bu.y, pp.x, im);
+      const double inv = 1.0 / (double)n;
+      p = make_double2(re * inv, im * inv);
+      acc.x += p.x; acc.y += p.y;
+    }
+    y = acc;
+  }
+  out = y;
+  return s;
+}
+
 // ---------------------------------------------------------------------------
 // krylov_dev.h: the Ritz step of the MULTI-launch Krylov loop on the device (one workgroup).  Reference semantics:
 // _iter_info warm-up (_integrator.py:178-186) is applied by the host (it decides WHICH iterations are inspected, a
@@ -386,20 +451,32 @@ __global__ __launch_bounds__(SS_THREADS) void k_kry_ritz(KryRitzArgs a) {
   zc* M4 = M3 + MAXK * MAXK;
   zc* Pm = M4 + MAXK * MAXK;
   zc* Qm = Pm + MAXK * MAXK;
-  for (int t = tid; t < k * k; t += SS_THREADS) {
-    const int i = t / k, j = t - i * k;
-    zc z = make_double2(0.0, 0.0);
-    if (a.lanczos) {
-      if (i == j) { z = st->alpha[i]; if (real_alpha) z.y = 0.0; }
-      else if (i == j + 1) z = make_double2(st->beta[j], 0.0);
-      else if (j == i + 1) z = make_double2(st->beta[i], 0.0);
-    } else {
-      if (i <= j + 1) z = st->hess[i * MAXK + j];
+  bool vec_done = false;
+  if (a.lanczos && k > 1) {  // tridiagonal: vector form in one wave (wave_expm_tridiag)
+    zc cq;
+    const int sq_ = wave_expm_tridiag(st->alpha, st->beta, a.scale, k, real_alpha, cq);
+    if (sq_ <= SS_VEC_SMAX) {
+      if (tid < k) coef_s[tid] = cq;
+      __syncthreads();
+      vec_done = true;
     }
-    Tm[t] = make_double2(a.scale.x * z.x - a.scale.y * z.y, a.scale.x * z.y + a.scale.y * z.x);
   }
-  __syncthreads();
-  ss_expm_col0(Tm, M2, M3, M4, Pm, Qm, k, coef_s, wsh);
+  if (!vec_done) {
+    for (int t = tid; t < k * k; t += SS_THREADS) {
+      const int i = t / k, j = t - i * k;
+      zc z = make_double2(0.0, 0.0);
+      if (a.lanczos) {
+        if (i == j) { z = st->alpha[i]; if (real_alpha) z.y = 0.0; }
+        else if (i == j + 1) z = make_double2(st->beta[j], 0.0);
+        else if (j == i + 1) z = make_double2(st->beta[i], 0.0);
+      } else {
+        if (i <= j + 1) z = st->hess[i * MAXK + j];
+      }
+      Tm[t] = make_double2(a.scale.x * z.x - a.scale.y * z.y, a.scale.x * z.y + a.scale.y * z.x);
+    }
+    __syncthreads();
+    ss_expm_col0(Tm, M2, M3, M4, Pm, Qm, k, coef_s, wsh);
+  }
   const int have_prev = a.first ? 0 : st->have_prev;
   const int prev_len = a.first ? 0 : st->prev_len;
   if (tid < k) {
@@ -770,7 +847,17 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     if (act == 0) continue;
 
     // ---- coef = exp(scale * T_k) e_0 ------------------------------------------------------------
-    {
+    bool vec_done = false;
+    if (lanczos && k > 1) {  // tridiagonal: one wave, vector form (every wave runs it: the decision is uniform)
+      zc cq;
+      const int sq_ = wave_expm_tridiag(alpha, beta, scale, k, false, cq);
+      if (sq_ <= SS_VEC_SMAX) {
+        if (tid < k) coef[tid] = cq;
+        __syncthreads();
+        vec_done = true;
+      }
+    }
+    if (!vec_done) {
       zc* Tm = Bs;
       zc* M2 = Tm + MAXK * MAXK;
       zc* M3 = M2 + MAXK * MAXK;
