@@ -678,9 +678,52 @@ int qr_get_fast() { return qr_fast_enabled() ? 1 : 0; }
 // shapes whose panels keep failing the conditioning checks (rank-deficient / strongly graded tensors) skip the fast
 // attempt for a while: 2, 4, ... 64 factorisations after each consecutive failure
 struct QrBackoff { int fails = 0, skip = 0; };
-struct QrHistory { std::map<long, QrBackoff> by_shape; };
+// ... and where a factorisation's verdict reaches the host: one word of host-coherent mapped memory the device writes
+// behind a sequence number, the host spins on it (~7 us; hipMemcpyAsync + hipStreamSynchronize cost 15-50 us per QR
+// on this stack, tools/probes/sync_latency.hip)
+struct QrHistory {
+  std::map<long, QrBackoff> by_shape;
+  int* h_word = nullptr;       // [0] flag, [1] sequence number
+  int* d_word = nullptr;
+  int tag = 0;
+  ~QrHistory() { if (h_word) (void)hipHostFree(h_word); }
+};
 QrHistory* qr_history_new() { return new QrHistory(); }
 void qr_history_free(QrHistory* h) { delete h; }
+
+__global__ void k_qr_publish_flag(const int* __restrict__ flag, int* __restrict__ dst, int tag) {
+  dst[0] = *flag;
+  __threadfence_system();
+  *reinterpret_cast<volatile int*>(dst + 1) = tag;
+}
+// the sticky failure flag of the fast panels, read on the host
+static int qr_read_flag(hipStream_t st, const int* dev_flag, QrHistory* hist) {
+  if (hist) {
+    if (!hist->h_word) {
+      HIP_CHECK(hipHostMalloc((void**)&hist->h_word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+      hist->h_word[0] = hist->h_word[1] = 0;
+      void* dp = nullptr;
+      HIP_CHECK(hipHostGetDevicePointer(&dp, hist->h_word, 0));
+      hist->d_word = static_cast<int*>(dp);
+    }
+    const int tag = ++hist->tag;
+    hipLaunchKernelGGL(k_qr_publish_flag, dim3(1), dim3(1), 0, st, dev_flag, hist->d_word, tag);
+    HIP_CHECK(hipGetLastError());
+    volatile int* w = hist->h_word;
+    for (long spins = 0; w[1] != tag; ++spins) {
+      if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(st) != hipErrorNotReady) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (w[1] != tag) throw HipError("qr: the verdict of the fast panels was not published");
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return w[0];
+  }
+  int bad = 0;
+  HIP_CHECK(hipMemcpyAsync(&bad, dev_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return bad;
+}
 
 size_t qr_work_elems(int m, int n, int next) {
   const int nblk = (m + 31) / 32;  // upper bound over all row-block sizes
@@ -855,9 +898,7 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     }
   }
   if (fast) {  // one look at the conditioning checks of all panels
-    int bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, fflag, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    const int bad = qr_read_flag(st, fflag, hist);
     if (bad) {
       if (hist) {
         QrBackoff& bo = hist->by_shape[bkey];
