@@ -255,6 +255,14 @@ def roofline_report(cnt, L, d, D, M, gemm_mode, el_s, profile_in_timed, tp=False
             "flops_per_apply": cnt["heff_flops"] / max(cnt["n_heff"], 1),
             "ms_per_apply": cnt["heff_ms"] / max(cnt["n_heff"], 1),
             "stage_ms_per_apply": [x / max(cnt["n_heff"], 1) for x in cnt["heff_stage_ms"]],
+            # the roofline of each stage's kernel by itself: what that stage executes (identity blocks trimmed, zero blocks
+            # skipped, tile padding counted; x 6 / 8 for the 3M product) over its own HIP-event time.  Stages 0 and 2 are
+            # the two large launches of zgemm_kernel (the dominant kernel); stage 1 is the block-sparse W stage (chain
+            # form) or the transpose (edge form)
+            "stage_executed_tflops": [f * (0.75 if gemm_mode == "3m" else 1.0) / max(ms, 1e-9) / 1e9
+                                      for f, ms in zip(cnt.get("heff_stage_flops", [0, 0, 0]), cnt["heff_stage_ms"])],
+            "dominant_kernel_frac": max([f * (0.75 if gemm_mode == "3m" else 1.0) / max(ms, 1e-9) / 1e9
+                                         for f, ms in zip(cnt.get("heff_stage_flops", [0, 0, 0]), cnt["heff_stage_ms"])][::2]) / FP64_MFMA_PEAK_TFLOPS,
             "n_apply": cnt["n_heff"],
             "complex_product": gemm_mode,
             "executed_share_of_algorithmic": done_share * (0.75 if gemm_mode == "3m" else 1.0),

@@ -65,11 +65,13 @@ class Counters(C.Structure):
         ("heff_flops_skipped", C.c_double),
         ("n_host_waits", C.c_double),
         ("reserved", C.c_double * 1),
+        ("heff_stage_flops", C.c_double * 3),
     ]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "heff_stage_ms")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "heff_stage_ms", "heff_stage_flops")}
         d["heff_stage_ms"] = list(self.heff_stage_ms)
+        d["heff_stage_flops"] = list(self.heff_stage_flops)
         return d
 
 

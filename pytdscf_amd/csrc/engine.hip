@@ -632,6 +632,9 @@ void Engine::heff_apply_rect(const zc* L, const MpoSite& w, const zc* R, const z
   cnt_.n_heff += 1;
   cnt_.heff_flops += 8.0 * ((double)na * dli * ml * d * dri + (double)na * dri * ml * mr * d * d + (double)na * dro * dri * mr * d);
   cnt_.heff_flops_skipped += 8.0 * (1.0 - s2_frac) * ((double)na * dri * ml * mr * d * d);
+  cnt_.heff_stage_flops[0] += 8.0 * (double)na * (triml ? ml - 1 : ml) * dli * d * dri;
+  cnt_.heff_stage_flops[1] += 8.0 * s2_frac * ((double)na * dri * ml * mr * d * d);
+  cnt_.heff_stage_flops[2] += 8.0 * (double)na * d * dro * (trim ? mr - 1 : mr) * dri;
 }
 
 // The apply for an edge-structured core between canonical environments (MpoSite::edge; L[:, 0, :] = R[:, mr-1, :] = 1,
@@ -657,6 +660,7 @@ void Engine::heff_apply_edge(const zc* L, const MpoSite& w, const zc* R, const z
     first = false;
     cnt_.n_launch += 1;
     exe += 8.0 * ((double)dl * d * dr * mr * dr + (double)dl * dr * d * d * mr);
+    cnt_.heff_stage_flops[2] += 8.0 * ((double)dl * d * dr * mr * dr + (double)dl * dr * d * d * mr);
   }
   if (w.edge_has_l) {
     timer_begin(11);
@@ -672,6 +676,7 @@ void Engine::heff_apply_edge(const zc* L, const MpoSite& w, const zc* R, const z
     first = false;
     cnt_.n_launch += 2;
     exe += 8.0 * ((double)dl * ml * dl * d * dr + (double)dl * dr * d * ml * d);
+    cnt_.heff_stage_flops[0] += 8.0 * ((double)dl * ml * dl * d * dr + (double)dl * dr * d * ml * d);
   }
   if (first) HIP_CHECK(hipMemsetAsync(out, 0, (size_t)dl * d * dr * sizeof(zc), st_));  // a zero core
   cnt_.n_heff += 1;
