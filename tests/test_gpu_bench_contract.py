@@ -99,6 +99,11 @@ def test_bench_driver_command_line_fits_its_wall_budget():
     assert abs(o["config"]["norm_after"] - 1) < 1e-10
     assert abs(o["config"]["energy_after"] - o["config"]["energy_before"]) < 1e-7 * max(1.0, abs(o["config"]["energy_before"]))
     assert o["roofline"]["traffic_source"] and o["roofline"]["traffic_source"].startswith("profiles/")
+    # the dominant kernel by itself: the two large launches of the apply, executed flop over their own HIP-event time
+    st = o["roofline"]["stage_executed_tflops"]
+    assert len(st) == 3 and 0 < st[0] <= 78.6 and 0 < st[2] <= 78.6
+    assert abs(o["roofline"]["dominant_kernel_frac"] - max(st[0], st[2]) / 78.6) < 1e-12
+    assert o["roofline"]["dominant_kernel_frac"] >= o["roofline"]["frac"] - 1e-12  # the whole apply cannot beat its best stage
     # the other BASELINE configs ride on the same line, driver-observed
     assert sorted(o["secondary"]) == ["C2", "C3", "C5"]
     for w in ("C2", "C3", "C5"):
