@@ -193,6 +193,16 @@ def cpu_model():
     return None
 
 
+def cpu_placement():
+    """what the CPU baseline ran on: CPUs this process may use (no pinning is applied: the BLAS threads float over them)"""
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+        return {"affinity_cpus": len(aff), "pinned": False,
+                "note": "not pinned to a socket: OpenBLAS runs its own thread pool (cores) over the CPUs the process may use"}
+    except (AttributeError, OSError):
+        return {"affinity_cpus": None, "pinned": False}
+
+
 def blas_threads():
     nthr = os.cpu_count() or 1
     try:  # the threads the BLAS behind NumPy actually runs (OpenBLAS caps at its build-time maximum)
@@ -407,6 +417,7 @@ def secondary_leg(name, device, gemm_mode, seconds, steps_req, with_cpu, note):
         rec["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, blas_threads(), dt, budget_s=6.0, short=True)
         rec["cpu_baseline"]["host_cpus"] = os.cpu_count()
         rec["cpu_baseline"]["cpu_model"] = cpu_model()
+        rec["cpu_baseline"].update(cpu_placement())
     rec["leg_s"] = time.perf_counter() - t_leg
     return rec
 
@@ -751,6 +762,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, blas_threads(), dt)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             out["cpu_baseline"]["cpu_model"] = cpu_model()
+            out["cpu_baseline"].update(cpu_placement())
         # ---- the other BASELINE configs, driver-observed: short single-GPU legs after the headline run ----
         if mode == "single" and args.secondary != "none":
             names = [w for w in ("C2", "C3", "C5") if w != args.workload] if args.secondary == "auto" else \

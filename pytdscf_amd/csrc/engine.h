@@ -88,6 +88,7 @@ struct MpoSite {
   mutable unsigned long long edge_s = 0, edge_e = 0;
   mutable std::vector<hzc> edge_lam, edge_mu;
   mutable bool edge_has_l = false, edge_has_r = false;
+  mutable int edge_skip = 0;        // local solves for which the (failed) structure check is not repeated
   mutable DevBuf w_edge_l, w_edge_r;
   DevBuf wtr;  // Liouville trace operator: O2[f][(a,c,d)] = O[a,d,c,f], n = sqrt(site dim)
   int ntr = 0, mltr = 0, mrtr = 0;

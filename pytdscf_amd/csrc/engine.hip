@@ -357,7 +357,7 @@ void Engine::upload_mpo_core(MpoSite& s, const double* reim, int ml, int dout, i
   sparse_form(w2l, mr, ml, s.w2lt, s.kl_l, s.kl_stride_l, s.sp_frac_l, s.seg_l);
   sparse_form(w2r, ml, mr, s.w2rt, s.kl_r, s.kl_stride_r, s.sp_frac_r, s.seg_r);
   // what the edge form of an apply needs (heff_apply_edge): the core itself and the map of its non-zero blocks
-  s.whost.clear(); s.nzblk.clear(); s.edge_valid = false;
+  s.whost.clear(); s.nzblk.clear(); s.edge_valid = false; s.edge_skip = 0;
   if (ml <= 64 && mr <= 64) {
     s.whost.assign(W, W + (size_t)ml * d * d * mr);
     s.nzblk.assign((size_t)ml * mr, 0);
@@ -698,6 +698,12 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
                          // the size rule: the epilogue streams the d x (d M) reduced core once per tile -- cheap beside a
                          // tile's K loop only while d M is small (measured: profiles/r04_edge_apply_ab.txt)
                          (edge_mode_ > 0 || ((long)d * std::max(ml, mr) <= 64 && (long)dl * dr <= 512L * 512L));
+  if (edge_cand && w.edge_skip > 0) {  // a core that failed the structure check recently: the plain checks, no look at all blocks
+    w.edge_skip -= 1;
+    identity_blocks(trim_identity_ && dl >= 256 && ml > 1 ? Lb : nullptr, dl, ml,
+                    trim_identity_ && dr >= 256 && mr > 1 ? Rb : nullptr, dr, mr, &trim_l_, &trim_r_);
+    return;
+  }
   if (!edge_cand) {
     identity_blocks(trim_identity_ && dl >= 256 && ml > 1 ? Lb : nullptr, dl, ml,
                     trim_identity_ && dr >= 256 && mr > 1 ? Rb : nullptr, dr, mr, &trim_l_, &trim_r_);
@@ -730,7 +736,10 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
   trim_r_ = mr > 1 && ((E >> (mr - 1)) & 1ull) && std::abs(mu[mr - 1] - 1.0) < 1e-13;
   for (int c = 0; c < ml; ++c)
     for (int t = 0; t < mr; ++t)
-      if (w.nzblk[(size_t)c * mr + t] && !((S >> c) & 1ull) && !((E >> t) & 1ull)) return;  // a block between general states
+      if (w.nzblk[(size_t)c * mr + t] && !((S >> c) & 1ull) && !((E >> t) & 1ull)) {  // a block between general states
+        w.edge_skip = 16;  // not an edge-structured core (or not between canonical blocks): ask again in a while
+        return;
+      }
   bool same = w.edge_valid && w.edge_s == S && w.edge_e == E;
   if (same) {  // the multiples are compared exactly: they are +-1 or weights that do not change along a run
     for (int c = 0; c < ml && same; ++c) if (((S >> c) & 1ull) && w.edge_lam[c] != lam[c]) same = false;
