@@ -309,6 +309,7 @@ class Engine {
   unsigned seq_tag_ = 0;
   // device-resident convergence logic of the multi-launch Krylov loop (krylov_dev.h)
   bool device_ritz_ = true;      // MITDVP_DEVICE_RITZ=0: Ritz step and test on the host (two round trips per checked iteration)
+  bool defer_norm_ = true;       // MITDVP_DEFER_NORM=0: a normalisation launch per Krylov vector (device path only)
   KryDev* kst_ = nullptr;
   KryPub* h_kpub_ = nullptr;     // host-coherent, mapped into the device: h_kpub_dev_
   KryPub* h_kpub_dev_ = nullptr;

@@ -29,6 +29,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (const char* e = std::getenv("MITDVP_TRIM_IDENTITY")) trim_identity_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_DEVICE_RITZ")) device_ritz_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_EDGE_APPLY")) edge_mode_ = std::atoi(e);
+  if (const char* e = std::getenv("MITDVP_DEFER_NORM")) defer_norm_ = std::atoi(e) != 0;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");

@@ -30,6 +30,8 @@ struct KryDev {  // device memory, one per engine
   double part[NPART];
   int have_prev, prev_len, k, state, need_diff;
   unsigned ticket;
+  int deferred;         // the stored basis is unnormalised: v_j = u_j * invb[j]
+  double invb[MAXK];
 };
 
 struct KryPub {  // host-coherent mapped memory
@@ -50,6 +52,8 @@ struct KryRitzArgs {
   int lanczos, first;
   zc scale;
   double eps;
+  int deferred;   // Lanczos on an unnormalised basis: alpha_p holds raw dots <x | H u_q>; orthodox: x = u_q
+  int orthodox;
 };
 
 void kry_ritz(hipStream_t st, const KryRitzArgs& a);

@@ -427,6 +427,18 @@ __global__ __launch_bounds__(SS_THREADS) void k_kry_ritz(KryRitzArgs a) {
   __threadfence_block();
   __syncthreads();
   if (tid == 0) {
+    st->deferred = a.deferred;
+    if (a.deferred) {  // unnormalised basis: invb_q = 1 / beta_{q-1} (1 below eps), alpha_q = invb_q (^2) * raw dot
+      if (a.first) st->invb[0] = 1.0;
+      for (int q = a.q0; q <= a.l; ++q) {
+        const double f = st->invb[q];
+        const double fa = a.orthodox ? f * f : f;
+        st->alpha[q].x *= fa;
+        st->alpha[q].y *= fa;
+        const double b = st->beta[q];
+        if (q + 1 < MAXK) st->invb[q + 1] = b >= a.eps ? 1.0 / b : 1.0;
+      }
+    }
     int ld = a.l, exhausted = 0;
     for (int q = a.q0; q <= a.l; ++q) {
       const double b = st->beta[q];
@@ -486,6 +498,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_kry_ritz(KryRitzArgs a) {
       if (have_prev) {
         zc d = c;
         if (tid < prev_len) { const zc o = st->cprev[tid]; d.x -= o.x; d.y -= o.y; }
+        if (a.deferred) { const double f = st->invb[tid]; d.x *= f; d.y *= f; }  // kry_diff combines the STORED vectors
         st->dcoef[tid] = d;
       } else {
         st->cprev[tid] = c;

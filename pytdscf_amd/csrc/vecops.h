@@ -19,6 +19,10 @@ void vec_dot(hipStream_t st, const zc* x, const zc* y, long n, bool conj_x, zc* 
 void vec_sumsq(hipStream_t st, const zc* x, long n, double* out_p /*[NPART]*/);
 void vec_lanczos_update(hipStream_t st, zc* v, const zc* vm1, const zc* vm2 /*nullable*/, long n,
                         const zc* alpha_p, const double* betaprev_p, double* out_p);
+// the three-term update on an UNNORMALISED basis (v: H u_l -> u_{l+1}); alpha_raw_p: partials of the raw dot <x | H u_l>,
+// nrm_all: [MAXK][NPART] partials of |u_{j+1}|^2; no separate normalisation launch follows (vecops.hip)
+void vec_lanczos_update_deferred(hipStream_t st, zc* v, const zc* ul, const zc* ulm1 /*nullable*/, long n, const zc* alpha_raw_p,
+                                 const double* nrm_all, int l, bool orthodox, double eps, double* out_p);
 // one Lanczos vector step (dot with x, three-term update, norm, normalisation) in one
 // single-workgroup launch; n <= SMALL_VEC_N; same partial layout as the three separate kernels
 void vec_lanczos_step_small(hipStream_t st, zc* w, const zc* x, const zc* vl, const zc* vm2 /*nullable*/, long n,

@@ -102,6 +102,54 @@ __global__ __launch_bounds__(256) void k_lanczos_update(zc* __restrict__ v, cons
   if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
+// The same update with DEFERRED normalisation: the basis is kept unnormalised, u_j, and v_j = u_j * invb_j is formed
+// where it is used (invb_0 = 1, invb_j = 1 / beta_{j-1}, or 1 when beta_{j-1} < eps: exactly the factor the separate
+// normalisation kernel would have applied, so v_j has the same bits wherever it is formed).  v holds H u_l on entry
+// (H is linear: H v_l = invb_l H u_l) and u_{l+1} on exit; one launch and one pass over the vector less per iteration.
+//   alpha_l = invb_l <v_0 | H u_l>  (reference form; orthodox: invb_l^2 <u_l | H u_l>),  nrm_all[j][.] = partials of |u_{j+1}|^2
+__global__ __launch_bounds__(256) void k_lanczos_update_def(zc* __restrict__ v, const zc* __restrict__ ul,
+                                                            const zc* __restrict__ ulm1, long n,
+                                                            const zc* __restrict__ alpha_raw_p,
+                                                            const double* __restrict__ nrm_all, int l, int orthodox,
+                                                            double eps, int np, double* __restrict__ out) {
+  __shared__ double sh[5];
+  double invb_l = 1.0, invb_lm1 = 1.0, beta_prev = 0.0;
+  if (l > 0) {
+    beta_prev = sqrt(sum_partials_d(nrm_all + (long)(l - 1) * np, np, sh));
+    if (beta_prev >= eps) invb_l = 1.0 / beta_prev;
+  }
+  if (l > 1) {
+    const double b2 = sqrt(sum_partials_d(nrm_all + (long)(l - 2) * np, np, sh));
+    if (b2 >= eps) invb_lm1 = 1.0 / b2;
+  }
+  zc alpha = sum_partials_z(alpha_raw_p, np, sh);
+  const double fa = orthodox ? invb_l * invb_l : invb_l;
+  alpha.x *= fa;
+  alpha.y *= fa;
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    zc x = v[i];
+    x.x *= invb_l;
+    x.y *= invb_l;
+    zc a = ul[i];
+    a.x *= invb_l;
+    a.y *= invb_l;
+    x.x -= alpha.x * a.x - alpha.y * a.y;
+    x.y -= alpha.x * a.y + alpha.y * a.x;
+    if (ulm1) {
+      zc c = ulm1[i];
+      c.x *= invb_lm1;
+      c.y *= invb_lm1;
+      x.x -= beta_prev * c.x;
+      x.y -= beta_prev * c.y;
+    }
+    v[i] = x;
+    s += x.x * x.x + x.y * x.y;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 // v /= sqrt(sum(nrm_p)) unless that norm is below eps (Krylov space exhausted,
 // _integrator.py:563-567, :254-256)
 __global__ __launch_bounds__(256) void k_scale_inv_norm(zc* __restrict__ v, long n,
@@ -200,7 +248,11 @@ __global__ __launch_bounds__(256) void k_lincomb(zc* __restrict__ out, const zc*
 // workgroup to one counter; the last arriver, told by the value its add returned, reads with sc1 loads.)
 __device__ __forceinline__ void kry_publish(const KryDev* st, KryPub* pub, unsigned tag) {
   const int k = st->k;
-  for (int j = 0; j < k; ++j) pub->coef[j] = st->coef[j];
+  for (int j = 0; j < k; ++j) {  // what the host combines the STORED vectors with (deferred normalisation: u_j = v_j / invb_j)
+    const zc c = st->coef[j];
+    const double f = st->deferred ? st->invb[j] : 1.0;
+    pub->coef[j] = make_double2(c.x * f, c.y * f);
+  }
   pub->beta0 = st->beta0;
   pub->err = st->err;
   pub->state = st->state;
@@ -571,6 +623,10 @@ void vec_sumsq(hipStream_t st, const zc* x, long n, double* out_p) { LAUNCH(k_su
 void vec_lanczos_update(hipStream_t st, zc* v, const zc* vm1, const zc* vm2, long n, const zc* alpha_p,
                         const double* betaprev_p, double* out_p) {
   LAUNCH(k_lanczos_update, NPART, st, v, vm1, vm2, n, alpha_p, betaprev_p, NPART, out_p);
+}
+void vec_lanczos_update_deferred(hipStream_t st, zc* v, const zc* ul, const zc* ulm1, long n, const zc* alpha_raw_p,
+                                 const double* nrm_all, int l, bool orthodox, double eps, double* out_p) {
+  LAUNCH(k_lanczos_update_def, NPART, st, v, ul, ulm1, n, alpha_raw_p, nrm_all, l, orthodox ? 1 : 0, eps, NPART, out_p);
 }
 void vec_lanczos_step_small(hipStream_t st, zc* w, const zc* x, const zc* vl, const zc* vm2, long n, zc* alpha_p,
                             const double* betaprev_p, double* nrm_p, double eps) {
