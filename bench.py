@@ -646,9 +646,9 @@ def main():
         more, steps = plan_sweeps(budget, comm.max_over_ranks(elapsed()), t_sweep, warm_done, warm_target, steps_req, reserve)
         more, steps = (more // unit) * unit, max(unit, (steps // unit) * unit)
         warm_target = warm_done + more
-    if mode == "single" and t_sweep > 10.0 and (warm_done + steps) % 2 == 1 and steps > 1:
+    if mode == "single" and t_sweep > 10.0 and (warm_done + steps) % 2 == 1 and steps >= 4:
         # the energy after the run is read with the centre back at site 0, i.e. after an even number of sweeps: with
-        # minute-long sweeps one timed sweep less is cheaper than an extra untimed one
+        # minute-long sweeps one timed sweep less (of four or more) is cheaper than an extra untimed one
         steps -= 1
     if steps != args.steps or warm_done != args.warmup:
         note(f"wall budget {budget:.0f}s: running {warm_done} warm-up + {steps} timed sweeps "
@@ -699,9 +699,10 @@ def main():
         nrm = ss.norm()
         e1 = ss.expectation().real
     elif mode == "single":  # energy conservation of the run itself (a fresh chain of right blocks; not timed)
-        if not state["forward"]:  # an odd number of sweeps so far: the centre sits at the last site; bring it home
-            run_unit()
-        e1 = eng.expectation().real
+        if not state["forward"] and t_sweep <= 10.0:  # an odd number of sweeps so far: the centre sits at the last site
+            run_unit()  # cheap sweeps: bring it home
+        # (minute-long sweeps and an odd count that could not be made even: no energy_after rather than an untimed minute)
+        e1 = eng.expectation().real if state["forward"] else None
 
     if rank == 0:
         roof, brk, kh, kk = roofline_report(cnt, L, d, D, M, gemm_mode, el, profile_in_timed, tp=(mode == "tp"))
