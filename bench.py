@@ -342,6 +342,15 @@ def ensemble_leg(name, device, n_steps):
     return out
 
 
+def energy_at_centre(eng):
+    """<Psi|H|Psi> = <psi_c | H_eff psi_c> at the centre site, through the sweep's own apply kernels and the environment
+    blocks the last sweep left around the centre (valid at either end of the chain; `expectation` rebuilds a whole chain
+    of right blocks and wants the centre at site 0 like the reference's, _mps_cls.py:540-612)."""
+    sig, _ = eng.heff_apply_center()
+    c = next(p for p in range(eng.nsite) if eng.get_site_shape(p)[3] == 0)
+    return float(np.vdot(eng.get_site(c), sig).real)
+
+
 def secondary_leg(name, device, gemm_mode, seconds, steps_req, with_cpu, note):
     """One short single-GPU run of another BASELINE config after the headline one: the same measurement (warm-up, timed
     sweeps between synchronisations, counters -> roofline / breakdown, the oracle on the host cores), a few seconds of
@@ -394,7 +403,7 @@ def secondary_leg(name, device, gemm_mode, seconds, steps_req, with_cpu, note):
             eng.norm()
         cnt = eng.counters()
         eng.set_profiling(False)
-        e1 = eng.expectation().real
+        e1 = energy_at_centre(eng)
         roof, brk, kh, kk = roofline_report(cnt, L, d, D, M, gemm_mode, el, profile_in_timed)
         rec = {
             "workload": f"{name}: {desc}",
@@ -646,10 +655,6 @@ def main():
         more, steps = plan_sweeps(budget, comm.max_over_ranks(elapsed()), t_sweep, warm_done, warm_target, steps_req, reserve)
         more, steps = (more // unit) * unit, max(unit, (steps // unit) * unit)
         warm_target = warm_done + more
-    if mode == "single" and t_sweep > 10.0 and (warm_done + steps) % 2 == 1 and steps >= 4:
-        # the energy after the run is read with the centre back at site 0, i.e. after an even number of sweeps: with
-        # minute-long sweeps one timed sweep less (of four or more) is cheaper than an extra untimed one
-        steps -= 1
     if steps != args.steps or warm_done != args.warmup:
         note(f"wall budget {budget:.0f}s: running {warm_done} warm-up + {steps} timed sweeps "
              f"(requested {args.warmup} + {args.steps})")
@@ -699,10 +704,7 @@ def main():
         nrm = ss.norm()
         e1 = ss.expectation().real
     elif mode == "single":  # energy conservation of the run itself (a fresh chain of right blocks; not timed)
-        if not state["forward"] and t_sweep <= 10.0:  # an odd number of sweeps so far: the centre sits at the last site
-            run_unit()  # cheap sweeps: bring it home
-        # (minute-long sweeps and an odd count that could not be made even: no energy_after rather than an untimed minute)
-        e1 = eng.expectation().real if state["forward"] else None
+        e1 = energy_at_centre(eng)  # wherever the centre sits (first or last site), from the blocks the sweep left behind
 
     if rank == 0:
         roof, brk, kh, kk = roofline_report(cnt, L, d, D, M, gemm_mode, el, profile_in_timed, tp=(mode == "tp"))
