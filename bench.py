@@ -420,7 +420,10 @@ def secondary_leg(name, device, gemm_mode, seconds, steps_req, with_cpu, note):
     if D < 128 and seconds - (time.perf_counter() - t_leg) > 10.0:
         # small-bond regime: the data-parallel axis is the ensemble of trajectories: B replicas on
         # disjoint compute-unit ranges, one library call per batch of time steps (mitdvp_ensemble_step)
-        rec["ensemble"] = ensemble_leg(name, device, n_steps=max(10, steps // 2))
+        try:
+            rec["ensemble"] = ensemble_leg(name, device, n_steps=max(10, steps // 2))
+        except Exception as e:  # noqa: BLE001 -- the single-engine record stands on its own
+            rec["ensemble"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:
         note(f"{name}: timing the CPU baseline (oracle on the host cores)")
         rec["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, blas_threads(), dt, budget_s=6.0, short=True)

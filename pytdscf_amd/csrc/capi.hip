@@ -145,15 +145,24 @@ int mitdvp_ensemble_step(mitdvp_engine** hs, int n, double dt, int nsteps, int* 
   std::vector<int> rc((size_t)n, MITDVP_OK);
   std::vector<std::thread> th;
   th.reserve((size_t)n);
-  for (int i = 0; i < n; ++i)
-    th.emplace_back([&, i] {
-      mitdvp_engine* h = hs[i];
-      rc[(size_t)i] = guard(h, [&] {
-        for (int s = 0; s < nsteps; ++s) h->e->step(dt);
-        h->e->check_device_errors();
-        HIP_CHECK(hipStreamSynchronize(h->e->stream()));
-      });
+  auto run = [&](int i) {
+    mitdvp_engine* h = hs[i];
+    rc[(size_t)i] = guard(h, [&] {
+      for (int s = 0; s < nsteps; ++s) h->e->step(dt);
+      h->e->check_device_errors();
+      HIP_CHECK(hipStreamSynchronize(h->e->stream()));
     });
+  };
+  for (int i = 0; i < n; ++i) {
+    try {
+      th.emplace_back(run, i);
+    } catch (const std::exception&) {  // no more host threads: this replica runs on the caller's thread, after the others
+      for (auto& t : th) t.join();
+      th.clear();
+      for (int k = i; k < n; ++k) run(k);
+      break;
+    }
+  }
   for (auto& t : th) t.join();
   int first = MITDVP_OK;
   for (int i = 0; i < n; ++i) {

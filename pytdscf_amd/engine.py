@@ -708,7 +708,13 @@ class TDVPEnsemble:
         if per < 8:
             raise ValueError(f"{n_replicas} replicas do not fit {n_cu} compute units (8 per replica at least)")
         self.cu_per_replica = per
-        self.engines = [TDVPEngine(nsite, device=device, cu_range=(r * per, per), **engine_kw) for r in range(n_replicas)]
+        self.engines = []
+        try:
+            for r in range(n_replicas):
+                self.engines.append(TDVPEngine(nsite, device=device, cu_range=(r * per, per), **engine_kw))
+        except Exception:
+            self.close()
+            raise
         self._lib = _lib.load()
 
     def __len__(self):
