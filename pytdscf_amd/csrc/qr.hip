@@ -354,7 +354,10 @@ __global__ __launch_bounds__(256) void k_qr_extract_r(const zc* __restrict__ A, 
 // ---------------------------------------------------------------------------
 template <int RPT>
 __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int n, zc* __restrict__ R,
-                                                  zc* __restrict__ Wout, long long* __restrict__ trace) {
+                                                  zc* __restrict__ Wout, long long* __restrict__ trace,
+                                                  const int* __restrict__ run_if, zc* __restrict__ Qout) {
+  // queued behind the one-workgroup CholeskyQR2 (qr_fast.hip): runs only when that one's conditioning checks failed
+  if (run_if && *run_if == 0) return;
   // debugging (MITDVP_QR_TRACE): thread 0 stamps s_memrealtime (10 ns ticks) at the phase boundaries of every step
   auto stamp = [&](int j, int k) __attribute__((always_inline)) { if (trace && threadIdx.x == 0) trace[j * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime(); };
   constexpr int NRG = 16, NW = 8;  // 16 row groups x 32 columns = 512 threads: 256 registers per thread
@@ -467,6 +470,20 @@ __global__ __launch_bounds__(512) void k_qr_small(zc* __restrict__ A, int m, int
       Wout[(long)t * n + c] = wv;
     }
   }
+  if (Qout) {  // the fallback forms Q here (k_qr_small_q's sum with V read back from the factored A)
+    __threadfence_block();
+    __syncthreads();
+    for (int e = tid; e < m * n; e += 512) {
+      const int i = e / n, cc = e - i * n;
+      zc acc = make_double2(i == cc ? 1.0 : 0.0, 0.0);
+      const int smax = min(i, n - 1);
+      for (int sI = 0; sI <= smax; ++sI) {
+        const zc v = i == sI ? make_double2(1.0, 0.0) : A[(long)i * n + sI];
+        acc = zsub(acc, zmul(v, Ws[sI][cc]));
+      }
+      Qout[e] = acc;
+    }
+  }
 }
 
 
@@ -488,20 +505,34 @@ __global__ __launch_bounds__(256) void k_qr_small_q(const zc* __restrict__ A, in
 }
 
 // work: n x n complex (W).  Returns the number of launches, 0 when the shape does not qualify.
-static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work) {
+// qr_fast.hip: the one-workgroup CholeskyQR2 of a small matrix
+void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* Q1, int* fail);
+
+static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, bool fast) {
   if (n > 32 || m > 320) return 0;
   const int rpt = (m + 15) / 16;
+  // MITDVP_QR_SMALL_FAST=0: the per-column Householder kernel only (A/B runs)
+  static const bool sf_on = !(std::getenv("MITDVP_QR_SMALL_FAST") && std::atoi(std::getenv("MITDVP_QR_SMALL_FAST")) == 0);
+  // work: [0, 1024) W of the Householder kernel, [1024, 1024 + 32 m) the first round's Q, then the verdict word
+  const int* run_if = nullptr;
+  zc* q_in_kernel = nullptr;
+  if (fast && sf_on && Q) {
+    int* fail = reinterpret_cast<int*>(work + 1024 + (size_t)32 * m);
+    qr_small_fast_launch(st, A, m, n, Q, R, work + 1024, fail);
+    run_if = fail;
+    q_in_kernel = Q;
+  }
   static const bool tracing = std::getenv("MITDVP_QR_TRACE") != nullptr;
   static long long* trace = nullptr;
   if (tracing && !trace) {
     HIP_CHECK(hipMalloc(&trace, 1024 * sizeof(long long)));
     HIP_CHECK(hipMemset(trace, 0, 1024 * sizeof(long long)));
   }
-  if (rpt <= 2) hipLaunchKernelGGL(k_qr_small<2>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
-  else if (rpt <= 4) hipLaunchKernelGGL(k_qr_small<4>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
-  else if (rpt <= 8) hipLaunchKernelGGL(k_qr_small<8>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
-  else if (rpt <= 12) hipLaunchKernelGGL(k_qr_small<12>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
-  else hipLaunchKernelGGL(k_qr_small<20>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace);
+  if (rpt <= 2) hipLaunchKernelGGL(k_qr_small<2>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace, run_if, q_in_kernel);
+  else if (rpt <= 4) hipLaunchKernelGGL(k_qr_small<4>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace, run_if, q_in_kernel);
+  else if (rpt <= 8) hipLaunchKernelGGL(k_qr_small<8>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace, run_if, q_in_kernel);
+  else if (rpt <= 12) hipLaunchKernelGGL(k_qr_small<12>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace, run_if, q_in_kernel);
+  else hipLaunchKernelGGL(k_qr_small<20>, dim3(1), dim3(512), 0, st, A, m, n, R, work, trace, run_if, q_in_kernel);
   if (tracing) {  // mean duration of the phases of a column step (10 ns ticks -> us)
     long long h[1024];
     HIP_CHECK(hipMemcpyAsync(h, trace, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -514,7 +545,7 @@ static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc
     for (int k = 0; k + 1 < np; ++k) fprintf(stderr, " %.2f", ph[k]);
     fprintf(stderr, "\n");
   }
-  if (Q) hipLaunchKernelGGL(k_qr_small_q, dim3((m + 7) / 8), dim3(256), 0, st, A, m, n, work, Q);
+  if (Q && !q_in_kernel) hipLaunchKernelGGL(k_qr_small_q, dim3((m + 7) / 8), dim3(256), 0, st, A, m, n, work, Q);
   HIP_CHECK(hipGetLastError());
   return Q ? 2 : 1;
 }
@@ -776,7 +807,7 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     }
   }
   if (next == 0 && small_on) {  // factorisation in one launch (matrix in registers), Q in a second
-    const int nls = qr_small_launch(st, A, m, n, Q, R, work);
+    const int nls = qr_small_launch(st, A, m, n, Q, R, work, fast);
     if (nls) {
       if (nlaunch) *nlaunch += nls;
       return;

@@ -15,6 +15,7 @@
 // and the caller redoes the factorisation with the per-column Householder kernels (qr.hip), which are unconditionally
 // stable.  One flag read per QR, no host round trip per panel.
 #include <cstdlib>
+#include <mutex>
 
 #include "qr.h"
 #include "vecops.h"
@@ -414,5 +415,357 @@ int qr_fast_panel(hipStream_t st, zc* A, long lda, int m, int j0, int nbp, zc* V
   HIP_CHECK(hipGetLastError());
   return nl;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole factorisation of a SMALL matrix (m <= 320, n <= 32: the gauge moves of the small-bond regime, C2's 320 x 32)
+// in ONE workgroup: CholeskyQR2 with the two Gram matrices and the two triangular applies on the matrix cores, and
+// LAPACK's signs recovered by the LU chain of the reconstruction (only D is needed: Q' = Q D, R' = D R -- the caller of the
+// thin factorisation never sees V, T or tau).  The per-column Householder kernel of qr.hip spends 4.3 us per column on
+// two workgroup barriers and the reflector's scalar chain, 137 us for 320 x 32; here the only chains left are the 32
+// Cholesky pivots and the 32 LU pivots on a 32 x 32 matrix in LDS (the inverse of the triangular factor is built by
+// recursive doubling: 5 levels of small products instead of 31 substitution steps).
+//   Gram:   wave (row quarter, half) accumulates three of the six real streams {00re, 00im, 01re | 01im, 11re, 11im} of
+//           the 2 x 2 blocks of 16 x 16 with v_mfma_f64_16x16x4_f64 straight from global loads in operand layout
+//           (lane: row 4 s + lane / 16, column lane % 16); the four quarter partials are summed in a fixed order.
+//   apply:  each wave owns 16-row blocks (w, w + 8, w + 16); A-operand from global (lane: row lane % 16, column
+//           4 s + lane / 16), B-operand = the triangular inverse from LDS, kept in registers over the wave's blocks.
+// A failed conditioning check (same thresholds as the panels above) sets *fail and leaves Q / R untouched: the caller
+// has queued the Householder kernel behind this one, which runs only then.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int SF_T = 512;
+typedef double sf_d4 __attribute__((ext_vector_type(4)));
+
+struct SfSmem {
+  zc G[NB][NB + 1];   // Gram matrix -> R (upper)
+  zc W[NB][NB + 1];   // R^-1
+  zc P1[NB][NB + 1];  // R1, then R2 R1
+  zc Qt[NB][NB + 1];  // scratch of the inverse; then the top block of Q for the LU chain
+  double pb[4][6][4][64];  // Gram partials [row quarter][stream][accumulator register][lane]
+  double d0[NB];
+  double Dg[NB];
+  double emax[SF_T / 64];
+};
+
+__device__ __forceinline__ sf_d4 sf_mfma(double a, double b, sf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// G = src^H src (upper triangle), padded with the identity beyond n; W = I; d0 = diag
+__device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSmem& S, int cd_mode) {
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+  const int rq = w >> 1, half = w & 1;
+  const int nks = (m + 3) / 4, per = (nks + 3) / 4;
+  const int s0 = rq * per, s1 = min(nks, s0 + per);
+  sf_d4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = (sf_d4){0.0, 0.0, 0.0, 0.0};
+  for (int s = s0; s < s1; s += 4) {
+    zc x0[4], x1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = 4 * (s + u) + lk;
+      const bool ok = (s + u < s1) && row < m;
+      x0[u] = (ok && li < n) ? src[(long)row * ld + li] : make_double2(0.0, 0.0);
+      x1[u] = (ok && li + 16 < n) ? src[(long)row * ld + 16 + li] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (half == 0) {
+        acc[0] = sf_mfma(x0[u].x, x0[u].x, acc[0]);  acc[0] = sf_mfma(x0[u].y, x0[u].y, acc[0]);   // 00 re
+        acc[1] = sf_mfma(x0[u].x, x0[u].y, acc[1]);  acc[1] = sf_mfma(-x0[u].y, x0[u].x, acc[1]);  // 00 im
+        acc[2] = sf_mfma(x0[u].x, x1[u].x, acc[2]);  acc[2] = sf_mfma(x0[u].y, x1[u].y, acc[2]);   // 01 re
+      } else {
+        acc[0] = sf_mfma(x0[u].x, x1[u].y, acc[0]);  acc[0] = sf_mfma(-x0[u].y, x1[u].x, acc[0]);  // 01 im
+        acc[1] = sf_mfma(x1[u].x, x1[u].x, acc[1]);  acc[1] = sf_mfma(x1[u].y, x1[u].y, acc[1]);   // 11 re
+        acc[2] = sf_mfma(x1[u].x, x1[u].y, acc[2]);  acc[2] = sf_mfma(-x1[u].y, x1[u].x, acc[2]);  // 11 im
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S.pb[rq][half * 3 + t][r][l] = acc[t][r];
+  __syncthreads();
+  const int j = tid & 31, i0 = tid >> 5;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = i0 + 16 * q;
+    zc g = make_double2(0.0, 0.0);
+    if (j >= i) {
+      const int blk = (i >> 4) + (j >> 4), ii = i & 15, jj = j & 15;
+      const int lk_ = cd_mode == 0 ? (ii & 3) : (ii >> 2), r_ = cd_mode == 0 ? (ii >> 2) : (ii & 3);
+      const int ln = lk_ * 16 + jj;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { g.x += S.pb[p][2 * blk][r_][ln]; g.y += S.pb[p][2 * blk + 1][r_][ln]; }
+    }
+    if (i >= n || j >= n) g = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+    if (i == j) { g.y = 0.0; S.d0[i] = g.x; }
+    S.G[i][j] = g;
+  }
+  __syncthreads();
+}
+
+// G (upper) -> its Cholesky factor R (upper, real positive diagonal); d0 <- 1 / diag(R).  Returns true (uniformly) when
+// a pivot fails the conditioning check.
+__device__ bool sf_chol(SfSmem& S, bool second) {
+  const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
+  for (int k = 0; k < NB; ++k) {
+    const double d = S.G[k][k].x;
+    const bool ok = second ? (d > 0.5 && d < 2.0) : (d > CHOL_TOL * S.d0[k] && S.d0[k] > 0.0);
+    if (!ok) return true;  // uniform: every thread read the same words
+    const double id = fast_rcp(d);
+    const zc gkj = S.G[k][j];
+    const zc sc = make_double2(gkj.x * id, gkj.y * id);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = i0 + 16 * q;
+      if (i > k && j >= i) S.G[i][j] = csub(S.G[i][j], cmulc(S.G[k][i], sc));
+    }
+    __syncthreads();
+  }
+  zc r[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = i0 + 16 * q;
+    const double dd = S.G[i][i].x;
+    const double is = 1.0 / sqrt(dd);
+    r[q] = j > i ? make_double2(S.G[i][j].x * is, S.G[i][j].y * is) : (j == i ? make_double2(dd * is, 0.0) : make_double2(0.0, 0.0));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) S.G[i0 + 16 * q][j] = r[q];
+  __syncthreads();
+  return false;
+}
+
+// W = G^-1 for the upper-triangular G by recursive doubling: the inverse of [[R00, R01], [0, R11]] is
+// [[R00^-1, -R00^-1 R01 R11^-1], [0, R11^-1]]; 5 levels, two small products each (Qt is the scratch).
+__device__ void sf_tri_inverse(SfSmem& S) {
+  const int tid = threadIdx.x, j = tid & 31, i0 = tid >> 5;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = i0 + 16 * q;
+    S.W[i][j] = i == j ? make_double2(1.0 / S.G[i][i].x, 0.0) : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  for (int b = 1; b < NB; b <<= 1) {
+    const int ne = 16 * b;  // (NB / 2b) pairs x b x b elements
+    int ii = 0, jj = 0, c0 = 0;
+    if (tid < ne) {
+      const int p = tid / (b * b), rem = tid - p * b * b;
+      ii = rem / b; jj = rem - ii * b; c0 = p * 2 * b;
+      zc t = make_double2(0.0, 0.0);
+      for (int k = 0; k <= jj; ++k) t = cadd(t, cmul(S.G[c0 + ii][c0 + b + k], S.W[c0 + b + k][c0 + b + jj]));
+      S.Qt[c0 + ii][c0 + b + jj] = t;
+    }
+    __syncthreads();
+    if (tid < ne) {
+      zc x = make_double2(0.0, 0.0);
+      for (int k = ii; k < b; ++k) x = csub(x, cmul(S.W[c0 + ii][c0 + k], S.Qt[c0 + k][c0 + b + jj]));
+      S.W[c0 + ii][c0 + b + jj] = x;
+    }
+    __syncthreads();
+  }
+}
+
+// (rows of this wave's 16-row blocks) x W: results stay in qre / qim (accumulator layout: lane (li, lk) holds rows
+// cd_row(lk, r), column li of either column block); DST: also written to dst (ld = NB)
+template <bool DST>
+__device__ __forceinline__ void sf_apply(const zc* __restrict__ src, long ld, int m, int ncol, const SfSmem& S, int cd_mode,
+                                         zc* __restrict__ dst, sf_d4 (&qre)[3][2], sf_d4 (&qim)[3][2]) {
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+  zc b0[4], b1[8];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) b0[s] = S.W[4 * s + lk][li];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) b1[s] = S.W[4 * s + lk][16 + li];
+#pragma unroll
+  for (int bl = 0; bl < 3; ++bl) {
+    const int blk = w + 8 * bl;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) { qre[bl][cb] = (sf_d4){0.0, 0.0, 0.0, 0.0}; qim[bl][cb] = (sf_d4){0.0, 0.0, 0.0, 0.0}; }
+    if (blk * 16 >= m) continue;  // wave-uniform
+    const int row = blk * 16 + li;
+    zc a[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) a[s] = (row < m && 4 * s + lk < ncol) ? src[(long)row * ld + 4 * s + lk] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qre[bl][0] = sf_mfma(a[s].x, b0[s].x, qre[bl][0]);  qre[bl][0] = sf_mfma(-a[s].y, b0[s].y, qre[bl][0]);
+      qim[bl][0] = sf_mfma(a[s].x, b0[s].y, qim[bl][0]);  qim[bl][0] = sf_mfma(a[s].y, b0[s].x, qim[bl][0]);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      qre[bl][1] = sf_mfma(a[s].x, b1[s].x, qre[bl][1]);  qre[bl][1] = sf_mfma(-a[s].y, b1[s].y, qre[bl][1]);
+      qim[bl][1] = sf_mfma(a[s].x, b1[s].y, qim[bl][1]);  qim[bl][1] = sf_mfma(a[s].y, b1[s].x, qim[bl][1]);
+    }
+    if (DST) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = blk * 16 + (cd_mode == 0 ? lk + 4 * r : 4 * lk + r);
+          if (orow < m) dst[(long)orow * NB + 16 * cb + li] = make_double2(qre[bl][cb][r], qim[bl][cb][r]);
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A, int m, int n, zc* __restrict__ Q, zc* __restrict__ R,
+                                                        zc* __restrict__ Q1, int cd_mode, int* __restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) char sf_raw[];
+  SfSmem& S = *reinterpret_cast<SfSmem*>(sf_raw);
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+  const int j = tid & 31, i0 = tid >> 5;
+  sf_d4 qre[3][2], qim[3][2];
+  // ---- round 1 ----
+  sf_gram(A, n, m, n, S, cd_mode);
+  if (sf_chol(S, false)) { if (tid == 0) *fail = 1; return; }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) S.P1[i0 + 16 * q][j] = S.G[i0 + 16 * q][j];  // R1 (zero below the diagonal)
+  sf_tri_inverse(S);
+  sf_apply<true>(A, n, m, n, S, cd_mode, Q1, qre, qim);
+  __threadfence_block();
+  __syncthreads();
+  // ---- round 2 ----
+  sf_gram(Q1, NB, m, n, S, cd_mode);
+  {
+    // G = I + E: to first order chol(I + E) = I + U, U = triu(E, 1) + diag(E) / 2, (I + U)^-1 = I - U (see k_fq_chol)
+    double e = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = i0 + 16 * q;
+      if (j >= i) {
+        const zc g = S.G[i][j];
+        const double v = fmax(fabs(g.x - (i == j ? 1.0 : 0.0)), fabs(g.y));
+        e = (g.x != g.x || g.y != g.y) ? 1e308 : fmax(e, v);  // fmax drops a NaN: keep it visible
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e = fmax(e, __shfl_xor(e, o, 64));
+    if (l == 0) S.emax[w] = e;
+    __syncthreads();
+    double emax = 0.0;
+#pragma unroll
+    for (int u = 0; u < SF_T / 64; ++u) emax = fmax(emax, S.emax[u]);
+    zc rt[2];
+    if (emax < 1e-8) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = i0 + 16 * q;
+        const zc g = S.G[i][j];
+        const zc u = j > i ? g : (j == i ? make_double2(0.5 * (g.x - 1.0), 0.0) : make_double2(0.0, 0.0));
+        S.Qt[i][j] = u;
+        S.W[i][j] = make_double2((i == j ? 1.0 : 0.0) - u.x, -u.y);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = i0 + 16 * q;
+        zc t = S.P1[i][j];  // (I + U) R1
+        for (int k = i; k <= j; ++k) t = cadd(t, cmul(S.Qt[i][k], S.P1[k][j]));
+        rt[q] = t;
+      }
+    } else {
+      if (!(emax < 1e300)) { if (tid == 0) *fail = 1; return; }  // NaN / overflow in the first round
+      if (sf_chol(S, true)) { if (tid == 0) *fail = 1; return; }
+      sf_tri_inverse(S);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = i0 + 16 * q;
+        zc t = make_double2(0.0, 0.0);
+        for (int k = i; k <= j; ++k) t = cadd(t, cmul(S.G[i][k], S.P1[k][j]));
+        rt[q] = t;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) S.P1[i0 + 16 * q][j] = rt[q];  // R2 R1
+    __syncthreads();
+  }
+  sf_apply<false>(Q1, NB, m, NB, S, cd_mode, nullptr, qre, qim);
+  // top block -> LDS for the sign chain (rows / columns beyond n: identity)
+  if (w < 2) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = w * 16 + (cd_mode == 0 ? lk + 4 * r : 4 * lk + r), col = 16 * cb + li;
+        S.Qt[row][col] = (row < n && col < n) ? make_double2(qre[0][cb][r], qim[0][cb][r])
+                                              : (row == col ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0));
+      }
+  }
+  __syncthreads();
+  // ---- LAPACK's signs: LU of (Q - [D; 0]) with D_k = -sign(Re pivot_k) (k_fq_reconstruct's first chain) ----
+  for (int k = 0; k < NB; ++k) {
+    const zc piv = S.Qt[k][k];
+    const double dk = piv.x >= 0.0 ? -1.0 : 1.0;
+    const zc u = make_double2(piv.x - dk, piv.y);
+    const double un = u.x * u.x + u.y * u.y;
+    if (!(un > 0.25)) { if (tid == 0) *fail = 1; return; }  // uniform
+    if (tid == 0) S.Dg[k] = dk;
+    const double iun = fast_rcp(un);
+    const zc iu = make_double2(u.x * iun, -u.y * iun);
+    const zc qkj = S.Qt[k][j];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = i0 + 16 * q;
+      if (i > k && j > k) S.Qt[i][j] = csub(S.Qt[i][j], cmul(cmul(S.Qt[i][k], iu), qkj));
+    }
+    __syncthreads();
+  }
+  // ---- Q' = Q D, R' = D R ----
+  if (Q) {
+#pragma unroll
+    for (int bl = 0; bl < 3; ++bl) {
+      const int blk = w + 8 * bl;
+      if (blk * 16 >= m) continue;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int col = 16 * cb + li;
+        const double dc = S.Dg[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = blk * 16 + (cd_mode == 0 ? lk + 4 * r : 4 * lk + r);
+          if (row < m && col < n) Q[(long)row * n + col] = make_double2(dc * qre[bl][cb][r], dc * qim[bl][cb][r]);
+        }
+      }
+    }
+  }
+  if (R) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = i0 + 16 * q;
+      if (i < n && j < n) {
+        const zc r = S.P1[i][j];
+        const double di = S.Dg[i];
+        R[(long)i * n + j] = j >= i ? make_double2(di * r.x, di * r.y) : make_double2(0.0, 0.0);
+      }
+    }
+  }
+  if (tid == 0) *fail = 0;
+}
+}  // namespace
+
+size_t qr_small_fast_lds() { return sizeof(SfSmem); }
+
+// Q1: m x 32 scratch, fail: one word.  Always queues the launch; the caller queues the conditional Householder kernel.
+void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* Q1, int* fail) {
+  static std::mutex mu;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qr_small_fast), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(SfSmem)));
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+  }
+  const int cd_mode = zgemm_cd_mode(st);
+  hipLaunchKernelGGL(k_qr_small_fast, dim3(1), dim3(SF_T), sizeof(SfSmem), st, A, m, n, Q, R, Q1, cd_mode, fail);
+  HIP_CHECK(hipGetLastError());
+}
+
 
 }  // namespace mitdvp

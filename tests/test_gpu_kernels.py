@@ -226,6 +226,75 @@ def test_qr_panels_by_cholesky_qr2_and_householder_reconstruction(shape):
         assert np.abs(B - res[False][1][0]).max() < 1e-12
 
 
+@pytest.mark.parametrize("shape", [(32, 10, 32), (10, 10, 20), (16, 2, 32), (8, 4, 32), (1, 5, 3), (32, 10, 1), (7, 3, 17),
+                                   (20, 16, 31), (3, 1, 3)])
+def test_small_qr_in_one_workgroup(shape):
+    """Gauge moves of the small-bond regime (m <= 320, n <= 32; csrc/qr_fast.hip::k_qr_small_fast): CholeskyQR2 with the
+    Gram matrices and applies on the matrix cores in ONE workgroup, LAPACK's signs of diag(R) from the LU chain of the
+    Householder reconstruction.  Q and R must equal scipy's (_site_cls.py:264-282) like the per-column Householder kernel
+    they replace, and agree with that kernel far below the tolerance."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import engine as E
+
+    dl, d, dr = shape
+    rng = np.random.default_rng(1000 * dl + 10 * d + dr)
+    psi = crandn(rng, dl, d, dr)
+    res = {}
+    for fast in (True, False):
+        E.set_qr_fast(fast)
+        try:
+            res[fast] = E.gauge_trf(psi, "Psi2Asigma")
+        finally:
+            E.set_qr_fast(True)
+    A, s = res[True]
+    Ar, sr = orc.qr_psi2Asigma(psi)
+    np.testing.assert_allclose(A, Ar, atol=1e-11)
+    np.testing.assert_allclose(s, sr, atol=1e-11 * np.abs(sr).max())
+    Am = A.reshape(dl * d, dr)
+    assert np.abs(Am.conj().T @ Am - np.eye(dr)).max() < 1e-14 * max(dr, 4)
+    assert np.abs(np.tensordot(A, s, axes=(2, 0)) - psi).max() < 1e-13 * np.abs(psi).max() * max(dr, 4)
+    assert np.abs(np.tril(s, -1)).max() == 0.0 and np.abs(np.diag(s).imag).max() == 0.0
+    assert np.abs(A - res[False][0]).max() < 1e-12 and np.abs(s - res[False][1]).max() < 1e-12 * np.abs(sr).max()
+
+
+def test_small_qr_falls_back_on_rank_deficient_graded_and_nonfinite_input():
+    """The one-workgroup CholeskyQR2 must hand zero-padded product states and strongly graded tensors to the Householder
+    kernel queued behind it (no host decision in between), and its verdict must not leak into the next factorisation."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import engine as E
+
+    psi = np.zeros((16, 4, 16), dtype=np.complex128)
+    psi[0, :, 0] = [0.5, 0.5, 0.5, 0.5]
+    rng = np.random.default_rng(3)
+    good = crandn(rng, 16, 4, 16)
+    for _ in range(2):
+        A, s = E.gauge_trf(psi, "Psi2Asigma")
+        Ar, sr = orc.qr_psi2Asigma(psi)
+        Am = A.reshape(64, 16)
+        assert np.abs(Am.conj().T @ Am - np.eye(16)).max() < 1e-14
+        assert np.abs(np.tensordot(A, s, axes=(2, 0)) - psi).max() < 1e-14
+        np.testing.assert_allclose(A, Ar, atol=1e-12)
+        A2, s2 = E.gauge_trf(good, "Psi2Asigma")  # a well-conditioned one right after a failed one
+        Ar2, sr2 = orc.qr_psi2Asigma(good)
+        np.testing.assert_allclose(A2, Ar2, atol=1e-11)
+        np.testing.assert_allclose(s2, sr2, atol=1e-11)
+    x = crandn(rng, 16, 4, 24) * (10.0 ** (-1.0 * np.arange(24)))[None, None, :]  # columns graded over 24 decades
+    A, s = E.gauge_trf(x, "Psi2Asigma")
+    Ar, sr = orc.qr_psi2Asigma(x)
+    Am = A.reshape(64, 24)
+    assert np.abs(Am.conj().T @ Am - np.eye(24)).max() < 1e-13
+    assert np.abs(np.tensordot(A, s, axes=(2, 0)) - x).max() < 1e-14
+    np.testing.assert_allclose(s, sr, atol=1e-11)
+    # moderately ill-conditioned (cond ~ 1e4): still the fast path's business, orthogonality must be LAPACK's
+    y = crandn(rng, 32, 10, 32) * (10.0 ** (-4.0 * np.arange(32) / 31))[None, None, :]
+    A, s = E.gauge_trf(y, "Psi2Asigma")
+    Ar, sr = orc.qr_psi2Asigma(y)
+    Am = A.reshape(320, 32)
+    assert np.abs(Am.conj().T @ Am - np.eye(32)).max() < 1e-13
+    np.testing.assert_allclose(A, Ar, atol=1e-10)
+    np.testing.assert_allclose(s, sr, atol=1e-11)
+
+
 def test_qr_fast_panels_fall_back_on_rank_deficient_and_graded_input():
     """CholeskyQR2 cannot factor a rank-deficient panel: the device-side pivot checks must send zero-padded product
     states (the reference's starts, _site_cls.py:444-448) and strongly graded tensors to the Householder kernels, whose
