@@ -14,6 +14,8 @@
 // are not that.  Every Cholesky pivot and every LU pivot is checked on the device; a failed check raises a sticky flag
 // and the caller redoes the factorisation with the per-column Householder kernels (qr.hip), which are unconditionally
 // stable.  One flag read per QR, no host round trip per panel.
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -367,6 +369,11 @@ static int fq_rows_per_blk(int m) {  // at most 128 workgroups (= partial Gram m
   r = (r + 31) / 32 * 32;
   return r < 32 ? 32 : r;
 }
+// (Round 4, measured and dropped -- profiles/r04_qr_chain_ab.txt: fewer, larger Gram workgroups (sqrt(0.22 m) partials
+// instead of m / 32) take 13 us off the first-round Cholesky kernel, whose one workgroup streams the partials, and put
+// 12 us onto the two Gram launches, whose plain-FMA tiles cost ~5 us per 32 rows; the same chain kernels with 512
+// threads and the triangular inverses by recursive doubling (the building blocks of k_qr_small_fast below) run the
+// reconstruction in 27.0 instead of 23.7 us: a 31-step Gauss-Jordan chain builds both inverses at once.)
 
 size_t qr_fast_work_elems(int m, int n) {
   const size_t nblk = 128;
@@ -436,11 +443,12 @@ namespace {
 constexpr int SF_T = 512;
 typedef double sf_d4 __attribute__((ext_vector_type(4)));
 
+typedef zc SfMat[NB][NB + 1];
 struct SfSmem {
-  zc G[NB][NB + 1];   // Gram matrix -> R (upper)
-  zc W[NB][NB + 1];   // R^-1
-  zc P1[NB][NB + 1];  // R1, then R2 R1
-  zc Qt[NB][NB + 1];  // scratch of the inverse; then the top block of Q for the LU chain
+  SfMat G;   // Gram matrix -> R (upper)
+  SfMat W;   // R^-1
+  SfMat P1;  // R1, then R2 R1
+  SfMat Qt;  // scratch of the inverse; then the top block of Q for the LU chain
   double pb[4][6][4][64];  // Gram partials [row quarter][stream][accumulator register][lane]
   double d0[NB];
   double Dg[NB];
@@ -506,19 +514,21 @@ __device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSme
 
 // G (upper) -> its Cholesky factor R (upper, real positive diagonal); d0 <- 1 / diag(R).  Returns true (uniformly) when
 // a pivot fails the conditioning check.
-__device__ bool sf_chol(SfSmem& S, bool second) {
+// (512 threads, two elements each: a barrier of 8 waves and 0.30 us per pivot, against 0.7 us with one element per thread
+// of a 1024-thread workgroup)
+__device__ bool sf_chol(SfMat& G, const double* d0, bool second) {
   const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
   for (int k = 0; k < NB; ++k) {
-    const double d = S.G[k][k].x;
-    const bool ok = second ? (d > 0.5 && d < 2.0) : (d > CHOL_TOL * S.d0[k] && S.d0[k] > 0.0);
+    const double d = G[k][k].x;
+    const bool ok = second ? (d > 0.5 && d < 2.0) : (d > CHOL_TOL * d0[k] && d0[k] > 0.0);
     if (!ok) return true;  // uniform: every thread read the same words
     const double id = fast_rcp(d);
-    const zc gkj = S.G[k][j];
+    const zc gkj = G[k][j];
     const zc sc = make_double2(gkj.x * id, gkj.y * id);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int i = i0 + 16 * q;
-      if (i > k && j >= i) S.G[i][j] = csub(S.G[i][j], cmulc(S.G[k][i], sc));
+      if (i > k && j >= i) G[i][j] = csub(G[i][j], cmulc(G[k][i], sc));
     }
     __syncthreads();
   }
@@ -526,25 +536,35 @@ __device__ bool sf_chol(SfSmem& S, bool second) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int i = i0 + 16 * q;
-    const double dd = S.G[i][i].x;
+    const double dd = G[i][i].x;
     const double is = 1.0 / sqrt(dd);
-    r[q] = j > i ? make_double2(S.G[i][j].x * is, S.G[i][j].y * is) : (j == i ? make_double2(dd * is, 0.0) : make_double2(0.0, 0.0));
+    r[q] = j > i ? make_double2(G[i][j].x * is, G[i][j].y * is) : (j == i ? make_double2(dd * is, 0.0) : make_double2(0.0, 0.0));
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 2; ++q) S.G[i0 + 16 * q][j] = r[q];
+  for (int q = 0; q < 2; ++q) G[i0 + 16 * q][j] = r[q];
   __syncthreads();
   return false;
 }
 
-// W = G^-1 for the upper-triangular G by recursive doubling: the inverse of [[R00, R01], [0, R11]] is
-// [[R00^-1, -R00^-1 R01 R11^-1], [0, R11^-1]]; 5 levels, two small products each (Qt is the scratch).
-__device__ void sf_tri_inverse(SfSmem& S) {
+// W = U^-1 for an upper-triangular U by recursive doubling: the inverse of [[U00, U01], [0, U11]] is
+// [[U00^-1, -U00^-1 U01 U11^-1], [0, U11^-1]]; 5 levels, two small products each (T is the scratch) -- 10 barriers where a
+// substitution chain needs 31.  KIND 0: U = upper triangle of M, real diagonal; 1: the same with a complex diagonal;
+// 2: U = unit upper triangular, U[i][k] = conj(M[k][i]) (the V1^H of a block reflector stored as the unit-lower L).
+template <int KIND>
+__device__ void sf_tri_inverse(const SfMat& M, SfMat& W, SfMat& T) {
   const int tid = threadIdx.x, j = tid & 31, i0 = tid >> 5;
+  auto el = [&](int i, int k) __attribute__((always_inline)) -> zc {
+    if (KIND == 2) { const zc v = M[k][i]; return make_double2(v.x, -v.y); }
+    return M[i][k];
+  };
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int i = i0 + 16 * q;
-    S.W[i][j] = i == j ? make_double2(1.0 / S.G[i][i].x, 0.0) : make_double2(0.0, 0.0);
+    zc dinv = make_double2(1.0, 0.0);
+    if (KIND == 0) dinv = make_double2(1.0 / M[i][i].x, 0.0);
+    if (KIND == 1) dinv = cdiv(make_double2(1.0, 0.0), M[i][i]);
+    W[i][j] = i == j ? dinv : make_double2(0.0, 0.0);
   }
   __syncthreads();
   for (int b = 1; b < NB; b <<= 1) {
@@ -554,14 +574,14 @@ __device__ void sf_tri_inverse(SfSmem& S) {
       const int p = tid / (b * b), rem = tid - p * b * b;
       ii = rem / b; jj = rem - ii * b; c0 = p * 2 * b;
       zc t = make_double2(0.0, 0.0);
-      for (int k = 0; k <= jj; ++k) t = cadd(t, cmul(S.G[c0 + ii][c0 + b + k], S.W[c0 + b + k][c0 + b + jj]));
-      S.Qt[c0 + ii][c0 + b + jj] = t;
+      for (int k = 0; k <= jj; ++k) t = cadd(t, cmul(el(c0 + ii, c0 + b + k), W[c0 + b + k][c0 + b + jj]));
+      T[c0 + ii][c0 + b + jj] = t;
     }
     __syncthreads();
     if (tid < ne) {
       zc x = make_double2(0.0, 0.0);
-      for (int k = ii; k < b; ++k) x = csub(x, cmul(S.W[c0 + ii][c0 + k], S.Qt[c0 + k][c0 + b + jj]));
-      S.W[c0 + ii][c0 + b + jj] = x;
+      for (int k = ii; k < b; ++k) x = csub(x, cmul(W[c0 + ii][c0 + k], T[c0 + k][c0 + b + jj]));
+      W[c0 + ii][c0 + b + jj] = x;
     }
     __syncthreads();
   }
@@ -611,23 +631,32 @@ __device__ __forceinline__ void sf_apply(const zc* __restrict__ src, long ld, in
 }
 
 __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A, int m, int n, zc* __restrict__ Q, zc* __restrict__ R,
-                                                        zc* __restrict__ Q1, int cd_mode, int* __restrict__ fail) {
+                                                        zc* __restrict__ Q1, int cd_mode, int* __restrict__ fail,
+                                                        long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) char sf_raw[];
   SfSmem& S = *reinterpret_cast<SfSmem*>(sf_raw);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
   const int j = tid & 31, i0 = tid >> 5;
   sf_d4 qre[3][2], qim[3][2];
+  // debugging (MITDVP_QR_TRACE): thread 0 stamps s_memrealtime (10 ns ticks) at the phase boundaries
+  auto stamp = [&](int k) __attribute__((always_inline)) { if (trace && tid == 0) trace[k] = (long long)__builtin_amdgcn_s_memrealtime(); };
+  stamp(0);
   // ---- round 1 ----
   sf_gram(A, n, m, n, S, cd_mode);
-  if (sf_chol(S, false)) { if (tid == 0) *fail = 1; return; }
+  stamp(1);
+  if (sf_chol(S.G, S.d0, false)) { if (tid == 0) *fail = 1; return; }
 #pragma unroll
   for (int q = 0; q < 2; ++q) S.P1[i0 + 16 * q][j] = S.G[i0 + 16 * q][j];  // R1 (zero below the diagonal)
-  sf_tri_inverse(S);
+  stamp(2);
+  sf_tri_inverse<0>(S.G, S.W, S.Qt);
+  stamp(3);
   sf_apply<true>(A, n, m, n, S, cd_mode, Q1, qre, qim);
   __threadfence_block();
   __syncthreads();
+  stamp(4);
   // ---- round 2 ----
   sf_gram(Q1, NB, m, n, S, cd_mode);
+  stamp(5);
   {
     // G = I + E: to first order chol(I + E) = I + U, U = triu(E, 1) + diag(E) / 2, (I + U)^-1 = I - U (see k_fq_chol)
     double e = 0.0;
@@ -667,8 +696,8 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
       }
     } else {
       if (!(emax < 1e300)) { if (tid == 0) *fail = 1; return; }  // NaN / overflow in the first round
-      if (sf_chol(S, true)) { if (tid == 0) *fail = 1; return; }
-      sf_tri_inverse(S);
+      if (sf_chol(S.G, S.d0, true)) { if (tid == 0) *fail = 1; return; }
+      sf_tri_inverse<0>(S.G, S.W, S.Qt);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int i = i0 + 16 * q;
@@ -682,6 +711,7 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
     for (int q = 0; q < 2; ++q) S.P1[i0 + 16 * q][j] = rt[q];  // R2 R1
     __syncthreads();
   }
+  stamp(6);
   sf_apply<false>(Q1, NB, m, NB, S, cd_mode, nullptr, qre, qim);
   // top block -> LDS for the sign chain (rows / columns beyond n: identity)
   if (w < 2) {
@@ -695,6 +725,7 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
       }
   }
   __syncthreads();
+  stamp(7);
   // ---- LAPACK's signs: LU of (Q - [D; 0]) with D_k = -sign(Re pivot_k) (k_fq_reconstruct's first chain) ----
   for (int k = 0; k < NB; ++k) {
     const zc piv = S.Qt[k][k];
@@ -713,6 +744,7 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
     }
     __syncthreads();
   }
+  stamp(8);
   // ---- Q' = Q D, R' = D R ----
   if (Q) {
 #pragma unroll
@@ -743,6 +775,7 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
     }
   }
   if (tid == 0) *fail = 0;
+  stamp(9);
 }
 }  // namespace
 
@@ -763,8 +796,22 @@ void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* 
     }
   }
   const int cd_mode = zgemm_cd_mode(st);
-  hipLaunchKernelGGL(k_qr_small_fast, dim3(1), dim3(SF_T), sizeof(SfSmem), st, A, m, n, Q, R, Q1, cd_mode, fail);
+  static const bool tracing = std::getenv("MITDVP_QR_TRACE") != nullptr;
+  static long long* trace = nullptr;
+  if (tracing && !trace) {
+    HIP_CHECK(hipMalloc(&trace, 16 * sizeof(long long)));
+    HIP_CHECK(hipMemset(trace, 0, 16 * sizeof(long long)));
+  }
+  hipLaunchKernelGGL(k_qr_small_fast, dim3(1), dim3(SF_T), sizeof(SfSmem), st, A, m, n, Q, R, Q1, cd_mode, fail, trace);
   HIP_CHECK(hipGetLastError());
+  if (tracing) {  // phase durations in us: gram, chol, inverse, apply, gram, round 2, apply, sign chain, stores
+    long long h[16];
+    HIP_CHECK(hipMemcpyAsync(h, trace, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    fprintf(stderr, "[qr_trace] fast m=%d n=%d total %.2f us:", m, n, (double)(h[9] - h[0]) * 0.01);
+    for (int k = 0; k < 9; ++k) fprintf(stderr, " %.2f", (double)(h[k + 1] - h[k]) * 0.01);
+    fprintf(stderr, "\n");
+  }
 }
 
 
