@@ -339,8 +339,11 @@ __device__ __forceinline__ double wave_max64(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
   return v;
 }
+// compute: only the wave(s) that pass true run the Taylor sum (the scaling exponent is returned to every caller).  All 16
+// waves of a workgroup running it side by side shared four SIMDs: ~8 us per call in the MITDVP_SS_TRACE timelines, 2.4 us
+// with one wave (the others wait at the barrier that follows anyway) and 1 / n as literals of the unrolled sum.
 __device__ __forceinline__ int wave_expm_tridiag(const zc* alpha, const double* beta, zc scale, int k, bool real_alpha,
-                                                 zc& out) {
+                                                 zc& out, bool compute = true) {
   const int q = threadIdx.x & 63;
   zc a = make_double2(0.0, 0.0), bl = a, bu = a;
   if (q < k) {
@@ -354,13 +357,13 @@ __device__ __forceinline__ int wave_expm_tridiag(const zc* alpha, const double* 
   double nrm = wave_max64(sqrt(a.x * a.x + a.y * a.y) + sqrt(bl.x * bl.x + bl.y * bl.y) + sqrt(bu.x * bu.x + bu.y * bu.y));
   int s = 0;
   while (nrm > 1.0 && s < 60) { nrm *= 0.5; ++s; }
-  if (s > SS_VEC_SMAX) return s;
+  if (s > SS_VEC_SMAX || !compute) return s;
   const double sc = ldexp(1.0, -s);
   a.x *= sc; a.y *= sc; bl.x *= sc; bl.y *= sc; bu.x *= sc; bu.y *= sc;
   zc y = make_double2(q == 0 ? 1.0 : 0.0, 0.0);
   for (int rep = 0; rep < (1 << s); ++rep) {
     zc p = y, acc = y;
-#pragma unroll 4
+#pragma unroll
     for (int n = 1; n <= 20; ++n) {
       const zc pm = make_double2(wave_shr1(p.x), wave_shr1(p.y));  // p_{q-1}
       const zc pp = make_double2(wave_shl1(p.x), wave_shl1(p.y));  // p_{q+1}
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_kry_ritz(KryRitzArgs a) {
   bool vec_done = false;
   if (a.lanczos && k > 1) {  // tridiagonal: vector form in one wave (wave_expm_tridiag)
     zc cq;
-    const int sq_ = wave_expm_tridiag(st->alpha, st->beta, a.scale, k, real_alpha, cq);
+    const int sq_ = wave_expm_tridiag(st->alpha, st->beta, a.scale, k, real_alpha, cq, tid < 64);
     if (sq_ <= SS_VEC_SMAX) {
       if (tid < k) coef_s[tid] = cq;
       __syncthreads();
@@ -861,9 +864,10 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
 
     // ---- coef = exp(scale * T_k) e_0 ------------------------------------------------------------
     bool vec_done = false;
+    stamp(30);
     if (lanczos && k > 1) {  // tridiagonal: one wave, vector form (every wave runs it: the decision is uniform)
       zc cq;
-      const int sq_ = wave_expm_tridiag(alpha, beta, scale, k, false, cq);
+      const int sq_ = wave_expm_tridiag(alpha, beta, scale, k, false, cq, tid < 64);
       if (sq_ <= SS_VEC_SMAX) {
         if (tid < k) coef[tid] = cq;
         __syncthreads();
@@ -894,8 +898,12 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
       ss_expm_col0(Tm, M2, M3, M4, Pm, Qm, k, coef, wsh);
       stamp(18);
     }
+    stamp(31);
     if (act == 1) {
       if (have_prev) {  // || psi_k - psi_{k-1} ||  (:644-652)
+        // (round 4, measured and dropped: issuing the k agent-scope loads of an element in batches of eight before their
+        // first use, here, in the closing combination and in the own-range assembly -- C2 204 -> 201 sweeps/s on one box,
+        // the wider live ranges spill in the per-iteration loops)
         double s = 0.0;
         for (long e = e0 + tid; e < e1; e += SS_THREADS) {
           double re = 0.0, im = 0.0;
@@ -914,7 +922,9 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         __syncthreads();
         if (tid == 0) pay[0] = wtree(wsh);
         __syncthreads();
+        stamp(32);
         if (!ss_exchange(sy, pay, 1, red, wsh)) { fail(SS_ETIMEOUT); return; }
+        stamp(33);
         if (sqrt(red[0]) < ex.thresh) act = 2;
       }
       if (act == 1) {
