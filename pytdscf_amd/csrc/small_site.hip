@@ -598,25 +598,40 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
   stamp(0);
 
   // ---- operands that do not change during the launch -> LDS -------------------------------
-  for (int t = tid; t < c.nc * c.nb; t += SS_THREADS) {
-    const int cc = t / c.nb, b = t - cc * c.nb;
-    zc z = c.A[(long)a * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
-    if (c.conjA) z.y = -z.y;
-    As[t] = z;
-  }
+  // Every thread's first elements of the three operands are loaded before any of them is stored: one exposed L2 latency
+  // at the start of a launch instead of one per loop trip (As 1, Rs 2, Ws 4 trips at C2: ~4 of the ~10 us a launch
+  // spent before its first product in the MITDVP_SS_TRACE timelines).  Longer operands finish in the plain loops below.
   {
-    const int kk = c.nt * cs;  // rows of Rs: (t, sl)
-    for (int t = tid; t < kk * c.nr; t += SS_THREADS) {
+    const int nA = c.nc * c.nb, kk = c.nt * cs, nR = kk * c.nr, nW = c.W2 ? c.ni * c.nt * c.nc * c.nj : 0;
+    auto ldA = [&](int t) __attribute__((always_inline)) -> zc {
+      const int cc = t / c.nb, b = t - cc * c.nb;
+      zc z = c.A[(long)a * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
+      if (c.conjA) z.y = -z.y;
+      return z;
+    };
+    auto ldR = [&](int t) __attribute__((always_inline)) -> zc {
       // r fastest in LDS; pick the global order that keeps loads coalesced for the common layouts
       const int k = t / c.nr, r = t - k * c.nr;
       const int tt = k / cs, sl = k - tt * cs;
       zc z = make_double2(0.0, 0.0);
       if (sl < csl) z = c.R[(long)r * c.sRr + (long)tt * c.sRt + (long)(s0 + sl) * c.sRs];
-      Rs[t] = z;
-    }
+      return z;
+    };
+    zc za = make_double2(0.0, 0.0), zr[2], zw[4];
+    if (tid < nA) za = ldA(tid);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { zr[u] = make_double2(0.0, 0.0); if (tid + u * SS_THREADS < nR) zr[u] = ldR(tid + u * SS_THREADS); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { zw[u] = make_double2(0.0, 0.0); if (tid + u * SS_THREADS < nW) zw[u] = c.W2[tid + u * SS_THREADS]; }
+    if (tid < nA) As[tid] = za;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (tid + u * SS_THREADS < nR) Rs[tid + u * SS_THREADS] = zr[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (tid + u * SS_THREADS < nW) Ws[tid + u * SS_THREADS] = zw[u];
+    for (int t = tid + SS_THREADS; t < nA; t += SS_THREADS) As[t] = ldA(t);
+    for (int t = tid + 2 * SS_THREADS; t < nR; t += SS_THREADS) Rs[t] = ldR(t);
+    for (int t = tid + 4 * SS_THREADS; t < nW; t += SS_THREADS) Ws[t] = c.W2[t];
   }
-  if (c.W2)
-    for (int t = tid; t < c.ni * c.nt * c.nc * c.nj; t += SS_THREADS) Ws[t] = c.W2[t];
 
   // stage-1 operand of this chunk: Bs[b][(j, sl)] = scale * vec(b, j, s0 + sl)
   auto load_B = [&](const zc* vec, bool shared, double scl) {
@@ -802,18 +817,23 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
       double s = 0.0;
       const double bprev = l > 0 ? beta[l - 1] : 0.0;
       for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+        // v_l and v_{l-1} are requested before the chunk partials: their latencies overlap the partial loop's
+        zc vl = l == 0 ? g.x[e] : ldz_sh(g.U + (size_t)l * N + e);
+        zc vm = make_double2(0.0, 0.0);
+        if (lanczos && l > 0) vm = l == 1 ? g.x[e] : ldz_sh(g.U + (size_t)(l - 1) * N + e);
         zc u = make_double2(0.0, 0.0);
         for (int q = 0; q < nsc; ++q) {
           const zc p = ldz_sh(g.P + (size_t)q * N + e);
           u.x += p.x; u.y += p.y;
         }
-        const zc vl = basis(l, e);
+        { const double f = invb[l]; vl.x *= f; vl.y *= f; }
         if (lanczos) {  // _integrator.py:556-562
           const zc al = alpha[l];
           u.x -= al.x * vl.x - al.y * vl.y;
           u.y -= al.x * vl.y + al.y * vl.x;
           if (l > 0) {
-            const zc vm = basis(l - 1, e);
+            const double f = invb[l - 1];
+            vm.x *= f; vm.y *= f;
             u.x -= bprev * vm.x;
             u.y -= bprev * vm.y;
           }
