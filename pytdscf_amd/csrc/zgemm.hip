@@ -880,7 +880,19 @@ void zgemm_release_stream(hipStream_t st) {
   g_splitk.erase(it);
 }
 
+// The staging loads address a tile as uniform base + a 32-bit per-thread byte offset: the rows a tile spans times the row
+// stride must stay below 2^32 bytes (an untransposed A spans BM rows -- up to 2 BM + 2 stored rows with the identity-block
+// row skip --, a transposed one BK = 16; B likewise with BN).  64 x 64 tiles: lda, ldb < 2^22 elements untransposed.
+static void check_tile_offsets(const ZgemmDesc& d, int bm, int bn) {
+  constexpr long BKMAX = 16, LIM = 0xFFFFFFF0L / (long)sizeof(zc);
+  const long rowsA = d.transA ? BKMAX : (d.arow_skip > 1 ? 2L * bm + 2 : (long)bm), colsA = d.transA ? bm : BKMAX;
+  const long rowsB = d.transB ? (long)bn : BKMAX, colsB = d.transB ? BKMAX : bn;
+  if ((rowsA - 1) * d.lda + colsA >= LIM || (rowsB - 1) * d.ldb + colsB >= LIM)
+    throw ArgError("zgemm: row stride too wide for the 32-bit per-thread tile offsets (rows of a tile x stride x 16 B must stay below 2^32)");
+}
+
 static void launch_tiles(hipStream_t st, const ZgemmDesc& d, int cfg, int m3) {
+  check_tile_offsets(d, cfg == 0 ? 128 : (cfg == 1 ? 64 : 32), cfg == 0 ? (m3 ? 64 : 128) : (cfg == 1 ? 64 : 32));
   if (m3) {
     switch (cfg) {
       case 0: launch_cfg<4, 2, 16, true>(st, d); break;
@@ -902,6 +914,7 @@ static void launch_tiles(hipStream_t st, const ZgemmDesc& d, int cfg, int m3) {
 static void launch_sparse(hipStream_t st, const ZgemmDesc& d, int m3) {
   if (d.transA || d.transB || d.K % 16 != 0 || d.ksplit) throw ArgError("zgemm: the block-sparse form needs NN operands and K % 16 == 0");
   constexpr int BM = 64, BN = 64;
+  check_tile_offsets(d, BM, BN);
   const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, d.batch);
   constexpr size_t lds = 2 * (size_t)(BM * 17 + 16 * BN) * sizeof(zc);
@@ -932,7 +945,7 @@ void zgemm_reduce(hipStream_t st, const ZgemmDesc& d0) {
   if (d.transA || d.batch != 1 || d.ksplit || d.klist || d.arow_skip || d.rowmap_p || d.conjA || d.conjB)
     throw ArgError("zgemm_reduce: plain NN / NT operands only");
   if (d.M % d.epi_xm || d.N % d.epi_yn) throw ArgError("zgemm_reduce: M, N must be whole groups");
-  if (d.lda >= (1L << 20) || d.ldb >= (1L << 20)) throw ArgError("zgemm: row stride >= 2^20 elements (per-thread tile offsets are 32-bit)");
+  check_tile_offsets(d, 64, 64);
   (void)zgemm_cd_mode(st);
   const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;
   const int tu = 64 / d.epi_xm, tv = 64 / d.epi_yn;
@@ -979,7 +992,6 @@ void zgemm(hipStream_t st, const ZgemmDesc& d0) {
   if (d.K < 0) throw ArgError("zgemm: negative K");
   if (d.arow_skip && (d.transA || d.arow_skip < 2 || d.klist)) throw ArgError("zgemm: arow_skip needs a plain, untransposed A");
   if (d.batch > 65535) throw ArgError("zgemm: batch > 65535");
-  if (d.lda >= (1L << 20) || d.ldb >= (1L << 20)) throw ArgError("zgemm: row stride >= 2^20 elements (per-thread tile offsets are 32-bit)");
   (void)zgemm_cd_mode(st);
   int cfg = d.tile_cfg;
   const int m3 = d.mode3m < 0 ? zgemm_default_mode() : d.mode3m;

@@ -226,6 +226,35 @@ def test_qr_panels_by_cholesky_qr2_and_householder_reconstruction(shape):
         assert np.abs(B - res[False][1][0]).max() < 1e-12
 
 
+def test_zgemm_wide_row_strides():
+    """The staging loads of the MFMA GEMM address a tile with 32-bit per-thread byte offsets: a row stride is fine as long
+    as (rows of the operand a tile spans) x stride x 16 B < 2^32 -- 2^20 elements (D = 2048, d = 16, M = 32) must work,
+    a stride that would wrap is refused with EINVAL instead of being mis-addressed (advisor finding of round 3)."""
+    from pytdscf_amd import engine as E
+
+    rng = np.random.default_rng(5)
+    k = (1 << 20) + 16
+    A = (rng.standard_normal((40, k)) + 1j * rng.standard_normal((40, k))) / np.sqrt(k)
+    B = rng.standard_normal((k, 24)) + 1j * rng.standard_normal((k, 24))
+    C = E.zgemm(A, B)  # lda = 2^20 + 16 untransposed (split-K path), ldb = 24
+    ref = A @ B
+    assert np.abs(C - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    Bs = np.ascontiguousarray(B.T)  # (24, k): op(B) = Bs^T, ldb = 2^20 + 16
+    C2 = E.zgemm(A, Bs, transB=True)
+    assert np.abs(C2 - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    del A, B, Bs
+    As = rng.standard_normal((32, k)) + 1j * rng.standard_normal((32, k))  # stored (K, M): op(A) = As^T, lda = 2^20 + 16
+    B3 = rng.standard_normal((32, 8)) + 1j * rng.standard_normal((32, 8))
+    C3 = E.zgemm(As, B3, transA=True)
+    assert np.abs(C3 - As.T @ B3).max() < 1e-11 * np.abs(C3).max()
+    del As, C3
+    wide = (1 << 22) + 64  # a 128-row tile of an untransposed operand with this stride would wrap 32 bits
+    A = np.zeros((2, wide), dtype=np.complex128)
+    B = np.zeros((wide, 2), dtype=np.complex128)
+    with pytest.raises(ValueError):
+        E.zgemm(A, B, tile_cfg=0)
+
+
 @pytest.mark.parametrize("shape", [(32, 10, 32), (10, 10, 20), (16, 2, 32), (8, 4, 32), (1, 5, 3), (32, 10, 1), (7, 3, 17),
                                    (20, 16, 31), (3, 1, 3)])
 def test_small_qr_in_one_workgroup(shape):
