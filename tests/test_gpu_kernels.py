@@ -286,6 +286,36 @@ def test_small_qr_in_one_workgroup(shape):
     assert np.abs(A - res[False][0]).max() < 1e-12 and np.abs(s - res[False][1]).max() < 1e-12 * np.abs(sr).max()
 
 
+@pytest.mark.parametrize("shape", [(10, 10, 32, 6), (8, 4, 12, 4)])
+def test_small_regime_trajectory_is_the_same_with_either_qr(shape):
+    """A few time steps of the small-bond regime with the gauge moves by the one-workgroup CholeskyQR2 and by the
+    per-column Householder kernel: both return LAPACK's Q / R (signs included), so the propagated tensors themselves must
+    agree, with equal Krylov counts (the reference's gauge move: _site_cls.py:138-292)."""
+    from pytdscf_amd import TDVPEngine
+    from pytdscf_amd import engine as E
+    from pytdscf_amd import synthetic as syn
+
+    L, d, D, M = shape
+    mpo = syn.synthetic_mpo(L, d, M, seed=0)
+    res = {}
+    for fast in (True, False):
+        E.set_qr_fast(fast)
+        try:
+            eng = TDVPEngine(L)
+            eng.set_mpo(mpo)
+            eng.init_random([d] * L, D, seed=3)
+            for _ in range(3):
+                eng.propagate(2.0)
+            res[fast] = (eng.get_mps(), eng.krylov_stats(), eng.norm())
+            eng.close()
+        finally:
+            E.set_qr_fast(True)
+    assert res[True][1] == res[False][1]
+    assert abs(res[True][2] - 1) < 1e-12
+    for a, b in zip(res[True][0], res[False][0]):
+        assert np.abs(a - b).max() < 1e-10
+
+
 def test_small_qr_falls_back_on_rank_deficient_graded_and_nonfinite_input():
     """The one-workgroup CholeskyQR2 must hand zero-padded product states and strongly graded tensors to the Householder
     kernel queued behind it (no host decision in between), and its verdict must not leak into the next factorisation."""
