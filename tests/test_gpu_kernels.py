@@ -316,6 +316,26 @@ def test_small_regime_trajectory_is_the_same_with_either_qr(shape):
         assert np.abs(a - b).max() < 1e-10
 
 
+def test_small_qr_random_shapes():
+    """Forty random (m, n) with m <= 320, n <= min(m, 32) -- odd sizes, m not a multiple of the 4-row MFMA step or the
+    16-row blocks, n on either side of the 16-column block edge -- against scipy's QR (LAPACK's signs)."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import engine as E
+
+    rng = np.random.default_rng(2024)
+    for _ in range(40):
+        d = int(rng.integers(1, 11))
+        dl = int(rng.integers(1, 320 // d + 1))
+        dr = int(rng.integers(1, min(32, dl * d) + 1))
+        psi = crandn(rng, dl, d, dr)
+        A, s = E.gauge_trf(psi, "Psi2Asigma")
+        Ar, sr = orc.qr_psi2Asigma(psi)
+        assert np.abs(A - Ar).max() < 1e-10, (dl, d, dr)
+        assert np.abs(s - sr).max() < 1e-10 * max(1.0, np.abs(sr).max()), (dl, d, dr)
+        Am = A.reshape(dl * d, dr)
+        assert np.abs(Am.conj().T @ Am - np.eye(dr)).max() < 1e-13, (dl, d, dr)
+
+
 def test_small_qr_falls_back_on_rank_deficient_graded_and_nonfinite_input():
     """The one-workgroup CholeskyQR2 must hand zero-padded product states and strongly graded tensors to the Householder
     kernel queued behind it (no host decision in between), and its verdict must not leak into the next factorisation."""
