@@ -477,14 +477,16 @@ __device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSme
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      // a diagonal block's imaginary part is P - P^T with P = Xr^T Xi: one product instead of two (the transpose is
+      // taken when the partials are gathered)
       if (half == 0) {
         acc[0] = sf_mfma(x0[u].x, x0[u].x, acc[0]);  acc[0] = sf_mfma(x0[u].y, x0[u].y, acc[0]);   // 00 re
-        acc[1] = sf_mfma(x0[u].x, x0[u].y, acc[1]);  acc[1] = sf_mfma(-x0[u].y, x0[u].x, acc[1]);  // 00 im
+        acc[1] = sf_mfma(x0[u].x, x0[u].y, acc[1]);                                                // 00: P
         acc[2] = sf_mfma(x0[u].x, x1[u].x, acc[2]);  acc[2] = sf_mfma(x0[u].y, x1[u].y, acc[2]);   // 01 re
       } else {
         acc[0] = sf_mfma(x0[u].x, x1[u].y, acc[0]);  acc[0] = sf_mfma(-x0[u].y, x1[u].x, acc[0]);  // 01 im
         acc[1] = sf_mfma(x1[u].x, x1[u].x, acc[1]);  acc[1] = sf_mfma(x1[u].y, x1[u].y, acc[1]);   // 11 re
-        acc[2] = sf_mfma(x1[u].x, x1[u].y, acc[2]);  acc[2] = sf_mfma(-x1[u].y, x1[u].x, acc[2]);  // 11 im
+        acc[2] = sf_mfma(x1[u].x, x1[u].y, acc[2]);                                                // 11: P
       }
     }
   }
@@ -502,8 +504,15 @@ __device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSme
       const int blk = (i >> 4) + (j >> 4), ii = i & 15, jj = j & 15;
       const int lk_ = cd_mode == 0 ? (ii & 3) : (ii >> 2), r_ = cd_mode == 0 ? (ii >> 2) : (ii & 3);
       const int ln = lk_ * 16 + jj;
+      // streams: 0 = 00 re, 1 = 00 P, 2 = 01 re, 3 = 01 im, 4 = 11 re, 5 = 11 P
+      const int sre = blk == 0 ? 0 : (blk == 1 ? 2 : 4), sim = blk == 0 ? 1 : (blk == 1 ? 3 : 5);
+      const int lkt = cd_mode == 0 ? (jj & 3) : (jj >> 2), rt = cd_mode == 0 ? (jj >> 2) : (jj & 3);
+      const int lnt = lkt * 16 + ii;  // element (jj, ii) of the same block
 #pragma unroll
-      for (int p = 0; p < 4; ++p) { g.x += S.pb[p][2 * blk][r_][ln]; g.y += S.pb[p][2 * blk + 1][r_][ln]; }
+      for (int p = 0; p < 4; ++p) {
+        g.x += S.pb[p][sre][r_][ln];
+        g.y += blk == 1 ? S.pb[p][sim][r_][ln] : S.pb[p][sim][r_][ln] - S.pb[p][sim][rt][lnt];
+      }
     }
     if (i >= n || j >= n) g = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
     if (i == j) { g.y = 0.0; S.d0[i] = g.x; }
@@ -517,18 +526,33 @@ __device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSme
 // (512 threads, two elements each: a barrier of 8 waves and 0.30 us per pivot, against 0.7 us with one element per thread
 // of a 1024-thread workgroup)
 __device__ bool sf_chol(SfMat& G, const double* d0, bool second) {
+  // Two pivots per barrier: a thread forms the entries of row k + 1 it needs from rows k and k + 1 as they stand (the very
+  // operations the one-pivot step would have stored), so the results are those of 32 single steps; rows k and k + 1
+  // are not written (row k + 1 is finished in the scaling pass below): no read of a step races with a write of it.
   const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
-  for (int k = 0; k < NB; ++k) {
-    const double d = G[k][k].x;
-    const bool ok = second ? (d > 0.5 && d < 2.0) : (d > CHOL_TOL * d0[k] && d0[k] > 0.0);
-    if (!ok) return true;  // uniform: every thread read the same words
-    const double id = fast_rcp(d);
+  for (int k = 0; k < NB; k += 2) {
+    const double da = G[k][k].x;
+    const bool oka = second ? (da > 0.5 && da < 2.0) : (da > CHOL_TOL * d0[k] && d0[k] > 0.0);
+    if (!oka) return true;  // uniform: every thread read the same words
+    const double ida = fast_rcp(da);
+    const zc g01 = G[k][k + 1];
+    const zc s01 = make_double2(g01.x * ida, g01.y * ida);
+    const double db = csub(G[k + 1][k + 1], cmulc(g01, s01)).x;
+    const bool okb = second ? (db > 0.5 && db < 2.0) : (db > CHOL_TOL * d0[k + 1] && d0[k + 1] > 0.0);
+    if (!okb) return true;
+    const double idb = fast_rcp(db);
     const zc gkj = G[k][j];
-    const zc sc = make_double2(gkj.x * id, gkj.y * id);
+    const zc sa = make_double2(gkj.x * ida, gkj.y * ida);
+    const zc r1j = csub(G[k + 1][j], cmulc(g01, sa));  // row k + 1 after pivot k
+    const zc sb = make_double2(r1j.x * idb, r1j.y * idb);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int i = i0 + 16 * q;
-      if (i > k && j >= i) G[i][j] = csub(G[i][j], cmulc(G[k][i], sc));
+      if (i > k + 1 && j >= i) {
+        const zc gki = G[k][i];
+        const zc r1i = csub(G[k + 1][i], cmulc(g01, make_double2(gki.x * ida, gki.y * ida)));
+        G[i][j] = csub(csub(G[i][j], cmulc(gki, sa)), cmulc(r1i, sb));
+      }
     }
     __syncthreads();
   }
@@ -536,9 +560,17 @@ __device__ bool sf_chol(SfMat& G, const double* d0, bool second) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int i = i0 + 16 * q;
-    const double dd = G[i][i].x;
+    zc raw = G[i][j], rd = G[i][i];
+    if (i & 1) {  // odd rows still lack the update by the pivot above them
+      const double idp = fast_rcp(G[i - 1][i - 1].x);
+      const zc gp = G[i - 1][i];
+      const zc gpj = G[i - 1][j];
+      raw = csub(raw, cmulc(gp, make_double2(gpj.x * idp, gpj.y * idp)));
+      rd = csub(rd, cmulc(gp, make_double2(gp.x * idp, gp.y * idp)));
+    }
+    const double dd = rd.x;
     const double is = 1.0 / sqrt(dd);
-    r[q] = j > i ? make_double2(G[i][j].x * is, G[i][j].y * is) : (j == i ? make_double2(dd * is, 0.0) : make_double2(0.0, 0.0));
+    r[q] = j > i ? make_double2(raw.x * is, raw.y * is) : (j == i ? make_double2(dd * is, 0.0) : make_double2(0.0, 0.0));
   }
   __syncthreads();
 #pragma unroll
@@ -593,11 +625,14 @@ template <bool DST>
 __device__ __forceinline__ void sf_apply(const zc* __restrict__ src, long ld, int m, int ncol, const SfSmem& S, int cd_mode,
                                          zc* __restrict__ dst, sf_d4 (&qre)[3][2], sf_d4 (&qim)[3][2]) {
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+  // complex products in the three-multiplication form (as the large GEMMs): T1 = Ar Br, T2 = Ai Bi, T3 = (Ar + Ai)(Br + Bi),
+  // Re = T1 - T2, Im = T3 - T1 - T2 -- three matrix-core products per k-step instead of four, normwise the same error
   zc b0[4], b1[8];
+  double bs0[4], bs1[8];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) b0[s] = S.W[4 * s + lk][li];
+  for (int s = 0; s < 4; ++s) { b0[s] = S.W[4 * s + lk][li]; bs0[s] = b0[s].x + b0[s].y; }
 #pragma unroll
-  for (int s = 0; s < 8; ++s) b1[s] = S.W[4 * s + lk][16 + li];
+  for (int s = 0; s < 8; ++s) { b1[s] = S.W[4 * s + lk][16 + li]; bs1[s] = b1[s].x + b1[s].y; }
 #pragma unroll
   for (int bl = 0; bl < 3; ++bl) {
     const int blk = w + 8 * bl;
@@ -608,15 +643,21 @@ __device__ __forceinline__ void sf_apply(const zc* __restrict__ src, long ld, in
     zc a[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) a[s] = (row < m && 4 * s + lk < ncol) ? src[(long)row * ld + 4 * s + lk] : make_double2(0.0, 0.0);
+    sf_d4 t1[2], t2[2], t3[2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      qre[bl][0] = sf_mfma(a[s].x, b0[s].x, qre[bl][0]);  qre[bl][0] = sf_mfma(-a[s].y, b0[s].y, qre[bl][0]);
-      qim[bl][0] = sf_mfma(a[s].x, b0[s].y, qim[bl][0]);  qim[bl][0] = sf_mfma(a[s].y, b0[s].x, qim[bl][0]);
-    }
+    for (int cb = 0; cb < 2; ++cb) { t1[cb] = (sf_d4){0.0, 0.0, 0.0, 0.0}; t2[cb] = t1[cb]; t3[cb] = t1[cb]; }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      qre[bl][1] = sf_mfma(a[s].x, b1[s].x, qre[bl][1]);  qre[bl][1] = sf_mfma(-a[s].y, b1[s].y, qre[bl][1]);
-      qim[bl][1] = sf_mfma(a[s].x, b1[s].y, qim[bl][1]);  qim[bl][1] = sf_mfma(a[s].y, b1[s].x, qim[bl][1]);
+      const double as = a[s].x + a[s].y;
+      if (s < 4) {
+        t1[0] = sf_mfma(a[s].x, b0[s].x, t1[0]);  t2[0] = sf_mfma(a[s].y, b0[s].y, t2[0]);  t3[0] = sf_mfma(as, bs0[s], t3[0]);
+      }
+      t1[1] = sf_mfma(a[s].x, b1[s].x, t1[1]);  t2[1] = sf_mfma(a[s].y, b1[s].y, t2[1]);  t3[1] = sf_mfma(as, bs1[s], t3[1]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      qre[bl][cb] = t1[cb] - t2[cb];
+      qim[bl][cb] = t3[cb] - t1[cb] - t2[cb];
     }
     if (DST) {
 #pragma unroll
@@ -727,20 +768,34 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
   __syncthreads();
   stamp(7);
   // ---- LAPACK's signs: LU of (Q - [D; 0]) with D_k = -sign(Re pivot_k) (k_fq_reconstruct's first chain) ----
-  for (int k = 0; k < NB; ++k) {
-    const zc piv = S.Qt[k][k];
-    const double dk = piv.x >= 0.0 ? -1.0 : 1.0;
-    const zc u = make_double2(piv.x - dk, piv.y);
-    const double un = u.x * u.x + u.y * u.y;
-    if (!(un > 0.25)) { if (tid == 0) *fail = 1; return; }  // uniform
-    if (tid == 0) S.Dg[k] = dk;
-    const double iun = fast_rcp(un);
-    const zc iu = make_double2(u.x * iun, -u.y * iun);
+  for (int k = 0; k < NB; k += 2) {  // two pivots per barrier (see sf_chol); only D is kept, row / column k + 1 stay as they are
+    const zc piva = S.Qt[k][k];
+    const double dka = piva.x >= 0.0 ? -1.0 : 1.0;
+    const zc ua = make_double2(piva.x - dka, piva.y);
+    const double una = ua.x * ua.x + ua.y * ua.y;
+    if (!(una > 0.25)) { if (tid == 0) *fail = 1; return; }  // uniform
+    const double iuna = fast_rcp(una);
+    const zc iua = make_double2(ua.x * iuna, -ua.y * iuna);
+    const zc q01 = S.Qt[k][k + 1];
+    const zc l10 = cmul(S.Qt[k + 1][k], iua);
+    const zc pivb = csub(S.Qt[k + 1][k + 1], cmul(l10, q01));
+    const double dkb = pivb.x >= 0.0 ? -1.0 : 1.0;
+    const zc ub = make_double2(pivb.x - dkb, pivb.y);
+    const double unb = ub.x * ub.x + ub.y * ub.y;
+    if (!(unb > 0.25)) { if (tid == 0) *fail = 1; return; }
+    if (tid == 0) { S.Dg[k] = dka; S.Dg[k + 1] = dkb; }
+    const double iunb = fast_rcp(unb);
+    const zc iub = make_double2(ub.x * iunb, -ub.y * iunb);
     const zc qkj = S.Qt[k][j];
+    const zc r1j = csub(S.Qt[k + 1][j], cmul(l10, qkj));  // row k + 1 after pivot k
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int i = i0 + 16 * q;
-      if (i > k && j > k) S.Qt[i][j] = csub(S.Qt[i][j], cmul(cmul(S.Qt[i][k], iu), qkj));
+      if (i > k + 1 && j > k + 1) {
+        const zc lia = cmul(S.Qt[i][k], iua);
+        const zc c1i = csub(S.Qt[i][k + 1], cmul(lia, q01));  // column k + 1 after pivot k
+        S.Qt[i][j] = csub(csub(S.Qt[i][j], cmul(lia, qkj)), cmul(cmul(c1i, iub), r1j));
+      }
     }
     __syncthreads();
   }

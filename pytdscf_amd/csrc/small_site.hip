@@ -632,6 +632,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     for (int t = tid + 2 * SS_THREADS; t < nR; t += SS_THREADS) Rs[t] = ldR(t);
     for (int t = tid + 4 * SS_THREADS; t < nW; t += SS_THREADS) Ws[t] = c.W2[t];
   }
+  stamp(3);
 
   // stage-1 operand of this chunk: Bs[b][(j, sl)] = scale * vec(b, j, s0 + sl)
   auto load_B = [&](const zc* vec, bool shared, double scl) {
@@ -744,11 +745,13 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     beta0 = sqrt(red[0]);
     if (beta0 == 0.0) { fail(SS_EZERO); return; }
   }
+  stamp(4);
   if (tid == 0) {
     invb[0] = 1.0 / beta0;
     ctl[3] = 0;  // next_unread
   }
   __syncthreads();
+  stamp(5);
 
   bool have_prev = false;
   int prev_len = 0;
