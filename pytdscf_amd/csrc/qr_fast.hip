@@ -14,6 +14,7 @@
 // are not that.  Every Cholesky pivot and every LU pivot is checked on the device; a failed check raises a sticky flag
 // and the caller redoes the factorisation with the per-column Householder kernels (qr.hip), which are unconditionally
 // stable.  One flag read per QR, no host round trip per panel.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -385,44 +386,6 @@ size_t qr_fast_work_elems(int m, int n) {
          + 8;                     // flag
 }
 
-// One panel: A[j0:m, j0:j0+nbp] -> R' / V in place (LAPACK layout), Vp (mp x nbp unit lower trapezoid, contiguous),
-// Tp, tau[j0..].  `ws` = the part of the workspace behind the input copy (see qr_fast_work_elems).
-int qr_fast_panel(hipStream_t st, zc* A, long lda, int m, int j0, int nbp, zc* Vp, zc* Tp, zc* tau, zc* ws, int* flag) {
-  const int mp = m - j0;
-  zc* P = A + (long)j0 * lda + j0;
-  zc* Q1 = ws;
-  zc* Q2 = Q1 + (size_t)m * NB;
-  const int rpb = fq_rows_per_blk(mp);
-  const int nblk = (mp + rpb - 1) / rpb;
-  zc* part = Q2 + (size_t)m * NB;
-  zc* small = part + (size_t)128 * NB * NB;
-  zc* R1inv = small;
-  zc* R2inv = small + NB * NB;
-  zc* R1 = small + 2 * NB * NB;
-  zc* Rtot = small + 3 * NB * NB;
-  zc* Uinv = small + 4 * NB * NB;
-  // round 1
-  hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, P, lda, mp, nbp, part, rpb);
-  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R1inv, (const zc*)nullptr, R1, 0, flag);
-  // (the applies have no partial results to keep few: 32 rows per workgroup, four 8-row passes each)
-  const int arows = 32, ablk = (mp + arows - 1) / arows;
-  hipLaunchKernelGGL(k_fq_apply, dim3(ablk), dim3(256), 0, st, P, lda, mp, nbp, R1inv, Q1, (long)NB, (zc*)nullptr, 0L, 0, arows);
-  // round 2
-  hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, part, rpb);
-  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R2inv, R1, Rtot, 1, flag);
-  hipLaunchKernelGGL(k_fq_apply, dim3(ablk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, R2inv, Q2, (long)NB, (zc*)nullptr, 0L, 0, arows);
-  // Householder reconstruction: top block, then V2 = Q2[nbp:] U^-1 into the panel and into Vp
-  hipLaunchKernelGGL(k_fq_reconstruct, dim3(1), dim3(1024 / FQ_NQ), 0, st, Q2, (long)NB, Rtot, nbp, P, lda, Vp, Tp, tau + j0, Uinv, flag);
-  int nl = 7;
-  if (mp > nbp) {
-    const int nb2 = (mp - nbp + arows - 1) / arows;
-    hipLaunchKernelGGL(k_fq_apply, dim3(nb2), dim3(256), 0, st, Q2, (long)NB, mp, nbp, Uinv, P, lda, Vp, (long)nbp, nbp, arows);
-    ++nl;
-  }
-  HIP_CHECK(hipGetLastError());
-  return nl;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // The whole factorisation of a SMALL matrix (m <= 320, n <= 32: the gauge moves of the small-bond regime, C2's 320 x 32)
 // in ONE workgroup: CholeskyQR2 with the two Gram matrices and the two triangular applies on the matrix cores, and
@@ -444,12 +407,13 @@ constexpr int SF_T = 512;
 typedef double sf_d4 __attribute__((ext_vector_type(4)));
 
 typedef zc SfMat[NB][NB + 1];
+typedef double SfPart[4][6][4][64];
 struct SfSmem {
   SfMat G;   // Gram matrix -> R (upper)
   SfMat W;   // R^-1
   SfMat P1;  // R1, then R2 R1
   SfMat Qt;  // scratch of the inverse; then the top block of Q for the LU chain
-  double pb[4][6][4][64];  // Gram partials [row quarter][stream][accumulator register][lane]
+  SfPart pb;  // Gram partials [row quarter][stream][accumulator register][lane]
   double d0[NB];
   double Dg[NB];
   double emax[SF_T / 64];
@@ -457,8 +421,8 @@ struct SfSmem {
 
 __device__ __forceinline__ sf_d4 sf_mfma(double a, double b, sf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
-// G = src^H src (upper triangle), padded with the identity beyond n; W = I; d0 = diag
-__device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSmem& S, int cd_mode) {
+// the six real streams of the upper 2 x 2 blocks of src^H src, one partial per row quarter, left in pb (barrier included)
+__device__ void sf_gram_partials(const zc* __restrict__ src, long ld, int m, int n, SfPart& pb) {
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
   const int rq = w >> 1, half = w & 1;
   const int nks = (m + 3) / 4, per = (nks + 3) / 4;
@@ -493,27 +457,35 @@ __device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSme
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S.pb[rq][half * 3 + t][r][l] = acc[t][r];
+    for (int r = 0; r < 4; ++r) pb[rq][half * 3 + t][r][l] = acc[t][r];
   __syncthreads();
-  const int j = tid & 31, i0 = tid >> 5;
+}
+// element (i, j), j >= i, of the Gram matrix from the quarter partials (summed in a fixed order)
+__device__ __forceinline__ zc sf_gram_element(const SfPart& pb, int i, int j, int cd_mode) {
+  const int blk = (i >> 4) + (j >> 4), ii = i & 15, jj = j & 15;
+  const int lk_ = cd_mode == 0 ? (ii & 3) : (ii >> 2), r_ = cd_mode == 0 ? (ii >> 2) : (ii & 3);
+  const int ln = lk_ * 16 + jj;
+  // streams: 0 = 00 re, 1 = 00 P, 2 = 01 re, 3 = 01 im, 4 = 11 re, 5 = 11 P
+  const int sre = blk == 0 ? 0 : (blk == 1 ? 2 : 4), sim = blk == 0 ? 1 : (blk == 1 ? 3 : 5);
+  const int lkt = cd_mode == 0 ? (jj & 3) : (jj >> 2), rt = cd_mode == 0 ? (jj >> 2) : (jj & 3);
+  const int lnt = lkt * 16 + ii;  // element (jj, ii) of the same block
+  zc g = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    g.x += pb[p][sre][r_][ln];
+    g.y += blk == 1 ? pb[p][sim][r_][ln] : pb[p][sim][r_][ln] - pb[p][sim][rt][lnt];
+  }
+  return g;
+}
+// G = src^H src (upper triangle), padded with the identity beyond n; d0 = diag
+__device__ void sf_gram(const zc* __restrict__ src, long ld, int m, int n, SfSmem& S, int cd_mode) {
+  sf_gram_partials(src, ld, m, n, S.pb);
+  const int tid = threadIdx.x, j = tid & 31, i0 = tid >> 5;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int i = i0 + 16 * q;
     zc g = make_double2(0.0, 0.0);
-    if (j >= i) {
-      const int blk = (i >> 4) + (j >> 4), ii = i & 15, jj = j & 15;
-      const int lk_ = cd_mode == 0 ? (ii & 3) : (ii >> 2), r_ = cd_mode == 0 ? (ii >> 2) : (ii & 3);
-      const int ln = lk_ * 16 + jj;
-      // streams: 0 = 00 re, 1 = 00 P, 2 = 01 re, 3 = 01 im, 4 = 11 re, 5 = 11 P
-      const int sre = blk == 0 ? 0 : (blk == 1 ? 2 : 4), sim = blk == 0 ? 1 : (blk == 1 ? 3 : 5);
-      const int lkt = cd_mode == 0 ? (jj & 3) : (jj >> 2), rt = cd_mode == 0 ? (jj >> 2) : (jj & 3);
-      const int lnt = lkt * 16 + ii;  // element (jj, ii) of the same block
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        g.x += S.pb[p][sre][r_][ln];
-        g.y += blk == 1 ? S.pb[p][sim][r_][ln] : S.pb[p][sim][r_][ln] - S.pb[p][sim][rt][lnt];
-      }
-    }
+    if (j >= i) g = sf_gram_element(S.pb, i, j, cd_mode);
     if (i >= n || j >= n) g = i == j ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
     if (i == j) { g.y = 0.0; S.d0[i] = g.x; }
     S.G[i][j] = g;
@@ -832,7 +804,53 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
   if (tid == 0) *fail = 0;
   stamp(9);
 }
+// Partial Gram matrices of a tall panel on the matrix cores: workgroup b takes rows_per_blk rows (eight waves = four row
+// quarters x two halves of the six streams, as in the small kernel) and writes ONE 32 x 32 partial, Hermitian, zero beyond nb.
+// 128 rows cost about what k_fq_gram's plain-FMA tiles need for 32, so a 4096-row panel leaves 32 partials for the one
+// workgroup of the Cholesky kernel to stream instead of 128 (27 of that kernel's 38 us were that stream).
+__global__ __launch_bounds__(SF_T) void k_fq_gram_mfma(const zc* __restrict__ P, long ld, int mp, int nb, zc* __restrict__ part,
+                                                       int rows_per_blk, int cd_mode) {
+  __shared__ SfPart pb;
+  const long r0 = (long)blockIdx.x * rows_per_blk;
+  const int nr = (int)min((long)rows_per_blk, mp - r0);
+  sf_gram_partials(P + r0 * ld, ld, nr, nb, pb);
+  const int tid = threadIdx.x, j = tid & 31, i0 = tid >> 5;
+  zc* o = part + (size_t)blockIdx.x * NB * NB;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = i0 + 16 * q;
+    zc g = make_double2(0.0, 0.0);
+    if (i < nb && j < nb) {
+      if (j >= i) g = sf_gram_element(pb, i, j, cd_mode);
+      else { g = sf_gram_element(pb, j, i, cd_mode); g.y = -g.y; }
+    }
+    o[i * NB + j] = g;
+  }
+}
 }  // namespace
+
+// MITDVP_QR_GRAM_MFMA=0: the plain-FMA Gram kernel with 32 rows per workgroup (A/B runs)
+static bool fq_gram_mfma_on() {
+  static const bool on = !(std::getenv("MITDVP_QR_GRAM_MFMA") && std::atoi(std::getenv("MITDVP_QR_GRAM_MFMA")) == 0);
+  return on;
+}
+static int fq_rows_per_blk_mfma(int m) {  // 128 rows per workgroup (MITDVP_QR_GRAM_ROWS; QR ms per 6 sweeps at 64 / 128 / 256 / 512 rows: C3 12.1 / 11.6 / 11.9 / 12.9, C5 1565 / 1557 / 1602 / 1758; 13.2 / 1648 with k_fq_gram), at most 128 workgroups
+  static const int rows_env = [] { const char* e = std::getenv("MITDVP_QR_GRAM_ROWS"); return e ? std::max(32, std::atoi(e) / 4 * 4) : 128; }();
+  int r = rows_env;
+  if ((m + r - 1) / r > 128) r = ((m + 127) / 128 + 3) / 4 * 4;
+  return r;
+}
+// number of partials written
+static int fq_gram_launch(hipStream_t st, const zc* P, long ld, int mp, int nb, zc* part) {
+  if (fq_gram_mfma_on()) {
+    const int rpb = fq_rows_per_blk_mfma(mp), nblk = (mp + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_fq_gram_mfma, dim3(nblk), dim3(SF_T), 0, st, P, ld, mp, nb, part, rpb, zgemm_cd_mode(st));
+    return nblk;
+  }
+  const int rpb = fq_rows_per_blk(mp), nblk = (mp + rpb - 1) / rpb;
+  hipLaunchKernelGGL(k_fq_gram, dim3(nblk), dim3(256), 0, st, P, ld, mp, nb, part, rpb);
+  return nblk;
+}
 
 size_t qr_small_fast_lds() { return sizeof(SfSmem); }
 
@@ -867,6 +885,43 @@ void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* 
     for (int k = 0; k < 9; ++k) fprintf(stderr, " %.2f", (double)(h[k + 1] - h[k]) * 0.01);
     fprintf(stderr, "\n");
   }
+}
+
+
+// One panel: A[j0:m, j0:j0+nbp] -> R' / V in place (LAPACK layout), Vp (mp x nbp unit lower trapezoid, contiguous),
+// Tp, tau[j0..].  `ws` = the part of the workspace behind the input copy (see qr_fast_work_elems).
+int qr_fast_panel(hipStream_t st, zc* A, long lda, int m, int j0, int nbp, zc* Vp, zc* Tp, zc* tau, zc* ws, int* flag) {
+  const int mp = m - j0;
+  zc* P = A + (long)j0 * lda + j0;
+  zc* Q1 = ws;
+  zc* Q2 = Q1 + (size_t)m * NB;
+  zc* part = Q2 + (size_t)m * NB;
+  zc* small = part + (size_t)128 * NB * NB;
+  zc* R1inv = small;
+  zc* R2inv = small + NB * NB;
+  zc* R1 = small + 2 * NB * NB;
+  zc* Rtot = small + 3 * NB * NB;
+  zc* Uinv = small + 4 * NB * NB;
+  // round 1
+  int nblk = fq_gram_launch(st, P, lda, mp, nbp, part);
+  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R1inv, (const zc*)nullptr, R1, 0, flag);
+  // (the applies have no partial results to keep few: 32 rows per workgroup, four 8-row passes each)
+  const int arows = 32, ablk = (mp + arows - 1) / arows;
+  hipLaunchKernelGGL(k_fq_apply, dim3(ablk), dim3(256), 0, st, P, lda, mp, nbp, R1inv, Q1, (long)NB, (zc*)nullptr, 0L, 0, arows);
+  // round 2
+  nblk = fq_gram_launch(st, Q1, (long)NB, mp, nbp, part);
+  hipLaunchKernelGGL(k_fq_chol, dim3(1), dim3(1024 / FQ_NQ), 0, st, part, nblk, nbp, R2inv, R1, Rtot, 1, flag);
+  hipLaunchKernelGGL(k_fq_apply, dim3(ablk), dim3(256), 0, st, Q1, (long)NB, mp, nbp, R2inv, Q2, (long)NB, (zc*)nullptr, 0L, 0, arows);
+  // Householder reconstruction: top block, then V2 = Q2[nbp:] U^-1 into the panel and into Vp
+  hipLaunchKernelGGL(k_fq_reconstruct, dim3(1), dim3(1024 / FQ_NQ), 0, st, Q2, (long)NB, Rtot, nbp, P, lda, Vp, Tp, tau + j0, Uinv, flag);
+  int nl = 7;
+  if (mp > nbp) {
+    const int nb2 = (mp - nbp + arows - 1) / arows;
+    hipLaunchKernelGGL(k_fq_apply, dim3(nb2), dim3(256), 0, st, Q2, (long)NB, mp, nbp, Uinv, P, lda, Vp, (long)nbp, nbp, arows);
+    ++nl;
+  }
+  HIP_CHECK(hipGetLastError());
+  return nl;
 }
 
 
