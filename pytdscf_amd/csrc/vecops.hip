@@ -778,6 +778,22 @@ void vec_copy_raw(hipStream_t st, zc* dst, const zc* src, size_t n) {
   HIP_CHECK(hipGetLastError());
 }
 
+// the workgroup's maximum -> ONE atomic per workgroup.  (One per wave, all on the same word, was the whole cost of these
+// kernels: atomics on one address serialise at ~130 ns each -- 3 x 1024 of them made the masked check of the three identity
+// states of a C5 site 134 us for 12.6 MB, 1.5 % of a C5 sweep in profiles/r04_c5_kernel_stats.csv.)
+__device__ __forceinline__ void ident_block_max(double m, unsigned long long* out) {
+  __shared__ double wmax[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    // non-negative doubles order like their bit patterns
+    if (t > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(t));
+  }
+}
+
 __global__ __launch_bounds__(256) void k_ident_dev(const zc* __restrict__ blk, long ld, int n, unsigned long long* __restrict__ out) {
   double m = 0.0;
   const long tot = (long)n * n;
@@ -786,10 +802,7 @@ __global__ __launch_bounds__(256) void k_ident_dev(const zc* __restrict__ blk, l
     const zc v = blk[(long)r * ld + c];
     m = fmax(m, fmax(fabs(v.x - (r == c ? 1.0 : 0.0)), fabs(v.y)));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
-  // non-negative doubles order like their bit patterns
-  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+  ident_block_max(m, out);
 }
 // nblk blocks at once, against MULTIPLES of the identity: block c starts at base + c * blk_stride; lam[c] = its first
 // diagonal element, out[c] = max |blk - lam * 1|
@@ -807,16 +820,14 @@ __global__ __launch_bounds__(256) void k_ident_dev_multi(const zc* __restrict__ 
     const zc v = blk[(long)r * ld + c];
     m = fmax(m, r == c ? fmax(fabs(v.x - l.x), fabs(v.y - l.y)) : fmax(fabs(v.x), fabs(v.y)));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out + blockIdx.y, (unsigned long long)__double_as_longlong(m));
+  ident_block_max(m, out + blockIdx.y);
 }
 void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_stride, long ld, int n, double* out_dev,
                            zc* lam_dev, unsigned long long mask) {
   if (nblk < 1) return;
   HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)nblk * sizeof(double), st));
   const long tot = (long)n * n;
-  const int nb = (int)std::min<long>((tot + 255) / 256, 256);
+  const int nb = (int)std::min<long>((tot + 2047) / 2048, 64);  // eight elements per thread and pass, <= 64 atomics per block
   hipLaunchKernelGGL(k_ident_dev_multi, dim3(nb, nblk), dim3(256), 0, st, base, blk_stride, ld, n,
                      reinterpret_cast<unsigned long long*>(out_dev), lam_dev, mask);
   HIP_CHECK(hipGetLastError());
@@ -824,7 +835,7 @@ void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_st
 void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_dev) {
   HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(double), st));
   const long tot = (long)n * n;
-  const int nb = (int)std::min<long>((tot + 255) / 256, 1024);
+  const int nb = (int)std::min<long>((tot + 2047) / 2048, 256);
   hipLaunchKernelGGL(k_ident_dev, dim3(nb), dim3(256), 0, st, blk, ld, n, reinterpret_cast<unsigned long long*>(out_dev));
   HIP_CHECK(hipGetLastError());
 }
