@@ -59,6 +59,43 @@ import socket  # noqa: E402
 import subprocess  # noqa: E402
 import sys  # noqa: E402
 
+
+def one_socket_physical_cores():
+    """(socket id, one logical CPU per physical core of that socket) among the CPUs this process may use: the socket
+    that offers the most cores (the CPU baseline runs pinned to one socket, all its physical cores)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None, []
+    by_pkg = {}
+    for c in allowed:
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        by_pkg.setdefault(pkg, {}).setdefault(core, c)  # first logical CPU of each physical core
+    if not by_pkg:
+        return None, []
+    pkg = max(by_pkg, key=lambda k: (len(by_pkg[k]), -k))
+    return pkg, sorted(by_pkg[pkg].values())
+
+
+CPU_WORKER_FLAG = "--cpu-baseline-worker"
+CPU_PLACEMENT = None
+if CPU_WORKER_FLAG in sys.argv:
+    # The CPU-baseline leg runs in a process of its own, pinned BEFORE NumPy / OpenBLAS start their thread pool (threads
+    # inherit the affinity of the thread that creates them; the pool of an already running process cannot be re-pinned).
+    _pkg, _cpus = one_socket_physical_cores()
+    if _cpus:
+        os.sched_setaffinity(0, _cpus)
+        for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            os.environ[_v] = str(len(_cpus))
+    CPU_PLACEMENT = {"pinned": bool(_cpus), "socket": _pkg, "affinity_cpus": len(_cpus),
+                     "note": "one logical CPU per physical core of one socket (os.sched_setaffinity before NumPy / OpenBLAS "
+                             "start their threads; OPENBLAS_NUM_THREADS = that count)"}
+
 import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -163,13 +200,28 @@ def cpu_baseline(L, d, D, M, kh, kk, n_threads, dt, budget_s=15.0, short=False):
     return dict(value=n / el, unit="sweeps/s", cores=n_threads, kind="port", sample=f"{n} full sweeps of the oracle, {el:.1f}s")
 
 
-def committed_traffic(name, L, d, D, M):
+def workload_name(L, d, D, M):
+    for k, v in WORKLOADS.items():
+        if v[:4] == (L, d, D, M):
+            return k
+    return None
+
+
+def committed_traffic(name, L, d, D, M, form="chain"):
     """(HBM-side bytes per H_eff apply, the committed file they come from) -- PMC passes run beside the bench, NOT a
     measurement of this run (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per
-    MI355X_MICROARCH.md), newest round first; (None, None) for shapes that were not measured."""
-    cands = ["r%02d_%s_traffic.json" % (r, name) for r in (4, 3, 2, 1)]
-    if name == "heff":  # per-shape files of the other large-bond workloads
-        cands = ["r%02d_heff_traffic_D%d_d%d_M%d.json" % (r, D, d, M) for r in (4, 3)] + cands
+    MI355X_MICROARCH.md).  Newest round first, and only files of the apply FORM that ran (`form`: "chain" = the
+    three-stage chain, "edge" = the two-product form; the one-launch small-bond kernel has its own files); (None, None)
+    when no pass of that form and shape is committed."""
+    rounds = range(9, 0, -1)
+    if name == "heff":
+        wl = workload_name(L, d, D, M)
+        cands = ["r%02d_heff_traffic_%s_%s.json" % (r, wl, form) for r in rounds] if wl else []
+        if form == "chain":  # older files: per shape (round 3) or the C4 default (rounds 1-3), all of the chain form
+            cands += ["r%02d_heff_traffic_D%d_d%d_M%d.json" % (r, D, d, M) for r in (4, 3)]
+            cands += ["r%02d_heff_traffic.json" % r for r in (3, 2, 1)]
+    else:
+        cands = ["r%02d_%s_traffic.json" % (r, name) for r in rounds]
     for fn in cands:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", fn)))
@@ -193,14 +245,29 @@ def cpu_model():
     return None
 
 
-def cpu_placement():
-    """what the CPU baseline ran on: CPUs this process may use (no pinning is applied: the BLAS threads float over them)"""
+def cpu_baseline_pinned(L, d, D, M, kh, kk, dt, budget_s=15.0, short=False, timeout_s=240.0):
+    """The cpu_baseline leg in a child process pinned to one socket's physical cores (see CPU_WORKER_FLAG above); the
+    child never touches the GPU.  Returns the record of `cpu_baseline` plus placement, thread count and CPU model."""
+    req = json.dumps({"L": L, "d": d, "D": D, "M": M, "kh": kh, "kk": kk, "dt": dt, "budget_s": budget_s, "short": short})
     try:
-        aff = sorted(os.sched_getaffinity(0))
-        return {"affinity_cpus": len(aff), "pinned": False,
-                "note": "not pinned to a socket: OpenBLAS runs its own thread pool (cores) over the CPUs the process may use"}
-    except (AttributeError, OSError):
-        return {"affinity_cpus": None, "pinned": False}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), CPU_WORKER_FLAG, req], capture_output=True, text=True,
+                           timeout=timeout_s, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"rc={r.returncode}: {r.stderr.strip()[-300:]}")
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001 -- the GPU numbers stand on their own
+        return {"error": f"cpu baseline worker failed ({type(e).__name__}: {e})"}
+
+
+def cpu_worker_main(req_json):
+    q = json.loads(req_json)
+    nthr = blas_threads()
+    rec = cpu_baseline(q["L"], q["d"], q["D"], q["M"], q["kh"], q["kk"], nthr, q["dt"], budget_s=q["budget_s"], short=q["short"])
+    rec["host_cpus"] = os.cpu_count()
+    rec["cpu_model"] = cpu_model()
+    rec.update(CPU_PLACEMENT or {"pinned": False})
+    sys.stdout.write(json.dumps(rec) + "\n")
 
 
 def blas_threads():
@@ -231,7 +298,8 @@ def roofline_report(cnt, L, d, D, M, gemm_mode, el_s, profile_in_timed, tp=False
     small = D < 128
     bytes_apply = 16.0 * (2 * D * d * D + 2 * D * D * M + M * d * d * M)  # interior site, SURVEY 8d B_H
     ach_gbs = bytes_apply * cnt["n_heff"] / max(cnt["heff_ms"], 1e-9) / 1e6  # GB/s
-    traffic, traffic_src = committed_traffic("c2" if small else "heff", L, d, D, M)
+    form = "edge" if cnt.get("n_heff_edge", 0.0) > 0.5 * max(cnt["n_heff"], 1) else "chain"
+    traffic, traffic_src = committed_traffic("c2" if small else "heff", L, d, D, M, form)
     if small:
         roof = {
             "bound": "hbm",
@@ -252,7 +320,9 @@ def roofline_report(cnt, L, d, D, M, gemm_mode, el_s, profile_in_timed, tp=False
     else:
         roof = {
             "bound": "mfma",
-            "kernel": "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)" + (" -- per GPU, this rank's bond shard" if tp else ""),
+            "kernel": ("zgemm_kernel (H_eff apply, edge form = 2 launches with a reducing epilogue: psi.R^T (x) W, L.psi (x) W)" if form == "edge"
+                       else "zgemm_kernel (H_eff apply = 3 launches: L.psi, W., .R)") + (" -- per GPU, this rank's bond shard" if tp else ""),
+            "apply_form": form,
             "achieved": executed,
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -395,15 +465,18 @@ def secondary_leg(name, device, gemm_mode, seconds, steps_req, with_cpu, note):
             sweep()
         nrm = eng.norm()
         el = time.perf_counter() - t0
+        if profile_in_timed:
+            cnt = eng.counters()
+        eng.set_profiling(False)
+        e1 = energy_at_centre(eng)  # the state after exactly `steps` timed sweeps (the profiled repeat below moves it on)
         if not profile_in_timed:
             eng.counters_reset()
             eng.set_profiling(True)
             for _ in range(steps):
                 sweep()
             eng.norm()
-        cnt = eng.counters()
-        eng.set_profiling(False)
-        e1 = energy_at_centre(eng)
+            cnt = eng.counters()
+            eng.set_profiling(False)
         roof, brk, kh, kk = roofline_report(cnt, L, d, D, M, gemm_mode, el, profile_in_timed)
         rec = {
             "workload": f"{name}: {desc}",
@@ -426,12 +499,49 @@ def secondary_leg(name, device, gemm_mode, seconds, steps_req, with_cpu, note):
             rec["ensemble"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:
         note(f"{name}: timing the CPU baseline (oracle on the host cores)")
-        rec["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, blas_threads(), dt, budget_s=6.0, short=True)
-        rec["cpu_baseline"]["host_cpus"] = os.cpu_count()
-        rec["cpu_baseline"]["cpu_model"] = cpu_model()
-        rec["cpu_baseline"].update(cpu_placement())
+        rec["cpu_baseline"] = cpu_baseline_pinned(L, d, D, M, kh, kk, dt, budget_s=6.0, short=True, timeout_s=90.0)
     rec["leg_s"] = time.perf_counter() - t_leg
     return rec
+
+
+def compact_record(rec):
+    """A secondary leg's record without its prose (the headline `roofline` carries the notes once): the whole `secondary`
+    object stays under 8 KB so that the JSON line fits the driver's stdout tail."""
+    drop = {"note", "traffic_note", "w_stage", "kernel", "phases_from", "sample"}
+
+    def strip(x):
+        if isinstance(x, dict):
+            return {k: strip(v) for k, v in x.items() if k not in drop}
+        if isinstance(x, float):
+            return float(f"{x:.6g}")
+        if isinstance(x, list):
+            return [strip(v) for v in x]
+        return x
+
+    out = strip(rec)
+    if isinstance(rec, dict) and isinstance(rec.get("cpu_baseline"), dict) and "sample" in rec["cpu_baseline"]:
+        out["cpu_baseline"]["sample"] = rec["cpu_baseline"]["sample"][:90]
+    return out
+
+
+def secondary_summary(sec):
+    """{workload: {value, frac, ...}} of the secondary legs, carried inside the headline `config` (the driver's parsed
+    record keeps `config`; extra top-level keys are not guaranteed to survive)."""
+    out = {}
+    for w, r in sec.items():
+        if not isinstance(r, dict) or "value" not in r:
+            out[w] = {"error": str(r.get("error", "failed"))[:80] if isinstance(r, dict) else "failed"}
+            continue
+        roof = r.get("roofline", {})
+        out[w] = {"value": float(f"{r['value']:.5g}"), "unit": "sweeps/s", "frac": float(f"{roof.get('frac', 0.0):.4g}"),
+                  "bound": roof.get("bound"), "steps": r.get("steps")}
+        cb = r.get("cpu_baseline")
+        if isinstance(cb, dict) and "value" in cb:
+            out[w]["cpu_value"] = float(f"{cb['value']:.4g}")
+        ens = r.get("ensemble")
+        if isinstance(ens, dict) and "replicas" in ens:
+            out[w + "_ensemble"] = {b: float(f"{v['value']:.5g}") for b, v in ens["replicas"].items()}
+    return out
 
 
 def plan_sweeps(budget_s, elapsed_s, t_sweep, warm_done, warm_req, steps_req, reserve_s):
@@ -485,6 +595,9 @@ def self_launch(args, argv):
 
 
 def main():
+    if CPU_WORKER_FLAG in sys.argv:
+        cpu_worker_main(sys.argv[sys.argv.index(CPU_WORKER_FLAG) + 1])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -680,14 +793,24 @@ def main():
         value = steps / el
     else:
         value, el = replica_throughput(comm, float(steps), el_rank)
+    e1 = None
+    if profile_in_timed:
+        cnt = meas.counters()
+    meas.set_profiling(False)
+    # norm / energy of the state after exactly the timed sweeps, before the profiled repeat moves it on
+    if ss is not None:  # the sharded state's own norm and energy after the run (collective; not timed)
+        nrm = ss.norm()
+        e1 = ss.expectation().real
+    elif mode == "single":  # energy conservation of the run itself, from the blocks the last sweep left around the centre
+        e1 = energy_at_centre(eng)
     if not profile_in_timed:
         meas.counters_reset()
         meas.set_profiling(True)
         for i in range(0, steps, unit):
             run_unit()
         sync_norm()
-    cnt = meas.counters()
-    meas.set_profiling(False)
+        cnt = meas.counters()
+        meas.set_profiling(False)
     halo = ss.traffic() if ss is not None else (0, 0)
     per_rank = None
     if ss is not None:  # every rank's share of the time step: block half-sweeps vs junction updates (incl. waiting for them)
@@ -702,12 +825,6 @@ def main():
             per_rank = [[float(x) for x in a.tolist()] for a in allr]
         else:
             per_rank = [mine]
-    e1 = None
-    if ss is not None:  # the sharded state's own norm and energy after the run (collective; not timed)
-        nrm = ss.norm()
-        e1 = ss.expectation().real
-    elif mode == "single":  # energy conservation of the run itself (a fresh chain of right blocks; not timed)
-        e1 = energy_at_centre(eng)  # wherever the centre sits (first or last site), from the blocks the sweep left behind
 
     if rank == 0:
         roof, brk, kh, kk = roofline_report(cnt, L, d, D, M, gemm_mode, el, profile_in_timed, tp=(mode == "tp"))
@@ -765,10 +882,7 @@ def main():
         }
         if with_cpu:
             note("timing the CPU baseline (oracle on the host cores)")
-            out["cpu_baseline"] = cpu_baseline(L, d, D, M, kh, kk, blas_threads(), dt)
-            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
-            out["cpu_baseline"]["cpu_model"] = cpu_model()
-            out["cpu_baseline"].update(cpu_placement())
+            out["cpu_baseline"] = cpu_baseline_pinned(L, d, D, M, kh, kk, dt)
         # ---- the other BASELINE configs, driver-observed: short single-GPU legs after the headline run ----
         if mode == "single" and args.secondary != "none":
             names = [w for w in ("C2", "C3", "C5") if w != args.workload] if args.secondary == "auto" else \
@@ -786,6 +900,8 @@ def main():
                                                         not args.no_cpu_baseline, note)
                 except Exception as e:  # noqa: BLE001 -- the headline number stands on its own
                     out["secondary"][w] = {"error": f"{type(e).__name__}: {e}"}
+            out["config"]["secondary_summary"] = secondary_summary(out["secondary"])
+            out["secondary"] = {w: compact_record(r) for w, r in out["secondary"].items()}
         out["wall_s"] = elapsed()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if eng is not None:

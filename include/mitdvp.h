@@ -415,7 +415,7 @@ typedef struct {
   double collective_bytes; /* sum of the collective buffer sizes                       */
   double heff_flops_skipped; /* part of heff_flops NOT executed: zero blocks of W skipped by the block-sparse W stage */
   double n_host_waits;     /* device->host records the host waited for inside local exponentials (multi-launch regime) */
-  double reserved[1];
+  double n_heff_edge;      /* H_eff applies that took the two-product "edge" form (the others ran the three-stage chain or the one-launch kernel) */
   double heff_stage_flops[3]; /* 8-flop-per-complex-MAC count of what the three stages EXECUTE (trimmed identity blocks,
                                  skipped zero blocks and tile padding of the W stage accounted; the 3M product's 6 / 8 is
                                  applied by the reader): with heff_stage_ms the roofline of each stage's kernel */

@@ -64,7 +64,7 @@ class Counters(C.Structure):
         ("collective_bytes", C.c_double),
         ("heff_flops_skipped", C.c_double),
         ("n_host_waits", C.c_double),
-        ("reserved", C.c_double * 1),
+        ("n_heff_edge", C.c_double),
         ("heff_stage_flops", C.c_double * 3),
     ]
 

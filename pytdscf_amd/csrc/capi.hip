@@ -35,6 +35,9 @@ int guard(mitdvp_engine* h, F&& f) {
   } catch (const std::exception& ex) {
     *dst = ex.what();
     return MITDVP_ESTATE;
+  } catch (...) {  // nothing may leave an extern "C" entry point or a worker thread of mitdvp_ensemble_step
+    *dst = "unknown exception";
+    return MITDVP_ESTATE;
   }
 }
 
@@ -142,6 +145,9 @@ int mitdvp_ensemble_step(mitdvp_engine** hs, int n, double dt, int nsteps, int* 
   if (!hs || n < 1 || nsteps < 0) { g_err = "mitdvp_ensemble_step: bad arguments"; return MITDVP_EINVAL; }
   for (int i = 0; i < n; ++i)
     if (!hs[i] || !hs[i]->e) { g_err = "mitdvp_ensemble_step: null engine"; return MITDVP_EINVAL; }
+  for (int i = 0; i < n; ++i)  // a handle is driven by one host thread at a time
+    for (int k = 0; k < i; ++k)
+      if (hs[k] == hs[i]) { g_err = "mitdvp_ensemble_step: the same engine is listed twice"; return MITDVP_EINVAL; }
   std::vector<int> rc((size_t)n, MITDVP_OK);
   std::vector<std::thread> th;
   th.reserve((size_t)n);

@@ -113,6 +113,10 @@ struct PhaseTimer {
 };
 
 class SiteShard;
+// compute-unit ranges of CU-masked engines (engine_small.hip): overlapping claims throw ArgError
+void cu_range_claim(int device, int first, int count);
+void cu_range_release(int device, int first, int count);
+int cu_ranges_claimed(int device);
 
 class Engine {
   friend class SiteShard;  // shard.hip: the junction update works on the tensors and blocks of two engines in place
@@ -267,6 +271,12 @@ class Engine {
 
  private:
   int ptr_mode_ = 0;
+  // this engine's compute-unit range in the per-device claim table (engine_small.hip); a member, so that a constructor
+  // that throws later on gives the range back
+  struct CuClaim {
+    int dev = -1, first = 0, count = 0;
+    ~CuClaim() { if (dev >= 0) cu_range_release(dev, first, count); }
+  } cu_claim_;
   // H_eff applies of the current local exponential: the last MPO-bond block of the right environment is the identity
   // (sites right of the centre are right-canonical and the MPO passes "nothing applied yet" through: the reference
   // short-circuits such blocks as well, _mps_mpo.py:510-523) -- verified numerically per site, see local_site_exp

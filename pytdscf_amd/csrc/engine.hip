@@ -43,6 +43,8 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
       throw ArgError("cu_first / cu_count: a multiple of 8 compute units inside the device (8 k units = k CUs on every XCD)");
     std::vector<uint32_t> mask((size_t)(n_cu_ + 31) / 32, 0u);
     for (int u = c.cu_first; u < c.cu_first + c.cu_count; ++u) mask[(size_t)u / 32] |= 1u << (u % 32);
+    cu_range_claim(c.device, c.cu_first, c.cu_count);  // refuses a range that overlaps another engine's
+    cu_claim_.dev = c.device; cu_claim_.first = c.cu_first; cu_claim_.count = c.cu_count;
     HIP_CHECK(hipExtStreamCreateWithCUMask(&st_, (uint32_t)mask.size(), mask.data()));
     n_cu_ = c.cu_count;
     ss_.max_grid = c.cu_count;
@@ -681,6 +683,7 @@ void Engine::heff_apply_edge(const zc* L, const MpoSite& w, const zc* R, const z
   }
   if (first) HIP_CHECK(hipMemsetAsync(out, 0, (size_t)dl * d * dr * sizeof(zc), st_));  // a zero core
   cnt_.n_heff += 1;
+  cnt_.n_heff_edge += 1;
   const double alg = 8.0 * ((double)dl * dl * ml * d * dr + (double)dl * dr * ml * mr * d * d + (double)dl * dr * dr * mr * d);
   cnt_.heff_flops += alg;
   cnt_.heff_flops_skipped += alg - exe;

@@ -9,9 +9,52 @@
 // whenever their chain fits, whatever the mode.
 #include "engine_internal.h"
 
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
 namespace mitdvp {
 
-bool Engine::small_ok() const { return small_kernels_ && nranks_ == 1 && n_cu_ > 0; }
+// Compute-unit ranges claimed by CU-masked engines, per device.  Persistent grids (k_small_site, k_qr_panel) need all
+// their workgroups resident at once: two masked engines whose ranges overlap, or a masked engine beside a full-device one,
+// could each hold compute units the other's waiting workgroups need.  Overlapping claims are refused, and while any range
+// is claimed on a device the full-device engines there run the multi-launch kernels (small_ok()).
+namespace {
+struct CuClaims {
+  std::mutex mu;
+  std::vector<std::pair<int, int>> r[64];
+};
+CuClaims& cu_claims() { static CuClaims c; return c; }
+}  // namespace
+void cu_range_claim(int device, int first, int count) {
+  if (device < 0 || device >= 64) throw ArgError("cu_first / cu_count: device ordinal outside the claim table");
+  CuClaims& c = cu_claims();
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (const auto& q : c.r[device])
+    if (first < q.first + q.second && q.first < first + count)
+      throw ArgError("cu_first / cu_count: [" + std::to_string(first) + ", " + std::to_string(first + count) +
+                     ") overlaps the range [" + std::to_string(q.first) + ", " + std::to_string(q.first + q.second) +
+                     ") of another engine on this device");
+  c.r[device].push_back({first, count});
+}
+void cu_range_release(int device, int first, int count) {
+  if (device < 0 || device >= 64) return;
+  CuClaims& c = cu_claims();
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (size_t i = 0; i < c.r[device].size(); ++i)
+    if (c.r[device][i].first == first && c.r[device][i].second == count) { c.r[device].erase(c.r[device].begin() + i); return; }
+}
+int cu_ranges_claimed(int device) {
+  if (device < 0 || device >= 64) return 0;
+  CuClaims& c = cu_claims();
+  std::lock_guard<std::mutex> lk(c.mu);
+  return (int)c.r[device].size();
+}
+
+bool Engine::small_ok() const {
+  return small_kernels_ && nranks_ == 1 && n_cu_ > 0 && (ss_.partitioned || cu_ranges_claimed(cfg.device) == 0);
+}
 
 // sigma[a,i,r] = sum L[a,c,b] W[c,i,j,t] R[r,t,s] psi[b,j,s]   (_contraction.py:1182-1243)
 bool Engine::chain_heff(SmallChain& c, const zc* L, const MpoSite& w, const zc* R, int dl, int d, int dr, bool exp_mode) const {

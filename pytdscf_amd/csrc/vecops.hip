@@ -794,13 +794,20 @@ __device__ __forceinline__ void ident_block_max(double m, unsigned long long* ou
   }
 }
 
+// fmax drops a NaN: a non-finite element must make the block FAIL the identity test, not pass it with deviation 0 (the
+// edge form would then replace a corrupted environment block by a clean identity multiple and hide the corruption)
+__device__ __forceinline__ double finite_or_huge(zc v, double dev) {
+  return (v.x - v.x == 0.0 && v.y - v.y == 0.0 && dev == dev) ? dev : 1e308;  // x - x is NaN for NaN and +-Inf
+}
+
 __global__ __launch_bounds__(256) void k_ident_dev(const zc* __restrict__ blk, long ld, int n, unsigned long long* __restrict__ out) {
   double m = 0.0;
   const long tot = (long)n * n;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
     const int r = (int)(e / n), c = (int)(e % n);
     const zc v = blk[(long)r * ld + c];
-    m = fmax(m, fmax(fabs(v.x - (r == c ? 1.0 : 0.0)), fabs(v.y)));
+    const double dv = fmax(fabs(v.x - (r == c ? 1.0 : 0.0)), fabs(v.y));
+    m = fmax(m, finite_or_huge(v, dv));
   }
   ident_block_max(m, out);
 }
@@ -818,7 +825,8 @@ __global__ __launch_bounds__(256) void k_ident_dev_multi(const zc* __restrict__ 
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
     const int r = (int)(e / n), c = (int)(e % n);
     const zc v = blk[(long)r * ld + c];
-    m = fmax(m, r == c ? fmax(fabs(v.x - l.x), fabs(v.y - l.y)) : fmax(fabs(v.x), fabs(v.y)));
+    const double dv = r == c ? fmax(fabs(v.x - l.x), fabs(v.y - l.y)) : fmax(fabs(v.x), fabs(v.y));
+    m = fmax(m, finite_or_huge(v, dv));
   }
   ident_block_max(m, out + blockIdx.y);
 }

@@ -17,7 +17,9 @@ class Comm:
     barrier and the scalar reductions.  ``device`` is the HIP ordinal the engine runs on:
     LOCAL_RANK modulo the number of visible devices, so several ranks can share one GPU in tests."""
 
-    def __init__(self, n_devices: int | None = None):
+    def __init__(self, n_devices: int | None = None, backend: str | None = None):
+        """``backend``: "nccl" / "gloo" for the process group this Comm creates (default: MITDVP_DIST_BACKEND, else nccl
+        with one GPU per rank and gloo otherwise); ignored when the process group exists already."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -50,7 +52,7 @@ class Comm:
             import torch.distributed as dist
 
             # RCCL refuses two ranks on one device: ranks sharing a GPU (rehearsals, tests) use gloo
-            backend = os.environ.get("MITDVP_DIST_BACKEND") or ("nccl" if n_devices > 0 and not self.shared_gpu else "gloo")
+            backend = backend or os.environ.get("MITDVP_DIST_BACKEND") or ("nccl" if n_devices > 0 and not self.shared_gpu else "gloo")
             if n_devices > 0:
                 torch.cuda.set_device(self.gpu)
             if dist.is_initialized():
@@ -128,9 +130,17 @@ def world_comm(site_sharding: bool = False) -> Comm:
     every test of the sharded sweep run."""
     global _WORLD
     if _WORLD is None or (_WORLD.world > 1 and _WORLD.dist is None):
-        if site_sharding:
-            os.environ.setdefault("MITDVP_DIST_BACKEND", "gloo")
-        _WORLD = Comm()
+        # the preference is handed to this Comm only (the environment is left alone: a later, non-sharded Comm of the
+        # same process still gets its own default)
+        want = (os.environ.get("MITDVP_DIST_BACKEND") or "gloo") if site_sharding else None
+        _WORLD = Comm(backend=want)
+    elif site_sharding and _WORLD.world > 1 and _WORLD.backend and "nccl" in _WORLD.backend:
+        import warnings
+
+        warnings.warn("pytdscf_amd: the existing torch.distributed process group runs over nccl (RCCL); the site-sharded "
+                      "sweep brings its own RCCL communicator for the halo, so this process will hold two RCCL instances "
+                      "on its GPU.  Initialise the process group with gloo (or set MITDVP_DIST_BACKEND=gloo) before the "
+                      "first use to avoid that.", RuntimeWarning, stacklevel=2)
     return _WORLD
 
 

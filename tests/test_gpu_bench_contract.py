@@ -53,6 +53,7 @@ def _check_secondary(rec, name):
     assert "traffic_source" in r
     c = rec["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["unit"] == "sweeps/s" and c["sample"] and "cpu_model" in c
+    assert c["pinned"] is True and c["socket"] is not None and c["cores"] >= 1  # one socket, its physical cores
     cfg = rec["config"]
     if cfg["integrator"] == "lanczos":  # unitary: the norm stays 1 and the energy where it was
         assert abs(cfg["norm_after"] - 1) < 1e-10
@@ -71,8 +72,12 @@ def test_bench_single_gpu_contract():
     assert o["n_gpus"] == 1 and o["steps"] == 4 and o["warmup"] == 1
     c = o["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "sweeps/s" and c["sample"]
-    assert "cpu_model" in c
+    assert "cpu_model" in c and c["pinned"] is True and c["affinity_cpus"] >= c["cores"] >= 1
     assert abs(o["config"]["norm_after"] - 1) < 1e-10
+    # the C2 traffic figure comes from a pass of the one-launch kernel, the C3 one from a pass of the form that ran
+    assert o["roofline"]["traffic_source"].endswith("c2_traffic.json")
+    assert o["secondary"]["C3"]["roofline"]["apply_form"] in o["secondary"]["C3"]["roofline"]["traffic_source"]
+    assert o["config"]["secondary_summary"]["C3"]["value"] == pytest.approx(o["secondary"]["C3"]["value"], rel=1e-4)
     # energy conservation of the run itself, on one GPU as well
     assert abs(o["config"]["energy_after"] - o["config"]["energy_before"]) < 1e-7 * max(1.0, abs(o["config"]["energy_before"]))
     assert list(o["secondary"]) == ["C3"]
@@ -108,6 +113,11 @@ def test_bench_driver_command_line_fits_its_wall_budget():
     assert sorted(o["secondary"]) == ["C2", "C3", "C5"]
     for w in ("C2", "C3", "C5"):
         _check_secondary(o["secondary"][w], w)
+        assert o["config"]["secondary_summary"][w]["value"] == pytest.approx(o["secondary"][w]["value"], rel=1e-4)
+        src = o["secondary"][w]["roofline"]["traffic_source"]
+        assert src is None or w.lower() in src.lower() or "D%d_" % o["secondary"][w]["config"]["D"] in src, src
+    # the driver keeps the parsed `config` and a tail of stdout: the summary rides in `config`, the line stays short
+    assert len(json.dumps(o["secondary"])) < 8192 and len(p.stdout) < 14000, (len(json.dumps(o["secondary"])), len(p.stdout))
     assert wall < 520, wall  # budget 150 s + at most one sweep + the CPU sample + the secondary legs (100 s)
 
 
