@@ -79,3 +79,52 @@ def test_bad_compute_unit_ranges_are_refused():
     for rng in ((4, 32), (0, 12), (248, 16), (-8, 8)):
         with pytest.raises(ValueError):
             TDVPEngine(4, cu_range=rng)
+
+
+def test_overlapping_compute_unit_ranges_are_refused_and_released():
+    """Two CU-masked engines on one device must hold disjoint ranges (their persistent grids need every workgroup
+    resident at once); a range is free again once its engine is gone.  Listing one engine twice in an ensemble call is
+    refused as well."""
+    import ctypes as C
+
+    from pytdscf_amd import TDVPEngine, _lib
+
+    a = TDVPEngine(4, cu_range=(0, 64))
+    with pytest.raises(ValueError, match="overlaps"):
+        TDVPEngine(4, cu_range=(32, 64))
+    b = TDVPEngine(4, cu_range=(64, 64))  # disjoint: fine
+    lib = _lib.load()
+    hs = (C.c_void_p * 2)(a._h, a._h)
+    assert lib.mitdvp_ensemble_step(hs, 2, 0.1, 0, None) == _lib.EINVAL
+    b.close()
+    a.close()
+    c = TDVPEngine(4, cu_range=(32, 64))  # both ranges were given back
+    c.close()
+
+
+def test_full_device_engine_beside_masked_ones_uses_the_multi_launch_kernels():
+    """A full-device engine cannot rely on the co-residency of its persistent grids while CU-masked engines own part of
+    the chip: it runs the general kernels meanwhile (same results), and the one-launch family again afterwards."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+    from pytdscf_amd import synthetic as syn
+
+    mpo = syn.synthetic_mpo(L, d, M, seed=0)
+
+    def run(with_masked):
+        m = TDVPEngine(4, cu_range=(0, 32)) if with_masked else None
+        e = TDVPEngine(L)
+        e.set_mpo(mpo)
+        e.init_random([d] * L, D, seed=3)
+        e.counters_reset()
+        e.propagate(DT)
+        out, ks, nl = e.get_mps(), e.krylov_stats(), e.counters()["n_launch"]
+        e.close()
+        if m is not None:
+            m.close()
+        return out, ks, nl
+
+    ref, ks0, nl0 = run(False)
+    got, ks1, nl1 = run(True)
+    assert ks0 == ks1 and nl1 > 3 * nl0  # multi-launch kernels beside the masked engine
+    assert abs(abs(orc.overlap(ref, got)) - 1) < 1e-10

@@ -315,3 +315,34 @@ def test_reduced_density_nc_bytes_against_the_layout_written_out_by_hand(tmp_pat
             vals = np.frombuffer(buf, dtype=">f8", count=n, offset=begins[k] + r * recsize).reshape(rec[key].shape + (2,))
             np.testing.assert_array_equal(vals[..., 0], rec[key].real)
             np.testing.assert_array_equal(vals[..., 1], rec[key].imag)
+
+
+def test_bench_line_helpers():
+    """bench.py's bookkeeping: the traffic pass of the apply form that ran (newest round first), the compact `secondary`
+    object and its summary inside `config`, one socket's physical cores for the CPU baseline."""
+    import json
+    import os
+
+    import bench
+
+    L, d, D, M = bench.WORKLOADS["C5"][:4]
+    t, src = bench.committed_traffic("heff", L, d, D, M, "edge")
+    assert src and src.endswith("_heff_traffic_C5_edge.json") and t > 0
+    t2, src2 = bench.committed_traffic("heff", L, d, D, M, "chain")
+    assert src2 and "edge" not in src2 and t2 > 0 and src2 != src
+    assert int(os.path.basename(src)[1:3]) >= 4  # never an older round's file when a newer one of the same form exists
+    t3, src3 = bench.committed_traffic("heff", 7, 3, 48, 5, "chain")
+    assert t3 is None and src3 is None  # a shape nobody measured: no number
+    pkg, cpus = bench.one_socket_physical_cores()
+    assert pkg is not None and 1 <= len(cpus) <= len(os.sched_getaffinity(0)) and len(set(cpus)) == len(cpus)
+    rec = {"workload": "C3: x", "value": 64.94690741, "unit": "sweeps/s", "steps": 20,
+           "roofline": {"bound": "mfma", "frac": 0.5204772, "note": "long " * 200, "kernel": "k" * 300, "traffic_note": "t" * 200},
+           "breakdown_ms": {"wall": 307.94383899, "phases_from": "p" * 100},
+           "cpu_baseline": {"value": 0.107, "sample": "s" * 300, "pinned": True},
+           "ensemble": {"replicas": {"2": {"value": 407.123456}, "4": {"value": 566.0}}, "note": "n" * 300}}
+    c = bench.compact_record(rec)
+    assert len(json.dumps(c)) < 600 and c["value"] == pytest.approx(rec["value"], rel=1e-5) and len(c["cpu_baseline"]["sample"]) == 90
+    assert "note" not in c["roofline"] and c["roofline"]["frac"] == pytest.approx(0.5204772, rel=1e-5)
+    s = bench.secondary_summary({"C3": rec, "C5": {"error": "boom"}})
+    assert s["C3"]["value"] == pytest.approx(64.947, rel=1e-4) and s["C3"]["frac"] == pytest.approx(0.5205, rel=1e-3)
+    assert s["C3_ensemble"] == {"2": pytest.approx(407.12, rel=1e-4), "4": 566.0} and "error" in s["C5"]
