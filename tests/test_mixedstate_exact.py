@@ -27,9 +27,17 @@ CASES = {
 def _check(rdms, case, atol0, atol1):
     exact = sb.exact_rdms(**case["exact"])
     s = case["scale"]
+    last, ex_last = rdms[(sb.NSTEPS - 1) * s], exact[sb.NSTEPS - 1]
+    # the reference's assertions, literally (numpy's default rtol = 1e-7 rides on its atol)
     np.testing.assert_allclose(rdms[0], exact[0], atol=atol0)
-    np.testing.assert_allclose(rdms[(sb.NSTEPS - 1) * s], exact[sb.NSTEPS - 1], atol=atol1)
-    return np.abs(rdms[(sb.NSTEPS - 1) * s] - exact[sb.NSTEPS - 1]).max()
+    np.testing.assert_allclose(last, ex_last, atol=atol1)
+    # ... and without the relative allowance: where the method is exact at full bond dimension what is left is the
+    # Krylov threshold (1e-9 on successive approximants, ~1e-12 per local exponential, 11 steps): 2e-12 .. 5e-12 measured
+    # for the oracle and for the reference-equivalent iteration counts; 1e-11 is the bound asserted.  The split cases
+    # carry the O(dt^2) splitting error of the gate / Kraus map: 3.6e-4 at scale 2 against the reference's 2.5e-3.
+    err = np.abs(last - ex_last).max()
+    assert np.abs(rdms[0] - exact[0]).max() < 1e-15 + atol0 and err < (1e-11 if atol1 <= 1e-12 else 5e-4), err
+    return err
 
 
 def test_operators_written_out_by_hand_equal_the_dense_ones():
