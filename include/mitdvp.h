@@ -296,6 +296,15 @@ int mitdvp_set_qr_fast(int on);
 int mitdvp_get_qr_fast(void);
 /* device time (HIP events) of one m x n factorisation with Q and R formed, random full-rank input */
 int mitdvp_bench_qr(int device, int m, int n, int reps, double* ms_out, long* launches);
+/* The thin factorisation as the SWEEP issues it (csrc/qr.h qr_thin): gauge_free != 0 = the sign convention of LAPACK's
+ * diag(R) is not asked for (SiteCoef.gauge_trf's Q R = psi and Q^H Q = 1 are all a gauge move needs, _site_cls.py:264-282;
+ * SURVEY appendix B item 6) -> block Gram-Schmidt over Cholesky factors of 128-column blocks, R with a positive diagonal;
+ * falls back to the Householder panels when a conditioning check on the device fails.  a: m x n row-major complex128 on
+ * the host, or NULL = a random full-rank matrix generated on the device (timing); q_out (m x n), r_out (n x n) may be
+ * NULL.  *ms_out = device time per factorisation over `reps`, *launches per factorisation, *path_out = 1 when the
+ * gauge-free path delivered the result, 0 when the Householder panels did. */
+int mitdvp_qr_thin(int device, const double* a, int m, int n, int gauge_free, double* q_out, double* r_out, int reps,
+                   double* ms_out, long* launches, int* path_out);
 /* warm-up memory of the local solves at a site (_Debug.niter_krylov[isite], _integrator.py:178-186) */
 int mitdvp_get_krylov_memory(mitdvp_engine* h, int isite, int* k);
 int mitdvp_set_krylov_memory(mitdvp_engine* h, int isite, int k);

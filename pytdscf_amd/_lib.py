@@ -207,6 +207,7 @@ def load() -> C.CDLL:
         "mitdvp_set_qr_fast": (i, [i]),
         "mitdvp_get_qr_fast": (i, []),
         "mitdvp_bench_qr": (i, [i, i, i, i, dp, C.POINTER(C.c_long)]),
+        "mitdvp_qr_thin": (i, [i, dp, i, i, i, dp, dp, i, dp, C.POINTER(C.c_long), ip]),
         "mitdvp_get_krylov_memory": (i, [vp, i, ip]),
         "mitdvp_set_krylov_memory": (i, [vp, i, i]),
         "mitdvp_set_small_kernels": (i, [vp, i]),

@@ -501,6 +501,7 @@ int mitdvp_gauge_trf(int device, int key, const double* psi, int dl, int d, int 
     hipStream_t st = e.stream();
     const long ns = (long)dl * d * dr;
     e.ensure_work(ns, 1, 1, std::max(dl, dr) * d, std::max(dl, dr));
+    e.set_qr_gauge_free(false);  // SiteCoef.gauge_trf as LAPACK returns it (signs of diag(R) included)
     Dev dpsi(st, psi, ns), dsite(ns), dbt(ns);
     if (key == 0) {
       Dev dsig((size_t)dr * dr);
@@ -611,6 +612,49 @@ int mitdvp_bench_heff(int device, int dl, int d, int dr, int ml, int mr, int rep
     *ms_out = ms / std::max(reps, 1);
     HIP_CHECK(hipEventDestroy(a));
     HIP_CHECK(hipEventDestroy(b));
+  });
+}
+
+int mitdvp_qr_thin(int device, const double* a, int m, int n, int gauge_free, double* q_out, double* r_out, int reps,
+                   double* ms_out, long* launches, int* path_out) {
+  return guard(nullptr, [&] {
+    using namespace mitdvp;
+    if (m < n || n < 1 || reps < 1) throw ArgError("qr_thin: need m >= n >= 1, reps >= 1");
+    Engine e(unit_cfg(device));
+    hipStream_t st = e.stream();
+    Dev A((size_t)m * n), A0(st, a, (size_t)m * n), Q((size_t)m * n), R((size_t)n * n), work(qr_work_elems(m, n));
+    if (!a) vec_randn(st, A0.p(), (long)m * n, 21);
+    QrHistory* hist = qr_history_new();
+    long nl = 0;
+    bool used = false;
+    auto once = [&] {
+      HIP_CHECK(hipMemcpyAsync(A.p(), A0.p(), (size_t)m * n * sizeof(zc), hipMemcpyDeviceToDevice, st));
+      qr_thin(st, A.p(), m, n, Q.p(), R.p(), work.p(), &nl, nullptr, hist, gauge_free != 0, &used);
+    };
+    try {
+      once();
+      if (path_out) *path_out = used ? 1 : 0;
+      nl = 0;
+      hipEvent_t ea, eb;
+      HIP_CHECK(hipEventCreate(&ea));
+      HIP_CHECK(hipEventCreate(&eb));
+      HIP_CHECK(hipEventRecord(ea, st));
+      for (int i = 0; i < reps; ++i) once();
+      HIP_CHECK(hipEventRecord(eb, st));
+      HIP_CHECK(hipEventSynchronize(eb));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
+      if (ms_out) *ms_out = ms / reps;
+      if (launches) *launches = nl / reps;
+      HIP_CHECK(hipEventDestroy(ea));
+      HIP_CHECK(hipEventDestroy(eb));
+      if (q_out) to_host(st, q_out, Q.p(), (size_t)m * n);
+      if (r_out) to_host(st, r_out, R.p(), (size_t)n * n);
+    } catch (...) {
+      qr_history_free(hist);
+      throw;
+    }
+    qr_history_free(hist);
   });
 }
 

@@ -164,6 +164,7 @@ class Engine {
   void counters_get(mitdvp_counters* out);
   void counters_reset();
   void set_profiling(bool on) { profiling_ = on; }
+  void set_qr_gauge_free(bool on) { qr_gauge_free_ = on; }
   void set_parallel(int nranks, int rank, CollFn fn, void* user);
   // native RCCL collectives on the engine's stream (librccl resolved with dlopen)
   static void rccl_unique_id(char out[128]);
@@ -283,6 +284,9 @@ class Engine {
   bool trim_r_ = false;
   bool trim_l_ = false;  // the same for the FIRST MPO-bond block of the left environment (stage S1: rows (a, c = 0) of X = psi)
   bool left_block_is_identity(const zc* L, int dl, int m);
+  // gauge moves of the sweep without LAPACK's sign convention on diag(R) (qr_thin; MITDVP_QR_GAUGE_FREE=0: always the
+  // Householder panels).  The unit-level entry point mitdvp_gauge_trf keeps the convention.
+  bool qr_gauge_free_ = true;
   bool trim_identity_ = true;  // MITDVP_TRIM_IDENTITY=0 switches the shortcut off
   bool edge_ = false;          // the current local exponential's applies take heff_apply_edge
   int edge_mode_ = -1;         // MITDVP_EDGE_APPLY: 0 never, 1 wherever valid, -1 (default) the size rule of choose_apply_forms

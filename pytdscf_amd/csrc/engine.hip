@@ -30,6 +30,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (const char* e = std::getenv("MITDVP_DEVICE_RITZ")) device_ritz_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_EDGE_APPLY")) edge_mode_ = std::atoi(e);
   if (const char* e = std::getenv("MITDVP_DEFER_NORM")) defer_norm_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MITDVP_QR_GAUGE_FREE")) qr_gauge_free_ = std::atoi(e) != 0;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -887,7 +888,7 @@ void Engine::gauge_qr_left(const zc* psi, int dl, int d, int dr, zc* A_out, zc* 
   HIP_CHECK(hipMemcpyAsync(tmp1_.p, psi, n * sizeof(zc), hipMemcpyDeviceToDevice, st_));
   timer_begin(3);
   long nl = 0;
-  qr_householder(st_, tmp1_.p, dl * d, dr, A_out, sigma_out, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
+  qr_thin(st_, tmp1_.p, dl * d, dr, A_out, sigma_out, qrwork_.p, &nl, qr_sync(), qr_hist_, qr_gauge_free_);
   timer_end();
   cnt_.n_launch += nl;
   cnt_.n_qr += 1;
@@ -899,7 +900,7 @@ void Engine::gauge_qr_right(const zc* psi, int dl, int d, int dr, zc* B_out, zc*
   timer_begin(3);
   long nl = 0;
   transpose_rev3(st_, psi, tmp1_.p, dl, d, dr);  // (dr, d, dl)
-  qr_householder(st_, tmp1_.p, dr * d, dl, Bt_out, sig2_.p, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
+  qr_thin(st_, tmp1_.p, dr * d, dl, Bt_out, sig2_.p, qrwork_.p, &nl, qr_sync(), qr_hist_, qr_gauge_free_);
   transpose_batched(st_, sig2_.p, sigma_out, dl, dl, dl, dl, 1, 0, 0);  // sigma = R^T
   if (B_out) transpose_rev3(st_, Bt_out, B_out, dr, d, dl);             // (dl, d, dr)
   timer_end();
@@ -1099,7 +1100,7 @@ void Engine::sweep(double dt, bool forward) {
       // Psi2Asigma: site[p] (destroyed) -> A in spare, sigma in sig_
       timer_begin(3);
       long nl = 0;
-      qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
+      qr_thin(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, qr_sync(), qr_hist_, qr_gauge_free_);
       timer_end();
       cnt_.n_launch += nl; cnt_.n_qr += 1;
       cnt_.qr_flops += 4.0 * (4.0 * (double)dl * d * dr * dr - 4.0 * (double)dr * dr * dr / 3.0);

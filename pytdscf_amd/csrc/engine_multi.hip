@@ -361,7 +361,7 @@ void Engine::ms_sweep(double dt, bool forward) {
       if (forward) {
         timer_begin(3);
         long nl = 0;
-        qr_householder(st_, m.site[s][p].p, dl * d, dr, m.spare.p, m.sigstack.p + so[s], qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
+        qr_thin(st_, m.site[s][p].p, dl * d, dr, m.spare.p, m.sigstack.p + so[s], qrwork_.p, &nl, qr_sync(), qr_hist_, qr_gauge_free_);
         timer_end();
         cnt_.n_launch += nl; cnt_.n_qr += 1;
         cnt_.qr_flops += 4.0 * (4.0 * (double)dl * d * dr * dr - 4.0 * (double)dr * dr * dr / 3.0);

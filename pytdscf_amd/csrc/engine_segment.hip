@@ -122,7 +122,7 @@ void Engine::split_center(bool forward) {
     if (!envL_ok_[p]) throw ArgError("split_center: left environment missing");
     timer_begin(3);
     long nl = 0;
-    qr_householder(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
+    qr_thin(st_, site_[p].p, dl * d, dr, spare.p, sig_.p, qrwork_.p, &nl, qr_sync(), qr_hist_, qr_gauge_free_);
     timer_end();
     cnt_.n_launch += nl; cnt_.n_qr += 1;
     std::swap(site_[p], spare);

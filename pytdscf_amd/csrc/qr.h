@@ -24,6 +24,16 @@ void qr_history_free(QrHistory* h);
 void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next = 0,
                     SmallSync* sy = nullptr, QrHistory* hist = nullptr);
 
+// The thin factorisation (next = 0) for a caller that does not need LAPACK's signs on diag(R) -- the sweep's gauge moves
+// (a gauge freedom of the bond): gauge_free = true takes the block Gram-Schmidt / Cholesky path of
+// qr_gram.hip (R with a positive diagonal, A left intact) where the shape qualifies and its conditioning checks pass, and
+// qr_householder otherwise; gauge_free = false IS qr_householder.  MITDVP_QR_GRAM=0 switches the new path off.
+void qr_thin(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, SmallSync* sy, QrHistory* hist,
+             bool gauge_free, bool* used_gauge_free = nullptr);
+size_t qr_gram_work_elems(int m, int n);
+int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work);
+int* qr_gram_flag(zc* work, int m, int n);
+
 // panel factorisation: 1 = CholeskyQR2 + Householder reconstruction with the per-column kernels as the fallback
 // (default), 0 = per-column kernels only
 void qr_set_fast(int on);

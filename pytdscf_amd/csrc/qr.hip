@@ -756,7 +756,10 @@ static int qr_read_flag(hipStream_t st, const int* dev_flag, QrHistory* hist) {
   return bad;
 }
 
-size_t qr_work_elems(int m, int n, int next) {
+static size_t qr_work_elems_house(int m, int n, int next);
+// the Householder workspaces first, the gauge-free path's behind them (qr_thin finds it at qr_work_elems_house(m, n, 0))
+size_t qr_work_elems(int m, int n, int next) { return qr_work_elems_house(m, n, next) + qr_gram_work_elems(m, n); }
+static size_t qr_work_elems_house(int m, int n, int next) {
   const int nblk = (m + 31) / 32;  // upper bound over all row-block sizes
   const int npan = (n + QR_NB - 1) / QR_NB;
   size_t e = 0;
@@ -778,6 +781,38 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
 void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy,
                     QrHistory* hist) {
   qr_impl(st, A, m, n, Q, R, work, nlaunch, next, sy, qr_fast_enabled(), hist);
+}
+
+void qr_thin(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, SmallSync* sy, QrHistory* hist,
+             bool gauge_free, bool* used_gauge_free) {
+  if (used_gauge_free) *used_gauge_free = false;
+  static const bool gram_on = !(std::getenv("MITDVP_QR_GRAM") && std::atoi(std::getenv("MITDVP_QR_GRAM")) == 0);
+  static const bool small_on = !(std::getenv("MITDVP_SMALL_KERNELS") && std::atoi(std::getenv("MITDVP_SMALL_KERNELS")) == 0);
+  // matrices of up to 320 x 32 keep the one-workgroup kernel (one launch, no host wait); narrower than 16 columns there
+  // is nothing to gain over one panel
+  bool gram = gauge_free && gram_on && m >= n && n >= 16 && !(small_on && m <= 320 && n <= 32);
+  const long gkey = -((long)m * 100003L + n);  // the gauge-free path's own back-off entry
+  if (gram && hist) {
+    QrBackoff& bo = hist->by_shape[gkey];
+    if (bo.skip > 0) { bo.skip -= 1; gram = false; }
+  }
+  if (gram) {
+    zc* gw = work + qr_work_elems_house(m, n, 0);
+    const int nl = qr_gram(st, A, m, n, Q, R, gw);
+    if (nlaunch) *nlaunch += nl;
+    const int bad = qr_read_flag(st, qr_gram_flag(gw, m, n), hist);
+    if (!bad) {
+      if (hist) hist->by_shape[gkey].fails = 0;
+      if (used_gauge_free) *used_gauge_free = true;
+      return;
+    }
+    if (hist) {  // rank-deficient / strongly graded: the Householder panels from now on, asked again after 2, 4, .. 64 calls
+      QrBackoff& bo = hist->by_shape[gkey];
+      bo.fails = std::min(bo.fails + 1, 6);
+      bo.skip = 1 << bo.fails;
+    }
+  }
+  qr_impl(st, A, m, n, Q, R, work, nlaunch, 0, sy, qr_fast_enabled(), hist);
 }
 
 static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast,

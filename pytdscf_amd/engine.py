@@ -768,6 +768,24 @@ def bench_qr(m: int, n: int, reps: int = 10, device: int = 0):
     return ms.value, nl.value
 
 
+def qr_thin(a=None, shape=None, gauge_free: bool = True, reps: int = 1, device: int = 0):
+    """The thin QR of the sweep's gauge moves (``mitdvp_qr_thin``): ``a`` (m x n) or, with ``shape=(m, n)``, a random
+    matrix generated on the device.  Returns (Q, R, info) with info = {"ms", "launches", "gauge_free_path"}; Q, R are None
+    for a device-generated input."""
+    if a is not None:
+        a = _c128(a)
+        m, n = a.shape
+        q, r = np.empty((m, n), dtype=np.complex128), np.empty((n, n), dtype=np.complex128)
+    else:
+        m, n = shape
+        q = r = None
+    ms, nl, path = C.c_double(), C.c_long(), C.c_int()
+    _lib.check(_lib.load().mitdvp_qr_thin(device, _dp(a) if a is not None else None, m, n, int(bool(gauge_free)),
+                                          _dp(q) if q is not None else None, _dp(r) if r is not None else None, reps,
+                                          C.byref(ms), C.byref(nl), C.byref(path)))
+    return q, r, {"ms": ms.value, "launches": nl.value, "gauge_free_path": bool(path.value)}
+
+
 def get_qr_fast() -> bool:
     return bool(_lib.load().mitdvp_get_qr_fast())
 
