@@ -702,7 +702,10 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
                          zgemm_reduce_ok(d, mr, d) && zgemm_reduce_ok(ml, d, d) && (long)d * dr < (1L << 20) &&
                          // the size rule: the epilogue streams the d x (d M) reduced core once per tile -- cheap beside a
                          // tile's K loop only while d M is small (measured: profiles/r04_edge_apply_ab.txt)
-                         (edge_mode_ > 0 || ((long)d * std::max(ml, mr) <= 64 && (long)dl * dr <= 512L * 512L));
+                         // round 5: with the 4 x 4 x 4 epilogue (no padded products at d M = 512) the form also wins where the
+                         // W stage is a large share of the chain, i.e. at short bonds: C3 (D = 128) heff -9 %, C4 (D = 1024) +2 %
+                         (edge_mode_ > 0 || ((long)d * std::max(ml, mr) <= 64 && (long)dl * dr <= 512L * 512L) ||
+                          ((long)d * std::max(ml, mr) <= 512 && (long)dl * dr <= 256L * 256L && zgemm_reduce_b4_available(st_) != 0));
   if (edge_cand && w.edge_skip > 0) {  // a core that failed the structure check recently: the plain checks, no look at all blocks
     w.edge_skip -= 1;
     identity_blocks(trim_identity_ && dl >= 256 && ml > 1 ? Lb : nullptr, dl, ml,

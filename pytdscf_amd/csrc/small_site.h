@@ -22,6 +22,10 @@ struct SmallChain {
   long sBb, sBj, sBs;                          // vector operand B(b,j,s) = v[b*sBb + j*sBj + s*sBs]
   int na, nb, nc, nj, ni, nt, ns, nr;
   int nsc, cs;                                 // chunks over s and their width (nsc * cs >= ns)
+  // slabs per workgroup (0 / 1: one): an engine confined to a slice of the chip (ensemble mode) has fewer compute units
+  // than the chain has slabs; a workgroup then walks over spw consecutive slabs of its chunk (R, W and the stage-1 operand
+  // are shared by them).  a_resident: all spw slabs' A fit in LDS beside the rest (else A is re-staged per slab).
+  int spw, a_resident;
 };
 
 enum { SS_MODE_APPLY = 0, SS_MODE_EXP = 1 };

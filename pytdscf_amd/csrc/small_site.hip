@@ -529,7 +529,7 @@ struct Carve {
 __host__ __device__ inline Carve ss_carve(const SmallChain& c, bool exp_mode) {
   Carve k{};
   size_t o = 0;
-  k.As = o; o += (size_t)c.nc * c.nb;
+  k.As = o; o += (size_t)c.nc * c.nb * (c.a_resident ? (c.spw > 1 ? c.spw : 1) : 1);
   k.Rs = o; o += (size_t)c.nt * c.cs * c.nr;
   k.Ws = o; o += c.W2 ? (size_t)c.ni * c.nt * c.nc * c.nj : 0;
   k.Bs = o;
@@ -575,14 +575,20 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
 
   const int tid = threadIdx.x;
   const int nsc = c.nsc, cs = c.cs;
-  const int a = blockIdx.x / nsc, sc = blockIdx.x - a * nsc;
+  // a workgroup owns chunk sc of the contracted index for spw consecutive slabs (spw = 1: one slab -- the layout of a
+  // full-size grid; spw > 1: an engine confined to a slice of the chip, ensemble mode): R, W and the stage-1 operand B of
+  // the chunk are shared by its slabs, A_a is per slab (all resident in LDS when they fit, else re-staged per slab)
+  const int spw = c.spw > 1 ? c.spw : 1;
+  const int ag = blockIdx.x / nsc, sc = blockIdx.x - ag * nsc;
+  const int a_first = ag * spw;
+  const int nsl = min(spw, c.na - a_first);  // >= 1 by construction of the plan
   const int s0 = sc * cs;
   const int csl = min(cs, c.ns - s0);  // >= 1 by construction of the plan
   const int slab = c.ni * c.nr;
   const long N = (long)c.na * slab;
   const int rg = (slab + nsc - 1) / nsc;
-  const long e0 = (long)a * slab + min(sc * rg, slab);
-  const long e1 = (long)a * slab + min((sc + 1) * rg, slab);
+  const int r_lo = min(sc * rg, slab), r_hi = min((sc + 1) * rg, slab);  // this chunk's share of an output slab
+  const int nAone = c.nc * c.nb;
 
   Sync sy{g.gran, g.abort_w, (int)gridDim.x, (int)blockIdx.x, g.epoch0};
   int ntr = 1;
@@ -602,10 +608,11 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
   // at the start of a launch instead of one per loop trip (As 1, Rs 2, Ws 4 trips at C2: ~4 of the ~10 us a launch
   // spent before its first product in the MITDVP_SS_TRACE timelines).  Longer operands finish in the plain loops below.
   {
-    const int nA = c.nc * c.nb, kk = c.nt * cs, nR = kk * c.nr, nW = c.W2 ? c.ni * c.nt * c.nc * c.nj : 0;
+    const int nA = c.a_resident ? nAone * nsl : 0, kk = c.nt * cs, nR = kk * c.nr, nW = c.W2 ? c.ni * c.nt * c.nc * c.nj : 0;
     auto ldA = [&](int t) __attribute__((always_inline)) -> zc {
-      const int cc = t / c.nb, b = t - cc * c.nb;
-      zc z = c.A[(long)a * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
+      const int q = t / nAone, tt = t - q * nAone;
+      const int cc = tt / c.nb, b = tt - cc * c.nb;
+      zc z = c.A[(long)(a_first + q) * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
       if (c.conjA) z.y = -z.y;
       return z;
     };
@@ -661,10 +668,19 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
   };
 
   // the three stages; this chunk's partial of out[a][:][:] ends up in Sg (LDS)
-  auto chain = [&]() {
+  auto chain = [&](int q) {
+    const zc* Aq = As + (c.a_resident ? (size_t)q * nAone : 0);
+    if (!c.a_resident) {  // A of this slab -> LDS (the previous slab's stage 1 is long over: two barriers ago)
+      for (int t = tid; t < nAone; t += SS_THREADS) {
+        const int cc = t / c.nb, b = t - cc * c.nb;
+        zc z = c.A[(long)(a_first + q) * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
+        if (c.conjA) z.y = -z.y;
+        As[t] = z;
+      }
+    }
     __syncthreads();
     stamp(20);
-    lds_gemm(As, c.nb, Bs, c.nj * cs, Xs, c.nj * cs, c.nc, c.nj * cs, c.nb, 1.0);
+    lds_gemm(Aq, c.nb, Bs, c.nj * cs, Xs, c.nj * cs, c.nc, c.nj * cs, c.nb, 1.0);
     __syncthreads();
     stamp(21);
     if (c.W2) {
@@ -677,33 +693,39 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     stamp(23);
   };
 
-  zc* Pmine = g.P + (size_t)sc * N + (size_t)a * slab;
+  zc* Pchunk = g.P + (size_t)sc * N;  // this chunk's partials; slab a at + a * slab
 
   if (!exp_mode) {
     load_B(g.v, false, 1.0);
     stamp(1);
-    chain();
-    stamp(2);
-    for (int q = tid; q < slab; q += SS_THREADS) {
-      zc v = Sg[q];
-      if (g.add_shift && sc == 0) {  // the scalar term (coupleJ * ovlp, _contraction.py:1200-1216) rides on chunk 0
-        const zc x = g.v[(long)a * slab + q];
-        v.x += g.shift.x * x.x - g.shift.y * x.y;
-        v.y += g.shift.x * x.y + g.shift.y * x.x;
+    for (int sl = 0; sl < nsl; ++sl) {
+      const long a = a_first + sl;
+      chain(sl);
+      for (int q = tid; q < slab; q += SS_THREADS) {
+        zc v = Sg[q];
+        if (g.add_shift && sc == 0) {  // the scalar term (coupleJ * ovlp, _contraction.py:1200-1216) rides on chunk 0
+          const zc x = g.v[a * slab + q];
+          v.x += g.shift.x * x.x - g.shift.y * x.y;
+          v.y += g.shift.x * x.y + g.shift.y * x.x;
+        }
+        stz_sh(Pchunk + a * slab + q, v);
       }
-      stz_sh(Pmine + q, v);
     }
+    stamp(2);
     if (!ss_exchange(sy, pay, 0, red, wsh)) {
       if (blockIdx.x == 0 && tid == 0) atomicMax(g.err_w, (unsigned)SS_ETIMEOUT);
       return;
     }
-    for (long e = e0 + tid; e < e1; e += SS_THREADS) {
-      zc s = make_double2(0.0, 0.0);
-      for (int q = 0; q < nsc; ++q) {
-        const zc p = ldz_sh(g.P + (size_t)q * N + e);
-        s.x += p.x; s.y += p.y;
+    for (int sl = 0; sl < nsl; ++sl) {
+      const long eb = (long)(a_first + sl) * slab;
+      for (long e = eb + r_lo + tid; e < eb + r_hi; e += SS_THREADS) {
+        zc s = make_double2(0.0, 0.0);
+        for (int q = 0; q < nsc; ++q) {
+          const zc p = ldz_sh(g.P + (size_t)q * N + e);
+          s.x += p.x; s.y += p.y;
+        }
+        g.out[e] = s;
       }
-      g.out[e] = s;
     }
     return;
   }
@@ -731,11 +753,19 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     if (blockIdx.x == 0 && tid == 0) atomicMax(g.err_w, (unsigned)code);
   };
 
+  // the elements this workgroup owns in the assembled vectors: its chunk's share [r_lo, r_hi) of each of its slabs
+  auto own = [&](auto&& body) __attribute__((always_inline)) {
+    for (int sl = 0; sl < nsl; ++sl) {
+      const long eb = (long)(a_first + sl) * slab;
+      for (long e = eb + r_lo + tid; e < eb + r_hi; e += SS_THREADS) body(e);
+    }
+  };
+
   // ---- _normalize (_integrator.py:189-203) ---------------------------------------------
   double beta0 = 1.0;
   if (!cn) {
     double s = 0.0;
-    for (long e = e0 + tid; e < e1; e += SS_THREADS) { const zc z = g.x[e]; s += z.x * z.x + z.y * z.y; }
+    own([&](long e) { const zc z = g.x[e]; s += z.x * z.x + z.y * z.y; });
     s = wave_sum64(s);
     if ((tid & 63) == 0) wsh[tid >> 6] = s;
     __syncthreads();
@@ -763,45 +793,52 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     stamp(11);
     const int jlo = lanczos ? (ex.variant == 0 ? 0 : l) : 0;
     const int jhi = lanczos ? jlo : l;
-    chain();
-    stamp(12);
-    // store this chunk's partial (with the scalar term on chunk 0) and keep the shifted values in Sg
-    for (int q = tid; q < slab; q += SS_THREADS) {
-      zc v = Sg[q];
-      const long e = (long)a * slab + q;
-      if (g.add_shift && sc == 0) {  // (H + shift) v_l: the projections below must see the scalar term too
-        const zc vl = basis(l, e);
-        v.x += g.shift.x * vl.x - g.shift.y * vl.y;
-        v.y += g.shift.x * vl.y + g.shift.y * vl.x;
-        Sg[q] = v;
-      }
-      stz_sh(Pmine + q, v);
-    }
-    napply += 1;
+    const int nd = jhi - jlo + 1;
     {
-      const int nd = jhi - jlo + 1;
       const int lane = tid & 63, w = tid >> 6;
-      // projections <v_j | partial>, four basis vectors per pass (registers: 1024-thread workgroups get 128)
-      for (int j0 = 0; j0 < nd; j0 += 4) {
-        double dre[4] = {0.0, 0.0, 0.0, 0.0}, dim_[4] = {0.0, 0.0, 0.0, 0.0};
+      // per-wave sums of the projections accumulate over the workgroup's slabs in wsh (each slot has ONE writer: lane 0
+      // of its wave, which also clears it here)
+      if (lane == 0)
+        for (int j = 0; j < 2 * nd; ++j) wsh[j * SS_WAVES + w] = 0.0;
+      for (int sl = 0; sl < nsl; ++sl) {
+        const long ab = (long)(a_first + sl) * slab;
+        chain(sl);
+        // store this chunk's partial (with the scalar term on chunk 0) and keep the shifted values in Sg
         for (int q = tid; q < slab; q += SS_THREADS) {
-          const zc v = Sg[q];
-          const long e = (long)a * slab + q;
+          zc v = Sg[q];
+          const long e = ab + q;
+          if (g.add_shift && sc == 0) {  // (H + shift) v_l: the projections below must see the scalar term too
+            const zc vl = basis(l, e);
+            v.x += g.shift.x * vl.x - g.shift.y * vl.y;
+            v.y += g.shift.x * vl.y + g.shift.y * vl.x;
+            Sg[q] = v;
+          }
+          stz_sh(Pchunk + e, v);
+        }
+        // projections <v_j | partial>, four basis vectors per pass (registers: 1024-thread workgroups get 128)
+        for (int j0 = 0; j0 < nd; j0 += 4) {
+          double dre[4] = {0.0, 0.0, 0.0, 0.0}, dim_[4] = {0.0, 0.0, 0.0, 0.0};
+          for (int q = tid; q < slab; q += SS_THREADS) {
+            const zc v = Sg[q];
+            const long e = ab + q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j0 + j < nd) {
+                const zc b = basis(jlo + j0 + j, e);  // conj(b) * v
+                dre[j] += b.x * v.x + b.y * v.y;
+                dim_[j] += b.x * v.y - b.y * v.x;
+              }
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (j0 + j < nd) {
-              const zc b = basis(jlo + j0 + j, e);  // conj(b) * v
-              dre[j] += b.x * v.x + b.y * v.y;
-              dim_[j] += b.x * v.y - b.y * v.x;
+              const double r1 = wave_sum64(dre[j]), r2 = wave_sum64(dim_[j]);
+              if (lane == 0) { wsh[(2 * (j0 + j)) * SS_WAVES + w] += r1; wsh[(2 * (j0 + j) + 1) * SS_WAVES + w] += r2; }
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j0 + j < nd) {
-            const double r1 = wave_sum64(dre[j]), r2 = wave_sum64(dim_[j]);
-            if (lane == 0) { wsh[(2 * (j0 + j)) * SS_WAVES + w] = r1; wsh[(2 * (j0 + j) + 1) * SS_WAVES + w] = r2; }
-          }
       }
+      stamp(12);
+      napply += 1;
       __syncthreads();
       if (tid < 2 * nd) pay[tid] = wtree(wsh + tid * SS_WAVES);
       __syncthreads();
@@ -819,7 +856,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     {
       double s = 0.0;
       const double bprev = l > 0 ? beta[l - 1] : 0.0;
-      for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+      own([&](long e) {
         // v_l and v_{l-1} are requested before the chunk partials: their latencies overlap the partial loop's
         zc vl = l == 0 ? g.x[e] : ldz_sh(g.U + (size_t)l * N + e);
         zc vm = make_double2(0.0, 0.0);
@@ -850,7 +887,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         }
         stz_sh(g.U + (size_t)(l + 1) * N + e, u);
         s += u.x * u.x + u.y * u.y;
-      }
+      });
       s = wave_sum64(s);
       __syncthreads();
       if ((tid & 63) == 0) wsh[tid >> 6] = s;
@@ -928,7 +965,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         // first use, here, in the closing combination and in the own-range assembly -- C2 204 -> 201 sweeps/s on one box,
         // the wider live ranges spill in the per-iteration loops)
         double s = 0.0;
-        for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+        own([&](long e) {
           double re = 0.0, im = 0.0;
           for (int j = 0; j < k; ++j) {
             zc d = coef[j];
@@ -938,7 +975,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
             im += d.x * vj.y + d.y * vj.x;
           }
           s += re * re + im * im;
-        }
+        });
         s = wave_sum64(s);
         __syncthreads();
         if ((tid & 63) == 0) wsh[tid >> 6] = s;
@@ -966,7 +1003,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     {
       const double cs_ = cn ? 1.0 : beta0;
       double s = 0.0;
-      for (long e = e0 + tid; e < e1; e += SS_THREADS) {
+      own([&](long e) {
         double re = 0.0, im = 0.0;
         for (int j = 0; j < k; ++j) {
           const zc d = make_double2(coef[j].x * cs_, coef[j].y * cs_);
@@ -977,7 +1014,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         if (cn) g.U[e] = make_double2(re, im);
         else g.x[e] = make_double2(re, im);
         s += re * re + im * im;
-      }
+      });
       if (cn) {
         s = wave_sum64(s);
         __syncthreads();
@@ -987,11 +1024,11 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
         __syncthreads();
         if (!ss_exchange(sy, pay, 1, red, wsh)) { fail(SS_ETIMEOUT); return; }
         const double inv = 1.0 / sqrt(red[0]);
-        for (long e = e0 + tid; e < e1; e += SS_THREADS) {  // same thread wrote g.U[e] above
+        own([&](long e) {  // same thread wrote g.U[e] above
           zc z = g.U[e];
           z.x *= inv; z.y *= inv;
           g.x[e] = z;
-        }
+        });
       }
       if (blockIdx.x == 0 && tid == 0) {
         g.kprev[ex.site] = k;
@@ -1026,32 +1063,61 @@ size_t small_chain_lds(const SmallChain& c, bool exp_mode) { return ss_carve(c, 
 bool small_chain_plan(SmallChain& c, bool exp_mode, int n_cu) {
   if (c.na < 1 || c.ns < 1 || c.nr < 1 || c.nb < 1) return false;
   const int gmax = std::min(n_cu, SS_MAXG);
-  if (c.na > gmax) return false;
+  c.spw = 1;
+  c.a_resident = 1;
   // chunks over s: enough workgroups that one holds about 0.4 Mflop of the chain (beyond that the exchanges
   // between workgroups, not the arithmetic, set the pace), at least 4 columns per chunk, LDS permitting
   const double flops = 8.0 * c.na * ((double)c.nc * c.nb * c.nj * c.ns + (c.W2 ? (double)c.ni * c.nt * c.nc * c.nj * c.ns : 0.0) +
                                      (double)c.ni * c.nt * c.ns * c.nr);
   int want = 1;
   while (want < 8 && flops / ((double)c.na * want) > 0.6e6) want *= 2;
-  for (int nsc = want; nsc <= 8; nsc *= 2) {
-    if (c.na * nsc > gmax) break;
-    const int cs = (c.ns + nsc - 1) / nsc;
-    if (nsc > 1 && cs < 4) break;
-    if ((nsc - 1) * cs >= c.ns) continue;  // every chunk must be non-empty
-    c.nsc = nsc;
-    c.cs = cs;
-    if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
+  if (c.na <= gmax) {
+    for (int nsc = want; nsc <= 8; nsc *= 2) {
+      if (c.na * nsc > gmax) break;
+      const int cs = (c.ns + nsc - 1) / nsc;
+      if (nsc > 1 && cs < 4) break;
+      if ((nsc - 1) * cs >= c.ns) continue;  // every chunk must be non-empty
+      c.nsc = nsc;
+      c.cs = cs;
+      if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
+    }
+    // fewer chunks than wanted: an engine confined to part of the chip (ensemble mode) has fewer compute units than the
+    // chain would like workgroups
+    for (int nsc = want / 2; nsc >= 1; nsc /= 2) {
+      if (c.na * nsc > gmax) continue;
+      const int cs = (c.ns + nsc - 1) / nsc;
+      if ((nsc - 1) * cs >= c.ns) continue;
+      c.nsc = nsc;
+      c.cs = cs;
+      if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
+    }
   }
-  // fewer chunks than wanted: an engine confined to part of the chip (ensemble mode) has fewer compute units than the
-  // chain would like workgroups
-  for (int nsc = want / 2; nsc >= 1; nsc /= 2) {
-    if (c.na * nsc > gmax) continue;
-    const int cs = (c.ns + nsc - 1) / nsc;
-    if ((nsc - 1) * cs >= c.ns) continue;
-    c.nsc = nsc;
-    c.cs = cs;
-    if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
+  // Still not placed: one slab per workgroup wants more workgroups, or more LDS per workgroup (wide chunks), than the
+  // slice offers.  Several slabs per workgroup (round 5): narrow chunks keep B / R / X / Y small, the grid is
+  // ceil(na / spw) * nsc <= gmax.  Fewest slabs per workgroup first, then the most chunks that fit; A resident if it fits.
+  static const bool multi_on = !(std::getenv("MITDVP_SS_MULTISLAB") && std::atoi(std::getenv("MITDVP_SS_MULTISLAB")) == 0);
+  // (only for slices of at most 64 compute units -- four or more replicas: on larger grids a chain that does not fit with
+  // one slab per workgroup is better served by the general multi-launch kernels, which is what it got before)
+  if (!multi_on || n_cu > 64) return false;
+  for (int spw = 2; spw <= 64 && spw <= 2 * c.na; spw *= 2) {
+    const int ngrp = (c.na + spw - 1) / spw;
+    if (ngrp > gmax) continue;
+    for (int nsc = 8; nsc >= 1; nsc /= 2) {
+      if (ngrp * nsc > gmax) continue;
+      const int cs = (c.ns + nsc - 1) / nsc;
+      if (nsc > 1 && cs < 4) continue;
+      if ((nsc - 1) * cs >= c.ns) continue;
+      c.nsc = nsc;
+      c.cs = cs;
+      c.spw = spw;
+      for (int res = 1; res >= 0; --res) {
+        c.a_resident = res;
+        if (small_chain_lds(c, exp_mode) <= 155 * 1024) return true;
+      }
+    }
   }
+  c.spw = 1;
+  c.a_resident = 1;
   return false;
 }
 
@@ -1178,7 +1244,9 @@ static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
   const SmallChain& c = g.c;
   // validate what the kernel's indexing assumes before anything is launched
   if (c.nsc < 1 || c.cs < 1 || (c.nsc - 1) * c.cs >= c.ns || c.nsc * c.cs < c.ns) throw ArgError("small_site: bad chunking");
-  if (c.na * c.nsc > SS_MAXG) throw ArgError("small_site: grid exceeds the resident-workgroup bound");
+  const int spw_ = c.spw > 1 ? c.spw : 1;
+  const int grid_ = ((c.na + spw_ - 1) / spw_) * c.nsc;
+  if (grid_ > SS_MAXG || (sy.max_grid > 0 && grid_ > sy.max_grid)) throw ArgError("small_site: grid exceeds the resident-workgroup bound");
   if (!c.W2 && (c.ni != 1 || c.nj != 1 || c.nt != c.nc)) throw ArgError("small_site: chain without W stage needs ni = nj = 1, nt = nc");
   size_t lds = small_chain_lds(c, exp_mode);
   if (lds > 156 * 1024) throw ArgError("small_site: chain does not fit LDS");
@@ -1213,15 +1281,15 @@ static void ss_launch(hipStream_t st, SmallSync& sy, SsArgs& g, bool exp_mode) {
   g.trace = tracing ? trace_buf : nullptr;
   if (tracing) HIP_CHECK(hipMemsetAsync(trace_buf, 0, 1024 * sizeof(long long), st));
   {
-    PersistentLaunch chain(st, c.na * c.nsc, sy.partitioned);  // admitted only when it fits beside the persistent launches in flight
-    hipLaunchKernelGGL(k_small_site, dim3(c.na * c.nsc), dim3(SS_THREADS), lds, st, g);
+    PersistentLaunch chain(st, grid_, sy.partitioned);  // admitted only when it fits beside the persistent launches in flight
+    hipLaunchKernelGGL(k_small_site, dim3(grid_), dim3(SS_THREADS), lds, st, g);
   }
   HIP_CHECK(hipGetLastError());
   if (tracing) {  // debugging aid: phase timeline of workgroup 0, microseconds since its first stamp
     long long h[1024];
     HIP_CHECK(hipMemcpyAsync(h, trace_buf, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    fprintf(stderr, "[ss_trace] mode=%d G=%d (na=%d nsc=%d cs=%d) lds=%zu:", g.mode, c.na * c.nsc, c.na, c.nsc, c.cs, lds);
+    fprintf(stderr, "[ss_trace] mode=%d G=%d (na=%d nsc=%d cs=%d spw=%d res=%d) lds=%zu:", g.mode, grid_, c.na, c.nsc, c.cs, spw_, c.a_resident, lds);
     for (int i = 1; i < (int)h[0] && i < 250; ++i) fprintf(stderr, " %lld:%.2f", h[2 * i + 1], (double)(h[2 * i] - h[2]) * 0.01);
     const int nn = (int)h[0];
     if (nn > 2)

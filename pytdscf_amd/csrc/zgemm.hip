@@ -38,6 +38,15 @@ extern __shared__ zc smem_dyn[];
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// lane maps of v_mfma_f64_4x4x4_4b_f64, measured with one-hot operands (tools/probes/mfma_4x4x4_layout.hip, MI355X):
+// block = (lane / 4) % 4 for both operands and the result; A operand: row i = lane % 4, k = lane / 16; B operand: column
+// j = lane % 4, k = lane / 16; result: row i = lane / 16, column j = lane % 4.  Verified again at first use (b4_layout_ok).
+#define MITDVP_B4_BLK(lane) (((lane) >> 2) & 3)
+#define MITDVP_B4_Q(lane) ((lane) & 3)
+#define MITDVP_B4_K(lane) ((lane) >> 4)
+#define MITDVP_B4_D_ROW(lane) ((lane) >> 4)
+#define MITDVP_B4_D_COL(lane) ((lane) & 3)
+
 // C/D lane map of v_mfma_f64_16x16x4_f64, detected once by mfma_layout_probe():
 //   mode 0: row = (lane>>4) + 4*reg     (cdna_hip_programming.md section 3)
 //   mode 1: row = 4*(lane>>4) + reg     (the f32 16x16x4 map)
@@ -56,6 +65,8 @@ template <int RB, int CB>
 __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
 template <int RB, int CB>
 __device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
+template <int NIS, int NPG>
+__device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn);
 
 template <int WM, int WN, int BK, bool TA, bool TB, bool M3, bool SP = false, bool EPI = false>
 __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
@@ -413,6 +424,14 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     const int cbn = ((BM / d.epi_xm) * (BN / d.epi_yn) + 15) / 16;
     // four blocks of outputs: one block per wave over the whole contraction (no partials to exchange); fewer: the
     // contraction split over the waves
+    const int npair_ = (BM / d.epi_xm) * (BN / d.epi_yn);
+    if (d.epi_b4 && npair_ <= 8 && d.epi_di <= 32) {
+      // few (u, v) pairs per tile (d M = 512: eight): 4 x 4 x 4 products in four independent blocks per instruction
+      // instead of 16 x 16 x 4 products half of whose columns are padding
+      if (d.epi_di <= 16) { if (npair_ <= 4) reduce_epilogue_b4<1, 1>(d, smem, tm, tn); else reduce_epilogue_b4<1, 2>(d, smem, tm, tn); }
+      else { if (npair_ <= 4) reduce_epilogue_b4<2, 1>(d, smem, tm, tn); else reduce_epilogue_b4<2, 2>(d, smem, tm, tn); }
+      return;
+    }
     if (cbn == 1) {
       if (rbn == 1) reduce_epilogue<1, 1>(d, smem, tm, tn, cd_mode);
       else if (rbn == 2) reduce_epilogue<2, 1>(d, smem, tm, tn, cd_mode);
@@ -659,6 +678,134 @@ __device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* s
           if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
           *p = make_double2(re, im);
         }
+      }
+    }
+  }
+}
+
+// The same contraction with v_mfma_f64_4x4x4_4b_f64: FOUR independent 4 x 4 x 4 products per instruction (same multiply-add
+// rate as the 16 x 16 x 4 form).  A tile with few (u, v) pairs -- d M = 512 leaves eight -- fills only half of the sixteen
+// columns of a 16 x 16 product (profiles/r04_edge_apply_ab.txt: the reason the edge form lost at C3 / C4); here the four
+// blocks of an instruction are four groups of 4 output rows i against ONE group of 4 pairs, so nothing is padding while
+// DI is a multiple of 4 and the pairs come in fours.  NIS = sets of 16 output rows, NPG = groups of 4 pairs.
+// Lane maps of the instruction: the MITDVP_B4_* macros at the top of this file.
+template <int NIS, int NPG>
+__device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn) {
+  constexpr int LDT = 65;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int blk = MITDVP_B4_BLK(lane), q4 = MITDVP_B4_Q(lane), k4l = MITDVP_B4_K(lane);  // operand maps: (block, row / column, k)
+  const int XM = d.epi_xm, YN = d.epi_yn, KP = XM * YN, DI = d.epi_di;
+  const int TU = 64 / XM, TV = 64 / YN, npair = TU * TV;
+  const int nk4 = (KP + 3) / 4, per = (nk4 + 3) / 4;
+  const int k4a = w * per, k4b = min(nk4, k4a + per);
+  const zc* __restrict__ Wm = d.epi_w;
+  const long ldw = d.epi_ldw;
+  double zr[NIS][NPG], zi[NIS][NPG];
+#pragma unroll
+  for (int s = 0; s < NIS; ++s)
+#pragma unroll
+    for (int g = 0; g < NPG; ++g) zr[s][g] = zi[s][g] = 0.0;
+  // A operand of i-set s: w[(4 s + blk) 4 + q4][4 k4 + k4l];  B operand of pair group g: T of pair 4 g + q4 at k = 4 k4 + k4l
+  long woff[NIS];
+  bool wval[NIS];
+#pragma unroll
+  for (int s = 0; s < NIS; ++s) {
+    const int i = (4 * s + blk) * 4 + q4;
+    wval[s] = i < DI;
+    woff[s] = (long)(wval[s] ? i : 0) * ldw;
+  }
+  int toff[NPG];
+  bool tval[NPG];
+#pragma unroll
+  for (int g = 0; g < NPG; ++g) {
+    const int pr = 4 * g + q4;
+    tval[g] = pr < npair;
+    const int prc = tval[g] ? pr : 0;
+    const int ul = prc / TV, vl = prc - ul * TV;
+    toff[g] = ul * XM * LDT + vl * YN;
+  }
+  constexpr int CH = 4;  // k-steps per chunk of w fragments, loaded one chunk ahead
+  zc wv[2][CH][NIS];
+  auto load_w = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int kk = (k4s + c) * 4 + k4l;
+#pragma unroll
+      for (int s = 0; s < NIS; ++s) {
+        const bool ok = (k4s + c) < k4b && kk < KP && wval[s];
+        zc v = Wm[ok ? woff[s] + kk : 0];
+        v.x = ok ? v.x : 0.0;
+        v.y = ok ? v.y : 0.0;
+        wv[buf][c][s] = v;
+      }
+    }
+  };
+  auto chunk = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k4 = k4s + c;
+      if (k4 < k4b) {
+        const int kk = k4 * 4 + k4l;
+        const bool kv = kk < KP;
+        const int kc = kv ? kk : 0;
+        const int x = kc / YN, y = kc - x * YN;
+        zc tv[NPG];
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) {
+          const bool ok = kv && tval[g];
+          zc v = smem[ok ? toff[g] + x * LDT + y : 0];
+          v.x = ok ? v.x : 0.0;
+          v.y = ok ? v.y : 0.0;
+          tv[g] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < NIS; ++s) {
+          const zc a = wv[buf][c][s];
+          const double nai = -a.y;
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) {
+            zr[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, zr[s][g], 0, 0, 0);
+            zi[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].y, zi[s][g], 0, 0, 0);
+            zr[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(nai, tv[g].y, zr[s][g], 0, 0, 0);
+            zi[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].x, zi[s][g], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  load_w(0, k4a);
+  for (int k4s = k4a; k4s < k4b; k4s += 2 * CH) {
+    load_w(1, k4s + CH);
+    chunk(0, k4s);
+    load_w(0, k4s + 2 * CH);
+    chunk(1, k4s + CH);
+  }
+  __syncthreads();  // every wave has read its part of T
+  // partials of the four waves (the contraction index was split over them): [wave][set][lane]
+  constexpr int NQ = NIS * NPG;
+#pragma unroll
+  for (int s = 0; s < NIS; ++s)
+#pragma unroll
+    for (int g = 0; g < NPG; ++g) smem[(w * NQ + s * NPG + g) * 64 + lane] = make_double2(zr[s][g], zi[s][g]);
+  __syncthreads();
+  if (t < NQ * 64) {  // thread t owns result lane t % 64 of set t / 64
+    const int q = t >> 6, el = t & 63;
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const zc v = smem[(ww * NQ + q) * 64 + el];
+      re += v.x;
+      im += v.y;
+    }
+    const int s = q / NPG, g = q - s * NPG;
+    const int i = (4 * s + MITDVP_B4_BLK(el)) * 4 + MITDVP_B4_D_ROW(el), pr = 4 * g + MITDVP_B4_D_COL(el);
+    if (i < DI && pr < npair) {
+      const int ul = pr / TV, vl = pr - ul * TV;
+      const long u = (long)tm * TU + ul, v = (long)tn * TV + vl;
+      if (u * XM < d.M && v * YN < d.N) {
+        zc* p = d.C + u * d.epi_su + v * d.epi_sv + (long)i * d.epi_si;
+        if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
+        *p = make_double2(re, im);
       }
     }
   }
@@ -937,8 +1084,44 @@ bool zgemm_reduce_ok(int xm, int yn, int di) {
   return (cb == 1) || (cb == 2 && rb <= 2) || (cb <= 4 && rb == 1);
 }
 
+// v_mfma_f64_4x4x4_4b_f64 with the lane maps reduce_epilogue_b4 assumes, against the products formed on the host (small
+// integers: exact).  Once per process; a mismatch only switches the 4 x 4 x 4 epilogue off (the 16 x 16 form stays).
+__global__ void k_b4_layout(double* out) {
+  const int l = threadIdx.x, blk = MITDVP_B4_BLK(l), q = MITDVP_B4_Q(l), k = MITDVP_B4_K(l);
+  const double a = 1.0 + blk * 16 + q * 4 + k;            // A_blk[i = q][k]
+  const double b = 100.0 * (1.0 + blk * 16 + k * 4 + q);  // B_blk[k][j = q]
+  out[l] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);
+}
+static int g_b4_ok = -1;
+static int b4_layout_ok(hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [&] {
+    g_b4_ok = 0;
+    if (const char* e = std::getenv("MITDVP_EPI_B4")) { if (std::atoi(e) == 0) return; }
+    double* dout = nullptr;
+    double h[64];
+    HIP_CHECK(hipMalloc(&dout, sizeof(h)));
+    hipLaunchKernelGGL(k_b4_layout, dim3(1), dim3(64), 0, st, dout);
+    HIP_CHECK(hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipFree(dout));
+    bool ok = true;
+    for (int l = 0; l < 64 && ok; ++l) {
+      const int blk = MITDVP_B4_BLK(l), i = MITDVP_B4_D_ROW(l), j = MITDVP_B4_D_COL(l);
+      double want = 0.0;
+      for (int k = 0; k < 4; ++k) want += (1.0 + blk * 16 + i * 4 + k) * (100.0 * (1.0 + blk * 16 + k * 4 + j));
+      ok = h[l] == want;
+    }
+    g_b4_ok = ok ? 1 : 0;
+    if (!ok && std::getenv("MITDVP_VERBOSE")) fprintf(stderr, "[mitdvp] v_mfma_f64_4x4x4_4b_f64: unexpected lane map, 4 x 4 x 4 epilogue off\n");
+  });
+  return g_b4_ok;
+}
+int zgemm_reduce_b4_available(hipStream_t st) { return b4_layout_ok(st); }
+
 void zgemm_reduce(hipStream_t st, const ZgemmDesc& d0) {
   ZgemmDesc d = d0;
+  d.epi_b4 = b4_layout_ok(st);
   if (d.tune < 0) d.tune = zgemm_tune_default();
   if (d.M <= 0 || d.N <= 0) return;
   if (!zgemm_reduce_ok(d.epi_xm, d.epi_yn, d.epi_di) || !d.epi_w) throw ArgError("zgemm_reduce: shape outside the reducing epilogue's range");

@@ -6,9 +6,9 @@ engine confined to 128 / 32 compute units of its own (mitdvp_config.cu_first / c
   * bit-identical to the same engines stepped one after the other (the replicas share nothing but the MPO);
   * equal to an engine on the whole chip to rounding (its contraction chains are chunked differently: 1e-10 fidelity, equal
     Krylov counts);
-  * with 128 compute units per replica every local exponential is still one launch (no host wait inside a time step); with
-    32 the interior sites' chains (128 workgroups at this shape: DESIGN.md section 6) no longer fit a slice and run through
-    the multi-launch kernels -- slower, same results.
+  * every local exponential is one launch (no host wait inside a time step) on slices of 128, 32 and 16 compute units alike:
+    where a slice has fewer compute units than the chain has (slab, chunk) pairs, a workgroup walks over several slabs of
+    its chunk (SmallChain::spw, round 5).
 """
 
 import numpy as np
@@ -25,7 +25,7 @@ def _setup(ens_or_engs, mpo):
         e.init_random([d] * L, D, seed=11 + r)
 
 
-@pytest.mark.parametrize("B", [2, 8])
+@pytest.mark.parametrize("B", [2, 8, 16])
 def test_replicas_on_disjoint_compute_units(B):
     from oracle import tdvp_oracle as orc
     from pytdscf_amd import TDVPEngine, TDVPEnsemble
@@ -46,8 +46,10 @@ def test_replicas_on_disjoint_compute_units(B):
         assert abs(e.norm() - 1) < 1e-12
         c = e.counters()
         assert c["n_exp_site"] == 2 * nsteps * L
-        if B == 2:
-            assert c["n_host_waits"] <= 2  # the one-launch family throughout: no wait inside a time step
+        # the one-launch family throughout -- also on slices of 32 / 16 compute units, where a workgroup walks over several
+        # slabs of its chunk (round 5; before, the interior sites fell back to the multi-launch kernels there): no host
+        # wait inside a time step
+        assert c["n_host_waits"] <= 2, c["n_host_waits"]
     ens.close()
     # the same engines, one at a time
     for r in range(B):

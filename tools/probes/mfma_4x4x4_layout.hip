@@ -38,19 +38,15 @@ int main() {
       if (pair[la * 64 + lb] >= 0) printf("  (B lane %2d -> D lane %2d)", lb, pair[la * 64 + lb]);
     printf("\n");
   }
-  // hypothesis check: block = lane / 16; A: row i = lane % 4, k = (lane / 4) % 4; B: column j = lane % 4, k = (lane / 4) % 4;
-  // D: row i = (lane / 4) % 4 ... print which simple hypothesis fits
-  const char* names[] = {"A(i = l%4, k = l/4%4), B(j = l%4, k = l/4%4), D(i = l/4%4, j = l%4)",
-                         "A(i = l%4, k = l/4%4), B(j = l%4, k = l/4%4), D(i = l%4, j = l/4%4)"};
-  for (int h = 0; h < 2; ++h) {
-    bool ok = true;
-    for (int la = 0; la < 64 && ok; ++la)
-      for (int lb = 0; lb < 64 && ok; ++lb) {
-        const int ba = la / 16, ia = la % 4, ka = (la / 4) % 4, bb = lb / 16, jb = lb % 4, kb = (lb / 4) % 4;
-        const int want = (ba == bb && ka == kb) ? (h == 0 ? ba * 16 + ia * 4 + jb : ba * 16 + jb * 4 + ia) : -1;
-        if (pair[la * 64 + lb] != want) ok = false;
-      }
-    printf("hypothesis %d [%s]: %s\n", h, names[h], ok ? "FITS" : "no");
-  }
+  // the layout csrc/zgemm.hip assumes (MITDVP_B4_*): block = (l / 4) % 4; A(i = l % 4, k = l / 16); B(j = l % 4, k = l / 16);
+  // D(i = l / 16, j = l % 4)
+  bool ok = true;
+  for (int la = 0; la < 64 && ok; ++la)
+    for (int lb = 0; lb < 64 && ok; ++lb) {
+      const int ba = (la / 4) % 4, ia = la % 4, ka = la / 16, bb = (lb / 4) % 4, jb = lb % 4, kb = lb / 16;
+      const int want = (ba == bb && ka == kb) ? ia * 16 + ba * 4 + jb : -1;
+      if (pair[la * 64 + lb] != want) ok = false;
+    }
+  printf("layout assumed by csrc/zgemm.hip: %s\n", ok ? "FITS" : "does NOT fit");
   return 0;
 }
