@@ -529,7 +529,9 @@ struct Carve {
 __host__ __device__ inline Carve ss_carve(const SmallChain& c, bool exp_mode) {
   Carve k{};
   size_t o = 0;
-  k.As = o; o += (size_t)c.nc * c.nb * (c.a_resident ? (c.spw > 1 ? c.spw : 1) : 1);
+  // A_a of the workgroup's slabs: all of them when they fit (a_resident), else two slots -- the next slab's A is fetched
+  // while the current slab's stages run
+  k.As = o; o += (size_t)c.nc * c.nb * (c.spw > 1 ? (c.a_resident ? c.spw : 2) : 1);
   k.Rs = o; o += (size_t)c.nt * c.cs * c.nr;
   k.Ws = o; o += c.W2 ? (size_t)c.ni * c.nt * c.nc * c.nj : 0;
   k.Bs = o;
@@ -669,13 +671,27 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
 
   // the three stages; this chunk's partial of out[a][:][:] ends up in Sg (LDS)
   auto chain = [&](int q) {
-    const zc* Aq = As + (c.a_resident ? (size_t)q * nAone : 0);
-    if (!c.a_resident) {  // A of this slab -> LDS (the previous slab's stage 1 is long over: two barriers ago)
-      for (int t = tid; t < nAone; t += SS_THREADS) {
-        const int cc = t / c.nb, b = t - cc * c.nb;
-        zc z = c.A[(long)(a_first + q) * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
-        if (c.conjA) z.y = -z.y;
-        As[t] = z;
+    const bool stream = !c.a_resident && spw > 1;
+    const zc* Aq = As + (c.a_resident ? (size_t)q * nAone : (stream ? (size_t)(q & 1) * nAone : 0));
+    auto ldA1 = [&](int slabq, int t) __attribute__((always_inline)) -> zc {
+      const int cc = t / c.nb, b = t - cc * c.nb;
+      zc z = c.A[(long)(a_first + slabq) * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
+      if (c.conjA) z.y = -z.y;
+      return z;
+    };
+    // streamed A: slab 0's is fetched here (exposed once per sequence of slabs), slab q + 1's is requested now and
+    // lands in the other slot after this slab's stages -- its latency hides behind them
+    constexpr int APRE = 4;
+    zc apre[APRE];
+    const bool pre = stream && q + 1 < nsl && nAone <= APRE * SS_THREADS;
+    if (stream && q == 0)
+      for (int t = tid; t < nAone; t += SS_THREADS) As[t] = ldA1(0, t);
+    if (pre) {
+#pragma unroll
+      for (int u = 0; u < APRE; ++u) {
+        const int t = tid + u * SS_THREADS;
+        apre[u] = make_double2(0.0, 0.0);
+        if (t < nAone) apre[u] = ldA1(q + 1, t);
       }
     }
     __syncthreads();
@@ -689,6 +705,18 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     }
     stamp(22);
     lds_gemm(Ys, c.nt * cs, Rs, c.nr, Sg, c.nr, c.ni, c.nr, c.nt * cs, 1.0);
+    if (stream && q + 1 < nsl) {  // the other slot was last read by slab q - 1's stage 1
+      zc* An = As + (size_t)((q + 1) & 1) * nAone;
+      if (pre) {
+#pragma unroll
+        for (int u = 0; u < APRE; ++u) {
+          const int t = tid + u * SS_THREADS;
+          if (t < nAone) An[t] = apre[u];
+        }
+      } else {
+        for (int t = tid; t < nAone; t += SS_THREADS) An[t] = ldA1(q + 1, t);
+      }
+    }
     __syncthreads();
     stamp(23);
   };

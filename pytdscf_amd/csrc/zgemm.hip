@@ -65,8 +65,10 @@ template <int RB, int CB>
 __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
 template <int RB, int CB>
 __device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
-template <int NIS, int NPG>
+template <int NIS, int NPG, bool M3>
 __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn);
+template <bool M3>
+__device__ __forceinline__ void reduce_epilogue_b4w(const ZgemmDesc& d, zc* smem, int tm, int tn);
 
 template <int WM, int WN, int BK, bool TA, bool TB, bool M3, bool SP = false, bool EPI = false>
 __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(ZgemmDesc d, int ntm, int ntn, int cd_mode) {
@@ -425,11 +427,17 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     // four blocks of outputs: one block per wave over the whole contraction (no partials to exchange); fewer: the
     // contraction split over the waves
     const int npair_ = (BM / d.epi_xm) * (BN / d.epi_yn);
+    if (d.epi_b4 && d.epi_di <= 4 && npair_ <= 64) {
+      // few output rows, many pairs (d = 4: C5): four groups of 4 pairs per instruction against the same 4 rows of the
+      // core, one wave per 16 pairs over the whole contraction -- the 16 x 16 form used 4 of its 16 rows
+      reduce_epilogue_b4w<M3>(d, smem, tm, tn);
+      return;
+    }
     if (d.epi_b4 && npair_ <= 8 && d.epi_di <= 32) {
       // few (u, v) pairs per tile (d M = 512: eight): 4 x 4 x 4 products in four independent blocks per instruction
       // instead of 16 x 16 x 4 products half of whose columns are padding
-      if (d.epi_di <= 16) { if (npair_ <= 4) reduce_epilogue_b4<1, 1>(d, smem, tm, tn); else reduce_epilogue_b4<1, 2>(d, smem, tm, tn); }
-      else { if (npair_ <= 4) reduce_epilogue_b4<2, 1>(d, smem, tm, tn); else reduce_epilogue_b4<2, 2>(d, smem, tm, tn); }
+      if (d.epi_di <= 16) { if (npair_ <= 4) reduce_epilogue_b4<1, 1, M3>(d, smem, tm, tn); else reduce_epilogue_b4<1, 2, M3>(d, smem, tm, tn); }
+      else { if (npair_ <= 4) reduce_epilogue_b4<2, 1, M3>(d, smem, tm, tn); else reduce_epilogue_b4<2, 2, M3>(d, smem, tm, tn); }
       return;
     }
     if (cbn == 1) {
@@ -689,7 +697,7 @@ __device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* s
 // blocks of an instruction are four groups of 4 output rows i against ONE group of 4 pairs, so nothing is padding while
 // DI is a multiple of 4 and the pairs come in fours.  NIS = sets of 16 output rows, NPG = groups of 4 pairs.
 // Lane maps of the instruction: the MITDVP_B4_* macros at the top of this file.
-template <int NIS, int NPG>
+template <int NIS, int NPG, bool M3>
 __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn) {
   constexpr int LDT = 65;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -700,11 +708,11 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
   const int k4a = w * per, k4b = min(nk4, k4a + per);
   const zc* __restrict__ Wm = d.epi_w;
   const long ldw = d.epi_ldw;
-  double zr[NIS][NPG], zi[NIS][NPG];
+  double p1[NIS][NPG], p2[NIS][NPG], p3[NIS][NPG];
 #pragma unroll
   for (int s = 0; s < NIS; ++s)
 #pragma unroll
-    for (int g = 0; g < NPG; ++g) zr[s][g] = zi[s][g] = 0.0;
+    for (int g = 0; g < NPG; ++g) p1[s][g] = p2[s][g] = p3[s][g] = 0.0;
   // A operand of i-set s: w[(4 s + blk) 4 + q4][4 k4 + k4l];  B operand of pair group g: T of pair 4 g + q4 at k = 4 k4 + k4l
   long woff[NIS];
   bool wval[NIS];
@@ -758,16 +766,27 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
           v.y = ok ? v.y : 0.0;
           tv[g] = v;
         }
+        // the complex product as in the K loop: 4M (p1 = Re, p2 = Im), or 3M (Karatsuba): P1 = sum ar tr, P2 = sum ai ti,
+        // P3 = sum (ar + ai)(tr + ti) -- the sums cost NIS + NPG additions per k-step and save NIS NPG products
+        double ts[NPG];
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) ts[g] = tv[g].x + tv[g].y;
 #pragma unroll
         for (int s = 0; s < NIS; ++s) {
           const zc a = wv[buf][c][s];
-          const double nai = -a.y;
+          const double as = a.x + a.y, nai = -a.y;
 #pragma unroll
           for (int g = 0; g < NPG; ++g) {
-            zr[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, zr[s][g], 0, 0, 0);
-            zi[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].y, zi[s][g], 0, 0, 0);
-            zr[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(nai, tv[g].y, zr[s][g], 0, 0, 0);
-            zi[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].x, zi[s][g], 0, 0, 0);
+            if constexpr (M3) {
+              p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, p1[s][g], 0, 0, 0);
+              p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].y, p2[s][g], 0, 0, 0);
+              p3[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(as, ts[g], p3[s][g], 0, 0, 0);
+            } else {
+              p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, p1[s][g], 0, 0, 0);
+              p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].y, p2[s][g], 0, 0, 0);
+              p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(nai, tv[g].y, p1[s][g], 0, 0, 0);
+              p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].x, p2[s][g], 0, 0, 0);
+            }
           }
         }
       }
@@ -786,7 +805,9 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
 #pragma unroll
   for (int s = 0; s < NIS; ++s)
 #pragma unroll
-    for (int g = 0; g < NPG; ++g) smem[(w * NQ + s * NPG + g) * 64 + lane] = make_double2(zr[s][g], zi[s][g]);
+    for (int g = 0; g < NPG; ++g)  // 3M: Re = P1 - P2, Im = P3 - P1 - P2
+      smem[(w * NQ + s * NPG + g) * 64 + lane] =
+          M3 ? make_double2(p1[s][g] - p2[s][g], p3[s][g] - p1[s][g] - p2[s][g]) : make_double2(p1[s][g], p2[s][g]);
   __syncthreads();
   if (t < NQ * 64) {  // thread t owns result lane t % 64 of set t / 64
     const int q = t >> 6, el = t & 63;
@@ -807,6 +828,87 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
         if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
         *p = make_double2(re, im);
       }
+    }
+  }
+}
+
+// DI <= 4 output rows and up to 64 pairs per tile (d = 4, M = 16): wave w owns pairs 16 w .. 16 w + 15 over the whole
+// contraction index -- the four blocks of an instruction are four groups of 4 pairs against the same 4 rows of the core;
+// nothing is exchanged between the waves.
+template <bool M3>
+__device__ __forceinline__ void reduce_epilogue_b4w(const ZgemmDesc& d, zc* smem, int tm, int tn) {
+  constexpr int LDT = 65;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int blk = MITDVP_B4_BLK(lane), q4 = MITDVP_B4_Q(lane), k4l = MITDVP_B4_K(lane);
+  const int XM = d.epi_xm, YN = d.epi_yn, KP = XM * YN, DI = d.epi_di;
+  const int TU = 64 / XM, TV = 64 / YN, npair = TU * TV;
+  const int nk4 = (KP + 3) / 4;
+  const zc* __restrict__ Wm = d.epi_w;
+  const long ldw = d.epi_ldw;
+  const bool wval = q4 < DI;
+  const long woff = (long)(wval ? q4 : 0) * ldw;
+  const int pr = 16 * w + 4 * blk + q4;
+  const bool pval = pr < npair;
+  const int prc = pval ? pr : 0;
+  const int ul = prc / TV, vl = prc - ul * TV;
+  const int toff = ul * XM * LDT + vl * YN;
+  double p1 = 0.0, p2 = 0.0, p3 = 0.0;
+  constexpr int CH = 4;
+  zc wv[2][CH];
+  auto load_w = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int kk = (k4s + c) * 4 + k4l;
+      const bool ok = (k4s + c) < nk4 && kk < KP && wval;
+      zc v = Wm[ok ? woff + kk : 0];
+      v.x = ok ? v.x : 0.0;
+      v.y = ok ? v.y : 0.0;
+      wv[buf][c] = v;
+    }
+  };
+  auto chunk = [&](int buf, int k4s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k4 = k4s + c;
+      if (k4 < nk4) {
+        const int kk = k4 * 4 + k4l;
+        const bool ok = kk < KP && pval;
+        const int kc = kk < KP ? kk : 0;
+        const int x = kc / YN, y = kc - x * YN;
+        zc tv = smem[ok ? toff + x * LDT + y : 0];
+        tv.x = ok ? tv.x : 0.0;
+        tv.y = ok ? tv.y : 0.0;
+        const zc a = wv[buf][c];
+        if constexpr (M3) {
+          p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv.x, p1, 0, 0, 0);
+          p2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv.y, p2, 0, 0, 0);
+          p3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x + a.y, tv.x + tv.y, p3, 0, 0, 0);
+        } else {
+          p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv.x, p1, 0, 0, 0);
+          p2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv.y, p2, 0, 0, 0);
+          p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(-a.y, tv.y, p1, 0, 0, 0);
+          p2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv.x, p2, 0, 0, 0);
+        }
+      }
+    }
+  };
+  load_w(0, 0);
+  for (int k4s = 0; k4s < nk4; k4s += 2 * CH) {
+    load_w(1, k4s + CH);
+    chunk(0, k4s);
+    load_w(0, k4s + 2 * CH);
+    chunk(1, k4s + CH);
+  }
+  // result lane: row i = lane / 16, pair 16 w + 4 block + lane % 4
+  const int io = MITDVP_B4_D_ROW(lane), po = 16 * w + 4 * MITDVP_B4_BLK(lane) + MITDVP_B4_D_COL(lane);
+  if (io < DI && po < npair) {
+    const int uo = po / TV, vo = po - uo * TV;
+    const long u = (long)tm * TU + uo, v = (long)tn * TV + vo;
+    if (u * XM < d.M && v * YN < d.N) {
+      zc* p = d.C + u * d.epi_su + v * d.epi_sv + (long)io * d.epi_si;
+      double re = M3 ? p1 - p2 : p1, im = M3 ? p3 - p1 - p2 : p2;
+      if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
+      *p = make_double2(re, im);
     }
   }
 }
