@@ -19,6 +19,7 @@
 // element, a failed check (or a second pass that is not a small correction) raises a sticky flag and the caller redoes the
 // factorisation with the Householder panels -- the input is never modified here.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -45,7 +46,8 @@ constexpr int GQ_NB = 128;  // widest block: 32 x 32 threads holding 4 x 4 eleme
 template <int NG>
 __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(const zc* __restrict__ G, long ldg, int n,
                                                                                 zc* __restrict__ Rout, zc* __restrict__ Xout,
-                                                                                long ldo, int first_order, int* __restrict__ flag) {
+                                                                                long ldo, int first_order, int* __restrict__ flag,
+                                                                                long long* __restrict__ trace) {
   constexpr int NP = 4 * NG;
   constexpr int NTRI = NG * (NG + 1) / 2;
   constexpr int NW = (NTRI + 63) / 64;
@@ -148,7 +150,11 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
 
   // ---- Cholesky ----------------------------------------------------------------------------------------------
   const int nkb = (n + 3) / 4;
+  int ntr = 0;
+  auto stamp = [&]() { if (trace && t == 0 && ntr < 30) trace[ntr++] = (long long)__builtin_amdgcn_s_memrealtime(); };
+  stamp();
   for (int kb = 0; kb < nkb; ++kb) {
+    if ((kb & 7) == 0 && kb) stamp();
 #pragma unroll
     for (int kr = 0; kr < 4; ++kr) {
       const int k = 4 * kb + kr;
@@ -194,12 +200,15 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
     }
   }
   __syncthreads();
+  stamp();
   const bool bad = badw != 0;
   if (bad && t == 0) atomicOr(flag, 1);
   store(Rout);
+  stamp();
 
   // ---- X = R^-1 in place -------------------------------------------------------------------------------------
   for (int kb = 0; kb < nkb; ++kb) {
+    if ((kb & 7) == 0 && kb) stamp();
 #pragma unroll
     for (int kr = 0; kr < 4; ++kr) {
       const int k = 4 * kb + kr;
@@ -252,15 +261,32 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
       }
     }
   }
+  stamp();
   store(Xout);
+  stamp();
+  if (trace && t == 0) trace[31] = ntr;
 }
 
 static void gq_chol_launch(hipStream_t st, const zc* G, long ldg, int n, zc* R, zc* X, long ldo, int first_order, int* flag) {
+  // MITDVP_QR_TRACE=1: thread 0 stamps the 100 MHz clock every eight block rows of both chains; printed per launch
+  static const bool tracing = std::getenv("MITDVP_QR_TRACE") && std::atoi(std::getenv("MITDVP_QR_TRACE")) != 0;
+  static long long* tbuf = nullptr;
+  if (tracing && !tbuf) HIP_CHECK(hipMalloc(&tbuf, 32 * sizeof(long long)));
+  long long* trace = tracing ? tbuf : nullptr;
+  if (tracing) HIP_CHECK(hipMemsetAsync(tbuf, 0, 32 * sizeof(long long), st));
   auto nthr = [](int ng) { return (ng * (ng + 1) / 2 + 63) / 64 * 64; };
-  if (n <= 32) hipLaunchKernelGGL(k_gq_chol<8>, dim3(1), dim3(nthr(8)), 0, st, G, ldg, n, R, X, ldo, first_order, flag);
-  else if (n <= 64) hipLaunchKernelGGL(k_gq_chol<16>, dim3(1), dim3(nthr(16)), 0, st, G, ldg, n, R, X, ldo, first_order, flag);
-  else hipLaunchKernelGGL(k_gq_chol<32>, dim3(1), dim3(nthr(32)), 0, st, G, ldg, n, R, X, ldo, first_order, flag);
+  if (n <= 32) hipLaunchKernelGGL(k_gq_chol<8>, dim3(1), dim3(nthr(8)), 0, st, G, ldg, n, R, X, ldo, first_order, flag, trace);
+  else if (n <= 64) hipLaunchKernelGGL(k_gq_chol<16>, dim3(1), dim3(nthr(16)), 0, st, G, ldg, n, R, X, ldo, first_order, flag, trace);
+  else hipLaunchKernelGGL(k_gq_chol<32>, dim3(1), dim3(nthr(32)), 0, st, G, ldg, n, R, X, ldo, first_order, flag, trace);
   HIP_CHECK(hipGetLastError());
+  if (tracing) {
+    long long h[32];
+    HIP_CHECK(hipMemcpyAsync(h, tbuf, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    fprintf(stderr, "[qr_trace] n=%d first_order=%d:", n, first_order);
+    for (int i = 1; i < (int)h[31] && i < 30; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) * 0.01);
+    fprintf(stderr, " us\n");
+  }
 }
 
 // workspace (complex elements): S ((n + NB) x NB: W above G), WX (n x NB), T1 (m x NB), Ra, Rb, Xa, Xb (NB x NB each), the flag

@@ -235,18 +235,47 @@ class SiteShard {
   struct PostedOp { bool send; const zc* src; zc* dst; size_t elems; int peer; };
   std::vector<PostedOp> posted_;
   bool open_ = false;
+  // Library RCCL: the group runs on the block engine's stream, operands may have been written on the junction engines'
+  // streams and are read there afterwards -- ordered by EVENTS (the junction streams' work before the group, the group
+  // before their next work), the host does not wait.  (Round 4 drained all three streams before and the block stream
+  // after every group: four host synchronisations per message group.)  The callback transport stages through the host
+  // and keeps the drains.
+  hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t event(int i) {
+    if (!ev_[i]) HIP_CHECK(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
+    return ev_[i];
+  }
+  void order_before_group() {
+    Engine* js[2] = {joint_, jleft_};
+    for (int i = 0; i < 2; ++i)
+      if (js[i] && js[i]->st_ != block_->st_) {
+        HIP_CHECK(hipEventRecord(event(i), js[i]->st_));
+        HIP_CHECK(hipStreamWaitEvent(block_->st_, event(i), 0));
+      }
+  }
+  void order_after_group() {
+    HIP_CHECK(hipEventRecord(event(2), block_->st_));
+    Engine* js[2] = {joint_, jleft_};
+    for (int i = 0; i < 2; ++i)
+      if (js[i] && js[i]->st_ != block_->st_) HIP_CHECK(hipStreamWaitEvent(js[i]->st_, event(2), 0));
+  }
   void xfer_begin() {
     if (open_) throw ArgError("shard: message groups do not nest");
+    if (!fn_) {
+      if (!comm_.load()) throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)");
+      order_before_group();
+      open_ = true;
+      posted_.clear();
+      const ncclResult_t r = RcclApi::get().group_start();
+      if (r != ncclSuccess) { open_ = false; rccl_check(r, "ncclGroupStart"); }
+      in_group_ = true;
+      return;
+    }
     HIP_CHECK(hipStreamSynchronize(block_->st_));
     if (joint_) HIP_CHECK(hipStreamSynchronize(joint_->st_));  // operands may come from any of the engines
     if (jleft_) HIP_CHECK(hipStreamSynchronize(jleft_->st_));
     open_ = true;
     posted_.clear();
-    if (!fn_) {
-      if (!comm_.load()) { open_ = false; throw ArgError("shard: no transport (mitdvp_shard_attach_rccl or mitdvp_shard_set_transport)"); }
-      rccl_check(RcclApi::get().group_start(), "ncclGroupStart");
-      in_group_ = true;
-    }
   }
   void send_dev(const zc* p, size_t elems, int peer) {
     if (!open_) throw ArgError("shard: send outside a message group");
@@ -273,7 +302,7 @@ class SiteShard {
     if (in_group_) {
       in_group_ = false;
       rccl_check(RcclApi::get().group_end(), "ncclGroupEnd");
-      HIP_CHECK(hipStreamSynchronize(block_->st_));  // the joint engine reads the buffers from ITS stream next
+      order_after_group();  // the junction engines read the received buffers from THEIR streams next
       return;
     }
     if (posted_.empty()) return;

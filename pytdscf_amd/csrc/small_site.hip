@@ -44,7 +44,11 @@
 namespace mitdvp {
 namespace {
 
-constexpr int SS_THREADS = 1024;  // 16 waves: four per SIMD hide the LDS / L2 latencies of the short dependent chains
+#ifndef MITDVP_SS_THREADS
+#define MITDVP_SS_THREADS 1024
+#endif
+constexpr int SS_THREADS = MITDVP_SS_THREADS;  // 16 waves: four per SIMD hide the LDS / L2 latencies of the short dependent chains (512: A/B builds)
+static_assert(SS_THREADS == 1024 || SS_THREADS == 512, "small-site workgroups have 16 or 8 waves");
 constexpr int SS_WAVES = SS_THREADS / 64;
 constexpr int SS_PAYMAX = 2 * MAXK + 2;  // doubles one workgroup contributes to an exchange
 constexpr int SS_MAXG = 256;
@@ -95,9 +99,13 @@ struct Sync {
 // fixed-order sum of the SS_WAVES per-wave partials p[0..SS_WAVES)
 __device__ __forceinline__ double wtree(const double* p) {
   // written out (halving tree: i += i + 8, then 4, 2, 1): as loops over a local array hipcc kept the array in scratch
-  static_assert(SS_WAVES == 16, "wtree is written for 16 waves");
-  const double b0 = p[0] + p[8], b1 = p[1] + p[9], b2 = p[2] + p[10], b3 = p[3] + p[11];
-  const double b4 = p[4] + p[12], b5 = p[5] + p[13], b6 = p[6] + p[14], b7 = p[7] + p[15];
+  double b0, b1, b2, b3, b4, b5, b6, b7;
+  if constexpr (SS_WAVES == 16) {
+    b0 = p[0] + p[8]; b1 = p[1] + p[9]; b2 = p[2] + p[10]; b3 = p[3] + p[11];
+    b4 = p[4] + p[12]; b5 = p[5] + p[13]; b6 = p[6] + p[14]; b7 = p[7] + p[15];
+  } else {
+    b0 = p[0]; b1 = p[1]; b2 = p[2]; b3 = p[3]; b4 = p[4]; b5 = p[5]; b6 = p[6]; b7 = p[7];
+  }
   const double c0 = b0 + b4, c1 = b1 + b5, c2 = b2 + b6, c3 = b3 + b7;
   const double d0 = c0 + c2, d1 = c1 + c3;
   return d0 + d1;
@@ -529,9 +537,8 @@ struct Carve {
 __host__ __device__ inline Carve ss_carve(const SmallChain& c, bool exp_mode) {
   Carve k{};
   size_t o = 0;
-  // A_a of the workgroup's slabs: all of them when they fit (a_resident), else two slots -- the next slab's A is fetched
-  // while the current slab's stages run
-  k.As = o; o += (size_t)c.nc * c.nb * (c.spw > 1 ? (c.a_resident ? c.spw : 2) : 1);
+  // A_a of the workgroup's slabs: all of them when they fit (a_resident), else one slot re-staged per slab
+  k.As = o; o += (size_t)c.nc * c.nb * (c.a_resident && c.spw > 1 ? c.spw : 1);
   k.Rs = o; o += (size_t)c.nt * c.cs * c.nr;
   k.Ws = o; o += c.W2 ? (size_t)c.ni * c.nt * c.nc * c.nj : 0;
   k.Bs = o;
@@ -671,27 +678,16 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
 
   // the three stages; this chunk's partial of out[a][:][:] ends up in Sg (LDS)
   auto chain = [&](int q) {
-    const bool stream = !c.a_resident && spw > 1;
-    const zc* Aq = As + (c.a_resident ? (size_t)q * nAone : (stream ? (size_t)(q & 1) * nAone : 0));
-    auto ldA1 = [&](int slabq, int t) __attribute__((always_inline)) -> zc {
-      const int cc = t / c.nb, b = t - cc * c.nb;
-      zc z = c.A[(long)(a_first + slabq) * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
-      if (c.conjA) z.y = -z.y;
-      return z;
-    };
-    // streamed A: slab 0's is fetched here (exposed once per sequence of slabs), slab q + 1's is requested now and
-    // lands in the other slot after this slab's stages -- its latency hides behind them
-    constexpr int APRE = 4;
-    zc apre[APRE];
-    const bool pre = stream && q + 1 < nsl && nAone <= APRE * SS_THREADS;
-    if (stream && q == 0)
-      for (int t = tid; t < nAone; t += SS_THREADS) As[t] = ldA1(0, t);
-    if (pre) {
-#pragma unroll
-      for (int u = 0; u < APRE; ++u) {
-        const int t = tid + u * SS_THREADS;
-        apre[u] = make_double2(0.0, 0.0);
-        if (t < nAone) apre[u] = ldA1(q + 1, t);
+    const zc* Aq = As + (c.a_resident ? (size_t)q * nAone : 0);
+    if (!c.a_resident) {  // A of this slab -> LDS (the previous slab's stage 1 is long over: two barriers ago)
+      // (round 5, measured and dropped: requesting slab q + 1's A into registers before this slab's stages and storing it
+      // into a second slot afterwards -- the registers held across the three stages added spills to a kernel that is
+      // already spill-bound: 8 x 32 CUs 812 -> 634 sweeps/s, 16 x 16 CUs 998 -> 756, profiles/r05_ensemble_probe.txt)
+      for (int t = tid; t < nAone; t += SS_THREADS) {
+        const int cc = t / c.nb, b = t - cc * c.nb;
+        zc z = c.A[(long)(a_first + q) * c.sAa + (long)cc * c.sAc + (long)b * c.sAb];
+        if (c.conjA) z.y = -z.y;
+        As[t] = z;
       }
     }
     __syncthreads();
@@ -705,18 +701,6 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
     }
     stamp(22);
     lds_gemm(Ys, c.nt * cs, Rs, c.nr, Sg, c.nr, c.ni, c.nr, c.nt * cs, 1.0);
-    if (stream && q + 1 < nsl) {  // the other slot was last read by slab q - 1's stage 1
-      zc* An = As + (size_t)((q + 1) & 1) * nAone;
-      if (pre) {
-#pragma unroll
-        for (int u = 0; u < APRE; ++u) {
-          const int t = tid + u * SS_THREADS;
-          if (t < nAone) An[t] = apre[u];
-        }
-      } else {
-        for (int t = tid; t < nAone; t += SS_THREADS) An[t] = ldA1(q + 1, t);
-      }
-    }
     __syncthreads();
     stamp(23);
   };
