@@ -44,10 +44,16 @@
 namespace mitdvp {
 namespace {
 
+// Threads per workgroup.  Rounds 2-4 ran 1024 (16 waves: "four per SIMD hide the LDS / L2 latencies of the short dependent
+// chains") -- at a register budget of 128 per thread, which this kernel exceeds: 125 VGPRs spilled, 380 B of scratch per
+// lane (hipcc -Rpass-analysis=kernel-resource-usage).  With 512 threads (8 waves, 256 registers each: 233 used, no scratch)
+// the same code runs C2 at 237 instead of 208 sweeps/s and the ensembles at 468 / 806 / 882 / 1134 instead of 407 / 693 /
+// 782 / 995 (2 / 4 / 8 / 16 replicas, same box: profiles/r05_ss_threads_ab.txt).  make variantf DEFS=-DMITDVP_SS_THREADS=1024
+// builds the old form for A/B runs.
 #ifndef MITDVP_SS_THREADS
-#define MITDVP_SS_THREADS 1024
+#define MITDVP_SS_THREADS 512
 #endif
-constexpr int SS_THREADS = MITDVP_SS_THREADS;  // 16 waves: four per SIMD hide the LDS / L2 latencies of the short dependent chains (512: A/B builds)
+constexpr int SS_THREADS = MITDVP_SS_THREADS;
 static_assert(SS_THREADS == 1024 || SS_THREADS == 512, "small-site workgroups have 16 or 8 waves");
 constexpr int SS_WAVES = SS_THREADS / 64;
 constexpr int SS_PAYMAX = 2 * MAXK + 2;  // doubles one workgroup contributes to an exchange
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_small_site(SsArgs g) {
           }
           stz_sh(Pchunk + e, v);
         }
-        // projections <v_j | partial>, four basis vectors per pass (registers: 1024-thread workgroups get 128)
+        // projections <v_j | partial>, four basis vectors per pass (registers: four accumulator pairs at a time)
         for (int j0 = 0; j0 < nd; j0 += 4) {
           double dre[4] = {0.0, 0.0, 0.0, 0.0}, dim_[4] = {0.0, 0.0, 0.0, 0.0};
           for (int q = tid; q < slab; q += SS_THREADS) {

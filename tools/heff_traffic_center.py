@@ -2,7 +2,7 @@
 KiB; FETCH doubled on gfx950 per MI355X_MICROARCH.md).  The kernels of the LAST `reps` applies are taken: every apply
 issues the same sequence, found as the shortest period of the trailing kernel-name sequence.
     python tools/heff_traffic_center.py <fetch.csv> <write.csv> <name> <D> <d> <M> <reps> <tag>  ->  profiles/r04_heff_traffic_<name>_<tag>.json"""
-import collections, csv, json, sys
+import collections, csv, json, os, sys
 
 fetch_csv, write_csv, name = sys.argv[1:4]
 D, d, M, reps = (int(x) for x in sys.argv[4:8])
@@ -38,5 +38,6 @@ out = {"shape": {"D": D, "d": d, "M": M}, "workload": name, "form": tag, "launch
        "read_bytes": 2 * 1024 * rd_kib, "write_bytes": 1024 * wr_kib, "total_bytes": 2 * 1024 * rd_kib + 1024 * wr_kib,
        "algorithmic_bytes_B_H": B_H}
 out["ratio_to_algorithmic"] = out["total_bytes"] / B_H
-json.dump(out, open(f"profiles/r04_heff_traffic_{name}_{tag}.json", "w"), indent=1)
+rnd = os.environ.get("MITDVP_ROUND", "04")
+json.dump(out, open(f"profiles/r{rnd}_heff_traffic_{name}_{tag}.json", "w"), indent=1)
 print(json.dumps(out))

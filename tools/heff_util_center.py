@@ -34,5 +34,7 @@ for s in range(per):
                             "mfma_pipe_busy_frac": busy / (gui / 8 * 1024) if gui > 0 else None,
                             "clock_GHz_from_GRBM_GUI_ACTIVE": gui / 8 / (ms * 1e-3) / 1e9 if ms > 0 else None})
 out["apply_ms_under_the_profiler"] = tot
-json.dump(out, open(f"profiles/r04_heff_mfma_util_{name}_{tag}.json", "w"), indent=1)
+import os
+rnd = os.environ.get("MITDVP_ROUND", "04")
+json.dump(out, open(f"profiles/r{rnd}_heff_mfma_util_{name}_{tag}.json", "w"), indent=1)
 print(json.dumps(out)[:1500])
