@@ -385,7 +385,7 @@ def ensemble_leg(name, device, n_steps):
     mpo = syn.synthetic_mpo(L, d, M, seed=0)
     bytes_apply = 16.0 * (2 * D * d * D + 2 * D * D * M + M * d * d * M)
     out = {"unit": "sweeps/s", "steps_per_replica": 2 * n_steps, "replicas": {}}
-    for B in (4, 8, 16):
+    for B in (8, 16):
         ens = TDVPEnsemble(B, L, device=device, integrator=integ)
         try:
             ens.set_mpo(mpo)
@@ -513,7 +513,7 @@ def compact_record(rec):
         if isinstance(x, dict):
             return {k: strip(v) for k, v in x.items() if k not in drop}
         if isinstance(x, float):
-            return float(f"{x:.6g}")
+            return float(f"{x:.9g}")
         if isinstance(x, list):
             return [strip(v) for v in x]
         return x

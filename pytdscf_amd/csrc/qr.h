@@ -31,7 +31,7 @@ void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
 void qr_thin(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, SmallSync* sy, QrHistory* hist,
              bool gauge_free, bool* used_gauge_free = nullptr);
 size_t qr_gram_work_elems(int m, int n);
-int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work);
+int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work, int* pub = nullptr, int pub_tag = 0);
 int* qr_gram_flag(zc* work, int m, int n);
 
 // panel factorisation: 1 = CholeskyQR2 + Householder reconstruction with the per-column kernels as the fallback

@@ -727,28 +727,34 @@ __global__ void k_qr_publish_flag(const int* __restrict__ flag, int* __restrict_
   __threadfence_system();
   *reinterpret_cast<volatile int*>(dst + 1) = tag;
 }
+// the host-coherent word a factorisation's verdict travels through: [0] flag, [1] sequence number
+static void qr_pub_ensure(QrHistory* hist) {
+  if (hist->h_word) return;
+  HIP_CHECK(hipHostMalloc((void**)&hist->h_word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  hist->h_word[0] = hist->h_word[1] = 0;
+  void* dp = nullptr;
+  HIP_CHECK(hipHostGetDevicePointer(&dp, hist->h_word, 0));
+  hist->d_word = static_cast<int*>(dp);
+}
+static int qr_pub_wait(hipStream_t st, QrHistory* hist, int tag) {
+  volatile int* w = hist->h_word;
+  for (long spins = 0; w[1] != tag; ++spins) {
+    if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(st) != hipErrorNotReady) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (w[1] != tag) throw HipError("qr: the verdict of the fast panels was not published");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return w[0];
+}
 // the sticky failure flag of the fast panels, read on the host
 static int qr_read_flag(hipStream_t st, const int* dev_flag, QrHistory* hist) {
   if (hist) {
-    if (!hist->h_word) {
-      HIP_CHECK(hipHostMalloc((void**)&hist->h_word, 64, hipHostMallocMapped | hipHostMallocCoherent));
-      hist->h_word[0] = hist->h_word[1] = 0;
-      void* dp = nullptr;
-      HIP_CHECK(hipHostGetDevicePointer(&dp, hist->h_word, 0));
-      hist->d_word = static_cast<int*>(dp);
-    }
+    qr_pub_ensure(hist);
     const int tag = ++hist->tag;
     hipLaunchKernelGGL(k_qr_publish_flag, dim3(1), dim3(1), 0, st, dev_flag, hist->d_word, tag);
     HIP_CHECK(hipGetLastError());
-    volatile int* w = hist->h_word;
-    for (long spins = 0; w[1] != tag; ++spins) {
-      if ((spins & 0xFFFF) == 0xFFFF && hipStreamQuery(st) != hipErrorNotReady) {
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (w[1] != tag) throw HipError("qr: the verdict of the fast panels was not published");
-      }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return w[0];
+    return qr_pub_wait(st, hist, tag);
   }
   int bad = 0;
   HIP_CHECK(hipMemcpyAsync(&bad, dev_flag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -798,9 +804,18 @@ void qr_thin(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* 
   }
   if (gram) {
     zc* gw = work + qr_work_elems_house(m, n, 0);
-    const int nl = qr_gram(st, A, m, n, Q, R, gw);
-    if (nlaunch) *nlaunch += nl;
-    const int bad = qr_read_flag(st, qr_gram_flag(gw, m, n), hist);
+    int bad;
+    if (hist) {  // the factorisation's last Cholesky kernel publishes the verdict itself
+      qr_pub_ensure(hist);
+      const int tag = ++hist->tag;
+      const int nl = qr_gram(st, A, m, n, Q, R, gw, hist->d_word, tag);
+      if (nlaunch) *nlaunch += nl;
+      bad = qr_pub_wait(st, hist, tag);
+    } else {
+      const int nl = qr_gram(st, A, m, n, Q, R, gw);
+      if (nlaunch) *nlaunch += nl;
+      bad = qr_read_flag(st, qr_gram_flag(gw, m, n), nullptr);
+    }
     if (!bad) {
       if (hist) hist->by_shape[gkey].fails = 0;
       if (used_gauge_free) *used_gauge_free = true;

@@ -47,11 +47,12 @@ template <int NG>
 __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(const zc* __restrict__ G, long ldg, int n,
                                                                                 zc* __restrict__ Rout, zc* __restrict__ Xout,
                                                                                 long ldo, int first_order, int* __restrict__ flag,
-                                                                                long long* __restrict__ trace) {
+                                                                                long long* __restrict__ trace, int* __restrict__ pub,
+                                                                                int pub_tag) {
   constexpr int NP = 4 * NG;
   constexpr int NTRI = NG * (NG + 1) / 2;
   constexpr int NW = (NTRI + 63) / 64;
-  __shared__ zc rowbuf[2][NP + 1];  // [NP]: (1 / pivot, 1 / sqrt(pivot)) of the step
+  __shared__ zc rowbuf[2][NP + 4];  // [NP ..]: (1 / pivot, 1 / sqrt(pivot)) of the step (inversion: one per diagonal 32-block)
   __shared__ zc colbuf[2][NP];
   __shared__ double red[2][NW];
   __shared__ int badw;
@@ -65,6 +66,16 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
     tc = tr < NG ? tr + rem : NG;
   }
   const bool act = tr < NG;
+  // the LAST factorisation of a QR also hands the sticky verdict to the host (pub: host-coherent mapped memory, [0] flag,
+  // [1] sequence number the host spins on) -- one launch less per QR than a publishing kernel of its own
+  auto publish = [&]() {
+    if (pub && t == 0) {
+      const int f = atomicOr(flag, 0);
+      pub[0] = f;
+      __threadfence_system();
+      *reinterpret_cast<volatile int*>(pub + 1) = pub_tag;
+    }
+  };
   if (t == 0) badw = 0;
   zc g[4][4];
 #pragma unroll
@@ -126,6 +137,7 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
         for (int b = 0; b < 4; ++b) g[a][b] = make_double2((4 * tr + a) == (4 * tc + b) ? 1.0 : 0.0, 0.0);
       store(Rout);
       store(Xout);
+      publish();
       return;
     }
     if (emax < 1e-8) {
@@ -144,6 +156,7 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
             if (tc > tr) { Rout[(long)j * ldo + i] = make_double2(0.0, 0.0); Xout[(long)j * ldo + i] = make_double2(0.0, 0.0); }
           }
         }
+      publish();
       return;
     }
   }
@@ -207,25 +220,33 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
   stamp();
 
   // ---- X = R^-1 in place -------------------------------------------------------------------------------------
-  for (int kb = 0; kb < nkb; ++kb) {
-    if ((kb & 7) == 0 && kb) stamp();
+  // Blocked: the diagonal 32 x 32 blocks are inverted side by side (Gauss-Jordan steps as above, 32 of them instead of n:
+  // a step is latency bound -- write, barrier, read, update: 0.8 us with all of the triangle behind it in the timeline of
+  // MITDVP_QR_TRACE, 105 of the kernel's 175 us at n = 128), then the off-diagonal blocks level by level from
+  //   [X11 X12; 0 X22] = [R11 R12; 0 R22]^-1,  X12 = -X11 R12 X22
+  // as two products per level staged through LDS (the operands live in other threads' registers).
+  constexpr int NBK = NG / 8 > 0 ? NG / 8 : 1;  // diagonal 32-blocks
+  const int blk_r = tr >> 3, blk_c = tc >> 3;
+  const bool diag_blk = act && blk_r == blk_c;
+  for (int kbl = 0; kbl < (NG < 8 ? NG : 8); ++kbl) {
+    const int kb = 8 * blk_r + kbl;  // this thread's pivot block row (meaningful on diagonal blocks only)
 #pragma unroll
     for (int kr = 0; kr < 4; ++kr) {
-      const int k = 4 * kb + kr;
-      zc* rb = rowbuf[k & 1];
-      zc* cb = colbuf[k & 1];
-      if (tr == kb) {
+      const int step = 4 * kbl + kr;
+      zc* rb = rowbuf[step & 1];
+      zc* cb = colbuf[step & 1];
+      if (diag_blk && tr == kb) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) rb[4 * tc + b] = g[kr][b];
-        if (tc == kb) rb[NP] = make_double2(bad ? 1.0 : fast_rcp(g[kr][kr].x), 0.0);
+        if (tc == kb) rb[NP + blk_r] = make_double2(bad ? 1.0 : fast_rcp(g[kr][kr].x), 0.0);
       }
-      if (act && tc == kb) {
+      if (diag_blk && tc == kb) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) cb[4 * tr + a] = g[a][kr];
       }
       __syncthreads();
-      if (act && tr <= kb && tc >= kb) {
-        const double inv = rb[NP].x;
+      if (diag_blk && tr <= kb && tc >= kb) {
+        const double inv = rb[NP + blk_r].x;
         const bool prow = tr == kb, pcol = tc == kb;
         zc rj[4];
 #pragma unroll
@@ -262,12 +283,98 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
     }
   }
   stamp();
+  if constexpr (NBK > 1) {
+    extern __shared__ __attribute__((aligned(16))) char gq_dyn[];
+    zc* dyn = reinterpret_cast<zc*>(gq_dyn);
+    // a square h x h area of LDS <- the part of this thread's block inside [r0, r0 + h) x [c0, c0 + h); triangular operands
+    // are completed with zeros below the diagonal (there are no threads there)
+    auto stage = [&](zc* area, int h, int r0, int c0, bool tri) {
+      const int i0 = 4 * tr - r0, j0 = 4 * tc - c0;
+      if (!act || i0 < 0 || i0 >= h || j0 < 0 || j0 >= h) return;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bool low = tri && (4 * tc + b) < (4 * tr + a);
+          area[(i0 + a) * h + j0 + b] = low ? make_double2(0.0, 0.0) : g[a][b];
+          if (tri && tc > tr) area[(j0 + b) * h + i0 + a] = make_double2(0.0, 0.0);
+        }
+    };
+    // g <- sgn * A B for the threads of the region [r0, r0 + h) x [c0, c0 + h); A, B: h x h areas
+    auto product = [&](const zc* A, const zc* B, int h, int r0, int c0, double sgn) {
+      const int i0 = 4 * tr - r0, j0 = 4 * tc - c0;
+      if (!act || i0 < 0 || i0 >= h || j0 < 0 || j0 >= h) return;
+      zc acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = make_double2(0.0, 0.0);
+      for (int k = 0; k < h; ++k) {
+        zc av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) av[a] = A[(i0 + a) * h + k];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[b] = B[k * h + j0 + b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            acc[a][b].x = __builtin_fma(av[a].x, bv[b].x, acc[a][b].x);
+            acc[a][b].x = __builtin_fma(-av[a].y, bv[b].y, acc[a][b].x);
+            acc[a][b].y = __builtin_fma(av[a].x, bv[b].y, acc[a][b].y);
+            acc[a][b].y = __builtin_fma(av[a].y, bv[b].x, acc[a][b].y);
+          }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) g[a][b] = make_double2(sgn * acc[a][b].x, sgn * acc[a][b].y);
+    };
+#pragma unroll
+    for (int h = 32; h < 4 * NG; h *= 2) {
+      const int npair = (4 * NG) / (2 * h);
+      // T = R12 X22
+      for (int pr = 0; pr < npair; ++pr) {
+        const int p0 = pr * 2 * h;
+        zc* LA = dyn + (size_t)pr * 2 * h * h;
+        zc* LB = LA + (size_t)h * h;
+        stage(LA, h, p0, p0 + h, false);
+        stage(LB, h, p0 + h, p0 + h, true);
+      }
+      __syncthreads();
+      for (int pr = 0; pr < npair; ++pr) {
+        const int p0 = pr * 2 * h;
+        const zc* LA = dyn + (size_t)pr * 2 * h * h;
+        product(LA, LA + (size_t)h * h, h, p0, p0 + h, 1.0);
+      }
+      __syncthreads();
+      // X12 = -X11 T
+      for (int pr = 0; pr < npair; ++pr) {
+        const int p0 = pr * 2 * h;
+        zc* LA = dyn + (size_t)pr * 2 * h * h;
+        zc* LB = LA + (size_t)h * h;
+        stage(LA, h, p0, p0 + h, false);  // T
+        stage(LB, h, p0, p0, true);       // X11
+      }
+      __syncthreads();
+      for (int pr = 0; pr < npair; ++pr) {
+        const int p0 = pr * 2 * h;
+        const zc* LA = dyn + (size_t)pr * 2 * h * h;
+        product(LA + (size_t)h * h, LA, h, p0, p0 + h, -1.0);
+      }
+      __syncthreads();
+      stamp();
+    }
+  }
+  stamp();
   store(Xout);
   stamp();
   if (trace && t == 0) trace[31] = ntr;
+  publish();
 }
 
-static void gq_chol_launch(hipStream_t st, const zc* G, long ldg, int n, zc* R, zc* X, long ldo, int first_order, int* flag) {
+static void gq_chol_launch(hipStream_t st, const zc* G, long ldg, int n, zc* R, zc* X, long ldo, int first_order, int* flag,
+                           int* pub = nullptr, int pub_tag = 0) {
   // MITDVP_QR_TRACE=1: thread 0 stamps the 100 MHz clock every eight block rows of both chains; printed per launch
   static const bool tracing = std::getenv("MITDVP_QR_TRACE") && std::atoi(std::getenv("MITDVP_QR_TRACE")) != 0;
   static long long* tbuf = nullptr;
@@ -275,9 +382,22 @@ static void gq_chol_launch(hipStream_t st, const zc* G, long ldg, int n, zc* R, 
   long long* trace = tracing ? tbuf : nullptr;
   if (tracing) HIP_CHECK(hipMemsetAsync(tbuf, 0, 32 * sizeof(long long), st));
   auto nthr = [](int ng) { return (ng * (ng + 1) / 2 + 63) / 64 * 64; };
-  if (n <= 32) hipLaunchKernelGGL(k_gq_chol<8>, dim3(1), dim3(nthr(8)), 0, st, G, ldg, n, R, X, ldo, first_order, flag, trace);
-  else if (n <= 64) hipLaunchKernelGGL(k_gq_chol<16>, dim3(1), dim3(nthr(16)), 0, st, G, ldg, n, R, X, ldo, first_order, flag, trace);
-  else hipLaunchKernelGGL(k_gq_chol<32>, dim3(1), dim3(nthr(32)), 0, st, G, ldg, n, R, X, ldo, first_order, flag, trace);
+  // dynamic LDS: the staging areas of the blocked inversion (two h x h operands per pair of diagonal blocks; h up to 64)
+  constexpr size_t LDS16 = 2 * 32 * 32 * sizeof(zc), LDS32 = 2 * 64 * 64 * sizeof(zc);
+  if (n > 64) {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gq_chol<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS32));
+      if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+  }
+  if (n <= 32) hipLaunchKernelGGL(k_gq_chol<8>, dim3(1), dim3(nthr(8)), 0, st, G, ldg, n, R, X, ldo, first_order, flag, trace, pub, pub_tag);
+  else if (n <= 64) hipLaunchKernelGGL(k_gq_chol<16>, dim3(1), dim3(nthr(16)), LDS16, st, G, ldg, n, R, X, ldo, first_order, flag, trace, pub, pub_tag);
+  else hipLaunchKernelGGL(k_gq_chol<32>, dim3(1), dim3(nthr(32)), LDS32, st, G, ldg, n, R, X, ldo, first_order, flag, trace, pub, pub_tag);
   HIP_CHECK(hipGetLastError());
   if (tracing) {
     long long h[32];
@@ -300,8 +420,9 @@ int* qr_gram_flag(zc* work, int m, int n) {
 }
 
 // A (m x n, ld n, untouched) -> Q (m x n, ld n), R (n x n, ld n, upper, positive diagonal).  Returns the launches issued;
-// the sticky failure flag is *qr_gram_flag(work, m, n) (device memory, cleared here).
-int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work) {
+// the sticky failure flag is *qr_gram_flag(work, m, n) (device memory, cleared here); with pub the last Cholesky kernel
+// copies it to pub[0] and then writes pub_tag to pub[1] (host-coherent mapped memory the caller spins on).
+int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work, int* pub, int pub_tag) {
   if (m < n || n < 1) throw ArgError("qr_gram: needs m >= n >= 1");
   const int NBmax = std::min(n, GQ_NB);
   zc* S = work;                              // W (j0 x nb) above G (nb x nb)
@@ -319,7 +440,9 @@ int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work) {
   // One pass: the block P (m x nb, leading dimension ldp) is orthogonalised against Q[:, :j0] and within itself,
   //   out = (P - Q_prev W) R_p^-1,  W = Q_prev^H P,  R_p = chol(P^H P - W^H W);
   // W stays in S[:j0], R_p / X_p are written.
-  auto pass = [&](const zc* P, long ldp, int j0, int nb, zc* Rp, zc* Xp, int first_order, zc* out, long ldout) {
+  // Wd / ldw: where W goes (the first pass writes it straight into R's block column, where it belongs)
+  auto pass = [&](const zc* P, long ldp, int j0, int nb, zc* Rp, zc* Xp, int first_order, zc* out, long ldout, bool last,
+                  zc* Wd, long ldw) {
     zc* Gm = S + (size_t)j0 * nb;
     {
       ZgemmDesc g = zgemm_desc(P, P, Gm, nb, nb, m);  // G = P^H P
@@ -328,15 +451,15 @@ int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work) {
       nl += 2;
     }
     if (j0 > 0) {
-      ZgemmDesc w = zgemm_desc(Q, P, S, j0, nb, m);  // W = Q_prev^H P
-      w.transA = 1; w.conjA = 1; w.lda = n; w.ldb = ldp; w.ldc = nb;
+      ZgemmDesc w = zgemm_desc(Q, P, Wd, j0, nb, m);  // W = Q_prev^H P
+      w.transA = 1; w.conjA = 1; w.lda = n; w.ldb = ldp; w.ldc = ldw;
       zgemm(st, w);
-      ZgemmDesc g = zgemm_desc(S, S, Gm, nb, nb, j0);  // G -= W^H W
-      g.transA = 1; g.conjA = 1; g.lda = nb; g.ldb = nb; g.ldc = nb; g.alpha = mone; g.beta = one;
+      ZgemmDesc g = zgemm_desc(Wd, Wd, Gm, nb, nb, j0);  // G -= W^H W
+      g.transA = 1; g.conjA = 1; g.lda = ldw; g.ldb = ldw; g.ldc = nb; g.alpha = mone; g.beta = one;
       zgemm(st, g);
       nl += 3;
     }
-    gq_chol_launch(st, Gm, nb, nb, Rp, Xp, nb, first_order, flag);
+    gq_chol_launch(st, Gm, nb, nb, Rp, Xp, nb, first_order, flag, last ? pub : nullptr, pub_tag);
     nl += 1;
     {
       ZgemmDesc g = zgemm_desc(P, Xp, out, m, nb, nb);  // out = P X_p
@@ -345,8 +468,8 @@ int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work) {
       nl += 1;
     }
     if (j0 > 0) {  // out -= Q_prev (W X_p)
-      ZgemmDesc w = zgemm_desc(S, Xp, WX, j0, nb, nb);
-      w.lda = nb; w.ldb = nb; w.ldc = nb;
+      ZgemmDesc w = zgemm_desc(Wd, Xp, WX, j0, nb, nb);
+      w.lda = ldw; w.ldb = nb; w.ldc = nb;
       zgemm(st, w);
       ZgemmDesc g = zgemm_desc(Q, WX, out, m, nb, j0);
       g.lda = n; g.ldb = nb; g.ldc = ldout; g.alpha = mone; g.beta = one;
@@ -356,12 +479,8 @@ int qr_gram(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* work) {
   };
   for (int j0 = 0; j0 < n; j0 += GQ_NB) {
     const int nb = std::min(GQ_NB, n - j0);
-    pass(A + j0, n, j0, nb, Ra, Xa, 0, T1, nb);          // input block -> T1
-    if (R && j0 > 0) {  // W_a -> R[:j0, block]
-      copy2d(st, R + j0, n, S, nb, j0, nb, 0, one, false);
-      nl += 1;
-    }
-    pass(T1, nb, j0, nb, Rb, Xb, 1, Q + j0, n);          // T1 -> Q[:, block]
+    pass(A + j0, n, j0, nb, Ra, Xa, 0, T1, nb, false, R ? R + j0 : S, R ? (long)n : (long)nb);  // input block -> T1, W_a -> R[:j0, block]
+    pass(T1, nb, j0, nb, Rb, Xb, 1, Q + j0, n, j0 + GQ_NB >= n, S, nb);  // T1 -> Q[:, block]; the last pass publishes the verdict
     if (R) {
       if (j0 > 0) {  // R[:j0, block] += W_b R_a
         ZgemmDesc g = zgemm_desc(S, Ra, R + j0, j0, nb, nb);

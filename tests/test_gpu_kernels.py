@@ -565,6 +565,7 @@ def test_block_sparse_w_stage_is_bitwise_the_dense_one(monkeypatch):
     for flag in ("1", "0"):
         monkeypatch.setenv("MITDVP_SPARSE_W", flag)
         monkeypatch.setenv("MITDVP_SMALL_KERNELS", "0")  # the general three-launch chain is what carries the sparse stage
+        monkeypatch.setenv("MITDVP_EDGE_APPLY", "0")     # (not the two-product edge form, which has no W stage at all)
         eng = TDVPEngine(L)
         eng.set_mpo(mpo)
         eng.set_mps(mps)

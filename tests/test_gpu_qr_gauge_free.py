@@ -25,7 +25,7 @@ def _check(a, q, r, tol_rec=2e-13, tol_orth=1e-13):
     assert np.abs(np.tril(r, -1)).max() == 0.0
 
 
-@pytest.mark.parametrize("shape", [(4096, 128), (1024, 128), (4096, 32), (2048, 512), (600, 200), (700, 72), (8192, 256), (400, 16)])
+@pytest.mark.parametrize("shape", [(4096, 128), (1024, 128), (4096, 32), (2048, 512), (600, 200), (700, 72), (8192, 256), (400, 16), (900, 48), (1000, 64), (3000, 100)])
 def test_gauge_free_factorisation_equals_lapack_up_to_signs(shape):
     from pytdscf_amd.engine import qr_thin
 
