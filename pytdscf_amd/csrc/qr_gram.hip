@@ -57,13 +57,28 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
   __shared__ double red[2][NW];
   __shared__ int badw;
   const int t = threadIdx.x;
-  // thread -> block (tr, tc), tc >= tr, row-major over the upper triangle: block rows finish (Cholesky) / start (inversion)
-  // wave by wave.  Threads beyond the triangle get tr = tc = NG: every ownership test below is false for them.
-  int tr = 0, tc = 0;
+  // thread -> block (tr, tc), tc >= tr.  First the blocks of the diagonal 32 x 32 super-blocks (36 threads each, row-major
+  // inside: the only threads the inversion's pivot steps involve -- contiguous, they occupy three waves instead of a few
+  // lanes of every wave), then the other blocks row-major: block rows finish (Cholesky) wave by wave.  Threads beyond the
+  // triangle get tr = tc = NG: every ownership test below is false for them.
+  int tr = NG, tc = NG;
   {
-    int rem = t;
-    while (tr < NG && rem >= NG - tr) { rem -= NG - tr; ++tr; }
-    tc = tr < NG ? tr + rem : NG;
+    constexpr int NSB = NG / 8 > 0 ? NG / 8 : 1, SB = NG < 8 ? NG : 8, PER = SB * (SB + 1) / 2;
+    if (t < NSB * PER) {
+      const int sb = t / PER;
+      int rem = t - sb * PER, r = 0;
+      while (rem >= SB - r) { rem -= SB - r; ++r; }
+      tr = sb * SB + r;
+      tc = tr + rem;
+    } else {
+      int rem = t - NSB * PER;
+      for (int r = 0; r < NG; ++r) {
+        const int first = (r / SB + 1) * SB, cnt = NG - first;  // columns right of the row's diagonal super-block
+        if (cnt <= 0) continue;
+        if (rem < cnt) { tr = r; tc = first + rem; break; }
+        rem -= cnt;
+      }
+    }
   }
   const bool act = tr < NG;
   // the LAST factorisation of a QR also hands the sticky verdict to the host (pub: host-coherent mapped memory, [0] flag,
@@ -288,7 +303,9 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
     zc* dyn = reinterpret_cast<zc*>(gq_dyn);
     // a square h x h area of LDS <- the part of this thread's block inside [r0, r0 + h) x [c0, c0 + h); triangular operands
     // are completed with zeros below the diagonal (there are no threads there)
-    auto stage = [&](zc* area, int h, int r0, int c0, bool tri) {
+    // (tp: stored transposed -- the LEFT operand of a product is read down its columns: k-major storage keeps the four
+    // rows a thread needs contiguous and different threads' rows in different banks; row-major it was a 16-way conflict)
+    auto stage = [&](zc* area, int h, int r0, int c0, bool tri, bool tp) {
       const int i0 = 4 * tr - r0, j0 = 4 * tc - c0;
       if (!act || i0 < 0 || i0 >= h || j0 < 0 || j0 >= h) return;
 #pragma unroll
@@ -296,12 +313,13 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const bool low = tri && (4 * tc + b) < (4 * tr + a);
-          area[(i0 + a) * h + j0 + b] = low ? make_double2(0.0, 0.0) : g[a][b];
-          if (tri && tc > tr) area[(j0 + b) * h + i0 + a] = make_double2(0.0, 0.0);
+          const int ij = (i0 + a) * h + j0 + b, ji = (j0 + b) * h + i0 + a;
+          area[tp ? ji : ij] = low ? make_double2(0.0, 0.0) : g[a][b];
+          if (tri && tc > tr) area[tp ? ij : ji] = make_double2(0.0, 0.0);
         }
     };
-    // g <- sgn * A B for the threads of the region [r0, r0 + h) x [c0, c0 + h); A, B: h x h areas
-    auto product = [&](const zc* A, const zc* B, int h, int r0, int c0, double sgn) {
+    // g <- sgn * A B for the threads of the region [r0, r0 + h) x [c0, c0 + h); At: A stored transposed, B: row-major
+    auto product = [&](const zc* At, const zc* B, int h, int r0, int c0, double sgn) {
       const int i0 = 4 * tr - r0, j0 = 4 * tc - c0;
       if (!act || i0 < 0 || i0 >= h || j0 < 0 || j0 >= h) return;
       zc acc[4][4];
@@ -312,7 +330,7 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
       for (int k = 0; k < h; ++k) {
         zc av[4], bv[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) av[a] = A[(i0 + a) * h + k];
+        for (int a = 0; a < 4; ++a) av[a] = At[k * h + i0 + a];
 #pragma unroll
         for (int b = 0; b < 4; ++b) bv[b] = B[k * h + j0 + b];
 #pragma unroll
@@ -338,8 +356,8 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
         const int p0 = pr * 2 * h;
         zc* LA = dyn + (size_t)pr * 2 * h * h;
         zc* LB = LA + (size_t)h * h;
-        stage(LA, h, p0, p0 + h, false);
-        stage(LB, h, p0 + h, p0 + h, true);
+        stage(LA, h, p0, p0 + h, false, true);
+        stage(LB, h, p0 + h, p0 + h, true, false);
       }
       __syncthreads();
       for (int pr = 0; pr < npair; ++pr) {
@@ -353,8 +371,8 @@ __global__ __launch_bounds__((NG * (NG + 1) / 2 + 63) / 64 * 64) void k_gq_chol(
         const int p0 = pr * 2 * h;
         zc* LA = dyn + (size_t)pr * 2 * h * h;
         zc* LB = LA + (size_t)h * h;
-        stage(LA, h, p0, p0 + h, false);  // T
-        stage(LB, h, p0, p0, true);       // X11
+        stage(LA, h, p0, p0 + h, false, false);  // T
+        stage(LB, h, p0, p0, true, true);        // X11
       }
       __syncthreads();
       for (int pr = 0; pr < npair; ++pr) {
