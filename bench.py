@@ -519,6 +519,9 @@ def compact_record(rec):
         return x
 
     out = strip(rec)
+    roof = out.get("roofline") if isinstance(out, dict) else None
+    if isinstance(roof, dict) and roof.get("peak"):  # keep the identity frac = achieved / peak exact after the rounding
+        roof["frac"] = roof["achieved"] / roof["peak"]
     if isinstance(rec, dict) and isinstance(rec.get("cpu_baseline"), dict) and "sample" in rec["cpu_baseline"]:
         out["cpu_baseline"]["sample"] = rec["cpu_baseline"]["sample"][:90]
     return out

@@ -506,9 +506,9 @@ __global__ __launch_bounds__(256) void k_qr_small_q(const zc* __restrict__ A, in
 
 // work: n x n complex (W).  Returns the number of launches, 0 when the shape does not qualify.
 // qr_fast.hip: the one-workgroup CholeskyQR2 of a small matrix
-void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* Q1, int* fail);
+void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* Q1, int* fail, bool gauge_free);
 
-static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, bool fast) {
+static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, bool fast, bool gauge_free) {
   if (n > 32 || m > 320) return 0;
   const int rpt = (m + 15) / 16;
   // MITDVP_QR_SMALL_FAST=0: the per-column Householder kernel only (A/B runs)
@@ -518,7 +518,7 @@ static int qr_small_launch(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc
   zc* q_in_kernel = nullptr;
   if (fast && sf_on && Q) {
     int* fail = reinterpret_cast<int*>(work + 1024 + (size_t)32 * m);
-    qr_small_fast_launch(st, A, m, n, Q, R, work + 1024, fail);
+    qr_small_fast_launch(st, A, m, n, Q, R, work + 1024, fail, gauge_free);
     run_if = fail;
     q_in_kernel = Q;
   }
@@ -782,7 +782,7 @@ static size_t qr_work_elems_house(int m, int n, int next) {
 }
 
 static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast,
-                    QrHistory* hist);
+                    QrHistory* hist, bool gauge_free = false);
 
 void qr_householder(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy,
                     QrHistory* hist) {
@@ -827,11 +827,11 @@ void qr_thin(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* 
       bo.skip = 1 << bo.fails;
     }
   }
-  qr_impl(st, A, m, n, Q, R, work, nlaunch, 0, sy, qr_fast_enabled(), hist);
+  qr_impl(st, A, m, n, Q, R, work, nlaunch, 0, sy, qr_fast_enabled(), hist, gauge_free);
 }
 
 static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work, long* nlaunch, int next, SmallSync* sy, bool fast,
-                    QrHistory* hist) {
+                    QrHistory* hist, bool gauge_free) {
   if (m < n) throw ArgError("qr: m < n (bond dimension larger than the row space) is not supported");
   if (next < 0 || n + next > m) throw ArgError("qr: more orthogonal-complement columns requested than exist");
   if (n <= 0) return;
@@ -857,7 +857,7 @@ static void qr_impl(hipStream_t st, zc* A, int m, int n, zc* Q, zc* R, zc* work,
     }
   }
   if (next == 0 && small_on) {  // factorisation in one launch (matrix in registers), Q in a second
-    const int nls = qr_small_launch(st, A, m, n, Q, R, work, fast);
+    const int nls = qr_small_launch(st, A, m, n, Q, R, work, fast, gauge_free);
     if (nls) {
       if (nlaunch) *nlaunch += nls;
       return;

@@ -645,7 +645,7 @@ __device__ __forceinline__ void sf_apply(const zc* __restrict__ src, long ld, in
 
 __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A, int m, int n, zc* __restrict__ Q, zc* __restrict__ R,
                                                         zc* __restrict__ Q1, int cd_mode, int* __restrict__ fail,
-                                                        long long* __restrict__ trace) {
+                                                        long long* __restrict__ trace, int gauge_free) {
   extern __shared__ __attribute__((aligned(16))) char sf_raw[];
   SfSmem& S = *reinterpret_cast<SfSmem*>(sf_raw);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
@@ -726,8 +726,14 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
   }
   stamp(6);
   sf_apply<false>(Q1, NB, m, NB, S, cd_mode, nullptr, qre, qim);
+  // gauge_free (the sweep's moves, qr_thin): R2 R1 has a positive diagonal and Q is orthonormal -- that IS a thin
+  // factorisation; the chain below only reproduces LAPACK's signs of diag(R) (9.4 of this kernel's 66 us at 320 x 32)
+  if (gauge_free) {
+    if (tid < NB) S.Dg[tid] = 1.0;
+    __syncthreads();
+  }
   // top block -> LDS for the sign chain (rows / columns beyond n: identity)
-  if (w < 2) {
+  if (!gauge_free && w < 2) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(SF_T) void k_qr_small_fast(const zc* __restrict__ A
   __syncthreads();
   stamp(7);
   // ---- LAPACK's signs: LU of (Q - [D; 0]) with D_k = -sign(Re pivot_k) (k_fq_reconstruct's first chain) ----
-  for (int k = 0; k < NB; k += 2) {  // two pivots per barrier (see sf_chol); only D is kept, row / column k + 1 stay as they are
+  for (int k = 0; k < (gauge_free ? 0 : NB); k += 2) {  // two pivots per barrier (see sf_chol); only D is kept, row / column k + 1 stay as they are
     const zc piva = S.Qt[k][k];
     const double dka = piva.x >= 0.0 ? -1.0 : 1.0;
     const zc ua = make_double2(piva.x - dka, piva.y);
@@ -855,7 +861,7 @@ static int fq_gram_launch(hipStream_t st, const zc* P, long ld, int mp, int nb, 
 size_t qr_small_fast_lds() { return sizeof(SfSmem); }
 
 // Q1: m x 32 scratch, fail: one word.  Always queues the launch; the caller queues the conditional Householder kernel.
-void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* Q1, int* fail) {
+void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* R, zc* Q1, int* fail, bool gauge_free) {
   static std::mutex mu;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -875,7 +881,7 @@ void qr_small_fast_launch(hipStream_t st, const zc* A, int m, int n, zc* Q, zc* 
     HIP_CHECK(hipMalloc(&trace, 16 * sizeof(long long)));
     HIP_CHECK(hipMemset(trace, 0, 16 * sizeof(long long)));
   }
-  hipLaunchKernelGGL(k_qr_small_fast, dim3(1), dim3(SF_T), sizeof(SfSmem), st, A, m, n, Q, R, Q1, cd_mode, fail, trace);
+  hipLaunchKernelGGL(k_qr_small_fast, dim3(1), dim3(SF_T), sizeof(SfSmem), st, A, m, n, Q, R, Q1, cd_mode, fail, trace, gauge_free ? 1 : 0);
   HIP_CHECK(hipGetLastError());
   if (tracing) {  // phase durations in us: gram, chol, inverse, apply, gram, round 2, apply, sign chain, stores
     long long h[16];

@@ -287,11 +287,14 @@ def test_small_qr_in_one_workgroup(shape):
 
 
 @pytest.mark.parametrize("shape", [(10, 10, 32, 6), (8, 4, 12, 4)])
-def test_small_regime_trajectory_is_the_same_with_either_qr(shape):
+def test_small_regime_trajectory_is_the_same_with_either_qr(shape, monkeypatch):
     """A few time steps of the small-bond regime with the gauge moves by the one-workgroup CholeskyQR2 and by the
-    per-column Householder kernel: both return LAPACK's Q / R (signs included), so the propagated tensors themselves must
-    agree, with equal Krylov counts (the reference's gauge move: _site_cls.py:138-292)."""
+    per-column Householder kernel: asked for LAPACK's signs (MITDVP_QR_GAUGE_FREE=0; the sweep's default since round 5 is
+    the gauge-free form, tests/test_gpu_qr_gauge_free.py) both return LAPACK's Q / R, so the propagated tensors themselves
+    must agree, with equal Krylov counts (the reference's gauge move: _site_cls.py:138-292)."""
     from pytdscf_amd import TDVPEngine
+
+    monkeypatch.setenv("MITDVP_QR_GAUGE_FREE", "0")
     from pytdscf_amd import engine as E
     from pytdscf_amd import synthetic as syn
 

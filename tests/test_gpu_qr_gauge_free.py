@@ -95,7 +95,20 @@ def test_sweep_is_the_same_state_with_either_gauge(monkeypatch):
     from pytdscf_amd import TDVPEngine
     from pytdscf_amd import synthetic as syn
 
-    L, d, D, M = 5, 8, 64, 6
+    _sweep_either_gauge(monkeypatch, 5, 8, 64, 6, 0.7)
+
+
+def test_small_regime_sweep_is_the_same_state_with_either_gauge(monkeypatch):
+    """The same at BASELINE configs[1]'s shape, where every gauge move is the one-workgroup kernel (its sign chain is
+    skipped in the gauge-free form)."""
+    _sweep_either_gauge(monkeypatch, 10, 10, 32, 6, 2.0)
+
+
+def _sweep_either_gauge(monkeypatch, L, d, D, M, dt):
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+    from pytdscf_amd import synthetic as syn
+
     mpo = syn.synthetic_mpo(L, d, M, seed=0)
     out = {}
     for mode in ("1", "0"):
@@ -104,7 +117,7 @@ def test_sweep_is_the_same_state_with_either_gauge(monkeypatch):
         e.set_mpo(mpo)
         e.init_random([d] * L, D, seed=5)
         for _ in range(3):
-            e.propagate(0.7)
+            e.propagate(dt)
         out[mode] = (e.get_mps(), e.krylov_stats(), e.expectation(), e.norm())
         e.close()
     a, b = out["1"], out["0"]
