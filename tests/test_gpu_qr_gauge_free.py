@@ -99,8 +99,9 @@ def test_sweep_is_the_same_state_with_either_gauge(monkeypatch):
 
 
 def test_small_regime_sweep_is_the_same_state_with_either_gauge(monkeypatch):
-    """The same at BASELINE configs[1]'s shape, where every gauge move is the one-workgroup kernel (its sign chain is
-    skipped in the gauge-free form)."""
+    """The same at BASELINE configs[1]'s shape, where every gauge move is the one-workgroup kernel: its sign chain is
+    skipped when MITDVP_QR_SMALL_GAUGE_FREE=1 asks for it (off by default: the small-size parity tests compare tensors)."""
+    monkeypatch.setenv("MITDVP_QR_SMALL_GAUGE_FREE", "1")
     _sweep_either_gauge(monkeypatch, 10, 10, 32, 6, 2.0)
 
 
