@@ -340,6 +340,23 @@ class Engine {
   bool shard_range(int n, int& a0, int& a1) const;
   void collective(int op, zc* p, size_t elems);
 
+  // K_eff applies of the current bond exponential with the identity states of the two blocks skipped (round 5): with
+  // S = {c : L[:, c, :] = lam_c 1} and E = {c : R[:, c, :] = mu_c 1} (found numerically per bond, keff_prepare),
+  //   sigma' = sum_{c not in S u E} L_c sigma R_c^T + sum_{c in S \ E} lam_c sigma R_c^T + sum_{c in E \ S} mu_c L_c sigma
+  //            + (sum_{c in S n E} lam_c mu_c) sigma:
+  // the first GEMM runs over the blocks not in S, the second over those not in E (compact copies of the kept blocks, made
+  // once per exponential), the rest are scaled copies.  The reference skips such blocks outright (_mps_mpo.py:489-523).
+  struct KeffCompact {
+    bool on = false;
+    int n1 = 0, nE = 0, nG = 0, nS = 0;  // X row layout per slab: [E \ S | general | S \ E]; n1 = nE + nG rows come from GEMM 1
+    BlockList fillS{}, accE{};           // scaled copies lam_c sigma -> X; mu_c X_c -> out
+    zc both = make_double2(0.0, 0.0);
+    DevBuf Lc, Rc;
+  } kc_;
+  int kc_m_ = 0;               // MPO bond of the blocks kc_ was made from
+  bool keff_ident_ = true;     // MITDVP_KEFF_IDENT=0: off (A/B testing)
+  void keff_prepare(const zc* L, const zc* R, int d1, int d2, int m);
+  void keff_apply_compact(const zc* sig, zc* out, int d1, int d2, hzc shift);
   bool sparse_w_ = true;       // MITDVP_SPARSE_W=0: always the dense W stage (A/B testing)
   // the W stage of an apply / environment update: dense GEMM, or row ranges of dense / list kernels (returns the
   // executed share of the dense flop count)

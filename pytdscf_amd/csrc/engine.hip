@@ -31,6 +31,7 @@ Engine::Engine(const mitdvp_config& c) : cfg(c), L_(c.nsite) {
   if (const char* e = std::getenv("MITDVP_EDGE_APPLY")) edge_mode_ = std::atoi(e);
   if (const char* e = std::getenv("MITDVP_DEFER_NORM")) defer_norm_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("MITDVP_QR_GAUGE_FREE")) qr_gauge_free_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MITDVP_KEFF_IDENT")) keff_ident_ = std::atoi(e) != 0;
   int ndev = 0;
   HIP_CHECK(hipGetDeviceCount(&ndev));
   if (ndev < 1) throw HipError("no HIP device visible: the MI355X engine has no CPU fallback");
@@ -823,7 +824,89 @@ void Engine::keff_apply_rect(const zc* L, const zc* R, const zc* sig, zc* out, i
   cnt_.keff_flops += 8.0 * ((double)na * dli * m * dri + (double)na * dro * dri * m);
 }
 
+// Which MPO-bond states of the two blocks of a bond are multiples of the identity (one look at all blocks: two launches,
+// one copy, one synchronisation per bond exponential), the compact copies of the blocks that are not, and the lists of
+// scaled copies.  Off (kc_.on = false) when nothing, or too little, can be skipped.
+void Engine::keff_prepare(const zc* L, const zc* R, int d1, int d2, int m) {
+  kc_.on = false;
+  int a0, a1;
+  if (!keff_ident_ || !trim_identity_ || d1 != d2 || d1 < 256 || m < 2 || m > 64 || shard_range(d1, a0, a1)) return;
+  double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
+  zc* lam_dev = red_.p + RED_MISC + 64;
+  struct { double dev[128]; hzc lam[128]; } h;
+  ident_deviation_multi(st_, L, m, (long)d1, (long)m * d1, d1, dev, lam_dev, ~0ull);
+  ident_deviation_multi(st_, R, m, (long)d2, (long)m * d2, d2, dev + 64, lam_dev + 64, ~0ull);
+  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, st_));
+  HIP_CHECK(hipStreamSynchronize(st_));
+  cnt_.n_launch += 2;
+  BlockList gl{}, gr{};  // blocks gathered into Lc ([E \ S | general]) and Rc ([general | S \ E])
+  KeffCompact& k = kc_;
+  k.fillS.n = k.accE.n = 0;
+  hzc both(0.0, 0.0);
+  std::vector<int> onlyE, gen, onlyS;
+  for (int c = 0; c < m; ++c) {
+    const bool inS = h.dev[c] < 1e-13, inE = h.dev[64 + c] < 1e-13;
+    if (inS && inE) both += h.lam[c] * h.lam[64 + c];
+    else if (inS) onlyS.push_back(c);
+    else if (inE) onlyE.push_back(c);
+    else gen.push_back(c);
+  }
+  const int skipped = 2 * (m - (int)gen.size()) - (int)onlyS.size() - (int)onlyE.size();  // block products saved, of 2 m
+  if (skipped * 16 < 2 * m) return;  // less than 1 / 16 of the apply: not worth the extra launches
+  k.nE = (int)onlyE.size(); k.nG = (int)gen.size(); k.nS = (int)onlyS.size();
+  k.n1 = k.nE + k.nG;
+  for (int c : onlyE) gl.idx[gl.n++] = c;
+  for (int c : gen) { gl.idx[gl.n++] = c; gr.idx[gr.n++] = c; }
+  for (int c : onlyS) gr.idx[gr.n++] = c;
+  for (int q = 0; q < k.nS; ++q) { const hzc l = h.lam[onlyS[q]]; k.fillS.f[k.fillS.n++] = make_double2(l.real(), l.imag()); }
+  for (int q = 0; q < k.nE; ++q) {
+    const hzc mu = h.lam[64 + onlyE[q]];
+    k.accE.idx[k.accE.n] = q;  // position of the block in X's row layout
+    k.accE.f[k.accE.n++] = make_double2(mu.real(), mu.imag());
+  }
+  k.both = make_double2(both.real(), both.imag());
+  kc_m_ = m;
+  k.Lc.reserve((size_t)d1 * std::max(k.n1, 1) * d1);
+  k.Rc.reserve((size_t)d2 * std::max(k.nG + k.nS, 1) * d2);
+  gather_blocks(st_, k.Lc.p, k.n1, L, m, d1, d1, gl);
+  gather_blocks(st_, k.Rc.p, k.nG + k.nS, R, m, d2, d2, gr);
+  cnt_.n_launch += 2;
+  k.on = true;
+}
+
+void Engine::keff_apply_compact(const zc* sig, zc* out, int d1, int d2, hzc shift) {
+  const KeffCompact& k = kc_;
+  const int nx = k.nE + k.nG + k.nS;
+  const long ldx = (long)nx * d2;
+  timer_begin(2);
+  if (k.n1 > 0) {  // X[a][ci][s] = Lc[(a, ci)][b] sig[b][s], ci over [E \ S | general]
+    ZgemmDesc g = zgemm_desc(k.Lc.p, sig, X_.p, d1 * k.n1, d2, d1);
+    g.rowmap_p = k.n1; g.rowmap_s1 = d2; g.rowmap_s2 = ldx; g.rowmap_r0 = 0;
+    zgemm(st_, g);
+    cnt_.n_launch += 1;
+  }
+  fill_scaled_blocks(st_, X_.p, ldx, k.n1, sig, d1, d2, k.fillS);  // X[a][n1 + q][:] = lam_q sig[a][:]
+  if (k.fillS.n) cnt_.n_launch += 1;
+  const int n2 = k.nG + k.nS;
+  if (n2 > 0) {  // out[a][r] = X[a][(cj, s)] Rc[r][(cj, s)], cj over [general | S \ E]
+    ZgemmDesc g = zgemm_desc(X_.p + (size_t)k.nE * d2, k.Rc.p, out, d1, d2, n2 * d2);
+    g.lda = ldx; g.transB = 1; g.ldb = (long)n2 * d2;
+    zgemm(st_, g);
+    cnt_.n_launch += 1;
+  } else {
+    HIP_CHECK(hipMemsetAsync(out, 0, (size_t)d1 * d2 * sizeof(zc), st_));
+  }
+  const hzc tot = hzc(k.both.x, k.both.y) + shift;  // the scalar term of the operator rides on the same pass
+  accum_scaled_blocks(st_, out, X_.p, ldx, sig, d1, d2, k.accE, make_double2(tot.real(), tot.imag()));
+  cnt_.n_launch += 1;
+  timer_end();
+  cnt_.n_keff += 1;
+  // (algorithmic count: all m blocks, as SURVEY 8d F_K)
+  cnt_.keff_flops += 8.0 * ((double)d1 * d1 * kc_m_ * d2 + (double)d1 * d2 * d2 * kc_m_);
+}
+
 void Engine::keff_apply(const zc* L, const zc* R, const zc* sig, zc* out, int d1, int d2, int m, hzc shift) {
+  if (kc_.on) { keff_apply_compact(sig, out, d1, d2, shift); return; }
   SmallChain sc;
   if (small_ok() && chain_keff(sc, L, R, d1, d2, m, false)) {
     timer_begin(2);
@@ -1119,6 +1202,8 @@ void Engine::sweep(double dt, bool forward) {
       const int m = w.mr;
       auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dr, dr, m, shift); };
       if (cfg.relax != 2 && !small_bond_exp(p, Lb, Rb, dr, m, dt)) {  // improved relaxation leaves the bond matrix alone (_mps_cls.py:1159-1160)
+        keff_prepare(Lb, Rb, dr, dr, m);  // identity states of the two blocks: skipped in every apply of this solve
+        struct Off { bool& f; ~Off() { f = false; } } off{kc_.on};
         kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dr * dr, kprev_[p]);
         cnt_.n_exp_bond += 1;
       }
@@ -1144,6 +1229,8 @@ void Engine::sweep(double dt, bool forward) {
       const int m = w.ml;
       auto mk = [&](const zc* in, zc* out) { keff_apply(Lb, Rb, in, out, dl, dl, m, shift); };
       if (cfg.relax != 2 && !small_bond_exp(p, Lb, Rb, dl, m, dt)) {
+        keff_prepare(Lb, Rb, dl, dl, m);
+        struct Off { bool& f; ~Off() { f = false; } } off{kc_.on};
         kprev_[p] = krylov_exp(scale_bond(dt), mk, sig_.p, (long)dl * dl, kprev_[p]);
         cnt_.n_exp_bond += 1;
       }

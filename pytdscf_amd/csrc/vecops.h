@@ -49,6 +49,15 @@ void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_st
                            zc* lam_dev, unsigned long long mask = ~0ull);
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
             bool accumulate);
+// Block lists of the K_eff apply with identity states skipped (Engine::keff_prepare): up to 64 blocks, scalars by value.
+struct BlockList { int n; int idx[64]; zc f[64]; };
+// dst[a][k][:] = src[a][idx[k]][:]  for k < bl.n  (blocks of `cols` elements; src has m_src, dst n_dst blocks per row a)
+void gather_blocks(hipStream_t st, zc* dst, int n_dst, const zc* src, int m_src, long rows, int cols, const BlockList& bl);
+// X[a][pos0 + k][:] = f[k] * sig[a][:]  for k < bl.n  (row stride ldx of X, rows x cols matrix sig)
+void fill_scaled_blocks(hipStream_t st, zc* X, long ldx, int pos0, const zc* sig, long rows, int cols, const BlockList& bl);
+// out[a][:] += sum_k f[k] * X[a][idx[k]][:] + both * sig[a][:]
+void accum_scaled_blocks(hipStream_t st, zc* out, const zc* X, long ldx, const zc* sig, long rows, int cols, const BlockList& bl,
+                         zc both);
 // norm profiles for the adaptive-rank functional (plain device arrays, no partials)
 void col_sumsq(hipStream_t st, const zc* x, long rows, int cols, double* out /*[cols]*/);
 void row_sumsq(hipStream_t st, const zc* x, int rows, long cols, double* out /*[rows]*/);

@@ -721,6 +721,54 @@ void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long row
   if (n <= 0) return;
   LAUNCH(k_copy2d, vec_blocks(n), st, dst, ldd, src, lds, rows, cols, zero_to, a, accumulate ? 1 : 0);
 }
+__global__ __launch_bounds__(256) void k_gather_blocks(zc* __restrict__ dst, int n_dst, const zc* __restrict__ src, int m_src,
+                                                      long rows, int cols, BlockList bl) {
+  const long per = (long)bl.n * cols, tot = rows * per;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const long a = e / per;
+    const int r = (int)(e - a * per), k = r / cols, c = r - k * cols;
+    dst[(a * n_dst + k) * cols + c] = src[(a * m_src + bl.idx[k]) * cols + c];
+  }
+}
+__global__ __launch_bounds__(256) void k_fill_scaled_blocks(zc* __restrict__ X, long ldx, int pos0, const zc* __restrict__ sig,
+                                                           long rows, int cols, BlockList bl) {
+  const long per = (long)bl.n * cols, tot = rows * per;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const long a = e / per;
+    const int r = (int)(e - a * per), k = r / cols, c = r - k * cols;
+    const zc v = sig[a * cols + c], f = bl.f[k];
+    X[a * ldx + (long)(pos0 + k) * cols + c] = make_double2(f.x * v.x - f.y * v.y, f.x * v.y + f.y * v.x);
+  }
+}
+__global__ __launch_bounds__(256) void k_accum_scaled_blocks(zc* __restrict__ out, const zc* __restrict__ X, long ldx,
+                                                            const zc* __restrict__ sig, long rows, int cols, BlockList bl, zc both) {
+  const long tot = rows * cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)gridDim.x * 256) {
+    const long a = e / cols;
+    const int c = (int)(e - a * cols);
+    zc o = out[e];
+    const zc s0 = sig[e];
+    o.x += both.x * s0.x - both.y * s0.y;
+    o.y += both.x * s0.y + both.y * s0.x;
+    for (int k = 0; k < bl.n; ++k) {  // fixed order
+      const zc v = X[a * ldx + (long)bl.idx[k] * cols + c], f = bl.f[k];
+      o.x += f.x * v.x - f.y * v.y;
+      o.y += f.x * v.y + f.y * v.x;
+    }
+    out[e] = o;
+  }
+}
+void gather_blocks(hipStream_t st, zc* dst, int n_dst, const zc* src, int m_src, long rows, int cols, const BlockList& bl) {
+  if (bl.n > 0 && rows > 0) LAUNCH(k_gather_blocks, vec_blocks(rows * bl.n * cols), st, dst, n_dst, src, m_src, rows, cols, bl);
+}
+void fill_scaled_blocks(hipStream_t st, zc* X, long ldx, int pos0, const zc* sig, long rows, int cols, const BlockList& bl) {
+  if (bl.n > 0 && rows > 0) LAUNCH(k_fill_scaled_blocks, vec_blocks(rows * bl.n * cols), st, X, ldx, pos0, sig, rows, cols, bl);
+}
+void accum_scaled_blocks(hipStream_t st, zc* out, const zc* X, long ldx, const zc* sig, long rows, int cols, const BlockList& bl,
+                         zc both) {
+  if (rows > 0) LAUNCH(k_accum_scaled_blocks, vec_blocks(rows * cols), st, out, X, ldx, sig, rows, cols, bl, both);
+}
+
 void col_sumsq(hipStream_t st, const zc* x, long rows, int cols, double* out) {
   if (cols > 0) LAUNCH(k_col_sumsq, cols, st, x, rows, cols, out);
 }

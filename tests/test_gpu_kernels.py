@@ -695,6 +695,58 @@ def test_identity_block_of_the_right_environment_is_short_circuited(monkeypatch)
         assert max(np.abs(x - y).max() for x, y in zip(a, b)) < 1e-11
 
 
+@pytest.mark.parametrize("kind", ["fsm", "liouville", "dense"])
+def test_identity_states_are_skipped_in_the_bond_applies(kind, monkeypatch):
+    """Bonds >= 256: the MPO-bond states whose left / right block is a multiple of the identity (canonical chain under a
+    finite-state-machine MPO, or the direct sum of C5's Liouvillian: several such states, some carrying a sign) drop out
+    of the first / second product of a K_eff apply -- scaled copies instead (Engine::keff_prepare; the reference skips such
+    blocks, _mps_mpo.py:489-523).  Same state and Krylov counts as the full contraction, equal to the oracle; with a
+    random dense MPO nothing qualifies and the plain apply runs."""
+    from oracle import tdvp_oracle as orc
+    from pytdscf_amd import TDVPEngine
+    from pytdscf_amd import synthetic as syn
+
+    rng = np.random.default_rng(5)
+    if kind == "liouville":
+        L, d, M, D, integ, cn = 8, 4, 16, 256, "arnoldi", False
+        mpo = syn.synthetic_liouvillian_mpo(L, M, seed=0, gamma=0.002)
+    else:
+        L, d, M, D, integ, cn = 4, 16, 6, 256, "lanczos", True
+        mpo = syn.synthetic_mpo(L, d, M, seed=0)
+        if kind == "dense":
+            mpo = [0.02 * crandn(rng, w.shape[0], d, d, w.shape[3]) for w in mpo]
+            integ, cn = "arnoldi", False
+    mps = orc.synthetic_mps([d] * L, D, seed=1)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MITDVP_KEFF_IDENT", flag)
+        eng = TDVPEngine(L, integrator=integ, conserve_norm=cn)
+        eng.set_mpo(mpo)
+        eng.set_mps(mps)
+        eng.counters_reset()
+        eng.propagate(0.3)
+        c = eng.counters()
+        out[flag] = (eng.get_mps(), eng.krylov_stats(), c["n_launch"], c["n_keff"])
+        eng.close()
+    a, b = out["1"], out["0"]
+    assert a[1] == b[1] and a[3] == b[3]
+    nrm = np.sqrt(abs(orc.overlap(a[0], a[0])) * abs(orc.overlap(b[0], b[0])))
+    assert abs(abs(orc.overlap(a[0], b[0])) / nrm - 1) < 1e-12
+    # (Liouvillian chain: the bond of 256 = 4^4 is of full rank with singular values down to ~1e-6, the rows of the one
+    # right-canonical core beside it that belong to them move by rounding / 1e-6; every other core agrees to 1e-13)
+    assert max(np.abs(x - y).max() for x, y in zip(a[0], b[0])) < (1e-8 if kind == "liouville" else 1e-11)
+    if kind == "dense":
+        assert 0 <= a[2] - b[2] <= 16 * (L - 1)  # only the checking launches per bond exponential, nothing else changes
+    else:
+        assert a[2] != b[2]  # the compact form ran (different launch sequence)
+    if kind != "dense":  # ... and against the oracle
+        ref = orc.OracleMPS([c.copy() for c in mps], mpo, integrator=integ, conserve_norm=cn)
+        ref.propagate(0.3)
+        nr = np.sqrt(abs(orc.overlap(ref.cores, ref.cores)) * abs(orc.overlap(a[0], a[0])))
+        assert abs(abs(orc.overlap(ref.cores, a[0])) / nr - 1) < 1e-10
+        assert abs(abs(orc.overlap(ref.cores, ref.cores)) - abs(orc.overlap(a[0], a[0]))) < 1e-10
+
+
 def test_ranged_fold_block_sizes_its_output_from_the_mpo_bond_at_the_end_of_the_range():
     """mitdvp_fold_block_range through the Python handle without out_shape: the block that comes back has the MPO
     bond of the LAST core of the range (not of the chain's end cores), in both directions; values equal the oracle's
