@@ -101,6 +101,7 @@ struct ZgemmDesc {
   long epi_ldw, epi_su, epi_sv, epi_si;
   int epi_xm, epi_yn, epi_di, epi_acc;
   int epi_b4;  // internal: the 4 x 4 x 4 form of the reducing epilogue is available (set by zgemm_reduce)
+  int epi_full;  // internal: its unguarded variant may run when the shapes are whole (MITDVP_EPI_FULL=0: never)
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
 void zgemm(hipStream_t st, const ZgemmDesc& d);
@@ -115,7 +116,7 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.klist = nullptr; d.klist_stride = 0; d.rowmap_p = 0; d.rowmap_s1 = 0; d.rowmap_s2 = 0; d.rowmap_r0 = 0;
   d.arow_skip = 0;
   d.tune = -1;
-  d.epi_w = nullptr; d.epi_ldw = d.epi_su = d.epi_sv = d.epi_si = 0; d.epi_xm = d.epi_yn = d.epi_di = d.epi_acc = 0; d.epi_b4 = 0;
+  d.epi_w = nullptr; d.epi_ldw = d.epi_su = d.epi_sv = d.epi_si = 0; d.epi_xm = d.epi_yn = d.epi_di = d.epi_acc = 0; d.epi_b4 = 0; d.epi_full = 0;
   return d;
 }
 // the product with the reducing epilogue described at ZgemmDesc::epi_w (NN or NT operands, no batch); false when the

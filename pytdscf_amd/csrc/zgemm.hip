@@ -65,8 +65,8 @@ template <int RB, int CB>
 __device__ __forceinline__ void reduce_epilogue(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
 template <int RB, int CB>
 __device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* smem, int tm, int tn, int cd_mode);
-template <int NIS, int NPG, bool M3>
-__device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn);
+template <int NIS, int NPG, bool M3, bool FULL, class ST>
+__device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn, ST&& store_tile);
 template <bool M3>
 __device__ __forceinline__ void reduce_epilogue_b4w(const ZgemmDesc& d, zc* smem, int tm, int tn);
 
@@ -404,40 +404,48 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     static_assert(BM == 64 && BN == 64, "the reducing epilogue is written for 64 x 64 tiles");
     constexpr int LDT = BN + 1;
     static_assert((size_t)BM * LDT <= 2 * (size_t)STAGE, "tile does not fit the K loop's LDS");
+    auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (wm * WM + i) * 16 + cd_row(cd_mode, lk, r);
-          const int col = (wn * WN + j) * 16 + li;
-          zc v;
-          if (M3) {
-            const double p1 = acc[0][i][j][r], p2 = sgnA * sgnB * acc[1][i][j][r], p3 = acc[NACC - 1][i][j][r];
-            v = make_double2(p1 - p2, p3 - p1 - p2);
-          } else {
-            v = make_double2(acc[0][i][j][r], acc[1][i][j][r]);
+          for (int r = 0; r < 4; ++r) {
+            const int row = (wm * WM + i) * 16 + cd_row(cd_mode, lk, r);
+            const int col = (wn * WN + j) * 16 + li;
+            zc v;
+            if (M3) {
+              const double p1 = acc[0][i][j][r], p2 = sgnA * sgnB * acc[1][i][j][r], p3 = acc[NACC - 1][i][j][r];
+              v = make_double2(p1 - p2, p3 - p1 - p2);
+            } else {
+              v = make_double2(acc[0][i][j][r], acc[1][i][j][r]);
+            }
+            smem[row * LDT + col] = v;
           }
-          smem[row * LDT + col] = v;
-        }
-    __syncthreads();
+      __syncthreads();
+    };
     const int rbn = (d.epi_di + 15) / 16;
     const int cbn = ((BM / d.epi_xm) * (BN / d.epi_yn) + 15) / 16;
     // four blocks of outputs: one block per wave over the whole contraction (no partials to exchange); fewer: the
     // contraction split over the waves
     const int npair_ = (BM / d.epi_xm) * (BN / d.epi_yn);
+    if (d.epi_b4 && !(d.epi_di <= 4 && npair_ <= 64) && npair_ <= 8 && d.epi_di <= 32) {
+      // few (u, v) pairs per tile (d M = 512: eight): 4 x 4 x 4 products in four independent blocks per instruction
+      // instead of 16 x 16 x 4 products half of whose columns are padding.  (It stores the tile itself, after its first
+      // loads of the core have gone out.)  FULL: every set of output rows, group of pairs and k-step is whole.
+      const int kp_ = d.epi_xm * d.epi_yn;
+      const bool full = (d.epi_full != 0) && d.epi_yn % 4 == 0 && kp_ % 128 == 0;  // 4 waves x whole double chunks of 8 k-steps of 4
+      if (d.epi_di == 16 && npair_ == 8 && full) reduce_epilogue_b4<1, 2, M3, true>(d, smem, tm, tn, store_tile);
+      else if (d.epi_di == 32 && npair_ == 8 && full) reduce_epilogue_b4<2, 2, M3, true>(d, smem, tm, tn, store_tile);
+      else if (d.epi_di <= 16) { if (npair_ <= 4) reduce_epilogue_b4<1, 1, M3, false>(d, smem, tm, tn, store_tile); else reduce_epilogue_b4<1, 2, M3, false>(d, smem, tm, tn, store_tile); }
+      else { if (npair_ <= 4) reduce_epilogue_b4<2, 1, M3, false>(d, smem, tm, tn, store_tile); else reduce_epilogue_b4<2, 2, M3, false>(d, smem, tm, tn, store_tile); }
+      return;
+    }
+    store_tile();
     if (d.epi_b4 && d.epi_di <= 4 && npair_ <= 64) {
       // few output rows, many pairs (d = 4: C5): four groups of 4 pairs per instruction against the same 4 rows of the
       // core, one wave per 16 pairs over the whole contraction -- the 16 x 16 form used 4 of its 16 rows
       reduce_epilogue_b4w<M3>(d, smem, tm, tn);
-      return;
-    }
-    if (d.epi_b4 && npair_ <= 8 && d.epi_di <= 32) {
-      // few (u, v) pairs per tile (d M = 512: eight): 4 x 4 x 4 products in four independent blocks per instruction
-      // instead of 16 x 16 x 4 products half of whose columns are padding
-      if (d.epi_di <= 16) { if (npair_ <= 4) reduce_epilogue_b4<1, 1, M3>(d, smem, tm, tn); else reduce_epilogue_b4<1, 2, M3>(d, smem, tm, tn); }
-      else { if (npair_ <= 4) reduce_epilogue_b4<2, 1, M3>(d, smem, tm, tn); else reduce_epilogue_b4<2, 2, M3>(d, smem, tm, tn); }
       return;
     }
     if (cbn == 1) {
@@ -697,10 +705,11 @@ __device__ __forceinline__ void reduce_epilogue_blocks(const ZgemmDesc& d, zc* s
 // blocks of an instruction are four groups of 4 output rows i against ONE group of 4 pairs, so nothing is padding while
 // DI is a multiple of 4 and the pairs come in fours.  NIS = sets of 16 output rows, NPG = groups of 4 pairs.
 // Lane maps of the instruction: the MITDVP_B4_* macros at the top of this file.
-template <int NIS, int NPG, bool M3>
-__device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn) {
+template <int NIS, int NPG, bool M3, bool FULL, class ST>
+__device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem, int tm, int tn, ST&& store_tile) {
   constexpr int LDT = 65;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: the k ranges below live in scalar registers
   const int blk = MITDVP_B4_BLK(lane), q4 = MITDVP_B4_Q(lane), k4l = MITDVP_B4_K(lane);  // operand maps: (block, row / column, k)
   const int XM = d.epi_xm, YN = d.epi_yn, KP = XM * YN, DI = d.epi_di;
   const int TU = 64 / XM, TV = 64 / YN, npair = TU * TV;
@@ -719,89 +728,132 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
 #pragma unroll
   for (int s = 0; s < NIS; ++s) {
     const int i = (4 * s + blk) * 4 + q4;
-    wval[s] = i < DI;
-    woff[s] = (long)(wval[s] ? i : 0) * ldw;
+    wval[s] = FULL || i < DI;
+    woff[s] = (long)(wval[s] ? i : 0) * ldw + k4l;
   }
   int toff[NPG];
   bool tval[NPG];
 #pragma unroll
   for (int g = 0; g < NPG; ++g) {
     const int pr = 4 * g + q4;
-    tval[g] = pr < npair;
+    tval[g] = FULL || pr < npair;
     const int prc = tval[g] ? pr : 0;
     const int ul = prc / TV, vl = prc - ul * TV;
-    toff[g] = ul * XM * LDT + vl * YN;
+    toff[g] = ul * XM * LDT + vl * YN + (FULL ? k4l : 0);
   }
   constexpr int CH = 4;  // k-steps per chunk of w fragments, loaded one chunk ahead
   zc wv[2][CH][NIS];
   auto load_w = [&](int buf, int k4s) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int kk = (k4s + c) * 4 + k4l;
+      if constexpr (FULL) {
 #pragma unroll
-      for (int s = 0; s < NIS; ++s) {
-        const bool ok = (k4s + c) < k4b && kk < KP && wval[s];
-        zc v = Wm[ok ? woff[s] + kk : 0];
-        v.x = ok ? v.x : 0.0;
-        v.y = ok ? v.y : 0.0;
-        wv[buf][c][s] = v;
+        for (int s = 0; s < NIS; ++s) wv[buf][c][s] = Wm[woff[s] + (long)(k4s + c) * 4];
+      } else {
+        const int kk = (k4s + c) * 4 + k4l;
+#pragma unroll
+        for (int s = 0; s < NIS; ++s) {
+          const bool ok = (k4s + c) < k4b && kk < KP && wval[s];
+          zc v = Wm[ok ? woff[s] - k4l + kk : 0];
+          v.x = ok ? v.x : 0.0;
+          v.y = ok ? v.y : 0.0;
+          wv[buf][c][s] = v;
+        }
       }
     }
   };
+  auto products = [&](const zc (&av)[NIS], const zc (&tv)[NPG]) __attribute__((always_inline)) {
+    // the complex product as in the K loop: 4M (p1 = Re, p2 = Im), or 3M (Karatsuba): P1 = sum ar tr, P2 = sum ai ti,
+    // P3 = sum (ar + ai)(tr + ti) -- the sums cost NIS + NPG additions per k-step and save NIS NPG products
+    double ts[NPG];
+#pragma unroll
+    for (int g = 0; g < NPG; ++g) ts[g] = tv[g].x + tv[g].y;
+#pragma unroll
+    for (int s = 0; s < NIS; ++s) {
+      const zc a = av[s];
+      const double as = a.x + a.y, nai = -a.y;
+#pragma unroll
+      for (int g = 0; g < NPG; ++g) {
+        if constexpr (M3) {
+          p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, p1[s][g], 0, 0, 0);
+          p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].y, p2[s][g], 0, 0, 0);
+          p3[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(as, ts[g], p3[s][g], 0, 0, 0);
+        } else {
+          p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, p1[s][g], 0, 0, 0);
+          p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].y, p2[s][g], 0, 0, 0);
+          p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(nai, tv[g].y, p1[s][g], 0, 0, 0);
+          p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].x, p2[s][g], 0, 0, 0);
+        }
+      }
+    }
+  };
+  // FULL: position of k = 4 k4 inside the tile, x * LDT + y with (x, y) = (k / YN, k % YN): wave-uniform, advanced by
+  // four per k-step (YN is a multiple of 4: a k-step never straddles two rows x)
+  int tk = 0, ty = 0;
+  if constexpr (FULL) {
+    const int k0 = 4 * k4a, x0 = k0 / YN;
+    ty = k0 - x0 * YN;
+    tk = x0 * LDT + ty;
+  }
   auto chunk = [&](int buf, int k4s) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int k4 = k4s + c;
-      if (k4 < k4b) {
-        const int kk = k4 * 4 + k4l;
-        const bool kv = kk < KP;
-        const int kc = kv ? kk : 0;
-        const int x = kc / YN, y = kc - x * YN;
+      if constexpr (FULL) {
         zc tv[NPG];
 #pragma unroll
-        for (int g = 0; g < NPG; ++g) {
-          const bool ok = kv && tval[g];
-          zc v = smem[ok ? toff[g] + x * LDT + y : 0];
-          v.x = ok ? v.x : 0.0;
-          v.y = ok ? v.y : 0.0;
-          tv[g] = v;
-        }
-        // the complex product as in the K loop: 4M (p1 = Re, p2 = Im), or 3M (Karatsuba): P1 = sum ar tr, P2 = sum ai ti,
-        // P3 = sum (ar + ai)(tr + ti) -- the sums cost NIS + NPG additions per k-step and save NIS NPG products
-        double ts[NPG];
-#pragma unroll
-        for (int g = 0; g < NPG; ++g) ts[g] = tv[g].x + tv[g].y;
-#pragma unroll
-        for (int s = 0; s < NIS; ++s) {
-          const zc a = wv[buf][c][s];
-          const double as = a.x + a.y, nai = -a.y;
+        for (int g = 0; g < NPG; ++g) tv[g] = smem[toff[g] + tk];
+        tk += 4; ty += 4;
+        if (ty == YN) { ty = 0; tk += LDT - YN; }
+        products(wv[buf][c], tv);
+      } else {
+        const int k4 = k4s + c;
+        if (k4 < k4b) {
+          const int kk = k4 * 4 + k4l;
+          const bool kv = kk < KP;
+          const int kc = kv ? kk : 0;
+          const int x = kc / YN, y = kc - x * YN;
+          zc tv[NPG];
 #pragma unroll
           for (int g = 0; g < NPG; ++g) {
-            if constexpr (M3) {
-              p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, p1[s][g], 0, 0, 0);
-              p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].y, p2[s][g], 0, 0, 0);
-              p3[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(as, ts[g], p3[s][g], 0, 0, 0);
-            } else {
-              p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].x, p1[s][g], 0, 0, 0);
-              p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, tv[g].y, p2[s][g], 0, 0, 0);
-              p1[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(nai, tv[g].y, p1[s][g], 0, 0, 0);
-              p2[s][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, tv[g].x, p2[s][g], 0, 0, 0);
-            }
+            const bool ok = kv && tval[g];
+            zc v = smem[ok ? toff[g] + x * LDT + y : 0];
+            v.x = ok ? v.x : 0.0;
+            v.y = ok ? v.y : 0.0;
+            tv[g] = v;
           }
+          products(wv[buf][c], tv);
         }
       }
     }
   };
-  load_w(0, k4a);
+  load_w(0, k4a);  // the first fragments of the core are on their way while the tile goes to LDS
+  store_tile();
   for (int k4s = k4a; k4s < k4b; k4s += 2 * CH) {
-    load_w(1, k4s + CH);
+    if (!FULL || k4s + CH < k4b) load_w(1, k4s + CH);
     chunk(0, k4s);
-    load_w(0, k4s + 2 * CH);
+    if (!FULL || k4s + 2 * CH < k4b) load_w(0, k4s + 2 * CH);
     chunk(1, k4s + CH);
+  }
+  // where this thread's result goes (thread t owns result lane t % 64 of set t / 64), and -- accumulating stage -- what
+  // is there now: asked for before the exchange of the partials, not after it
+  constexpr int NQ = NIS * NPG;
+  zc* outp = nullptr;
+  zc old = make_double2(0.0, 0.0);
+  if (t < NQ * 64) {
+    const int q = t >> 6, el = t & 63;
+    const int s = q / NPG, g = q - s * NPG;
+    const int i = (4 * s + MITDVP_B4_BLK(el)) * 4 + MITDVP_B4_D_ROW(el), pr = 4 * g + MITDVP_B4_D_COL(el);
+    if (i < DI && pr < npair) {
+      const int ul = pr / TV, vl = pr - ul * TV;
+      const long u = (long)tm * TU + ul, v = (long)tn * TV + vl;
+      if (u * XM < d.M && v * YN < d.N) {
+        outp = d.C + u * d.epi_su + v * d.epi_sv + (long)i * d.epi_si;
+        if (d.epi_acc) old = *outp;
+      }
+    }
   }
   __syncthreads();  // every wave has read its part of T
   // partials of the four waves (the contraction index was split over them): [wave][set][lane]
-  constexpr int NQ = NIS * NPG;
 #pragma unroll
   for (int s = 0; s < NIS; ++s)
 #pragma unroll
@@ -809,7 +861,7 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
       smem[(w * NQ + s * NPG + g) * 64 + lane] =
           M3 ? make_double2(p1[s][g] - p2[s][g], p3[s][g] - p1[s][g] - p2[s][g]) : make_double2(p1[s][g], p2[s][g]);
   __syncthreads();
-  if (t < NQ * 64) {  // thread t owns result lane t % 64 of set t / 64
+  if (outp) {
     const int q = t >> 6, el = t & 63;
     double re = 0.0, im = 0.0;
 #pragma unroll
@@ -818,17 +870,7 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
       re += v.x;
       im += v.y;
     }
-    const int s = q / NPG, g = q - s * NPG;
-    const int i = (4 * s + MITDVP_B4_BLK(el)) * 4 + MITDVP_B4_D_ROW(el), pr = 4 * g + MITDVP_B4_D_COL(el);
-    if (i < DI && pr < npair) {
-      const int ul = pr / TV, vl = pr - ul * TV;
-      const long u = (long)tm * TU + ul, v = (long)tn * TV + vl;
-      if (u * XM < d.M && v * YN < d.N) {
-        zc* p = d.C + u * d.epi_su + v * d.epi_sv + (long)i * d.epi_si;
-        if (d.epi_acc) { const zc o = *p; re += o.x; im += o.y; }
-        *p = make_double2(re, im);
-      }
-    }
+    *outp = make_double2(re + old.x, im + old.y);
   }
 }
 
@@ -1224,6 +1266,8 @@ int zgemm_reduce_b4_available(hipStream_t st) { return b4_layout_ok(st); }
 void zgemm_reduce(hipStream_t st, const ZgemmDesc& d0) {
   ZgemmDesc d = d0;
   d.epi_b4 = b4_layout_ok(st);
+  static const int epi_full = [] { const char* e = std::getenv("MITDVP_EPI_FULL"); return (e && e[0] == '0') ? 0 : 1; }();
+  d.epi_full = epi_full;
   if (d.tune < 0) d.tune = zgemm_tune_default();
   if (d.M <= 0 || d.N <= 0) return;
   if (!zgemm_reduce_ok(d.epi_xm, d.epi_yn, d.epi_di) || !d.epi_w) throw ArgError("zgemm_reduce: shape outside the reducing epilogue's range");
