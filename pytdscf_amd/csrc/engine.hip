@@ -720,8 +720,11 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
   }
   double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
   zc* lam_dev = red_.p + RED_MISC + 64;  // behind the 128 deviations
-  struct { double dev[128]; hzc lam[128]; } h;
-  static_assert(sizeof(h) == 128 * 8 + 128 * 16, "layout of the identity-check record");
+  struct IdentRecord { double dev[128]; hzc lam[128]; };
+  static_assert(sizeof(IdentRecord) == 128 * 8 + 128 * 16 && sizeof(IdentRecord) <= 4 * NPART * sizeof(zc), "layout of the identity-check record");
+  // (the record comes back through the pinned mirror of the reduction area -- read_partials: ~10 us; a copy into pageable
+  // host memory followed by a stream synchronisation measured ~120 us of idle GPU per site, 9 % of a C3 sweep)
+  const IdentRecord& h = *reinterpret_cast<const IdentRecord*>(h_red_ + RED_MISC);
   // The identity states of a site do not change from sweep to sweep (they follow from the MPO's structure and the
   // canonical form): first only the blocks that were identity multiples last time are looked at (3 of 16 at C5); all of
   // them again when one of those has stopped being one, or when there is no previous answer.
@@ -729,10 +732,10 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
   std::vector<hzc> lam(ml), mu(mr);
   for (int attempt = (w.edge_valid ? 0 : 1); attempt < 2; ++attempt) {
     const unsigned long long ms = attempt == 0 ? w.edge_s : ~0ull, me = attempt == 0 ? w.edge_e : ~0ull;
-    ident_deviation_multi(st_, Lb, ml, dl, (long)ml * dl, dl, dev, lam_dev, ms);
-    ident_deviation_multi(st_, Rb, mr, dr, (long)mr * dr, dr, dev + 64, lam_dev + 64, me);
-    HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipStreamSynchronize(st_));
+    HIP_CHECK(hipMemsetAsync(dev, 0, 128 * sizeof(double), st_));  // both sides' deviations: one clear
+    ident_deviation_multi(st_, Lb, ml, dl, (long)ml * dl, dl, dev, lam_dev, ms, false);
+    ident_deviation_multi(st_, Rb, mr, dr, (long)mr * dr, dr, dev + 64, lam_dev + 64, me, false);
+    read_partials(RED_MISC, sizeof(IdentRecord) / sizeof(zc));
     cnt_.n_launch += 2;
     S = E = 0;
     for (int c = 0; c < ml; ++c) { lam[c] = h.lam[c]; if (((ms >> c) & 1ull) && h.dev[c] < 1e-13) S |= 1ull << c; }
@@ -750,10 +753,13 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
         return;
       }
   bool same = w.edge_valid && w.edge_s == S && w.edge_e == E;
-  if (same) {  // the multiples are compared exactly: they are +-1 or weights that do not change along a run
-    for (int c = 0; c < ml && same; ++c) if (((S >> c) & 1ull) && w.edge_lam[c] != lam[c]) same = false;
-    for (int t = 0; t < mr && same; ++t) if (((E >> t) & 1ull) && w.edge_mu[t] != mu[t]) same = false;
+  if (same) {  // the multiples are +-1 or weights that do not change along a run -- up to the rounding of the block's first
+    // diagonal element (1 +- 2e-16 from sweep to sweep): compared to the tolerance of the identity test itself, so that the
+    // reduced cores are not rebuilt on the host and uploaded again for every site of every sweep
+    for (int c = 0; c < ml && same; ++c) if (((S >> c) & 1ull) && std::abs(w.edge_lam[c] - lam[c]) > 1e-13) same = false;
+    for (int t = 0; t < mr && same; ++t) if (((E >> t) & 1ull) && std::abs(w.edge_mu[t] - mu[t]) > 1e-13) same = false;
   }
+  if (std::getenv("MITDVP_EDGE_TRACE")) fprintf(stderr, "[mitdvp] edge cores of a site: %s\n", same ? "kept" : "rebuilt");
   if (!same) {
     const hzc* W = w.whost.data();
     std::vector<hzc> wl((size_t)d * ml * d, hzc(0, 0)), wr((size_t)d * d * mr, hzc(0, 0));
@@ -833,11 +839,12 @@ void Engine::keff_prepare(const zc* L, const zc* R, int d1, int d2, int m) {
   if (!keff_ident_ || !trim_identity_ || d1 != d2 || d1 < 256 || m < 2 || m > 64 || shard_range(d1, a0, a1)) return;
   double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
   zc* lam_dev = red_.p + RED_MISC + 64;
-  struct { double dev[128]; hzc lam[128]; } h;
-  ident_deviation_multi(st_, L, m, (long)d1, (long)m * d1, d1, dev, lam_dev, ~0ull);
-  ident_deviation_multi(st_, R, m, (long)d2, (long)m * d2, d2, dev + 64, lam_dev + 64, ~0ull);
-  HIP_CHECK(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, st_));
-  HIP_CHECK(hipStreamSynchronize(st_));
+  struct IdentRecord { double dev[128]; hzc lam[128]; };
+  const IdentRecord& h = *reinterpret_cast<const IdentRecord*>(h_red_ + RED_MISC);
+  HIP_CHECK(hipMemsetAsync(dev, 0, 128 * sizeof(double), st_));
+  ident_deviation_multi(st_, L, m, (long)d1, (long)m * d1, d1, dev, lam_dev, ~0ull, false);
+  ident_deviation_multi(st_, R, m, (long)d2, (long)m * d2, d2, dev + 64, lam_dev + 64, ~0ull, false);
+  read_partials(RED_MISC, sizeof(IdentRecord) / sizeof(zc));
   cnt_.n_launch += 2;
   BlockList gl{}, gr{};  // blocks gathered into Lc ([E \ S | general]) and Rc ([general | S \ E])
   KeffCompact& k = kc_;
@@ -1127,13 +1134,10 @@ bool Engine::left_block_is_identity(const zc* L, int dl, int m) {
 // is not checked
 void Engine::identity_blocks(const zc* L, int dl, int ml, const zc* R, int dr, int mr, bool* left, bool* right) {
   double* dev = reinterpret_cast<double*>(red_.p + RED_MISC);
-  double h[2] = {1.0, 1.0};
+  const double* h = reinterpret_cast<const double*>(h_red_ + RED_MISC);
   if (L) ident_deviation(st_, L, (long)ml * dl, dl, dev);
   if (R) ident_deviation(st_, R + (size_t)(mr - 1) * dr, (long)mr * dr, dr, dev + 1);
-  if (L || R) {
-    HIP_CHECK(hipMemcpyAsync(h, dev, 2 * sizeof(double), hipMemcpyDeviceToHost, st_));
-    HIP_CHECK(hipStreamSynchronize(st_));
-  }
+  if (L || R) read_partials(RED_MISC, 1);
   *left = L && h[0] < 1e-13;
   *right = R && h[1] < 1e-13;
 }

@@ -46,7 +46,7 @@ void ident_deviation(hipStream_t st, const zc* blk, long ld, int n, double* out_
 // lam_dev[c] = the block's first diagonal element, out_dev[c] = max |block - lam 1|
 // mask: bit c set = block c is looked at (the others' outputs are meaningless)
 void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_stride, long ld, int n, double* out_dev,
-                           zc* lam_dev, unsigned long long mask = ~0ull);
+                           zc* lam_dev, unsigned long long mask = ~0ull, bool clear = true);
 void copy2d(hipStream_t st, zc* dst, long ldd, const zc* src, long lds, long rows, int cols, int zero_to, zc a,
             bool accumulate);
 // Block lists of the K_eff apply with identity states skipped (Engine::keff_prepare): up to 64 blocks, scalars by value.

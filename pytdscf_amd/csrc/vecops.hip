@@ -879,9 +879,9 @@ __global__ __launch_bounds__(256) void k_ident_dev_multi(const zc* __restrict__ 
   ident_block_max(m, out + blockIdx.y);
 }
 void ident_deviation_multi(hipStream_t st, const zc* base, int nblk, long blk_stride, long ld, int n, double* out_dev,
-                           zc* lam_dev, unsigned long long mask) {
+                           zc* lam_dev, unsigned long long mask, bool clear) {
   if (nblk < 1) return;
-  HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)nblk * sizeof(double), st));
+  if (clear) HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)nblk * sizeof(double), st));
   const long tot = (long)n * n;
   const int nb = (int)std::min<long>((tot + 2047) / 2048, 64);  // eight elements per thread and pass, <= 64 atomics per block
   hipLaunchKernelGGL(k_ident_dev_multi, dim3(nb, nblk), dim3(256), 0, st, base, blk_stride, ld, n,

@@ -3,9 +3,9 @@
 O=$PWD/gpurun_out/r05t
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/tr -o c3 -- python3 $GRAFT_REPO_ROOT/bench.py --workload C3 --steps 6 --warmup 2 --no-cpu-baseline --secondary none > $O/bench.json 2> $O/bench.err || { tail $O/bench.err; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $O/tr -o c3 -- python3 $GRAFT_REPO_ROOT/bench.py --workload C3 --steps 8 --warmup 2 --no-cpu-baseline --secondary none > $O/bench.json 2> $O/bench.err || { tail $O/bench.err; exit 1; }
 cd $GRAFT_REPO_ROOT
 f=$(find $O/tr -name '*kernel_trace.csv' | head -1)
-python tools/timeline_gaps.py $f 0.3 4.0 > $O/gaps.txt
-head -30 $O/gaps.txt
+python tools/timeline_gaps.py $f 2 4.0 > $O/gaps.txt
+head -60 $O/gaps.txt
 rm -rf $O/tr
