@@ -101,6 +101,7 @@ struct ZgemmDesc {
   long epi_ldw, epi_su, epi_sv, epi_si;
   int epi_xm, epi_yn, epi_di, epi_acc;
   int epi_b4;  // internal: the 4 x 4 x 4 form of the reducing epilogue is available (set by zgemm_reduce)
+  const zc* epi_wf;  // the same core in the fragment order of the unguarded 4 x 4 x 4 epilogue (zgemm_reduce_pack_core), or nullptr
   int epi_full;  // internal: its unguarded variant may run when the shapes are whole (MITDVP_EPI_FULL=0: never)
 };
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]   (row-major, complex128)
@@ -116,7 +117,7 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
   d.klist = nullptr; d.klist_stride = 0; d.rowmap_p = 0; d.rowmap_s1 = 0; d.rowmap_s2 = 0; d.rowmap_r0 = 0;
   d.arow_skip = 0;
   d.tune = -1;
-  d.epi_w = nullptr; d.epi_ldw = d.epi_su = d.epi_sv = d.epi_si = 0; d.epi_xm = d.epi_yn = d.epi_di = d.epi_acc = 0; d.epi_b4 = 0; d.epi_full = 0;
+  d.epi_w = nullptr; d.epi_ldw = d.epi_su = d.epi_sv = d.epi_si = 0; d.epi_xm = d.epi_yn = d.epi_di = d.epi_acc = 0; d.epi_b4 = 0; d.epi_full = 0; d.epi_wf = nullptr;
   return d;
 }
 // the product with the reducing epilogue described at ZgemmDesc::epi_w (NN or NT operands, no batch); false when the
@@ -124,6 +125,8 @@ inline ZgemmDesc zgemm_desc(const zc* A, const zc* B, zc* C, int M, int N, int K
 bool zgemm_reduce_ok(int xm, int yn, int di);
 // 1 when the 4 x 4 x 4 form of the reducing epilogue is in use (lane maps verified on this device, MITDVP_EPI_B4 != 0)
 int zgemm_reduce_b4_available(hipStream_t st);
+// the core of a reducing product in the fragment order of the unguarded 4 x 4 x 4 epilogue (ZgemmDesc::epi_wf); false: shape not served
+bool zgemm_reduce_pack_core(hipStream_t st, const zc* w, long ldw, int di, int kp, zc* wf);
 void zgemm_reduce(hipStream_t st, const ZgemmDesc& d);
 int zgemm_default_mode();
 void zgemm_set_default_mode(int m);

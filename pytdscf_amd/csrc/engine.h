@@ -90,6 +90,8 @@ struct MpoSite {
   mutable bool edge_has_l = false, edge_has_r = false;
   mutable int edge_skip = 0;        // local solves for which the (failed) structure check is not repeated
   mutable DevBuf w_edge_l, w_edge_r;
+  mutable DevBuf w_edge_lf, w_edge_rf;  // the same cores in the epilogue's fragment order (zgemm_reduce_pack_core)
+  mutable bool edge_lf_ok = false, edge_rf_ok = false;
   DevBuf wtr;  // Liouville trace operator: O2[f][(a,c,d)] = O[a,d,c,f], n = sqrt(site dim)
   int ntr = 0, mltr = 0, mrtr = 0;
   int dtr = 0;  // physical entries per (a, f) of wtr: n*n, or the size of the site's subspace when it was set

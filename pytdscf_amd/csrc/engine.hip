@@ -659,6 +659,7 @@ void Engine::heff_apply_edge(const zc* L, const MpoSite& w, const zc* R, const z
     ZgemmDesc g = zgemm_desc(psi, R, out, dl * d, dr * mr, dr);
     g.transB = 1; g.ldb = dr;
     g.epi_w = w.w_edge_r.p; g.epi_ldw = (long)d * mr; g.epi_xm = d; g.epi_yn = mr; g.epi_di = d;
+    g.epi_wf = w.edge_rf_ok ? w.w_edge_rf.p : nullptr;
     g.epi_su = (long)d * dr; g.epi_sv = 1; g.epi_si = dr; g.epi_acc = 0;
     zgemm_reduce(st_, g);
     timer_end();
@@ -675,6 +676,7 @@ void Engine::heff_apply_edge(const zc* L, const MpoSite& w, const zc* R, const z
     // L side: rows (a, c), columns (s, j)
     ZgemmDesc g = zgemm_desc(L, X_.p, out, dl * ml, dr * d, dl);
     g.epi_w = w.w_edge_l.p; g.epi_ldw = (long)ml * d; g.epi_xm = ml; g.epi_yn = d; g.epi_di = d;
+    g.epi_wf = w.edge_lf_ok ? w.w_edge_lf.p : nullptr;
     g.epi_su = (long)d * dr; g.epi_sv = 1; g.epi_si = dr; g.epi_acc = first ? 0 : 1;
     zgemm_reduce(st_, g);
     timer_end();
@@ -782,6 +784,10 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
     w.w_edge_r.reserve(wr.size());
     HIP_CHECK(hipMemcpyAsync(w.w_edge_l.p, wl.data(), wl.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
     HIP_CHECK(hipMemcpyAsync(w.w_edge_r.p, wr.data(), wr.size() * sizeof(zc), hipMemcpyHostToDevice, st_));
+    w.w_edge_lf.reserve(wl.size());
+    w.w_edge_rf.reserve(wr.size());
+    w.edge_lf_ok = zgemm_reduce_pack_core(st_, w.w_edge_l.p, (long)ml * d, d, ml * d, w.w_edge_lf.p);
+    w.edge_rf_ok = zgemm_reduce_pack_core(st_, w.w_edge_r.p, (long)d * mr, d, d * mr, w.w_edge_rf.p);
     HIP_CHECK(hipStreamSynchronize(st_));
     w.edge_s = S; w.edge_e = E; w.edge_lam = lam; w.edge_mu = mu;
     w.edge_has_l = has_l; w.edge_has_r = has_r; w.edge_valid = true;

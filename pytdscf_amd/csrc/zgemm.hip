@@ -290,7 +290,9 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     }
   };
 
-  const int nkt = SP ? nlist : (K + BK - 1) / BK;
+  // (MITDVP_ZGEMM_TUNE bits 4 / 5 -- TIMING EXPERIMENTS ONLY, the product is wrong: 16 = the reducing epilogue's products
+  // skipped, 32 = the K loop skipped)
+  const int nkt = (EPI && (d.tune & 32)) ? 0 : (SP ? nlist : (K + BK - 1) / BK);
   // prologue: tile 0 -> LDS stage 0, tile 1 -> registers (set 1 of two)
 #pragma unroll
   for (int it = NP; it < 2 * NP; ++it) side(it, nullptr, K, 0, I0{}, I0{}, GEN{});
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     if (!abl_nobar) __syncthreads();
   };
   // tiles kt whose prefetch target kt+2 lies inside K as a whole run the FULL form, the last ones the general one
-  const int nfull = max((SP ? nlist : K / BK) - 2, 0);
+  const int nfull = (EPI && (d.tune & 32)) ? 0 : max((SP ? nlist : K / BK) - 2, 0);
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
   int kt = 0;
@@ -404,7 +406,14 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
     static_assert(BM == 64 && BN == 64, "the reducing epilogue is written for 64 x 64 tiles");
     constexpr int LDT = BN + 1;
     static_assert((size_t)BM * LDT <= 2 * (size_t)STAGE, "tile does not fit the K loop's LDS");
-    auto store_tile = [&]() __attribute__((always_inline)) {
+    // PM (pair-major, the unguarded 4 x 4 x 4 epilogue; xm, yn powers of two): the xm x yn block of pair (u, v) is stored as
+    // one run of xm yn elements in the epilogue's contraction order, runs 4 elements apart modulo 16 -- the four pairs a
+    // 16-lane group of the epilogue reads at once then sit in different LDS banks (row-major 64 x 65: pair offsets are
+    // multiples of 256 bytes at xm = 16, every fragment read was a 4-way bank conflict and the epilogue LDS-bound)
+    auto store_tile = [&](auto PM) __attribute__((always_inline)) {
+      constexpr bool pm = decltype(PM)::value;
+      const int xs = pm ? __builtin_ctz(d.epi_xm) : 0, ys = pm ? __builtin_ctz(d.epi_yn) : 0;
+      const int prs = d.epi_xm * d.epi_yn + 4;
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -420,7 +429,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
             } else {
               v = make_double2(acc[0][i][j][r], acc[1][i][j][r]);
             }
-            smem[row * LDT + col] = v;
+            if (pm) smem[(((row >> xs) << (6 - ys)) + (col >> ys)) * prs + ((row & (d.epi_xm - 1)) << ys) + (col & (d.epi_yn - 1))] = v;
+            else smem[row * LDT + col] = v;
           }
       __syncthreads();
     };
@@ -434,14 +444,16 @@ __global__ __launch_bounds__(256, (WM * WN <= 4 ? 2 : 1)) void zgemm_kernel(Zgem
       // instead of 16 x 16 x 4 products half of whose columns are padding.  (It stores the tile itself, after its first
       // loads of the core have gone out.)  FULL: every set of output rows, group of pairs and k-step is whole.
       const int kp_ = d.epi_xm * d.epi_yn;
-      const bool full = (d.epi_full != 0) && d.epi_yn % 4 == 0 && kp_ % 128 == 0;  // 4 waves x whole double chunks of 8 k-steps of 4
+      // 4 waves x whole rings of 8 k-steps of 4; powers of two (pair-major tile: 8 (xm yn + 4) <= 2 STAGE elements)
+      const bool full = (d.epi_full != 0) && d.epi_wf != nullptr && d.epi_yn % 4 == 0 && kp_ % 128 == 0 && !(d.epi_xm & (d.epi_xm - 1)) &&
+                        !(d.epi_yn & (d.epi_yn - 1)) && 8 * (kp_ + 4) <= 2 * STAGE;
       if (d.epi_di == 16 && npair_ == 8 && full) reduce_epilogue_b4<1, 2, M3, true>(d, smem, tm, tn, store_tile);
       else if (d.epi_di == 32 && npair_ == 8 && full) reduce_epilogue_b4<2, 2, M3, true>(d, smem, tm, tn, store_tile);
       else if (d.epi_di <= 16) { if (npair_ <= 4) reduce_epilogue_b4<1, 1, M3, false>(d, smem, tm, tn, store_tile); else reduce_epilogue_b4<1, 2, M3, false>(d, smem, tm, tn, store_tile); }
       else { if (npair_ <= 4) reduce_epilogue_b4<2, 1, M3, false>(d, smem, tm, tn, store_tile); else reduce_epilogue_b4<2, 2, M3, false>(d, smem, tm, tn, store_tile); }
       return;
     }
-    store_tile();
+    store_tile(std::false_type{});
     if (d.epi_b4 && d.epi_di <= 4 && npair_ <= 64) {
       // few output rows, many pairs (d = 4: C5): four groups of 4 pairs per instruction against the same 4 rows of the
       // core, one wave per 16 pairs over the whole contraction -- the 16 x 16 form used 4 of its 16 rows
@@ -714,7 +726,7 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
   const int XM = d.epi_xm, YN = d.epi_yn, KP = XM * YN, DI = d.epi_di;
   const int TU = 64 / XM, TV = 64 / YN, npair = TU * TV;
   const int nk4 = (KP + 3) / 4, per = (nk4 + 3) / 4;
-  const int k4a = w * per, k4b = min(nk4, k4a + per);
+  const int k4a = w * per, k4b = (d.tune & 16) ? k4a : min(nk4, k4a + per);
   const zc* __restrict__ Wm = d.epi_w;
   const long ldw = d.epi_ldw;
   double p1[NIS][NPG], p2[NIS][NPG], p3[NIS][NPG];
@@ -739,7 +751,7 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
     tval[g] = FULL || pr < npair;
     const int prc = tval[g] ? pr : 0;
     const int ul = prc / TV, vl = prc - ul * TV;
-    toff[g] = ul * XM * LDT + vl * YN + (FULL ? k4l : 0);
+    toff[g] = FULL ? prc * (KP + 4) + k4l : ul * XM * LDT + vl * YN;
   }
   constexpr int CH = 4;  // k-steps per chunk of w fragments, loaded one chunk ahead
   zc wv[2][CH][NIS];
@@ -787,14 +799,7 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
       }
     }
   };
-  // FULL: position of k = 4 k4 inside the tile, x * LDT + y with (x, y) = (k / YN, k % YN): wave-uniform, advanced by
-  // four per k-step (YN is a multiple of 4: a k-step never straddles two rows x)
-  int tk = 0, ty = 0;
-  if constexpr (FULL) {
-    const int k0 = 4 * k4a, x0 = k0 / YN;
-    ty = k0 - x0 * YN;
-    tk = x0 * LDT + ty;
-  }
+  int tk = 4 * k4a;  // FULL (pair-major tile): a pair's fragments are read in the order they are stored in
   auto chunk = [&](int buf, int k4s) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -802,8 +807,7 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
         zc tv[NPG];
 #pragma unroll
         for (int g = 0; g < NPG; ++g) tv[g] = smem[toff[g] + tk];
-        tk += 4; ty += 4;
-        if (ty == YN) { ty = 0; tk += LDT - YN; }
+        tk += 4;
         products(wv[buf][c], tv);
       } else {
         const int k4 = k4s + c;
@@ -826,13 +830,46 @@ __device__ __forceinline__ void reduce_epilogue_b4(const ZgemmDesc& d, zc* smem,
       }
     }
   };
-  load_w(0, k4a);  // the first fragments of the core are on their way while the tile goes to LDS
-  store_tile();
-  for (int k4s = k4a; k4s < k4b; k4s += 2 * CH) {
-    if (!FULL || k4s + CH < k4b) load_w(1, k4s + CH);
-    chunk(0, k4s);
-    if (!FULL || k4s + 2 * CH < k4b) load_w(0, k4s + 2 * CH);
-    chunk(1, k4s + CH);
+  if constexpr (FULL) {
+    // a ring of eight k-steps of core fragments, requested RD steps ahead of their use (the core comes from L2: ~0.6 us under
+    // load, three k-steps of products), and the tile's fragments read one k-step ahead
+    constexpr int RING = 2 * CH, RD = RING - 2;
+    zc (&ring)[RING][NIS] = reinterpret_cast<zc (&)[RING][NIS]>(wv);
+    // (the core in fragment order: the 64 lanes of one load read 1 KB in a row -- eight whole cache lines; from the
+    // row-major core a load touched sixteen half lines 8 KB apart, and the core loads, not the products, set the
+    // epilogue's pace: 52 us of a 155 us stage at C3 against 27 us without them)
+    const zc* __restrict__ Wf = d.epi_wf + lane;
+    auto ld = [&](int slot, int k4) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < NIS; ++s) ring[slot][s] = Wf[(long)(k4 * NIS + s) * 64];
+    };
+#pragma unroll
+    for (int q = 0; q < RD; ++q) ld(q, k4a + q);  // on their way while the tile goes to LDS (k4b - k4a >= RING)
+    store_tile(std::true_type{});
+    zc tv[2][NPG];
+    auto ldt = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < NPG; ++g) tv[b][g] = smem[toff[g] + tk];
+      tk += 4;
+    };
+    ldt(0);
+    for (int k4s = k4a; k4s < k4b; k4s += RING) {
+#pragma unroll
+      for (int c = 0; c < RING; ++c) {
+        if (k4s + c + RD < k4b && !(d.tune & 64)) ld((c + RD) % RING, k4s + c + RD);  // (tune 64 / 128: timing experiments)
+        if (k4s + c + 1 < k4b && !(d.tune & 128)) ldt((c + 1) & 1);
+        products(ring[c], tv[c & 1]);
+      }
+    }
+  } else {
+    load_w(0, k4a);  // the first fragments of the core are on their way while the tile goes to LDS
+    store_tile(std::false_type{});
+    for (int k4s = k4a; k4s < k4b; k4s += 2 * CH) {
+      load_w(1, k4s + CH);
+      chunk(0, k4s);
+      load_w(0, k4s + 2 * CH);
+      chunk(1, k4s + CH);
+    }
   }
   // where this thread's result goes (thread t owns result lane t % 64 of set t / 64), and -- accumulating stage -- what
   // is there now: asked for before the exchange of the partials, not after it
@@ -1039,6 +1076,23 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, 
   if (stamps && blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
 }
 
+// the same chain with v_mfma_f64_4x4x4_4b_f64 (four 4 x 4 x 4 products per instruction: 256 multiply-adds)
+__global__ __launch_bounds__(256) void mfma_peak_kernel_b4(double* out, int iters, unsigned long long* stamps) {
+  double acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+  double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < 8; ++i) s += acc[i];
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (s == 123.456) out[0] = s;
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = t1 - t0;
+}
+
 // Raw v_mfma_f64_16x16x4_f64 issue rate with `waves_per_simd` resident waves on
 // every SIMD.  Prints cycles per MFMA and the in-kernel clock when
 // MITDVP_VERBOSE is set (MI355X_MICROARCH.md, DVFS give-back item 6).
@@ -1071,6 +1125,22 @@ double mfma_peak_probe(hipStream_t st) {
       fprintf(stderr, "[mitdvp] f64 mfma probe: %d wave/SIMD: %.1f TFLOP/s, %.1f cycles per MFMA per wave, clock %.2f GHz\n",
               wps, tf, (double)hs[0] / (iters * 8.0), (double)hs[0] / (double)hs[1] * 0.1);
     best = std::max(best, tf);
+    if (verbose) {  // the 4 x 4 x 4 form's rate beside it
+      HIP_CHECK(hipEventCreate(&e0));
+      HIP_CHECK(hipEventCreate(&e1));
+      hipLaunchKernelGGL(mfma_peak_kernel_b4, dim3(blocks), dim3(256), 0, st, dout, 10, nullptr);
+      HIP_CHECK(hipEventRecord(e0, st));
+      hipLaunchKernelGGL(mfma_peak_kernel_b4, dim3(blocks), dim3(256), 0, st, dout, iters, dst);
+      HIP_CHECK(hipEventRecord(e1, st));
+      HIP_CHECK(hipEventSynchronize(e1));
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      HIP_CHECK(hipEventDestroy(e0));
+      HIP_CHECK(hipEventDestroy(e1));
+      HIP_CHECK(hipMemcpy(hs, dst, 8, hipMemcpyDeviceToHost));
+      const double f4 = (double)blocks * 4 * iters * 8.0 * (2.0 * 4 * 4 * 4 * 4);
+      fprintf(stderr, "[mitdvp] f64 mfma 4x4x4_4b probe: %d wave/SIMD: %.1f TFLOP/s, %.1f cycles per MFMA per wave\n", wps,
+              f4 / (ms * 1e-3) / 1e12, (double)hs[0] / (iters * 8.0));
+    }
   }
   HIP_CHECK(hipFree(dout));
   HIP_CHECK(hipFree(dst));
@@ -1262,6 +1332,25 @@ static int b4_layout_ok(hipStream_t st) {
   return g_b4_ok;
 }
 int zgemm_reduce_b4_available(hipStream_t st) { return b4_layout_ok(st); }
+
+// the reduced core w[di][kp] (row stride ldw) in the order the unguarded 4 x 4 x 4 epilogue reads it:
+// wf[(k4 * (di / 16) + s) * 64 + lane] = w[(4 s + blk(lane)) * 4 + q(lane)][4 k4 + k(lane)]
+__global__ __launch_bounds__(256) void k_pack_core(const zc* __restrict__ w, long ldw, int nis, long total, zc* __restrict__ wf) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int lane = (int)(e & 63);
+    const long f = e >> 6;
+    const int s = (int)(f % nis);
+    const long k4 = f / nis;
+    wf[e] = w[(long)((4 * s + MITDVP_B4_BLK(lane)) * 4 + MITDVP_B4_Q(lane)) * ldw + 4 * k4 + MITDVP_B4_K(lane)];
+  }
+}
+bool zgemm_reduce_pack_core(hipStream_t st, const zc* w, long ldw, int di, int kp, zc* wf) {
+  if (di % 16 || kp % 4 || di < 16 || !zgemm_reduce_b4_available(st)) return false;
+  const long total = (long)di * kp;
+  hipLaunchKernelGGL(k_pack_core, dim3((unsigned)std::min<long>((total + 255) / 256, 1024)), dim3(256), 0, st, w, ldw, di / 16, total, wf);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
 
 void zgemm_reduce(hipStream_t st, const ZgemmDesc& d0) {
   ZgemmDesc d = d0;
