@@ -126,6 +126,7 @@ bool zgemm_reduce_ok(int xm, int yn, int di);
 // 1 when the 4 x 4 x 4 form of the reducing epilogue is in use (lane maps verified on this device, MITDVP_EPI_B4 != 0)
 int zgemm_reduce_b4_available(hipStream_t st);
 // the core of a reducing product in the fragment order of the unguarded 4 x 4 x 4 epilogue (ZgemmDesc::epi_wf); false: shape not served
+bool zgemm_reduce_full_ok(hipStream_t st, int xm, int yn, int di);
 bool zgemm_reduce_pack_core(hipStream_t st, const zc* w, long ldw, int di, int kp, zc* wf);
 void zgemm_reduce(hipStream_t st, const ZgemmDesc& d);
 int zgemm_default_mode();

@@ -708,7 +708,11 @@ void Engine::choose_apply_forms(const zc* Lb, const MpoSite& w, const zc* Rb, in
                          // round 5: with the 4 x 4 x 4 epilogue (no padded products at d M = 512) the form also wins where the
                          // W stage is a large share of the chain, i.e. at short bonds: C3 (D = 128) heff -9 %, C4 (D = 1024) +2 %
                          (edge_mode_ > 0 || ((long)d * std::max(ml, mr) <= 64 && (long)dl * dr <= 512L * 512L) ||
-                          ((long)d * std::max(ml, mr) <= 512 && (long)dl * dr <= 256L * 256L && zgemm_reduce_b4_available(st_) != 0));
+                          // (later in round 5: with the cores in fragment order and the unguarded epilogue the form is level with
+                          // the chain at C4 too -- 0.02064 against 0.02058 sweeps/s, H_eff frac 0.899 against 0.875, a ninth of the
+                          // chain's intermediate traffic -- so shapes that run that variant take it at any bond)
+                          ((long)d * std::max(ml, mr) <= 512 && zgemm_reduce_b4_available(st_) != 0 &&
+                           ((long)dl * dr <= 256L * 256L || (zgemm_reduce_full_ok(st_, d, mr, d) && zgemm_reduce_full_ok(st_, ml, d, d)))));
   if (edge_cand && w.edge_skip > 0) {  // a core that failed the structure check recently: the plain checks, no look at all blocks
     w.edge_skip -= 1;
     identity_blocks(trim_identity_ && dl >= 256 && ml > 1 ? Lb : nullptr, dl, ml,

@@ -1344,6 +1344,14 @@ __global__ __launch_bounds__(256) void k_pack_core(const zc* __restrict__ w, lon
     wf[e] = w[(long)((4 * s + MITDVP_B4_BLK(lane)) * 4 + MITDVP_B4_Q(lane)) * ldw + 4 * k4 + MITDVP_B4_K(lane)];
   }
 }
+// whether a reducing product of this shape runs the unguarded 4 x 4 x 4 epilogue (the condition of zgemm_kernel's EPI branch)
+bool zgemm_reduce_full_ok(hipStream_t st, int xm, int yn, int di) {
+  if (!zgemm_reduce_b4_available(st) || xm < 1 || yn < 1 || xm > 64 || yn > 64) return false;
+  static const bool on = !(std::getenv("MITDVP_EPI_FULL") && std::getenv("MITDVP_EPI_FULL")[0] == '0');
+  const int kp = xm * yn, npair = (64 / xm) * (64 / yn);
+  return on && (di == 16 || di == 32) && npair == 8 && yn % 4 == 0 && kp % 128 == 0 && !(xm & (xm - 1)) && !(yn & (yn - 1)) &&
+         8 * (kp + 4) <= 2 * (64 * 17 + 16 * 64);
+}
 bool zgemm_reduce_pack_core(hipStream_t st, const zc* w, long ldw, int di, int kp, zc* wf) {
   if (di % 16 || kp % 4 || di < 16 || !zgemm_reduce_b4_available(st)) return false;
   const long total = (long)di * kp;
