@@ -91,6 +91,12 @@ int mitdvp_get_site(mitdvp_engine* h, int isite, double* reim_out);
  * alloc_superblock_random (:2684-2699).  For workloads too large to stage
  * through the host. */
 int mitdvp_init_random(mitdvp_engine* h, const int* dims, int bond_dim, uint64_t seed);
+/* The raw (not canonicalised) tensors mitdvp_init_random draws for sites [first, first + nsite) of an nsite_total-site
+ * chain (shapes and seeds follow the GLOBAL site index; h holds nsite sites): one block of a site-range sharded state
+ * (MPSCoefParallel keeps one block per rank, _mps_parallel.py:64-118) without the whole chain on every rank; the ranks
+ * then canonicalise in a pipeline with mitdvp_split_center / mitdvp_absorb_bond.  balance != 0: each tensor times the
+ * largest power of two <= 1 / sqrt(d_l d), so the weight handed along the chain stays O(1). */
+int mitdvp_init_random_block(mitdvp_engine* h, const int* dims, int nsite_total, int first, int bond_dim, uint64_t seed, int balance);
 /* alloc_superblock_random's C2sigmaB sweep for tensors given by set_site
  * with gauge "C": site 0 becomes "Psi", scaled to norm `scale`; scale <= 0 keeps
  * the state's own normalisation (Liouville space: trace-normalised start,

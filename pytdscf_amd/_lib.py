@@ -112,6 +112,7 @@ def load() -> C.CDLL:
         "mitdvp_get_site_shape": (i, [vp, i, ip, ip, ip, ip]),
         "mitdvp_get_site": (i, [vp, i, dp]),
         "mitdvp_init_random": (i, [vp, ip, i, C.c_uint64]),
+        "mitdvp_init_random_block": (i, [vp, ip, i, i, i, C.c_uint64, i]),
         "mitdvp_canonicalize": (i, [vp, d]),
         "mitdvp_set_mpo_core": (i, [vp, i, i, dp, i, i, i, i]),
         "mitdvp_set_shift": (i, [vp, i, d, d]),

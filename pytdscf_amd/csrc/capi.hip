@@ -133,6 +133,9 @@ int mitdvp_get_site(mitdvp_engine* h, int isite, double* out) { ENG_CALL(h, { NE
 int mitdvp_init_random(mitdvp_engine* h, const int* dims, int bond_dim, uint64_t seed) {
   ENG_CALL(h, { NEED(dims); h->e->init_random(dims, bond_dim, seed); });
 }
+int mitdvp_init_random_block(mitdvp_engine* h, const int* dims, int nsite_total, int first, int bond_dim, uint64_t seed, int balance) {
+  ENG_CALL(h, { NEED(dims); h->e->init_random_block(dims, nsite_total, first, bond_dim, seed, balance != 0); });
+}
 int mitdvp_canonicalize(mitdvp_engine* h, double scale) { ENG_CALL(h, h->e->canonicalize(scale)); }
 int mitdvp_set_mpo_core(mitdvp_engine* h, int op_id, int isite, const double* reim, int ml, int d_out, int d_in,
                         int mr) {

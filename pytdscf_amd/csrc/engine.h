@@ -132,6 +132,7 @@ class Engine {
   void get_site_shape(int isite, int* l, int* n, int* r, int* gauge) const;
   void get_site(int isite, double* out);
   void init_random(const int* dims, int bond_dim, uint64_t seed);
+  void init_random_block(const int* dims, int ntot, int first, int D, uint64_t seed, bool balance);  // raw tensors of a block
   void canonicalize(double scale);
   void set_mpo_core(int op_id, int isite, const double* reim, int ml, int dout, int din, int mr);
   void set_shift(int op_id, double re, double im);

@@ -1041,6 +1041,43 @@ void Engine::init_random(const int* dims, int D, uint64_t seed) {
   canonicalize(1.0);
 }
 
+// The raw (not canonicalised) random tensors of sites [first, first + L_) of an ntot-site chain: shapes and seeds by the
+// GLOBAL site index, i.e. what init_random draws for those sites before it canonicalises -- a rank of a site-sharded
+// state fills only its own block and the ranks canonicalise in a pipeline (parallel_sites.py).  balance: every tensor is
+// multiplied by the largest power of two <= 1 / sqrt(d_l d) (exact in floating point; the right-canonical factors do not
+// change, the weight passed on along the chain stays O(1) instead of growing by ~sqrt(D d D) per site).
+void Engine::init_random_block(const int* dims, int ntot, int first, int D, uint64_t seed, bool balance) {
+  if (D < 1) throw ArgError("bond_dim must be >= 1");
+  if (first < 0 || first + L_ > ntot) throw ArgError("init_random_block: the block lies outside the chain");
+  auto satprod = [&](int lo, int hi) {
+    double p = 1;
+    for (int i = lo; i < hi; ++i) { p *= dims[i]; if (p > D) return (long)D + 1; }
+    return (long)p;
+  };
+  for (int q = 0; q < L_; ++q) {
+    const int i = first + q;
+    if (dims[i] < 1) throw ArgError("bad physical dimension");
+    const long left = i == 0 ? 1 : std::min<long>(D, satprod(0, i));
+    const long right = i == ntot - 1 ? 1 : std::min<long>(D, satprod(i + 1, ntot));
+    const long dc = dims[i];
+    dl_[q] = (int)std::min({left, dc * right, (long)D});
+    dr_[q] = (int)std::min({left * dc, right, (long)D});
+    dd_[q] = dims[i];
+    const size_t e = (size_t)dl_[q] * dd_[q] * dr_[q];
+    site_[q].reserve(e);
+    vec_randn(st_, site_[q].p, (long)e, seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
+    if (balance) {
+      int ex = 0;
+      (void)std::frexp(1.0 / std::sqrt((double)dl_[q] * dd_[q]), &ex);  // 1 / sqrt = m 2^ex, m in [0.5, 1)
+      vec_scale(st_, site_[q].p, (long)e, make_double2(std::ldexp(1.0, ex - 1), 0.0));
+    }
+    gauge_[q] = -1;
+  }
+  center_ = -1;
+  bond_ = -1;
+  invalidate_env();
+}
+
 void Engine::canonicalize(double scale) {
   require_ready();
   DevBuf spare = pool_get(V_.n / MAXK);

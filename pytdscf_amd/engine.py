@@ -181,6 +181,12 @@ class TDVPEngine:
         arr = (C.c_int * len(dims))(*dims)
         self._ck(self._lib.mitdvp_init_random(self._h, arr, bond_dim, seed))
 
+    def init_random_block(self, dims, first: int, bond_dim: int, seed: int = 1, balance: bool = True):
+        """the raw tensors ``init_random`` draws for sites [first, first + nsite) of the chain with physical dimensions
+        ``dims`` (global shapes and seeds), not canonicalised: one block of a site-sharded state (parallel_sites.py)"""
+        arr = (C.c_int * len(dims))(*dims)
+        self._ck(self._lib.mitdvp_init_random_block(self._h, arr, len(dims), int(first), bond_dim, seed, int(bool(balance))))
+
     def set_mpo(self, cores, op_id: int = 0, shift: complex = 0.0):
         cores = list(cores)
         if cores:

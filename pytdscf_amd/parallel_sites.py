@@ -177,7 +177,7 @@ class SiteShardedTDVP:
     def _ck(self, rc):
         _lib.check(rc, self._h, shard=True)
 
-    def _setup(self, cores, dims, bond_dim, seed, shared):
+    def _replicated_state(self, cores, dims, bond_dim, seed, shared):
         L, r, N = self.nsite, self.rank, self.world
         g = TDVPEngine(L, device=self.device, **self.kw)  # replicated full chain: B world, then A world
         if shared:
@@ -209,6 +209,122 @@ class SiteShardedTDVP:
         if not even and hi == L:
             acores.append(g.get_site(L - 1))  # the A world's centre
         g.close()
+        return bcores, acores, left_b, right_b, X_left, X_right
+
+    def _setup_pipeline(self, b, cores, dims, bond_dim, seed, shared):
+        """The block engine ``b`` (MPO set) filled rank by rank; returns the junction matrix to the right (or None).
+
+        B world, from the last rank down: a rank takes the weight matrix sigma and the right boundary block from its right
+        neighbour, brings its own sites into gauge B (C2sigmaB site by site, _mps_cls.py:2684-2693; given ``cores`` are in
+        that gauge already) and passes sigma of its first site and the block through its sites on.  A world, from rank 0
+        up: a rank takes the junction matrix X and the left boundary block, absorbs X into its first site and walks the
+        centre through its block (Psi -> A sigma, sigma B -> Psi); the matrix left after its last site is the junction
+        matrix to the right.  Even ranks keep the state before that walk (it runs on a scratch copy of the block), odd
+        ranks the state at its end."""
+        L, r, N, link = self.nsite, self.rank, self.world, self.link
+        lo, hi, n = self.lo, self.hi, self.n
+        even = r % 2 == 0
+        one = np.ones((1, 1, 1), dtype=np.complex128)
+        Dl, Dr = self.shapes[lo][0], self.shapes[hi - 1][2]
+        ml = 1 if lo == 0 else self.mpo[lo].shape[0]
+        mr = 1 if hi == L else self.mpo[hi].shape[0]
+        # ---- B world ----------------------------------------------------------------------------------------
+        if r > 0:  # a segment wants both boundary blocks in place; the left one arrives with the A world below
+            b.set_boundary_env(0, np.zeros((Dl, ml, Dl), dtype=np.complex128))
+        if cores is not None:
+            for i in range(n):
+                b.set_site(i, cores[lo + i], "Psi" if lo + i == 0 else "B")
+            right_b = one if r == N - 1 else link.recv((Dr, mr, Dr), r + 1)
+            b.set_boundary_env(1, right_b)
+            if r > 0:
+                link.send(b.fold_block(right_b, op_id=0, conj=True, from_left=False, out_shape=(Dl, ml, Dl)), r - 1)
+        else:
+            b.init_random_block(list(dims), lo, bond_dim, seed=seed)
+            if r == N - 1:
+                right_b = one
+                b.set_boundary_env(1, right_b)
+                b.set_site(n - 1, b.get_site(n - 1), "Psi")  # (d, d, 1) at most: marks the chain's last site as the centre
+            else:
+                sig = link.recv((Dr, Dr), r + 1)
+                right_b = link.recv((Dr, mr, Dr), r + 1)
+                b.set_boundary_env(1, right_b)
+                b.set_bond(n, sig)
+                b.absorb_bond(False)
+            for _ in range(n - 1):
+                b.split_center(False)
+                b.absorb_bond(False)
+            if r > 0:
+                b.split_center(False)
+                sig = b.get_bond()
+                link.send(sig / np.linalg.norm(sig), r - 1)
+                link.send(b.get_env(1, 0), r - 1)
+            else:  # the chain's first site carries the norm (alloc_superblock_random, _mps_cls.py:2695-2699)
+                x = b.get_site(0)
+                b.set_site(0, x / np.linalg.norm(x), "Psi")
+        # ---- A world ----------------------------------------------------------------------------------------
+        if r == 0:
+            left_b = one
+            b.set_boundary_env(0, left_b)
+        else:
+            X_left = link.recv((Dl, Dl), r - 1)
+            left_b = link.recv((Dl, ml, Dl), r - 1)
+            b.set_boundary_env(0, left_b)
+            b.set_bond(0, X_left)
+            b.absorb_bond(True)
+        X_right = None
+        if even:
+            b.build_envs(1)
+            if r < N - 1:  # the walk to the right junction, on a scratch copy: this rank keeps the B world
+                g = TDVPEngine(n, device=self.device, **self.kw)
+                if shared:
+                    g.set_small_kernels(False)
+                g.set_mpo(self.mpo[lo:hi])
+                for i in range(n):
+                    g.set_site(i, b.get_site(i), "Psi" if i == 0 else "B")
+                g.set_boundary_env(0, left_b)
+                g.set_boundary_env(1, right_b)
+                for i in range(n):
+                    g.split_center(True)
+                    if i < n - 1:
+                        g.absorb_bond(True)
+                X_right = g.get_bond()
+                link.send(X_right, r + 1)
+                link.send(g.get_env(0, n), r + 1)
+                g.close()
+        else:
+            for _ in range(n - 1):
+                b.split_center(True)
+                b.absorb_bond(True)
+            if hi < L:
+                b.split_center(True)
+                X_right = b.get_bond()
+                link.send(X_right, r + 1)
+                link.send(b.get_env(0, n), r + 1)
+                b.absorb_bond(False)  # back into the last site: this rank's centre
+            b.build_envs(0)
+        return X_right
+
+    def _setup(self, cores, dims, bond_dim, seed, shared):
+        """Every rank ends with its block in the mixed gauge of the parallel scheme (even ranks: B world, centre on the
+        first site; odd ranks: A world, centre on the last), the two boundary blocks and the junction matrices.
+        ``MITDVP_SHARD_SETUP=pipeline`` (default): the ranks canonicalise their own blocks one after the other and hand
+        the weight matrix and the boundary block on (_setup_pipeline) -- a block per rank in memory; ``replicated``: every
+        rank walks a copy of the whole chain (rounds 2-4; kept for comparison)."""
+        L, r, N = self.nsite, self.rank, self.world
+        mode = os.environ.get("MITDVP_SHARD_SETUP", "pipeline")
+        if mode not in ("pipeline", "replicated"):
+            raise ValueError("MITDVP_SHARD_SETUP must be 'pipeline' or 'replicated'")
+        self.setup_mode = mode
+        even = r % 2 == 0
+        lo, hi, n = self.lo, self.hi, self.n
+        if mode == "replicated":
+            bcores, acores, left_b, right_b, X_left, X_right = self._replicated_state(cores, dims, bond_dim, seed, shared)
+        elif cores is not None:
+            self.shapes = [tuple(int(x) for x in np.shape(c)) for c in cores]
+        else:
+            from .mps import bond_dims
+
+            self.shapes = [(bl, int(dd), br) for (bl, br), dd in zip(bond_dims(list(dims), bond_dim), dims)]
         # the native shard: block engine + two-site junction engine + transport
         lib = _lib.load()
         cfg = _lib.Config()
@@ -252,7 +368,9 @@ class SiteShardedTDVP:
                 if j is not None:
                     j.set_small_kernels(False)
         b.set_mpo(self.mpo[lo:hi])
-        if even:
+        if mode == "pipeline":
+            X_right = self._setup_pipeline(b, cores, dims, bond_dim, seed, shared)
+        elif even:
             for i, c in enumerate(bcores):
                 b.set_site(i, c, "Psi" if (i == 0 and r == 0) else "B")
             b.set_boundary_env(0, left_b)

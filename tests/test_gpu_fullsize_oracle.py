@@ -195,13 +195,14 @@ def test_c5_shape_liouvillian_sweep_properties():
     eng.close()
 
 
-def test_c4_interior_apply_and_environment_update_through_the_sweeps_own_kernels():
-    """The kernels bench.py times at D = 1024 -- the block-sparse W stage (list kernel + row map) selected by the
-    finite-state-machine core of the bench's generator, the gathered-row first stage and the copy + accumulate third
-    stage selected by the identity blocks of CANONICAL environments -- against the oracle over the whole output
-    (_contraction.py:1182-1243; identity shortcuts _mps_mpo.py:510-523).  A 7-site chain reaches the C4 interior shape
-    (1024 x 16 x 1024) at its middle site; mitdvp_heff_apply_center issues the apply as a local exponential does and
-    reports which variants ran."""
+def test_c4_interior_apply_and_environment_update_through_the_sweeps_own_kernels(monkeypatch):
+    """The kernels bench.py times at D = 1024, against the oracle over the whole output (_contraction.py:1182-1243;
+    identity shortcuts _mps_mpo.py:510-523): the edge form (two products with the reducing 4 x 4 x 4 epilogue, cores in
+    fragment order: what the size rule selects at C4 since round 5), and the three-stage chain it replaced -- block-sparse W
+    stage (list kernel + row map) selected by the finite-state-machine core of the bench's generator, gathered-row first
+    stage and copy + accumulate third stage selected by the identity blocks of CANONICAL environments.  A 7-site chain
+    reaches the C4 interior shape (1024 x 16 x 1024) at its middle site; mitdvp_heff_apply_center issues the apply as a
+    local exponential does and reports which variants ran."""
     from oracle import tdvp_oracle as orc
     from pytdscf_amd import TDVPEngine
     from pytdscf_amd import synthetic as syn
@@ -218,13 +219,29 @@ def test_c4_interior_apply_and_environment_update_through_the_sweeps_own_kernels
         eng.split_center(True)
         eng.absorb_bond(True)
     got, flags = eng.heff_apply_center()
-    assert flags & 7 == 7, flags  # S1 trimmed, S3 trimmed, block-sparse W stage: the bench's configuration
+    assert flags & 0x10, flags  # the edge form: the bench's configuration
     Lb, Rb, psi = eng.get_env(0, c), eng.get_env(1, c + 1), eng.get_site(c)
     assert np.abs(Lb[:, 0, :] - np.eye(D)).max() < 1e-12 and np.abs(Rb[:, M - 1, :] - np.eye(D)).max() < 1e-12
     ch = max(1, min(D, int(6.4e7 // (M * d * D))))
     want = orc.heff_apply_chunked(Lb, mpo[c], Rb, psi, ch)
     assert _rel(got, want) < 1e-12
-    del got, want
+    del want
+    # the three-stage chain on the same operands (a second engine: the form is chosen at construction)
+    monkeypatch.setenv("MITDVP_EDGE_APPLY", "0")
+    eng2 = TDVPEngine(L)
+    monkeypatch.delenv("MITDVP_EDGE_APPLY")
+    eng2.set_mpo(mpo)
+    eng2.init_random([d] * L, D, seed=1)
+    eng2.build_envs(1)
+    for _ in range(c):
+        eng2.split_center(True)
+        eng2.absorb_bond(True)
+    assert np.array_equal(eng2.get_site(c), psi)  # same state, same blocks
+    got2, flags2 = eng2.heff_apply_center()
+    assert flags2 & 7 == 7 and not flags2 & 0x10, flags2  # S1 trimmed, S3 trimmed, block-sparse W stage
+    assert _rel(got2, got) < 1e-12
+    eng2.close()
+    del got, got2
     # a second, random input vector through the same operands (nothing about the apply may depend on x being the state)
     x = _crandn(np.random.default_rng(5), D, d, D)
     got, _ = eng.heff_apply_center(x)

@@ -402,6 +402,55 @@ def test_junction_update_bond_sharded_over_the_pair(world, tmp_path):
         assert abs(r["energy"] - s["energy"]) < 1e-12 and abs(r["norm"] - s["norm"]) < 1e-12
 
 
+SETUP_WORKER = """
+import os, sys, json
+os.environ["MITDVP_SMALL_KERNELS"] = "0"
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+comm = Comm()
+L, d, M, D, dt = {L}, 4, 4, 16, 0.2
+mpo = orc.synthetic_mpo(L, d, M, seed=0)
+out = {{}}
+for mode in ("replicated", "pipeline"):
+    os.environ["MITDVP_SHARD_SETUP"] = mode
+    eng = SiteShardedTDVP(comm, mpo, dims=[d] * L, bond_dim=D, seed=3)
+    assert eng.setup_mode == mode and eng.selftest()
+    g0 = eng.gather()
+    n0, e0 = eng.norm(), eng.expectation()
+    x0 = eng.X if comm.rank < comm.world - 1 else None
+    eng.step(dt)
+    out[mode] = (g0, n0, e0, x0, eng.gather(), eng.expectation())
+    eng.close()
+a, b = out["replicated"], out["pipeline"]
+if a[3] is not None:   # the junction matrix this rank holds: the same up to the gauge of the QR factors (singular values)
+    sa, sb = np.linalg.svd(a[3], compute_uv=False), np.linalg.svd(b[3], compute_uv=False)
+    assert np.abs(sa - sb).max() < 1e-12, (sa, sb)
+if comm.rank == 0:
+    ov = lambda x, y: abs(orc.overlap(x, y)) / np.sqrt(abs(orc.overlap(x, x)) * abs(orc.overlap(y, y)))
+    print("RESULT " + json.dumps(dict(start=abs(ov(a[0], b[0]) - 1), norm0=abs(a[1] - b[1]), norm=abs(b[1] - 1), e0=abs(a[2] - b[2]),
+                                      after=abs(ov(a[4], b[4]) - 1), e1=abs(a[5] - b[5]))), flush=True)
+comm.barrier()
+comm.close()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_pipelined_setup_gives_the_state_of_the_replicated_one(world, tmp_path):
+    """Random start (what bench.py's site-sharded leg uses): every rank draws and canonicalises only its own block and the
+    ranks hand weight matrix and boundary blocks on (MITDVP_SHARD_SETUP=pipeline, the default), against the set-up of
+    rounds 2-4 in which every rank walked a copy of the whole chain: same state, norm, energy and junction spectra at the
+    start, same state after a time step."""
+    script = tmp_path / f"setup{world}.py"
+    script.write_text(textwrap.dedent(SETUP_WORKER.format(root=ROOT, L=9 if world == 3 else 8)))
+    r = _launch(script, world)
+    assert r["start"] < 1e-12 and r["norm0"] < 1e-12 and r["norm"] < 1e-12 and r["e0"] < 1e-11, r
+    assert r["after"] < 1e-10 and r["e1"] < 1e-10, r
+
+
 @pytest.mark.gpu
 def test_site_sharded_arnoldi_without_renormalisation(tmp_path):
     r = _run(2, tmp_path, integ="arnoldi", cn=False)

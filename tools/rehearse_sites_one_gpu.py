@@ -1,6 +1,8 @@
 """Two site-sharded ranks on ONE GPU (gloo) at the C4 interior shape (D = 1024, d = 16, M = 32, L = 8): one time
 step next to the serial engine on the same inputs -- exercises the 1024^2 pseudo-inverse, the full-size junction
-update and the host-staged halo messages.  Start with:  python tools/rehearse_sites_one_gpu.py  (spawns its ranks)."""
+update and the host-staged halo messages.  Start with:  python tools/rehearse_sites_one_gpu.py  (spawns its ranks).
+RS_WORLD ranks (default 2, at most 6 on one GPU), RS_L / RS_D / RS_STEPS; RS_SETUP_ONLY=1: the set-up alone (seconds per
+rank, device memory in use by all ranks together afterwards) -- the full C4 chain is RS_L=64."""
 import json, os, socket, subprocess, sys, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,9 +10,9 @@ sys.path.insert(0, ROOT)
 
 if "WORLD_SIZE" not in os.environ:
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", MITDVP_DIST_BACKEND="gloo",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=os.environ.get("RS_WORLD", "2"), MITDVP_DIST_BACKEND="gloo",
                MITDVP_SMALL_KERNELS="0")
-    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK="0")) for r in range(2)]
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK="0")) for r in range(int(os.environ.get("RS_WORLD", "2")))]
     rc = 0
     for p in ps:
         rc = rc or p.wait()
@@ -28,6 +30,18 @@ t0 = time.time()
 eng = SiteShardedTDVP(comm, mpo, dims=[d] * L, bond_dim=D, seed=1)
 assert eng.selftest()
 t_setup = time.time() - t0
+if os.environ.get("RS_SETUP_ONLY"):
+    import torch
+
+    comm.barrier()
+    free, total = torch.cuda.mem_get_info(0)
+    allt = comm.max_over_ranks(t_setup)
+    print(json.dumps(dict(rank=comm.rank, world=comm.world, L=L, D=D, setup_mode=eng.setup_mode, setup_s=t_setup, setup_s_max=allt,
+                          device_GB_in_use_all_ranks=(total - free) / 1e9, norm=eng.norm(), energy=eng.expectation().real)), flush=True)
+    comm.barrier()
+    eng.close()
+    comm.close()
+    sys.exit(0)
 nsteps = int(os.environ.get("RS_STEPS", 1))
 trace = [(0, eng.norm(), eng.expectation().real)]  # folded rank by rank on the device, no gather
 t0 = time.time()
