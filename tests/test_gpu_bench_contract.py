@@ -21,6 +21,42 @@ KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "vs_baseline", "dtype", "data", "config", "roofline")
 
 
+class _Done:
+    def __init__(self, returncode, stdout, stderr):
+        self.returncode, self.stdout, self.stderr = returncode, stdout, stderr
+
+
+def _run_bench(cmd, timeout, env=None):
+    """subprocess.run(capture_output=True) with the child's progress notes (stderr) ALSO appended to
+    gpurun_out/bench_contract_progress.txt as they come: a run of several minutes under captured output looks hung to a
+    watchdog that only sees stdout, stderr and that directory."""
+    import threading
+
+    prog_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(prog_dir, exist_ok=True)
+    err = []
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+
+    def pump():
+        with open(os.path.join(prog_dir, "bench_contract_progress.txt"), "a") as f:
+            for line in p.stderr:
+                err.append(line)
+                f.write(line)
+                f.flush()
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    killer = threading.Timer(timeout, p.kill)  # stdout is one line: read to the end of the run, bounded by the timer
+    killer.start()
+    try:
+        out = p.stdout.read()
+        p.wait()
+    finally:
+        killer.cancel()
+    th.join(10)
+    return _Done(p.returncode, out, "".join(err))
+
+
 def _line(out):
     # stdout carries the JSON line and NOTHING else (library banners -- gloo, RCCL -- are sent to stderr)
     lines = [l for l in out.splitlines() if l.strip()]
@@ -90,8 +126,8 @@ def test_bench_driver_command_line_fits_its_wall_budget():
     them to the wall budget, say so, and still print the full line.  The budget is set low here
     (one warm-up + one timed sweep + the CPU sample) to keep the test short."""
     t0 = time.time()
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
-                       capture_output=True, text=True, timeout=660, cwd=ROOT, env=dict(os.environ, MITDVP_BENCH_BUDGET="150"))
+    p = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                   timeout=660, env=dict(os.environ, MITDVP_BENCH_BUDGET="150"))
     wall = time.time() - t0
     assert p.returncode == 0, p.stderr[-2000:]
     o = _line(p.stdout)
