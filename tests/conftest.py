@@ -12,6 +12,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # kill -USR1 <pid of this pytest>: Python stacks of all threads on the REAL stderr (bypasses the capture), for a run that
+    # sits inside a library call
+    import faulthandler
+    import signal
+    import sys
+
+    try:
+        faulthandler.register(signal.SIGUSR1, file=sys.__stderr__, all_threads=True)
+    except (AttributeError, ValueError, OSError):
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
