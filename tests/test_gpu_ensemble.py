@@ -27,6 +27,22 @@ def _setup(ens_or_engs, mpo):
 
 @pytest.mark.parametrize("B", [2, 8, 16])
 def test_replicas_on_disjoint_compute_units(B):
+    """Runs in a fresh interpreter (_replicas_body below, 240 s limit).  Twice in about ten runs of the whole GPU suite in
+    round 5 this test sat without output until the box's watchdog ended the run (once at B = 2 right after the mixed-state
+    tests, once at B = 16); alone -- as a file, or in a fresh process -- it takes four seconds and has never done so.  The
+    cause is not known (tools/r05_suite.sh dumps Python and native stacks should it happen again); until it is, the state
+    other tests leave in a long-lived process is kept away from it, and a run that sits is ended with an error."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = f"import sys; sys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]; import test_gpu_ensemble as t; t._replicas_body({B}); print('REPLICAS OK')"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, cwd=os.path.dirname(here))
+    assert p.returncode == 0 and "REPLICAS OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+def _replicas_body(B):
     from oracle import tdvp_oracle as orc
     from pytdscf_amd import TDVPEngine, TDVPEnsemble
     from pytdscf_amd import synthetic as syn
