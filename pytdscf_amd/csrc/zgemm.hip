@@ -1285,7 +1285,14 @@ static void launch_sparse(hipStream_t st, const ZgemmDesc& d, int m3) {
 }
 
 static int zgemm_tune_default() {
-  static const int v = [] { const char* e = std::getenv("MITDVP_ZGEMM_TUNE"); return e ? std::atoi(e) : 0; }();
+  // bits 0-2 change scheduling only.  Bits 4-7 switch parts of the reducing epilogue OFF for timing (the product is
+  // wrong): they are honoured only together with MITDVP_TIMING_ABLATION=1, so that a stray value cannot corrupt a run.
+  static const int v = [] {
+    const char* e = std::getenv("MITDVP_ZGEMM_TUNE");
+    const int t = e ? std::atoi(e) : 0;
+    const char* a = std::getenv("MITDVP_TIMING_ABLATION");
+    return (a && a[0] == '1') ? t : (t & 7);
+  }();
   return v;
 }
 

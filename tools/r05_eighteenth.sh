@@ -5,11 +5,11 @@ mkdir -p $O
 timeout -k 20 300 python -m pytest tests/test_gpu_edge_apply.py -q -m gpu -x > $O/test.txt 2>&1 || { tail -40 $O/test.txt; exit 1; }
 tail -2 $O/test.txt
 for t in 0 32; do
-  MITDVP_ZGEMM_TUNE=$t timeout -k 10 120 python tools/heff_per_site.py C3 40 > $O/tune_$t.txt 2>&1 || { tail $O/tune_$t.txt; exit 1; }
+  MITDVP_TIMING_ABLATION=1 MITDVP_ZGEMM_TUNE=$t timeout -k 10 120 python tools/heff_per_site.py C3 40 > $O/tune_$t.txt 2>&1 || { tail $O/tune_$t.txt; exit 1; }
   echo "tune $t"; sed -n 3,4p $O/tune_$t.txt | cut -c1-120
 done
 for t in 0; do
-  MITDVP_ZGEMM_TUNE=$t timeout -k 20 300 python bench.py --workload C3 --steps 30 --warmup 3 --no-cpu-baseline --secondary none > $O/c3_$t.json 2> $O/c3_$t.err || { tail -20 $O/c3_$t.err; exit 1; }
+  MITDVP_TIMING_ABLATION=1 MITDVP_ZGEMM_TUNE=$t timeout -k 20 300 python bench.py --workload C3 --steps 30 --warmup 3 --no-cpu-baseline --secondary none > $O/c3_$t.json 2> $O/c3_$t.err || { tail -20 $O/c3_$t.err; exit 1; }
   python - <<P
 import json
 r=json.loads(open("$O/c3_$t.json").read().strip().splitlines()[-1])

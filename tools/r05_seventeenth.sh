@@ -3,7 +3,7 @@
 O=gpurun_out/r05x
 mkdir -p $O
 for t in 0 16 32 48; do
-  MITDVP_ZGEMM_TUNE=$t timeout -k 10 120 python tools/heff_per_site.py C3 40 > $O/tune_$t.txt 2>&1 || { tail $O/tune_$t.txt; exit 1; }
+  MITDVP_TIMING_ABLATION=1 MITDVP_ZGEMM_TUNE=$t timeout -k 10 120 python tools/heff_per_site.py C3 40 > $O/tune_$t.txt 2>&1 || { tail $O/tune_$t.txt; exit 1; }
   echo "tune $t"; sed -n 3,4p $O/tune_$t.txt | cut -c1-120
 done
 MITDVP_VERBOSE=1 python -c "

@@ -5,7 +5,7 @@ mkdir -p $O
 timeout -k 20 400 python -m pytest tests/test_gpu_edge_apply.py tests/test_gpu_3m_numerics.py -q -m gpu -x > $O/test.txt 2>&1 || { tail -40 $O/test.txt; exit 1; }
 tail -2 $O/test.txt
 for t in 0 32; do
-  MITDVP_ZGEMM_TUNE=$t timeout -k 10 120 python tools/heff_per_site.py C3 40 > $O/tune_$t.txt 2>&1 || { tail $O/tune_$t.txt; exit 1; }
+  MITDVP_TIMING_ABLATION=1 MITDVP_ZGEMM_TUNE=$t timeout -k 10 120 python tools/heff_per_site.py C3 40 > $O/tune_$t.txt 2>&1 || { tail $O/tune_$t.txt; exit 1; }
   echo "tune $t"; sed -n 1,6p $O/tune_$t.txt | cut -c1-120
 done
 for w in C3 C5; do
