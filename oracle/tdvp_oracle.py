@@ -724,6 +724,9 @@ class OracleMPS:
             x0 = np.zeros((l, c, newD), dtype=np.complex128)
             x0[:, :, :r] = self.cores[p]
             self.cores[p] = self._exp(-1.0j * dt / 2, mv, x0, p, l * c * r)
+            hook = getattr(self, "site_hook", None)  # the junction update's regularisation (_mps_parallel.py:362-370)
+            if hook is not None:
+                self.cores[p] = hook(self.cores[p])
             A, sval = qr_psi2Asigma(self.cores[p])
             self.cores[p] = A
             self.left[q] = env_update_left(self.left[p], A, W[p])

@@ -28,6 +28,16 @@ What the fixtures taught about the reference (all reproduced or stated here):
   * ``to_MPSCoefMPO`` (the checkpoint) concatenates per-rank B worlds saved at different half steps; the fixtures
     therefore hold the state as ``MPSCoefParallel.ovlp`` reads it (:872-897), not that chain.
 
+Adaptive bond dimensions (``adaptive={"Dmax", "dD", "p_proj"}``, round 5): the block half-sweeps run the serial
+adaptive step with the frozen boundary blocks (``propagate_along_sweep`` with ``const.adaptive``, _mps_cls.py:863-987;
+the end site of a block is an orthonormal tensor at the start of the sweep and is widened like any other, the bond
+beyond it is not touched), and the junction update widens the right site's B tensor and chooses the junction's new
+rank with the same functional (``get_superblock_full`` / ``get_adaptive_rank_and_block`` on the two-site superblock,
+_mps_parallel.py:319-345, :371-374); the joint matrix, both facing tensors and both boundary blocks come out at the
+new rank.  Pinned against ``parallel_adaptive_r2.npz`` at the looseness the reference itself accepts (from a product
+start the lifted null directions are arbitrary; from a full-rank start the reference's own junction update fails, see
+``make_golden_parallel.py``) and, where nothing can grow, exactly against the non-adaptive scheme.
+
 All ranks are simulated in one process, in the order the real ranks would act; what one rank reads
 from another is exactly what ``pytdscf_amd/parallel_sites.py`` sends over RCCL / gloo.
 
@@ -106,6 +116,7 @@ class Block:
     integrator: str = "lanczos"
     thresh: float = 1e-9
     conserve_norm: bool = True
+    adaptive: dict | None = None  # {"Dmax", "dD", "p_proj"}: const.adaptive (_const_cls.py:120-124, :212-216)
     kprev: dict = field(default_factory=dict)
     left: dict = field(default_factory=dict)  # left[i]: environment left of local site i
     right: dict = field(default_factory=dict)  # right[i]: environment right of local site i
@@ -115,9 +126,9 @@ class Block:
         self.left = {0: self.left_b}
         self.right = {self.n - 1: self.right_b}
 
-    def _exp(self, scale, mv, x, site):
+    def _exp(self, scale, mv, x, site, size=None):
         fn = orc.sil_lanczos if self.integrator == "lanczos" else orc.sil_arnoldi
-        out, k = fn(scale, mv, x, self.thresh, self.kprev.get(site, 0), self.conserve_norm, None)
+        out, k = fn(scale, mv, x, self.thresh, self.kprev.get(site, 0), self.conserve_norm, size)
         self.kprev[site] = k
         return out
 
@@ -135,10 +146,16 @@ class Block:
         n = self.n
         sites = range(0, n) if forward else range(n - 1, -1, -1)
         end = n - 1 if forward else 0
+        view = full = None
+        if self.adaptive:  # get_superblock_full over the block (_mps_cls.py:863-874): every site but the centre widened
+            full = orc.superblock_full(self.cores, 0 if forward else n - 1, self.adaptive["dD"])
+            view = _AdaptiveView(self, self.cores, self.mpo, self.left, self.right, lambda q: self.lo + q)
         for p in sites:
             g = self.lo + p
             if skip_end and p == end:
                 return
+            if view is not None and p != end and orc.OracleMPS._adaptive_site(view, p, dt, forward, full):
+                continue
             L, W, R = self.left[p], self.mpo[p], self.right[p]
             self.cores[p] = self._exp(-0.5j * dt, lambda x: orc.heff_apply(L, W, R, x), self.cores[p], g)
             if p == end:
@@ -159,6 +176,27 @@ class Block:
                 self.cores[p - 1] = np.tensordot(self.cores[p - 1], s, axes=(2, 0))
 
 
+class _AdaptiveView:
+    """What ``OracleMPS._adaptive_site`` (the serial adaptive step, pinned by the a1TDVP fixtures) reads and writes of
+    its object, laid over a block's -- or a junction's two -- tensors, blocks and warm-up memories."""
+
+    relax = False
+    shift = 0.0
+
+    def __init__(self, blk: Block, cores, mpo, left, right, key, site_hook=None):
+        self.blk, self.cores, self.mpo, self.left, self.right, self.key = blk, cores, mpo, left, right, key
+        self.integrator = blk.integrator
+        self.Dmax, self.p_proj = int(blk.adaptive["Dmax"]), float(blk.adaptive["p_proj"])
+        self.site_hook = site_hook
+
+    def _exp(self, scale, mv, x, site, size=None):
+        return self.blk._exp(scale, mv, x, self.key(site), size)
+
+    @staticmethod
+    def _keff(L, R):
+        return lambda x: orc.keff_apply(L, R, x)
+
+
 def joint_update(bl: Block, br: Block, X: np.ndarray, dt: float, regularize: bool = False, p_svd: float | None = None):
     """propagate_joint_two_sites (_mps_parallel.py:270-470) for the junction between ``bl`` (centre on
     its last site) and ``br`` (centre on its first site).  Returns the new X; both blocks end with
@@ -175,13 +213,26 @@ def joint_update(bl: Block, br: Block, X: np.ndarray, dt: float, regularize: boo
     B = np.ascontiguousarray(B)
     theta = np.tensordot(theta, s, axes=(2, 0))
     R1 = orc.env_update_right(Renv, B, Wr)
-    theta = bl._exp(-0.5j * dt, lambda x: orc.heff_apply(Lenv, Wl, R1, x), theta, mem)
-    if regularize:  # trans_next_psite_AsigmaB(..., regularize=True), :362-370
-        theta = regularize_site(theta)
-    A, s = orc.qr_psi2Asigma(theta)
-    L1 = orc.env_update_left(Lenv, A, Wl)
-    s = bl._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R1, x), s, mem)
-    psi_r = np.tensordot(s, B, axes=(1, 0))
+    grown = False
+    if bl.adaptive:
+        # const.adaptive, :319-345, :371-374: the two-site superblock [Psi, B] widened (get_superblock_full), the
+        # junction's rank chosen by get_adaptive_rank_and_block, the left site propagated into the widened bond with the
+        # truncated applies, regularised, split, the bond matrix propagated in the blocks at the new rank -- the serial
+        # adaptive step on two sites whose outer blocks are the two ranks' environments
+        cores2, left2, right2 = [theta, B], {0: Lenv}, {0: R1, 1: Renv}
+        view = _AdaptiveView(bl, cores2, [Wl, Wr], left2, right2, lambda q: mem, regularize_site if regularize else None)
+        full = orc.superblock_full(cores2, 0, bl.adaptive["dD"])
+        grown = orc.OracleMPS._adaptive_site(view, 0, dt, True, full)
+        if grown:
+            A, L1, psi_r = cores2[0], left2[1], cores2[1]
+    if not grown:
+        theta = bl._exp(-0.5j * dt, lambda x: orc.heff_apply(Lenv, Wl, R1, x), theta, mem)
+        if regularize:  # trans_next_psite_AsigmaB(..., regularize=True), :362-370
+            theta = regularize_site(theta)
+        A, s = orc.qr_psi2Asigma(theta)
+        L1 = orc.env_update_left(Lenv, A, Wl)
+        s = bl._exp(+0.5j * dt, lambda x: orc.keff_apply(L1, R1, x), s, mem)
+        psi_r = np.tensordot(s, B, axes=(1, 0))
     psi_r = bl._exp(-0.5j * dt, lambda x: orc.heff_apply(L1, Wr, Renv, x), psi_r, mem)
     s, B = orc.qr_psi2sigmaB(psi_r)
     B = np.ascontiguousarray(B)
@@ -208,11 +259,12 @@ class ParallelOracle:
     """N blocks in one process.  ``cores``: site-0-centred canonical MPS (Psi, B, ..., B)."""
 
     def __init__(self, cores, mpo, nrank, integrator="lanczos", thresh=1e-9, conserve_norm=True, ranges=None,
-                 regularize=False, p_svd=None):
+                 regularize=False, p_svd=None, adaptive=None):
         """``regularize`` / ``p_svd``: the reference's lifting of small singular values and the cumulative-weight
         truncation of the joint matrix (it runs with regularize=True, p_svd=const.p_svd, default 1e-7)."""
         self.regularize = regularize
         self.p_svd = p_svd
+        self.adaptive = dict(adaptive) if adaptive else None  # {"Dmax", "dD", "p_proj"}
         self.nsite = len(cores)
         self.nrank = nrank
         # explicit [lo, hi) ranges = the reference's parallel_split_indices [(first, last), ...] (_const_cls.py:236-250)
@@ -251,7 +303,7 @@ class ParallelOracle:
                 if r < nrank - 1:
                     cs[-1] = np.tensordot(A[hi - 1], xs[hi], axes=(2, 0))
                 # (the last rank's last site already is the A-world centre)
-            blk = Block(cs, mpo[lo:hi], lo, La[lo], Rb[hi - 1], integrator, thresh, conserve_norm)
+            blk = Block(cs, mpo[lo:hi], lo, La[lo], Rb[hi - 1], integrator, thresh, conserve_norm, self.adaptive)
             self.blocks.append(blk)
         self.X = [xs[c] for c in cuts]
         for r, blk in enumerate(self.blocks):
@@ -311,3 +363,7 @@ class ParallelOracle:
     def norm(self):
         g = self.gather()
         return float(np.sqrt(abs(orc.overlap(g, g))))
+
+    def bond_dims(self):
+        """right bond of every site but the last, over the whole chain"""
+        return [c.shape[2] for b in self.blocks for c in b.cores][:-1]
