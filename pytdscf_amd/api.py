@@ -512,6 +512,9 @@ class _ShardedEngine:
     def propagate(self, dt):
         self.sh.step(dt)
 
+    def bond_dims(self):
+        return self.sh.bond_dims()
+
     def close(self):
         self.sh.close()
 
@@ -668,14 +671,15 @@ class Simulator:
         lead = True  # the rank that writes the files (const.mpi_rank == 0 in the reference)
         if sharded:
             # const.mpi_size > 1 (simulator_cls.py:364-370, :526-531): one site range per rank, each on its own GPU
-            if multi or liou or adaptive or restart or not self.t2_trick or self.model.one_gate_to_apply is not None or self.model.kraus_op:
+            if multi or liou or restart or not self.t2_trick or self.model.one_gate_to_apply is not None or self.model.kraus_op:
                 raise NotImplementedError("parallel_split_indices: one electronic state in Hilbert space with t2_trick, "
-                                          "without adaptive bonds, restart, gates or Kraus operators")
-            eng, ids = self._sharded_engine(parallel_split_indices, integrator, conserve_norm, thresh_sil, adaptive_p_svd)
+                                          "without restart, gates or Kraus operators")
+            eng, ids = self._sharded_engine(parallel_split_indices, integrator, conserve_norm, thresh_sil, adaptive_p_svd,
+                                            dict(Dmax=adaptive_Dmax, dD=adaptive_dD, p_proj=adaptive_p_proj) if adaptive else None)
             lead = eng.rank == 0
         else:
             eng, ids = self._engine(integrator, conserve_norm, thresh_sil, restart_ext=loadfile_ext if restart else None)
-        if adaptive:  # const.adaptive / Dmax / dD / p_proj (_const_cls.py:212-216); p_svd is unused there too (:968-983)
+        if adaptive and not sharded:  # const.adaptive / Dmax / dD / p_proj (_const_cls.py:212-216); p_svd is unused there too (:968-983)
             eng.set_adaptive(True, Dmax=adaptive_Dmax, dD=adaptive_dD, p_proj=adaptive_p_proj)
         wf = None if sharded else self._wfunc(eng, ids)
         outdir = f"{self.jobname}_prop"
@@ -748,7 +752,7 @@ class Simulator:
                 eng.close()
         return ener, wf
 
-    def _sharded_engine(self, split, integrator, conserve_norm, thresh, p_svd):
+    def _sharded_engine(self, split, integrator, conserve_norm, thresh, p_svd, adaptive=None):
         """The engine of ``propagate(parallel_split_indices=...)``: this rank's site range of the real-space parallel
         sweep (MPSCoefParallel, _mps_parallel.py), with the reference's junction regularisation and ``adaptive_p_svd``
         truncation always on as there.  Ranks come from RANK / WORLD_SIZE / MASTER_* (torchrun), one GPU each."""
@@ -773,7 +777,8 @@ class Simulator:
         if shift:  # the scalar term of the Hamiltonian rides on the first core's identity route
             mpo = _add_scalar_to_mpo(mpo, shift)
         sh = SiteShardedTDVP(comm, mpo, cores=m.initial_cores(), integrator=integrator, thresh=thresh,
-                             conserve_norm=conserve_norm, split=[tuple(r) for r in split], regularize=True, p_svd=p_svd)
+                             conserve_norm=conserve_norm, split=[tuple(r) for r in split], regularize=True, p_svd=p_svd,
+                             adaptive=adaptive)
         return _ShardedEngine(sh, ops, mpo), ids
 
     def _gathered_wfunc(self, eng, integrator, conserve_norm, thresh):

@@ -1,5 +1,6 @@
 // engine.h -- device-resident one-site TDVP engine (host orchestration).
 #pragma once
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -240,6 +241,7 @@ class Engine {
   void ms_pops(double* out);
   // one block of a site-range sharded chain (engine_segment.hip)
   void replace_site(int isite, const double* reim, int gauge);  // same shape, environment cache kept
+  void reshape_site(int isite, const double* reim, int l, int n, int r, int gauge);  // a junction site whose outer bond changed, cache kept
   void set_boundary_env(int side, const double* reim, int d, int m);
   void env_shape(int side, int bond, int* d, int* m);
   void get_env(int side, int bond, double* out);
@@ -404,6 +406,9 @@ class Engine {
   void build_superblock_full(bool forward);
   int select_rank(const zc* hl, long hl_rows, const zc* ks, const zc* hr, long hr_cols, int dmin, int dmax);
   bool adaptive_site(int p, double dt, bool forward, DevBuf& spare);
+  // runs between the site exponential and the gauge move of an adaptive step (the junction update's regularisation
+  // of the centre tensor, _mps_parallel.py:362-370); the centre is still on site p, at its new shape
+  std::function<void()> ad_site_hook_;
 
   // counters
   mitdvp_counters cnt_{};

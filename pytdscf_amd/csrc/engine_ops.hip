@@ -205,14 +205,15 @@ void Engine::adaptive_prepare() {
   std::vector<long> cap(L_ + 1, 1);  // cap[b]: largest possible dimension of the bond left of site b
   {
     std::vector<double> lp(L_ + 1, 1.0), rp(L_ + 1, 1.0);
+    lp[0] = dl_[0]; rp[L_] = dr_[L_ - 1];  // 1 for a whole chain; a segment's outer bonds are its neighbours' (fixed during a sweep)
     for (int b = 1; b <= L_; ++b) lp[b] = std::min(1e15, lp[b - 1] * dd_[b - 1]);
     for (int b = L_ - 1; b >= 0; --b) rp[b] = std::min(1e15, rp[b + 1] * dd_[b]);
     for (int b = 0; b <= L_; ++b) cap[b] = (long)std::min(lp[b], rp[b]);
   }
   auto bound = [&](int b) -> long {  // bond left of site b, widened tensors included
-    const long cur = b == 0 ? 1 : (b == L_ ? 1 : dl_[b]);
-    if (b == 0 || b == L_) return 1;
-    return std::min<long>(cap[b], std::max<long>(cur, ad_dmax_) + ad_dd_);
+    if (b == 0) return dl_[0];
+    if (b == L_) return dr_[L_ - 1];
+    return std::min<long>(cap[b], std::max<long>(dl_[b], ad_dmax_) + ad_dd_);
   };
   long ms = 1, mx = 1, my = 1;
   int qm = 1, qn = 1;
@@ -401,6 +402,7 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
       cnt_.n_exp_site += 1;
     }
     pool_put(std::move(env_bra));
+    if (ad_site_hook_) ad_site_hook_();
     // from here on the plain step at the new rank
     timer_begin(3);
     qr_householder(st_, site_[p].p, l * c, newD, spare.p, sig_.p, qrwork_.p, &nl, 0, qr_sync(), qr_hist_);
@@ -494,6 +496,7 @@ bool Engine::adaptive_site(int p, double dt, bool forward, DevBuf& spare) {
     cnt_.n_exp_site += 1;
   }
   pool_put(std::move(env_bra));
+  if (ad_site_hook_) ad_site_hook_();
   gauge_qr_right(site_[p].p, newD, c, r, spare.p, tmp2_.p, sig_.p);
   std::swap(site_[p], spare);
   gauge_[p] = MITDVP_GAUGE_B;

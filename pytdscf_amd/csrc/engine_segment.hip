@@ -28,6 +28,22 @@ void Engine::replace_site(int i, const double* reim, int gauge) {
   else if (center_ == i) center_ = -1;
 }
 
+// new values AND a new shape for a site tensor while the environment cache survives: the junction site of a block
+// whose junction bond has grown (adaptive ranks across junctions); the caller replaces the boundary block of that
+// side as well, every other cached block is built from tensors this one does not enter
+void Engine::reshape_site(int i, const double* reim, int l, int n, int r, int gauge) {
+  if (i < 0 || i >= L_ || !site_[i].p) throw ArgError("reshape_site: bad or unset site");
+  if (l < 1 || r < 1 || n != dd_[i]) throw ArgError("reshape_site: bad shape");
+  if (i != 0 && i != L_ - 1) throw ArgError("reshape_site: only a block's first or last site faces a junction");
+  if ((i > 0 && l != dl_[i]) || (i < L_ - 1 && r != dr_[i])) throw ArgError("reshape_site: only the outer bond may change");
+  const size_t e = (size_t)l * n * r;
+  site_[i].reserve(e);
+  copy_in(site_[i].p, reim, e);
+  dl_[i] = l; dr_[i] = r; gauge_[i] = gauge;
+  if (gauge == MITDVP_GAUGE_PSI) center_ = i;
+  else if (center_ == i) center_ = -1;
+}
+
 // side 0: block left of site 0, L[a][c][b] (d, m, d); side 1: block right of the last site, R[r][t][s]
 void Engine::set_boundary_env(int side, const double* reim, int d, int m) {
   if (side != 0 && side != 1) throw ArgError("set_boundary_env: side must be 0 (left) or 1 (right)");

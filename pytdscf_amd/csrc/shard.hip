@@ -84,13 +84,32 @@ class SiteShard {
   void sweep_block(double dt, bool forward, bool skip_end) {
     Engine& b = *block_;
     const int end = forward ? n_ - 1 : 0;
+    // const.adaptive (_mps_cls.py:863-987): every site but the centre widened at the start of the half-sweep
+    // (get_superblock_full over the block; its end site is an orthonormal tensor then, the bond beyond it is not
+    // touched), the serial adaptive step at every site but the end site, against the frozen boundary blocks
+    const bool ad = b.adaptive_ && n_ > 1;
+    DevBuf spare;
+    if (ad) {
+      b.require_ready();
+      if (b.center_ != (forward ? 0 : n_ - 1)) throw ArgError("shard: an adaptive half-sweep starts at the block's centre site");
+      if (forward) b.build_right_envs();
+      else b.build_left_envs();
+      b.adaptive_prepare();
+      b.build_superblock_full(forward);
+      spare = b.pool_get(b.V_.n / MAXK);
+    }
     for (int p = forward ? 0 : n_ - 1; forward ? p < n_ : p >= 0; p += forward ? 1 : -1) {
-      if (skip_end && p == end) return;
+      if (skip_end && p == end) break;
+      if (ad && p != end && b.adaptive_site(p, dt, forward, spare)) continue;
       b.site_exp(dt);
-      if (p == end) return;
+      if (p == end) break;
       b.split_center(forward);
       b.bond_exp(dt);
       b.absorb_bond(forward);
+    }
+    if (ad) {
+      b.pool_put(std::move(spare));
+      b.ss_check();
     }
   }
 
@@ -326,6 +345,25 @@ class SiteShard {
     posted_.clear();
   }
 
+  // adaptive ranks: the shapes travel ahead of the tensors (a receive is posted with its exact size), one complex
+  // number per message group of its own
+  DevBuf hdr_;
+  void send_dims(int peer, int x, int y) {
+    hdr_.reserve(1);
+    const hzc h((double)x, (double)y);
+    HIP_CHECK(hipMemcpy(hdr_.p, &h, sizeof(zc), hipMemcpyHostToDevice));
+    xfer_begin(); send_dev(hdr_.p, 1, peer); xfer_end();
+    HIP_CHECK(hipStreamSynchronize(block_->st_));  // hdr_ is written again by the next header
+  }
+  void recv_dims(int peer, int* x, int* y) {
+    hdr_.reserve(1);
+    xfer_begin(); recv_dev(hdr_.p, 1, peer); xfer_end();
+    HIP_CHECK(hipStreamSynchronize(block_->st_));
+    hzc h(0.0, 0.0);
+    HIP_CHECK(hipMemcpy(&h, hdr_.p, sizeof(zc), hipMemcpyDeviceToHost));
+    *x = (int)std::lround(h.real()); *y = (int)std::lround(h.imag());
+  }
+
   struct DeviceMode {  // the engines' tensor arguments are device pointers while the shard drives them
     Engine& e; int old;
     explicit DeviceMode(Engine& en) : e(en), old(en.ptr_mode_) { e.ptr_mode_ = 1; }
@@ -435,14 +473,20 @@ class SiteShard {
   void junction_left(double dt) {
     Engine& b = *block_;
     Engine& J = *joint_;
+    const bool ad = b.adaptive_;
     const int nb = rank_ + 1, pl = n_ - 1;
     const int dl = b.dl_[pl], d0 = b.dd_[pl], D = b.dr_[pl];
     if (xdim_ != D) throw ArgError("shard: joint matrix and block bond dimension differ");
     const MpoSite& w0 = J.mpo(0, 0);
     const MpoSite& w1 = J.mpo(0, 1);
     const int d1 = w1.d, Mr = w1.mr;
-    if (dr_next_ < 1) throw ArgError("shard: the right neighbour's bond dimension was not given at creation");
-    const int Dr = dr_next_;
+    int Dr = dr_next_;
+    if (ad) {  // the neighbour's bonds change from step to step: (its junction bond, the right bond of its first site)
+      int Dchk = 0;
+      recv_dims(nb, &Dchk, &Dr);
+      if (Dchk != D) throw ArgError("shard: the neighbour's junction bond differs from this rank's");
+    }
+    if (Dr < 1) throw ArgError("shard: the right neighbour's bond dimension was not given at creation");
     psi_r_.reserve((size_t)D * d1 * Dr);
     env_r_.reserve((size_t)Dr * Mr * Dr);
     xfer_begin();
@@ -467,29 +511,55 @@ class SiteShard {
     J.replace_site(1, dp(psi_r_.p), MITDVP_GAUGE_PSI);
     J.split_center(false);  // psi_R = sigma B, block through B
     J.absorb_bond(false);
-    J.site_exp(dt);
-    if (regularize_) regularize_center(J);  // trans_next_psite_AsigmaB(regularize=True), :362-370
-    J.split_center(true);
-    J.bond_exp(dt);
-    J.kprev_set(1, J.kprev_get(0));
-    J.absorb_bond(true);
+    bool grown = false;
+    if (ad) {
+      // const.adaptive at the junction (_mps_parallel.py:319-345, :371-374): the two-site superblock [Psi, B] widened
+      // (get_superblock_full), the junction's rank chosen by get_adaptive_rank_and_block, the left site propagated into
+      // the widened bond, regularised, split, the bond matrix propagated in the blocks at the new rank: the serial
+      // adaptive step on two sites whose outer blocks are the two ranks' environments
+      J.set_adaptive(true, b.ad_dmax_, b.ad_dd_, b.ad_p_);
+      J.adaptive_prepare();
+      J.build_superblock_full(true);
+      DevBuf spare = J.pool_get(J.V_.n / MAXK);
+      if (regularize_) J.ad_site_hook_ = [this, &J] { regularize_center(J); };
+      struct Unhook { Engine& e; ~Unhook() { e.ad_site_hook_ = nullptr; } } unhook{J};
+      grown = J.adaptive_site(0, dt, true, spare);
+      J.pool_put(std::move(spare));
+      J.ss_check();
+    }
+    if (!grown) {
+      J.site_exp(dt);
+      if (regularize_) regularize_center(J);  // trans_next_psite_AsigmaB(regularize=True), :362-370
+      J.split_center(true);
+      J.bond_exp(dt);
+      J.kprev_set(1, J.kprev_get(0));
+      J.absorb_bond(true);
+    } else {
+      J.kprev_set(1, J.kprev_get(0));
+    }
     J.site_exp(dt);
     J.split_center(false);
     J.bond_exp(dt);
     b.kprev_set(mem, J.kprev_get(1));
     if (p_svd_ >= 0.0) truncate_joint(J);  // truncate=True, :437-466
+    const int Dn = J.dr_[0];  // the junction's rank after the update (= D without adaptive ranks)
     HIP_CHECK(hipStreamSynchronize(J.st_));
+    if (ad) send_dims(nb, Dn, 0);
     // B, X', the block left of B
     xfer_begin();
-    send_dev(J.site_[1].p, (size_t)D * d1 * Dr, nb);
-    send_dev(J.sig_.p, (size_t)D * D, nb);
-    send_dev(J.envL_[1].p, (size_t)D * w0.mr * D, nb);
+    send_dev(J.site_[1].p, (size_t)Dn * d1 * Dr, nb);
+    send_dev(J.sig_.p, (size_t)Dn * Dn, nb);
+    send_dev(J.envL_[1].p, (size_t)Dn * w0.mr * Dn, nb);
     xfer_end();
-    HIP_CHECK(hipMemcpyAsync(X_.p, J.sig_.p, (size_t)D * D * sizeof(zc), hipMemcpyDeviceToDevice, b.st_));
+    HIP_CHECK(hipStreamSynchronize(b.st_));  // the group read J's buffers on the block's stream (callback transport: done)
+    X_.reserve((size_t)Dn * Dn);
+    xdim_ = Dn;
+    HIP_CHECK(hipMemcpyAsync(X_.p, J.sig_.p, (size_t)Dn * Dn * sizeof(zc), hipMemcpyDeviceToDevice, b.st_));
     HIP_CHECK(hipStreamSynchronize(b.st_));
-    b.replace_site(pl, dp(J.site_[0].p), MITDVP_GAUGE_A);
-    b.set_boundary_env(1, dp(J.envR_[1].p), D, w0.mr);
-    b.set_bond(n_, dp(X_.p), D);
+    if (Dn != D) b.reshape_site(pl, dp(J.site_[0].p), dl, d0, Dn, MITDVP_GAUGE_A);
+    else b.replace_site(pl, dp(J.site_[0].p), MITDVP_GAUGE_A);
+    b.set_boundary_env(1, dp(J.envR_[1].p), Dn, w0.mr);
+    b.set_bond(n_, dp(X_.p), Dn);
     b.absorb_bond(false);
   }
 
@@ -532,6 +602,7 @@ class SiteShard {
   // X', the block left of B): nothing is sent back.
   void junction_pair(double dt, bool is_left) {
     Engine& b = *block_;
+    if (b.adaptive_) throw ArgError("shard: adaptive ranks across junctions run in the single junction mode");
     Engine& J = is_left ? *joint_ : *jleft_;
     const int peer = is_left ? rank_ + 1 : rank_ - 1;
     const MpoSite& w0 = J.mpo(0, 0);
@@ -627,27 +698,35 @@ class SiteShard {
   // The right rank: sends its centre tensor and the block right of it, takes B, X' and the block left of B.
   void junction_right() {
     Engine& b = *block_;
+    const bool ad = b.adaptive_;
     const int nb = rank_ - 1;
     const int D = b.dl_[0], d = b.dd_[0], dr = b.dr_[0];
     const MpoSite& w = b.mpo(0, 0);
     if (b.center_ != 0) throw ArgError("shard: the block's first site must be the centre before a junction update");
     if (!b.envR_ok_[1]) throw ArgError("shard: the block's right environment at its first site is missing");
+    if (ad) send_dims(nb, D, dr);
     xfer_begin();
     send_dev(b.site_[0].p, (size_t)D * d * dr, nb);
     send_dev(b.envR_[1].p, (size_t)dr * w.mr * dr, nb);
     xfer_end();
-    tmpa_.reserve((size_t)D * d * dr);
-    tmpb_.reserve((size_t)D * w.ml * D);
-    xin_.reserve((size_t)D * D);
+    int Dn = D, unused = 0;
+    if (ad) {
+      recv_dims(nb, &Dn, &unused);
+      if (Dn < D) throw ArgError("shard: the junction's rank came back smaller");
+    }
+    tmpa_.reserve((size_t)Dn * d * dr);
+    tmpb_.reserve((size_t)Dn * w.ml * Dn);
+    xin_.reserve((size_t)Dn * Dn);
     xfer_begin();
-    recv_dev(tmpa_.p, (size_t)D * d * dr, nb);
-    recv_dev(xin_.p, (size_t)D * D, nb);
-    recv_dev(tmpb_.p, (size_t)D * w.ml * D, nb);
+    recv_dev(tmpa_.p, (size_t)Dn * d * dr, nb);
+    recv_dev(xin_.p, (size_t)Dn * Dn, nb);
+    recv_dev(tmpb_.p, (size_t)Dn * w.ml * Dn, nb);
     xfer_end();
     DeviceMode mb(b);
-    b.replace_site(0, dp(tmpa_.p), MITDVP_GAUGE_B);
-    b.set_boundary_env(0, dp(tmpb_.p), D, w.ml);
-    b.set_bond(0, dp(xin_.p), D);
+    if (Dn != D) b.reshape_site(0, dp(tmpa_.p), Dn, d, dr, MITDVP_GAUGE_B);
+    else b.replace_site(0, dp(tmpa_.p), MITDVP_GAUGE_B);
+    b.set_boundary_env(0, dp(tmpb_.p), Dn, w.ml);
+    b.set_bond(0, dp(xin_.p), Dn);
     b.absorb_bond(true);
   }
 };

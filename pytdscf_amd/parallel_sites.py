@@ -24,8 +24,13 @@ block from it on the device; it is not part of the timed region.  ``regularize``
 reference's lifting of small singular values (SQRT_EPSRHO = 1e-4, ``_site_cls.py:22, :207-246, :657-664``) and the
 cumulative-weight truncation of the joint matrix (``truncate_sigvec``, :586-690); with both on (the reference's
 setting) the path reproduces ``MPSCoefParallel`` to 1e-8 (``tests/test_gpu_site_sharding.py`` against
-``tests/golden/parallel_*.npz``); both are off by default.  Hilbert space, one electronic state, fixed bond
-dimension.
+``tests/golden/parallel_*.npz``); both are off by default.  Hilbert space, one electronic state.
+
+``adaptive={"Dmax", "dD", "p_proj"}`` (round 5): adaptive bond dimensions in the blocks AND across the junctions
+(``const.adaptive`` in ``propagate_along_sweep``, _mps_cls.py:863-987, and in ``propagate_joint_two_sites``,
+_mps_parallel.py:319-345, :371-374): the left rank of a junction widens the right site's tensor, chooses the junction's
+new rank and hands B, X' and the boundary block back at that rank; the shapes travel ahead of the tensors.  Single
+junction mode only.
 """
 
 from __future__ import annotations
@@ -134,7 +139,8 @@ class SiteShardedTDVP:
     like the reference (``MITDVP_JUNCTION`` overrides); same results to rounding."""
 
     def __init__(self, comm, mpo, *, cores=None, dims=None, bond_dim=None, seed=1, integrator="lanczos", thresh=1e-9,
-                 conserve_norm=True, device=None, split=None, regularize=False, p_svd=None, transport=None, junction=None):
+                 conserve_norm=True, device=None, split=None, regularize=False, p_svd=None, transport=None, junction=None,
+                 adaptive=None):
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
         self.device = comm.gpu if device is None else device
@@ -165,6 +171,12 @@ class SiteShardedTDVP:
         self.junction = junction or os.environ.get("MITDVP_JUNCTION") or "pair"
         if self.junction not in ("pair", "single"):
             raise ValueError("junction must be 'pair' or 'single'")
+        self.adaptive = None
+        if adaptive:
+            self.adaptive = dict(Dmax=int(adaptive["Dmax"]), dD=int(adaptive["dD"]), p_proj=float(adaptive["p_proj"]))
+            if self.junction == "pair" and self._junction_explicit:
+                raise ValueError("adaptive ranks across junctions run in the single junction mode")
+            self.junction = "single"  # the pair mode shards the junction's bond over two ranks: fixed bonds only
         self._h = None
         self._cb = None
         import time as _time
@@ -390,6 +402,8 @@ class SiteShardedTDVP:
                 b.absorb_bond(False)
             b.build_envs(0)
         self.block = b
+        if self.adaptive:  # the junction engine takes the same settings inside the library
+            b.set_adaptive(True, **self.adaptive)
         if r < N - 1:  # joint matrix of the junction to the right (held by the left rank of every junction)
             x = np.ascontiguousarray(X_right, dtype=np.complex128)
             self._ck(lib.mitdvp_shard_set_joint(h, x.ctypes.data_as(C.POINTER(C.c_double)), x.shape[0]))
@@ -452,6 +466,23 @@ class SiteShardedTDVP:
     def step(self, dt):
         """One time step = two half-sweeps of every block + one joint update of every junction: one library call."""
         self._ck(self._lib.mitdvp_shard_step(self._h, float(dt)))
+        if self.adaptive:
+            self._refresh_shapes()
+
+    def _refresh_shapes(self):
+        """adaptive ranks: every rank learns the new site shapes of the whole chain (gathers and folds post receives
+        with them).  Collective."""
+        mine = [tuple(int(x) for x in self.block.get_site_shape(i)[:3]) for i in range(self.n)]
+        if self.world == 1:
+            self.shapes = mine
+            return
+        box = [None] * self.world
+        self.comm.dist.all_gather_object(box, mine)
+        self.shapes = [s for part in box for s in part]
+
+    def bond_dims(self):
+        """right bond of every site but the last, over the whole chain (properties.py:255-262)"""
+        return [int(s[2]) for s in self.shapes[:-1]]
 
     # ------------------------------------------------------------------ the whole state (tests, observables)
     def gather(self):

@@ -1,0 +1,243 @@
+"""GPU: adaptive bond dimensions ACROSS the junctions of the site-sharded sweep (csrc/shard.hip: adaptive block
+half-sweeps, the junction update on the widened two-site superblock, shapes travelling ahead of the tensors) with 2 and
+3 ranks sharing the test GPU, against
+
+(a) the REFERENCE's own adaptive two-rank run (``tests/golden/parallel_adaptive_r2.npz``: MPSCoefParallel with
+    ``adaptive=True`` on the model of its tests/test_mpi_exiciton_propagate.py; ``get_adaptive_rank_and_block`` at the
+    junction, _mps_parallel.py:319-345, :371-374): ranks exactly, the state after the first step -- in which every bond,
+    the junction's too, grows from 1 to its final rank -- tightly, the later steps at the looseness the scheme has from
+    a rank-1 start (the reference's test accepts rel 1e-1 on the energy, :220);
+(b) the oracle of the same algorithm (oracle/tdvp_parallel_oracle.py, held against the same fixture on the CPU) on a
+    full-rank chain whose bonds grow inside the blocks in the first step and at the junction in the second;
+(c) the reference's MPI test script with ``adaptive=True`` through the shell (its own assertion).
+"""
+
+import json
+import os
+import socket
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from helpers.ranks import run_ranks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(script, world, timeout=150):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               MITDVP_DIST_BACKEND="gloo")
+    rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
+                          timeout=timeout)
+    assert rcs == [0] * world, "\n".join(outs)
+    return json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][7:])
+
+
+EXC_WORKER = """
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from oracle import tdvp_parallel_oracle as par
+from pytdscf_amd import mps as M, operators as O
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+comm = Comm()
+g = np.load(os.path.join({root!r}, "tests", "golden", "parallel_adaptive_r2.npz"))
+pot = [g[f"pot{{i}}"] for i in range(4)]
+kin = [g[f"kin{{i}}"] for i in range(3)]
+mpo = O.merge_operator_terms([(pot, [0, 1, 2, 3]), (kin, [0, 1, 2])], dims=[8, 8, 8, 2])
+start = orc.canonicalize_site0(M.product_state_cores([g[f"weight{{i}}"] for i in range(4)], bond_dim=1))
+ad = dict(Dmax=int(g["Dmax"]), dD=int(g["dD"]), p_proj=float(g["p_proj"]))
+eng = SiteShardedTDVP(comm, mpo, cores=start, split=[(0, 1), (2, 3)], regularize=True, p_svd=float(g["p_svd"]), adaptive=ad)
+assert eng.junction == "single"
+ref_o = par.ParallelOracle(start, mpo, 2, ranges=[(0, 2), (2, 4)], regularize=True, p_svd=float(g["p_svd"]), adaptive=ad) if comm.rank == 0 else None
+dt = float(g["dt_au"])
+n = int(g["nstep"])
+out = dict(dims=[], xdim=[], infid_ref=[], norm2=[], norm2_ref=[], energy=[], energy_ref=[], infid_oracle=[], norm2_oracle=[], dims_oracle=[])
+for k in range(n + 1):
+    e, n2 = eng.expectation().real, eng.overlap(True).real
+    mine = eng.gather()
+    xd = eng.X.shape[0] if comm.rank == 0 else None
+    if comm.rank == 0:
+        ref = [g[f"step{{k}}_site{{i}}"] for i in range(4)]
+        r2 = abs(orc.overlap(ref, ref))
+        m2 = abs(orc.overlap(mine, mine))
+        out["dims"].append([int(c.shape[2]) for c in mine[:-1]])
+        out["xdim"].append(int(xd))
+        out["infid_ref"].append(1 - abs(orc.overlap(ref, mine)) / np.sqrt(r2 * m2))
+        out["norm2"].append(n2)
+        out["norm2_ref"].append(r2)
+        out["energy"].append(e / n2)
+        out["energy_ref"].append(float(g["energy_ref"][k].real))
+        go = ref_o.gather()
+        o2 = abs(orc.overlap(go, go))
+        out["infid_oracle"].append(1 - abs(orc.overlap(go, mine)) / np.sqrt(o2 * m2))
+        out["norm2_oracle"].append(o2)
+        out["dims_oracle"].append(ref_o.bond_dims())
+    if k < n:
+        eng.step(dt)
+        if comm.rank == 0:
+            ref_o.step(dt)
+if comm.rank == 0:
+    out["dims_ref"] = [[int(x) for x in r] for r in g["bond_dims"]]
+    out["bond_dims_api"] = eng.bond_dims()
+    print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+eng.close()
+comm.close()
+"""
+
+
+@pytest.mark.gpu
+def test_adaptive_junction_against_the_reference_adaptive_run(tmp_path):
+    script = tmp_path / "exc_ad.py"
+    script.write_text(textwrap.dedent(EXC_WORKER.format(root=ROOT)))
+    r = _launch(script, 2)
+    print(json.dumps(r))
+    assert r["dims"] == r["dims_ref"] == r["dims_oracle"], r              # (1,1,1) -> (8,7,2) within the first step
+    assert r["xdim"] == [d[1] for d in r["dims_ref"]] and r["bond_dims_api"] == r["dims_ref"][-1]
+    # the first step: every bond grows inside it; the state is the reference's (oracle on the CPU: 6e-8)
+    assert r["infid_ref"][0] < 1e-12 and r["infid_ref"][1] < 1e-6, r
+    assert abs(r["norm2"][1] - r["norm2_ref"][1]) < 2e-4
+    assert r["energy"][1] == pytest.approx(r["energy_ref"][1], rel=5e-4)
+    assert r["infid_oracle"][1] < 1e-8 and abs(r["norm2"][1] - r["norm2_oracle"][1]) < 1e-8, r
+    # later steps: the lifted null directions are each SVD's own completion, amplified by the pseudo-inverse
+    for k in range(2, len(r["dims"])):
+        assert r["infid_ref"][k] < 5e-3 and abs(r["norm2"][k] - 1) < 0.1, r
+        assert r["energy"][k] == pytest.approx(r["energy_ref"][k], rel=2e-2)
+
+
+CHAIN_WORKER = """
+import os, sys, json
+os.environ["MITDVP_SMALL_KERNELS"] = "0"   # several processes share one GPU here: no persistent kernels
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from oracle import tdvp_parallel_oracle as par
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+comm = Comm()
+L, d, M = {L}, 3, 4
+rng = np.random.default_rng(20261004)
+mpo = orc.synthetic_mpo(L, d, M, seed=3)
+start = orc.canonicalize_site0([rng.standard_normal((dl, d, dr)) + 1j * rng.standard_normal((dl, d, dr)) for dl, dr in orc.bond_dims([d] * L, 3)])
+ad = dict(Dmax=6, dD=3, p_proj={p_proj})
+dt = {dt_fs} * 41.341373335
+opts = dict(regularize=True, p_svd=1e-8)
+eng = SiteShardedTDVP(comm, mpo, cores=start, adaptive=ad, **opts)
+ref = par.ParallelOracle([c.copy() for c in start], mpo, comm.world, adaptive=ad, **opts) if comm.rank == 0 else None
+out = dict(dims=[], dims_oracle=[], infid=[], norm_gap=[], sv_gap=[], norm2=[], energy_gap=[])
+for k in range({nstep}):
+    eng.step(dt)
+    e, n2 = eng.expectation().real, eng.overlap(True).real
+    g = eng.gather()
+    sv = np.linalg.svd(eng.X, compute_uv=False) if comm.rank < comm.world - 1 else None
+    box = [None] * comm.world
+    comm.dist.all_gather_object(box, sv)
+    if comm.rank == 0:
+        ref.step(dt)
+        go = ref.gather()
+        m2, o2 = abs(orc.overlap(g, g)), abs(orc.overlap(go, go))
+        out["dims"].append(eng.bond_dims())
+        out["dims_oracle"].append(ref.bond_dims())
+        out["infid"].append(abs(1 - abs(orc.overlap(go, g)) / np.sqrt(m2 * o2)))
+        out["norm_gap"].append(abs(m2 - o2))
+        out["norm2"].append(m2)
+        eo = orc.OracleMPS(orc.canonicalize_site0(go, scale=None), mpo).expectation().real
+        out["energy_gap"].append(abs(e - eo))
+        gap = 0.0
+        for j in range(comm.world - 1):
+            so = np.linalg.svd(ref.X[j], compute_uv=False)
+            gap = max(gap, float(np.abs(box[j] - so).max()) if len(so) == len(box[j]) else 1.0)
+        out["sv_gap"].append(gap)
+kry = [eng.block.krylov_memory(i) for i in range(eng.n)]
+box = [None] * comm.world
+comm.dist.all_gather_object(box, kry)
+if comm.rank == 0:
+    out["krylov"] = box
+    out["krylov_oracle"] = [[b.kprev.get(b.lo + i, 0) for i in range(b.n)] for b in ref.blocks]
+    print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+eng.close()
+comm.close()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world, L", [(2, 8), (3, 9)])
+def test_adaptive_sharded_sweep_against_its_oracle(world, L, tmp_path):
+    """A full-rank chain of bond dimension 3 with room to grow (Dmax = 6, dD = 3, p_proj = 1e-6, dt = 0.02 fs): the
+    bonds inside the blocks grow in the first step, a junction's bond in the second (the oracle on the CPU shows both,
+    tests/test_oracle_parallel.py).  Same ranks as the oracle at every bond after every step, same state, same joint
+    spectra, same Krylov counts."""
+    script = tmp_path / "chain_ad.py"
+    script.write_text(textwrap.dedent(CHAIN_WORKER.format(root=ROOT, L=L, p_proj=1e-6, dt_fs=0.02, nstep=2)))
+    r = _launch(script, world)
+    print(json.dumps(r))
+    assert r["dims"] == r["dims_oracle"], r
+    assert max(max(d) for d in r["dims"]) > 3                                   # bonds did grow
+    assert max(r["infid"]) < 1e-8 and max(r["norm_gap"]) < 1e-8 and max(r["sv_gap"]) < 1e-8 and max(r["energy_gap"]) < 1e-8, r
+    assert r["krylov"] == r["krylov_oracle"], r
+
+
+SHELL_WORKER = """
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+import pytest
+from pytdscf_amd import Exciton, HarmonicOscillator as HO, Model, Simulator, TensorHamiltonian, TensorOperator
+rank = int(os.environ["RANK"])
+os.chdir({cwd!r})
+g = np.load(os.path.join({root!r}, "tests", "golden", "parallel_adaptive_r2.npz"))
+prim_info = [HO(8, f, units="cm-1") for f in (1000, 2000, 3000)] + [Exciton(nstate=2, names=["S0", "S1"])]
+if rank == 0:  # like the reference's test: the operators exist on rank 0 only
+    pot = [g[f"pot{{i}}"] for i in range(4)]
+    kin = [g[f"kin{{i}}"] for i in range(3)]
+    potential = [[{{(0, 1, 2, (3, 3)): TensorOperator(mpo=pot, legs=(0, 1, 2, 3, 3))}}]]
+    kinetic = [[{{((0, 0), (1, 1), (2, 2)): TensorOperator(mpo=kin, legs=(0, 0, 1, 1, 2, 2))}}]]
+else:
+    potential = kinetic = None
+hamiltonian = TensorHamiltonian(ndof=4, potential=potential, kinetic=kinetic, backend="hip")
+model = Model(prim_info, {{"hamiltonian": hamiltonian}})
+model.m_aux_max = 1                                                  # tests/test_mpi_exiciton_propagate.py:189-190
+model.init_HartreeProduct = [[ho.get_unitary()[0].tolist() for ho in prim_info[:3]] + [np.array([0.0, 1.0]).tolist()]]
+simulator = Simulator("mpi_LVC_Exciton_test_adaptive", model, backend="hip")
+ener_calc, wf = simulator.propagate(stepsize=0.05, maxstep=20, reduced_density=([(3, 3)], 1),
+                                    parallel_split_indices=[(0, 1), (2, 3)], adaptive=True, adaptive_dD=60, adaptive_Dmax=60,
+                                    adaptive_p_proj=1e-05, adaptive_p_svd=1e-06)
+if rank == 0:
+    assert pytest.approx(ener_calc, rel=1.0e-01) == 0.01000          # the reference's assertion, verbatim (:220)
+    t, rdm = simulator.rdm_trace[-1]
+    print("RESULT " + json.dumps(dict(energy=ener_calc, norm=wf.norm(), tr=float(np.trace(rdm[(3, 3)]).real),
+                                      bonds=wf.engine.bond_dims())), flush=True)
+else:
+    assert wf is None
+from pytdscf_amd.dist import world_comm
+world_comm().close()
+"""
+
+
+@pytest.mark.gpu
+def test_reference_mpi_test_script_adaptive_through_the_shell(tmp_path):
+    """tests/test_mpi_exiciton_propagate.py of the reference with its ``adaptive=True`` parameter (:39, :189-213) as a
+    user would run it here: ``Simulator.propagate(parallel_split_indices=[(0, 1), (2, 3)], adaptive=True, ...)`` under
+    two ranks, its own assertion on the returned energy, the bond-dimension record rank 0 writes."""
+    script = tmp_path / "shell_ad.py"
+    script.write_text(textwrap.dedent(SHELL_WORKER.format(root=ROOT, cwd=str(tmp_path))))
+    r = _launch(script, 2)
+    print(json.dumps(r))
+    assert r["energy"] == pytest.approx(0.01000, rel=1e-1)
+    assert r["bonds"] == [8, 7, 2] and abs(r["norm"] - 1) < 0.1 and abs(r["tr"] - 1) < 0.15
+    lines = open(tmp_path / "mpi_LVC_Exciton_test_adaptive_prop" / "bonddim.dat").read().splitlines()
+    assert len(lines) == 21 and lines[1].split()[1:] == ["1", "1", "1"] and lines[-1].split()[1:] == ["8", "7", "2"]

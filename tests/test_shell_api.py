@@ -78,8 +78,10 @@ def test_parallel_split_indices_must_match_the_ranks(golden, monkeypatch):
     sim = Simulator("j", _exciton_model(golden("exciton.npz")), backend="hip")
     with pytest.raises(ValueError, match="2 ranges but the job has 1 rank"):
         sim.propagate(maxstep=1, parallel_split_indices=[(0, 1), (2, 3)])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="2 ranges but the job has 1 rank"):  # adaptive ranks across junctions are built (round 5)
         sim.propagate(maxstep=1, parallel_split_indices=[(0, 1), (2, 3)], adaptive=True)
+    with pytest.raises(NotImplementedError):
+        sim.propagate(maxstep=1, parallel_split_indices=[(0, 1), (2, 3)], restart=True)
 
 
 @pytest.mark.gpu
