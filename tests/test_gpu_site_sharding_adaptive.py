@@ -132,11 +132,11 @@ from oracle import tdvp_parallel_oracle as par
 from pytdscf_amd.dist import Comm
 from pytdscf_amd.parallel_sites import SiteShardedTDVP
 comm = Comm()
-L, d, M = {L}, 3, 4
+L, d, M = {L}, {d}, {M}
 rng = np.random.default_rng({seed})
 mpo = orc.synthetic_mpo(L, d, M, seed=3)
-start = orc.canonicalize_site0([rng.standard_normal((dl, d, dr)) + 1j * rng.standard_normal((dl, d, dr)) for dl, dr in orc.bond_dims([d] * L, 3)])
-ad = dict(Dmax=6, dD=3, p_proj={p_proj})
+start = orc.canonicalize_site0([rng.standard_normal((dl, d, dr)) + 1j * rng.standard_normal((dl, d, dr)) for dl, dr in orc.bond_dims([d] * L, {D0})])
+ad = dict(Dmax={Dmax}, dD={dD}, p_proj={p_proj})
 dt = {dt_fs} * 41.341373335
 opts = dict(regularize=True, p_svd={p_svd})
 eng = SiteShardedTDVP(comm, mpo, cores=start, adaptive=ad, **opts)
@@ -205,7 +205,8 @@ def test_adaptive_sharded_sweep_against_its_oracle(world, L, seed, p_proj, p_svd
     to 5 in the oracle, metric 1.16e-6 against p_proj = 1e-6) -- a property of the reference's functional, not of
     either implementation."""
     script = tmp_path / "chain_ad.py"
-    script.write_text(textwrap.dedent(CHAIN_WORKER.format(root=ROOT, L=L, p_proj=p_proj, dt_fs=0.02, nstep=nstep, seed=seed, p_svd=p_svd)))
+    script.write_text(textwrap.dedent(CHAIN_WORKER.format(root=ROOT, L=L, p_proj=p_proj, dt_fs=0.02, nstep=nstep, seed=seed, p_svd=p_svd,
+                                                          d=3, M=4, D0=3, Dmax=6, dD=3)))
     r = _launch(script, world)
     print(json.dumps(r))
     assert r["dims"] == r["dims_oracle"], r
@@ -214,6 +215,23 @@ def test_adaptive_sharded_sweep_against_its_oracle(world, L, seed, p_proj, p_svd
         cut = L // world if world == 2 else 3                                   # first junction's bond index + 1
         assert r["dims"][0][cut - 1] > 3, r                                     # ... the junction's too
     assert max(r["infid"]) < 1e-8 and max(r["norm_gap"]) < 1e-8 and max(r["sv_gap"]) < 1e-8 and max(r["energy_gap"]) < 1e-8, r
+    assert r["krylov"] == r["krylov_oracle"], r
+
+
+@pytest.mark.gpu
+def test_adaptive_sharded_sweep_at_a_larger_shape(tmp_path):
+    """d = 8, MPO bond 5, bonds 16 -> up to 19 with Dmax = 40, dD = 12 (two ranks, no truncation, one step): the general
+    kernels (64 x 64 tiles, the blocked Householder QR with up to twelve completion columns, rectangular applies of the
+    rank functional at 28 candidate ranks) instead of the small-size paths of the cases above.  The junction grows
+    16 -> 19 inside the step; the new joint matrix has singular values down to 1.4e-4, so <Psi|Psi> is 1.40 afterwards --
+    in the oracle (and the reference's scheme) as here -- and rounding differences are amplified by ~1e4: bar 1e-7."""
+    script = tmp_path / "chain_ad_big.py"
+    script.write_text(textwrap.dedent(CHAIN_WORKER.format(root=ROOT, L=8, p_proj=7e-7, dt_fs=0.02, nstep=1, seed=5, p_svd=None,
+                                                          d=8, M=5, D0=16, Dmax=40, dD=12)))
+    r = _launch(script, 2)
+    print(json.dumps(r))
+    assert r["dims"] == r["dims_oracle"] and r["dims"][0][3] > 16, r
+    assert max(r["infid"]) < 1e-7 and max(r["norm_gap"]) < 1e-7 and max(r["sv_gap"]) < 1e-7 and max(r["energy_gap"]) < 1e-7, r
     assert r["krylov"] == r["krylov_oracle"], r
 
 
