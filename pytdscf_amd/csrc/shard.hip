@@ -13,6 +13,8 @@
 // (the one-GPU test box: RCCL refuses two ranks on one device) plug in a host callback instead
 // (mitdvp_shard_set_transport); the junction code is the same.
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <mutex>
 
@@ -371,6 +373,26 @@ class SiteShard {
   };
   static const double* dp(const zc* p) { return reinterpret_cast<const double*>(p); }
 
+  static double fro(const zc* p, size_t n) {  // debugging aid (MITDVP_SHARD_DEBUG): Frobenius norm through the host
+    HIP_CHECK(hipDeviceSynchronize());
+    std::vector<hzc> h(n);
+    HIP_CHECK(hipMemcpy(h.data(), p, n * sizeof(zc), hipMemcpyDeviceToHost));
+    double a = 0;
+    for (auto& v : h) a += std::norm(v);
+    return std::sqrt(a);
+  }
+  static void peek(const char* what, int rank, const zc* p, int D, int M) {  // a few entries of an environment block (d, m, d)
+    HIP_CHECK(hipDeviceSynchronize());
+    std::vector<hzc> h((size_t)D * M * D);
+    HIP_CHECK(hipMemcpy(h.data(), p, h.size() * sizeof(zc), hipMemcpyDeviceToHost));
+    double tr = 0, a = 0;
+    for (int i = 0; i < D; ++i) tr += h[((size_t)i * M) * D + i].real();
+    for (auto& v : h) a += std::norm(v);
+    std::fprintf(stderr, "[shard %d] %s: D %d M %d trace(m=0) %.6g fro %.6g  [0,0]=%.4g [1,1]=%.4g [0,1]=%.4g%+.4gi\n", rank, what, D, M, tr, std::sqrt(a),
+                 h[0].real(), D > 1 ? h[((size_t)1 * M) * D + 1].real() : 0.0, D > 1 ? h[1].real() : 0.0, D > 1 ? h[1].imag() : 0.0);
+  }
+  static bool dbg() { static const bool d = std::getenv("MITDVP_SHARD_DEBUG") != nullptr; return d; }
+
   // x (D x D) -> pinv(x, rcond) = V diag(1/s) U^H on the engine's stream (multiply_sigvec_pinv, _site_cls.py:734)
   void pinv_dev(Engine& J, const zc* x, int D, zc* out) {
     DevBuf U = J.pool_get((size_t)D * D), Vh = J.pool_get((size_t)D * D), work = J.pool_get(svd_work_elems(D, D)),
@@ -391,8 +413,11 @@ class SiteShard {
   }
 
   // SiteCoef.gauge_trf(regularize=True) on the centre tensor (_site_cls.py:207-246): SVD of the (D_l D_r x d)
-  // unfolding, small singular values lifted, tensor rebuilt.  (Directions whose singular value is exactly zero get
-  // no weight here; LAPACK hands the reference an arbitrary unit vector for them.)
+  // unfolding, small singular values lifted, tensor rebuilt.  Singular values that are exactly zero are lifted along an
+  // orthonormal completion of the singular vectors, as LAPACK's are in the reference (svd_jacobi completes the vectors
+  // of a numerically rank-deficient input; round 5 -- before, they were rounding residue parallel to the leading vectors,
+  // and truncate_joint built environment blocks from them: 4 % of <Psi|Psi> lost per step on the zero-padded product
+  // start of the reference's tests/test_mpi.py).
   void regularize_center(Engine& J) {
     const int p = J.center_;
     if (p < 0) throw ArgError("shard: no centre site to regularise");
@@ -404,6 +429,12 @@ class SiteShard {
     std::vector<double> s(k);
     int sweeps = 0;
     svd_jacobi(J.st_, M.p, r, d, U.p, s.data(), Vh.p, work.p, &sweeps);
+    if (dbg()) {
+      std::fprintf(stderr, "[shard %d] regularize_center (%d x %d): |theta| %.15g |U| %.15g |Vh| %.15g s =", rank_, r, d,
+                   fro(J.site_[p].p, (size_t)r * d), fro(U.p, (size_t)r * k), fro(Vh.p, (size_t)k * d));
+      for (int i = 0; i < std::min(k, 6); ++i) std::fprintf(stderr, " %.6e", s[i]);
+      std::fprintf(stderr, "\n");
+    }
     for (int i = 0; i < k; ++i) s[i] = lift(s[i]);
     HIP_CHECK(hipMemcpyAsync(sc.p, s.data(), k * sizeof(double), hipMemcpyHostToDevice, J.st_));
     scale_cols(J.st_, U.p, r, k, k, reinterpret_cast<const double*>(sc.p));
@@ -411,6 +442,7 @@ class SiteShard {
     zgemm(J.st_, g);
     permute_0213(J.st_, M.p, J.site_[p].p, dl, dr, d, 1);  // back to (dl, d, dr)
     HIP_CHECK(hipStreamSynchronize(J.st_));
+    if (dbg()) std::fprintf(stderr, "[shard %d] regularize_center out: |theta| %.15g\n", rank_, fro(J.site_[p].p, (size_t)r * d));
     J.pool_put(std::move(M)); J.pool_put(std::move(U)); J.pool_put(std::move(Vh)); J.pool_put(std::move(work));
     J.pool_put(std::move(sc));
   }
@@ -424,7 +456,17 @@ class SiteShard {
     DevBuf U = J.pool_get((size_t)D * D), Vh = J.pool_get((size_t)D * D), work = J.pool_get(svd_work_elems(D, D));
     std::vector<double> s(D);
     int sweeps = 0;
+    if (dbg()) {
+      HIP_CHECK(hipStreamSynchronize(J.st_));
+      std::fprintf(stderr, "[shard %d] truncate_joint in: |sigma| %.15g |A| %.15g |B| %.15g D %d\n", rank_, fro(J.sig_.p, (size_t)D * D),
+                   fro(J.site_[0].p, (size_t)dl * d0 * D), fro(J.site_[1].p, (size_t)D * d1 * dr), D);
+    }
     svd_jacobi(J.st_, J.sig_.p, D, D, U.p, s.data(), Vh.p, work.p, &sweeps);
+    if (dbg()) {
+      std::fprintf(stderr, "[shard %d] svd: sweeps %d s =", rank_, sweeps);
+      for (int k = 0; k < std::min(D, 6); ++k) std::fprintf(stderr, " %.6e", s[k]);
+      std::fprintf(stderr, " |U| %.15g |Vh| %.15g\n", fro(U.p, (size_t)D * D), fro(Vh.p, (size_t)D * D));
+    }
     double tot = 0, cum = 0;
     for (double v : s) tot += v;
     // a zero or non-finite spectrum: refuse before any tensor is overwritten (the reference would divide by zero and
@@ -463,6 +505,10 @@ class SiteShard {
     transpose_rev3(J.st_, J.site_[1].p, J.tmp2_.p, D, d1, dr);
     J.env_update(J.envR_[2].p, J.tmp2_.p, w1.w2r.p, J.envR_[1].p, dr, w1.mr, d1, D, w1.ml, w1.w2er.p, &w1, 1);
     J.ss_check();
+    if (dbg()) { peek("truncate out: envL[1]", rank_, J.envL_[1].p, D, w0.mr); peek("truncate out: envR[1]", rank_, J.envR_[1].p, D, w1.ml); }
+    if (dbg())
+      std::fprintf(stderr, "[shard %d] truncate_joint out: idx %d |X'| %.15g |A U| %.15g |Vh B| %.15g\n", rank_, idx, fro(J.sig_.p, (size_t)D * D),
+                   fro(J.site_[0].p, (size_t)dl * d0 * D), fro(J.site_[1].p, (size_t)D * d1 * dr));
     J.pool_put(std::move(U)); J.pool_put(std::move(Vh)); J.pool_put(std::move(work));
     J.pool_put(std::move(a2)); J.pool_put(std::move(b2));
   }

@@ -496,7 +496,7 @@ size_t svd_work_elems(int r, int c) {
 }
 
 // A (r x c, row-major) = U (r x k) diag(S) Vh (k x c), k = min(r, c); S descending (host array).
-void svd_jacobi(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host, zc* Vh, zc* work, int* sweeps_out) {
+static void svd_jacobi_raw(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host, zc* Vh, zc* work, int* sweeps_out) {
   if (r < 1 || c < 1) throw ArgError("svd: bad shape");
   const bool tr = r > c;  // work on the transpose so that the rotated vectors are the (fewer) rows
   const int nr = tr ? c : r, nc = tr ? r : c;
@@ -602,6 +602,55 @@ void svd_jacobi(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(st));  // idx / s host vectors go out of scope
   if (sweeps_out) *sweeps_out = sweeps;
+}
+
+// Column j of C (m x k, row-major) <- column j of Q times the phase of R[j][j]: the columns that were orthonormal come
+// back as they were (C = Q R with R diagonal, |R_jj| = 1 there), the others as an orthonormal completion.
+__global__ __launch_bounds__(256) void k_complete_cols(zc* __restrict__ C, const zc* __restrict__ Q, const zc* __restrict__ R, long m, int k) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= m * k) return;
+  const int j = (int)(e % k);
+  const zc d = R[(size_t)j * k + j];
+  const double a = sqrt(d.x * d.x + d.y * d.y);
+  const zc ph = a > 0.5 ? make_double2(d.x / a, d.y / a) : make_double2(1.0, 0.0);
+  const zc q = Q[e];
+  C[e] = make_double2(q.x * ph.x - q.y * ph.y, q.x * ph.y + q.y * ph.x);
+}
+
+// The one-sided Jacobi sweep leaves the singular vectors of (numerically) ZERO singular values as whatever its rotations
+// cancel down to: the factor accumulated from the rotations is unitary, but the rows of the rotated matrix -- divided by
+// their own norm -- are rounding residue, typically PARALLEL to the leading vectors.  LAPACK returns an orthonormal
+// completion there, and callers that keep the dimension rely on it (truncate_sigvec(keepdim=True) rebuilds environment
+// blocks from A U and Vh B; gauge_trf(regularize=True) lifts zero singular values ALONG those vectors).  For a
+// numerically rank-deficient input both factors are therefore passed through a Householder QR: vectors that were
+// orthonormal come back unchanged (to rounding), the rest as an orthonormal completion.  Rare path, own allocations.
+static void complete_cols(hipStream_t st, zc* C, int m, int k) {  // C (m x k, row-major), m >= k
+  zc *P = nullptr, *Q = nullptr, *R = nullptr, *wk = nullptr;
+  struct Free { zc** p[4]; ~Free() { for (auto q : p) if (*q) (void)hipFree(*q); } } fr{{&P, &Q, &R, &wk}};
+  HIP_CHECK(hipMalloc(&P, (size_t)m * k * sizeof(zc)));
+  HIP_CHECK(hipMalloc(&Q, (size_t)m * k * sizeof(zc)));
+  HIP_CHECK(hipMalloc(&R, (size_t)k * k * sizeof(zc)));
+  HIP_CHECK(hipMalloc(&wk, qr_work_elems(m, k) * sizeof(zc)));
+  HIP_CHECK(hipMemcpyAsync(P, C, (size_t)m * k * sizeof(zc), hipMemcpyDeviceToDevice, st));
+  long nl = 0;
+  qr_householder(st, P, m, k, Q, R, wk, &nl);
+  hipLaunchKernelGGL(k_complete_cols, dim3((unsigned)(((long)m * k + 255) / 256)), dim3(256), 0, st, C, Q, R, (long)m, k);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(st));
+}
+
+void svd_jacobi(hipStream_t st, const zc* A, int r, int c, zc* U, double* S_host, zc* Vh, zc* work, int* sweeps_out) {
+  svd_jacobi_raw(st, A, r, c, U, S_host, Vh, work, sweeps_out);
+  const int k = std::min(r, c);
+  if (k < 2 || S_host[k - 1] > 1e-12 * S_host[0]) return;  // every singular vector is determined
+  complete_cols(st, U, r, k);
+  zc* T = nullptr;  // Vh (k x c): its rows are the vectors
+  struct Free { zc*& p; ~Free() { if (p) (void)hipFree(p); } } fr{T};
+  HIP_CHECK(hipMalloc(&T, (size_t)k * c * sizeof(zc)));
+  transpose_batched(st, Vh, T, k, c, c, k, 1, 0, 0);
+  complete_cols(st, T, c, k);
+  transpose_batched(st, T, Vh, c, k, k, c, 1, 0, 0);
+  HIP_CHECK(hipStreamSynchronize(st));
 }
 
 }  // namespace mitdvp

@@ -36,10 +36,24 @@ def test_replicas_on_disjoint_compute_units(B):
     import subprocess
     import sys
 
+    import signal
+
     here = os.path.dirname(os.path.abspath(__file__))
-    code = f"import sys; sys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]; import test_gpu_ensemble as t; t._replicas_body({B}); print('REPLICAS OK')"
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, cwd=os.path.dirname(here))
-    assert p.returncode == 0 and "REPLICAS OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    # SIGUSR1 -> the Python stacks of all threads on stderr: what a run that sits leaves behind before it is ended
+    code = (f"import sys, faulthandler, signal; faulthandler.register(signal.SIGUSR1, all_threads=True); "
+            f"sys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]; import test_gpu_ensemble as t; t._replicas_body({B}); print('REPLICAS OK')")
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=os.path.dirname(here))
+    try:
+        out, err = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        p.send_signal(signal.SIGUSR1)
+        try:
+            out, err = p.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+        pytest.fail(f"the replica run sat for 240 s (B = {B}); stacks at that point:\n{err[-6000:]}\nstdout: {out[-1000:]}")
+    assert p.returncode == 0 and "REPLICAS OK" in out, (out[-2000:], err[-4000:])
 
 
 def _replicas_body(B):

@@ -285,3 +285,62 @@ def test_reference_mpi_test_script_adaptive_through_the_shell(tmp_path):
     assert r["bonds"] == [8, 7, 2] and abs(r["norm"] - 1) < 0.1 and abs(r["tr"] - 1) < 0.15
     lines = open(tmp_path / "mpi_LVC_Exciton_test_adaptive_prop" / "bonddim.dat").read().splitlines()
     assert len(lines) == 21 and lines[1].split()[1:] == ["1", "1", "1"] and lines[-1].split()[1:] == ["8", "7", "2"]
+
+
+# ----------------------------------------------------------------------------- the reference's tests/test_mpi.py
+MPI_WORKER = """
+import os, sys, json
+os.environ["MITDVP_SMALL_KERNELS"] = "0"   # several processes share one GPU here: no persistent kernels
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import tdvp_oracle as orc
+from pytdscf_amd import mps as M
+from pytdscf_amd.dist import Comm
+from pytdscf_amd.parallel_sites import SiteShardedTDVP
+comm = Comm()
+adaptive = {adaptive}
+split = {{2: [(0, 5), (6, 11)], 3: [(0, 3), (4, 7), (8, 11)], 4: [(0, 2), (3, 5), (6, 8), (9, 11)]}}[comm.world]   # test_mpi.py:30-59
+weight_vib = [[1.0, 0.0, 0.0, 0.0], [1.0, 1.0, 0.0, 0.0], [1.0, 1.0, 1.0, 0.0]] + [[1.0, 1.0, 1.0, 1.0]] * 9          # :69-82
+start = orc.canonicalize_site0(M.product_state_cores(weight_vib, bond_dim=1 if not adaptive else 10))               # :83-87
+mpo = [np.eye(4, dtype=complex).reshape(1, 4, 4, 1) * (2.0 if i == 0 else 1.0) for i in range(12)]                    # :101-110
+ad = dict(Dmax=30, dD=30, p_proj=1e-4) if adaptive else None                                                         # :33-38
+eng = SiteShardedTDVP(comm, mpo, cores=start, split=split, regularize=True, p_svd=1e-7, adaptive=ad)
+out = dict(autocorr0=[eng.autocorr().real, eng.autocorr().imag], norm0=eng.norm(), expectation=eng.expectation().real)
+rd55 = eng.reduced_density((5, 5))
+rd0 = eng.reduced_density((0,))
+rd014 = eng.reduced_density((0, 1, 4))
+eng.step(0.1)                                                                                                       # :277-278
+eng.step(0.1)
+a = eng.autocorr()
+out.update(rd55=float(np.abs(rd55 - 0.25).max()), rd0=float(np.abs(rd0 - np.array([1.0, 0.0, 0.0, 0.0])).max()),
+           rd014_shape=list(rd014.shape), rd014=float(np.abs(rd014[:1, :2, :4] - 1 / 8).max()),
+           norm2=eng.norm(), autocorr2=[a.real, a.imag], energy2=eng.expectation().real, bonds=eng.bond_dims())
+if comm.rank == 0:
+    print("RESULT " + json.dumps(out), flush=True)
+comm.barrier()
+eng.close()
+comm.close()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_reference_mpi_unit_tests(world, adaptive, tmp_path):
+    """The reference's tests/test_mpi.py (twelve sites of dimension 4, product state of given weights, H = 2 x identity;
+    2, 3 and 4 ranks, adaptive on and off, its split indices and adaptive settings): its known answers --
+    ``test_mpi_autocorr_norm`` (1 to 1e-5, :204-214), ``test_mpi_expectation`` (2, :243-249), ``test_mpi_reduced_density``
+    (keys (5, 5), (0,), (0, 1, 4): 1/4, e_0, shape (4, 4, 4) with 1/8 on [:1, :2, :4], :259-282) -- and
+    ``test_mpi_propagate``'s two steps of 0.1 (:293-296), which the reference only runs; here their result is checked
+    too: under H = 2 the state picks up exp(-2 i t), so <Psi*|Psi> = exp(-0.8 i), the norm stays 1, no bond grows."""
+    script = tmp_path / "mpi_unit.py"
+    script.write_text(textwrap.dedent(MPI_WORKER.format(root=ROOT, adaptive=adaptive)))
+    r = _launch(script, world)
+    print(json.dumps(r))
+    assert r["autocorr0"][0] == pytest.approx(1.0, abs=1e-5) and abs(r["autocorr0"][1]) < 1e-5
+    assert r["norm0"] == pytest.approx(1.0, abs=1e-5)
+    assert r["expectation"] == pytest.approx(2.0)
+    assert r["rd55"] < 1e-7 and r["rd0"] < 1e-7 and r["rd014_shape"] == [4, 4, 4] and r["rd014"] < 1e-7
+    assert r["norm2"] == pytest.approx(1.0, abs=1e-6) and r["energy2"] == pytest.approx(2.0, abs=1e-6)
+    assert abs(complex(*r["autocorr2"]) - np.exp(-0.8j)) < 1e-6
+    assert max(r["bonds"]) == (10 if adaptive else 1)
