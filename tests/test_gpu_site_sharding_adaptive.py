@@ -107,19 +107,19 @@ def test_adaptive_junction_against_the_reference_adaptive_run(tmp_path):
     print(json.dumps(r))
     assert r["dims"] == r["dims_ref"] == r["dims_oracle"], r              # (1,1,1) -> (8,7,2) within the first step
     assert r["xdim"] == [d[1] for d in r["dims_ref"]] and r["bond_dims_api"] == r["dims_ref"][-1]
-    # the first step: every bond grows inside it; the state is the reference's.  Measured: infidelity 2.6e-6 (the oracle
-    # on the CPU: 6e-8), <Psi|Psi> 7.5e-4 off -- from the rank-1 start the regularisation lifts EXACTLY zero singular
-    # values along whatever unit vectors each SVD completes its basis with (LAPACK's there, the Jacobi sweep's none
-    # here), and the pseudo-inverse of the joint matrix amplifies them; the serial adaptive run of this model is
-    # noise-limited at 1e-5 in the same way (tests/test_gpu_adaptive.py)
-    assert r["infid_ref"][0] < 1e-12 and r["infid_ref"][1] < 1e-5, r
-    assert abs(r["norm2"][1] - r["norm2_ref"][1]) < 2e-3
+    # the first step: every bond grows inside it; the state is the reference's.  Measured: infidelity 7.5e-8 against the
+    # reference, 3.5e-8 against the oracle (the oracle against the reference on the CPU: 6e-8), <Psi|Psi> 1.6e-4 off.
+    # (Before svd_jacobi completed the singular vectors of rank-deficient inputs orthonormally -- see csrc/svd.hip -- the
+    # regularisation lifted the exactly-zero singular values of this rank-1 start along rounding residue: 2.6e-6.)
+    assert r["infid_ref"][0] < 1e-12 and r["infid_ref"][1] < 1e-6, r
+    assert abs(r["norm2"][1] - r["norm2_ref"][1]) < 5e-4
     assert r["energy"][1] == pytest.approx(r["energy_ref"][1], rel=5e-4)
-    assert r["infid_oracle"][1] < 1e-5 and abs(r["norm2"][1] - r["norm2_oracle"][1]) < 2e-3, r
+    assert r["infid_oracle"][1] < 1e-6 and abs(r["norm2"][1] - r["norm2_oracle"][1]) < 5e-4, r
     # later steps: the lifted null directions are each SVD's own completion, amplified by the pseudo-inverse
+    # (measured: 2.0e-5 ... 2.7e-5 against the reference, energy rel 2e-3; the oracle itself is 7e-4 / 1.2e-2 from it)
     for k in range(2, len(r["dims"])):
-        assert r["infid_ref"][k] < 5e-3 and abs(r["norm2"][k] - 1) < 0.1, r
-        assert r["energy"][k] == pytest.approx(r["energy_ref"][k], rel=2e-2)
+        assert r["infid_ref"][k] < 1e-3 and abs(r["norm2"][k] - 1) < 0.1, r
+        assert r["energy"][k] == pytest.approx(r["energy_ref"][k], rel=1e-2)
 
 
 CHAIN_WORKER = """
