@@ -318,3 +318,30 @@ def test_adaptive_growth_inside_the_blocks_follows_the_serial_sweep():
     assert abs(abs(orc.overlap(s.cores, one.gather())) - 1) < 1e-12
     g = two.gather()
     assert 1 - abs(orc.overlap(s.cores, g)) / np.sqrt(abs(orc.overlap(g, g))) < 1e-5
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("nrank", [2, 3, 4])
+def test_reference_mpi_unit_state(nrank, adaptive):
+    """The state and operator of the reference's tests/test_mpi.py (twelve sites of dimension 4, product state of given
+    weights -- zero-padded to bond 10 when ``adaptive`` --, H = 2 x identity; its split indices and adaptive settings,
+    :30-59, :69-87, :101-110): <Psi|Psi> = <Psi*|Psi> = 1 and <H> = 2 as it asserts (:204-214, :243-249), and after the
+    two steps of 0.1 that ``test_mpi_propagate`` runs (:293-296) the state has picked up exp(-2 i t): the norm stays 1,
+    <Psi*|Psi> = exp(-0.8 i) (to 1e-7: the lifted zero singular values of the padded start carry 1e-4 of amplitude)."""
+    from pytdscf_amd import mps as M
+
+    split = {2: [(0, 6), (6, 12)], 3: [(0, 4), (4, 8), (8, 12)], 4: [(0, 3), (3, 6), (6, 9), (9, 12)]}[nrank]
+    wv = [[1.0, 0.0, 0.0, 0.0], [1.0, 1.0, 0.0, 0.0], [1.0, 1.0, 1.0, 0.0]] + [[1.0, 1.0, 1.0, 1.0]] * 9
+    mpo = [np.eye(4, dtype=complex).reshape(1, 4, 4, 1) * (2.0 if i == 0 else 1.0) for i in range(12)]
+    start = orc.canonicalize_site0(M.product_state_cores(wv, bond_dim=10 if adaptive else 1))
+    p = par.ParallelOracle(start, mpo, nrank, ranges=split, regularize=True, p_svd=1e-7,
+                           adaptive=dict(Dmax=30, dD=30, p_proj=1e-4) if adaptive else None)
+    g = p.gather()
+    assert abs(orc.overlap(g, g) - 1) < 1e-12 and abs(orc.overlap([c.conj() for c in g], g) - 1) < 1e-12
+    assert abs(orc.OracleMPS(orc.canonicalize_site0(g, scale=None), mpo).expectation() - 2) < 1e-12
+    p.step(0.1)
+    p.step(0.1)
+    g = p.gather()
+    assert abs(p.norm() - 1) < 1e-7
+    assert abs(orc.overlap([c.conj() for c in g], g) - np.exp(-0.8j)) < 1e-7
+    assert max(p.bond_dims()) == (10 if adaptive else 1)
