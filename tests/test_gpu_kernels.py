@@ -463,6 +463,27 @@ def test_jacobi_svd_graded_and_rank_deficient(precond):
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("shape, rank", [((10, 10), 1), ((100, 4), 1), ((4, 100), 2), ((40, 40), 7), ((256, 256), 208), ((300, 140), 20)])
+def test_jacobi_svd_completes_the_null_space(shape, rank):
+    """A numerically rank-deficient input: BOTH factors come back unitary -- the singular vectors of the zero singular
+    values are an orthonormal completion, as LAPACK's are (callers that keep the dimension rebuild environment blocks
+    from A U / Vh B and lift zero singular values along those vectors: truncate_sigvec(keepdim=True),
+    gauge_trf(regularize=True), _site_cls.py:207-246, :586-690).  Before round 5 they were rounding residue parallel to
+    the leading vectors."""
+    from pytdscf_amd import engine as E
+
+    r, c = shape
+    k = min(r, c)
+    rng = np.random.default_rng(r * 7 + c)
+    A = crandn(rng, r, rank) @ crandn(rng, rank, c)
+    U, S, Vh, _ = E.svd(A)
+    Sref = np.linalg.svd(A, compute_uv=False)
+    assert np.abs(S - Sref).max() < 1e-12 * Sref[0]
+    assert np.abs((U * S) @ Vh - A).max() < 1e-12 * Sref[0]
+    assert np.abs(U.conj().T @ U - np.eye(k)).max() < 1e-12
+    assert np.abs(Vh @ Vh.conj().T - np.eye(k)).max() < 1e-12
+
+
 def test_concurrent_engines_from_host_threads():
     """Several engines (one HIP stream each) stepped concurrently from host threads give the
     same states as when they run one after the other: per-stream split-K workspaces, no shared

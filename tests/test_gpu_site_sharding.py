@@ -287,6 +287,7 @@ def test_reference_mpi_exciton_model_two_ranks(tmp_path):
     script = tmp_path / "exc.py"
     script.write_text(textwrap.dedent(EXC_WORKER.format(root=ROOT)))
     r = _launch(script, 2)
+    print(json.dumps(r))
     e19 = r["energy"][5]
     assert e19 == pytest.approx(0.01000, rel=1e-1)                       # the reference-held pin
     assert e19 == pytest.approx(0.010000180312707298, rel=2e-2)          # the serial pin, at the scheme's accuracy
