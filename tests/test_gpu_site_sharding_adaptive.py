@@ -301,7 +301,7 @@ comm = Comm()
 adaptive = {adaptive}
 split = {{2: [(0, 5), (6, 11)], 3: [(0, 3), (4, 7), (8, 11)], 4: [(0, 2), (3, 5), (6, 8), (9, 11)]}}[comm.world]   # test_mpi.py:30-59
 weight_vib = [[1.0, 0.0, 0.0, 0.0], [1.0, 1.0, 0.0, 0.0], [1.0, 1.0, 1.0, 0.0]] + [[1.0, 1.0, 1.0, 1.0]] * 9          # :69-82
-start = orc.canonicalize_site0(M.product_state_cores(weight_vib, bond_dim=1 if not adaptive else 10))               # :83-87
+start = orc.canonicalize_site0(M.product_state_cores(weight_vib, bond_dim={bond}))                                  # :83-87
 mpo = [np.eye(4, dtype=complex).reshape(1, 4, 4, 1) * (2.0 if i == 0 else 1.0) for i in range(12)]                    # :101-110
 ad = dict(Dmax=30, dD=30, p_proj=1e-4) if adaptive else None                                                         # :33-38
 eng = SiteShardedTDVP(comm, mpo, cores=start, split=split, regularize=True, p_svd=1e-7, adaptive=ad)
@@ -324,17 +324,20 @@ comm.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("adaptive, bond", [(False, 1), (True, 10), (False, 10)])
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_reference_mpi_unit_tests(world, adaptive, tmp_path):
+def test_reference_mpi_unit_tests(world, adaptive, bond, tmp_path):
     """The reference's tests/test_mpi.py (twelve sites of dimension 4, product state of given weights, H = 2 x identity;
     2, 3 and 4 ranks, adaptive on and off, its split indices and adaptive settings): its known answers --
     ``test_mpi_autocorr_norm`` (1 to 1e-5, :204-214), ``test_mpi_expectation`` (2, :243-249), ``test_mpi_reduced_density``
     (keys (5, 5), (0,), (0, 1, 4): 1/4, e_0, shape (4, 4, 4) with 1/8 on [:1, :2, :4], :259-282) -- and
     ``test_mpi_propagate``'s two steps of 0.1 (:293-296), which the reference only runs; here their result is checked
-    too: under H = 2 the state picks up exp(-2 i t), so <Psi*|Psi> = exp(-0.8 i), the norm stays 1, no bond grows."""
+    too: under H = 2 the state picks up exp(-2 i t), so <Psi*|Psi> = exp(-0.8 i), the norm stays 1, no bond grows.
+    The reference pads the product start to bond 10 when ``adaptive`` and not otherwise (m_aux_max, :84); the third
+    parameter set is the padded start WITHOUT adaptive ranks, i.e. the default pair mode of the junction on a
+    rank-deficient joint matrix (the case that lost 4 % of the norm per step before svd_jacobi completed null spaces)."""
     script = tmp_path / "mpi_unit.py"
-    script.write_text(textwrap.dedent(MPI_WORKER.format(root=ROOT, adaptive=adaptive)))
+    script.write_text(textwrap.dedent(MPI_WORKER.format(root=ROOT, adaptive=adaptive, bond=bond)))
     r = _launch(script, world)
     print(json.dumps(r))
     assert r["autocorr0"][0] == pytest.approx(1.0, abs=1e-5) and abs(r["autocorr0"][1]) < 1e-5
@@ -343,4 +346,4 @@ def test_reference_mpi_unit_tests(world, adaptive, tmp_path):
     assert r["rd55"] < 1e-7 and r["rd0"] < 1e-7 and r["rd014_shape"] == [4, 4, 4] and r["rd014"] < 1e-7
     assert r["norm2"] == pytest.approx(1.0, abs=1e-6) and r["energy2"] == pytest.approx(2.0, abs=1e-6)
     assert abs(complex(*r["autocorr2"]) - np.exp(-0.8j)) < 1e-6
-    assert max(r["bonds"]) == (10 if adaptive else 1)
+    assert max(r["bonds"]) == bond
