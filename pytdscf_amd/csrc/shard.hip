@@ -366,6 +366,20 @@ class SiteShard {
     *x = (int)std::lround(h.real()); *y = (int)std::lround(h.imag());
   }
 
+  // both directions in one message group (the pair mode's two ranks tell each other the shapes of what they are about to send)
+  DevBuf hdr_in_;
+  void exchange_dims(int peer, int x, int y, int* ox, int* oy) {
+    hdr_.reserve(1);
+    hdr_in_.reserve(1);
+    const hzc h((double)x, (double)y);
+    HIP_CHECK(hipMemcpy(hdr_.p, &h, sizeof(zc), hipMemcpyHostToDevice));
+    exchange(hdr_.p, 1, hdr_in_.p, 1, peer);
+    HIP_CHECK(hipStreamSynchronize(block_->st_));
+    hzc g(0.0, 0.0);
+    HIP_CHECK(hipMemcpy(&g, hdr_in_.p, sizeof(zc), hipMemcpyDeviceToHost));
+    *ox = (int)std::lround(g.real()); *oy = (int)std::lround(g.imag());
+  }
+
   struct DeviceMode {  // the engines' tensor arguments are device pointers while the shard drives them
     Engine& e; int old;
     explicit DeviceMode(Engine& en) : e(en), old(en.ptr_mode_) { e.ptr_mode_ = 1; }
@@ -648,7 +662,7 @@ class SiteShard {
   // X', the block left of B): nothing is sent back.
   void junction_pair(double dt, bool is_left) {
     Engine& b = *block_;
-    if (b.adaptive_) throw ArgError("shard: adaptive ranks across junctions run in the single junction mode");
+    const bool ad = b.adaptive_;
     Engine& J = is_left ? *joint_ : *jleft_;
     const int peer = is_left ? rank_ + 1 : rank_ - 1;
     const MpoSite& w0 = J.mpo(0, 0);
@@ -660,6 +674,11 @@ class SiteShard {
     if (is_left) {
       const int pl = n_ - 1;
       dl = b.dl_[pl]; d0 = b.dd_[pl]; D = b.dr_[pl]; d1 = w1.d; Dr = dr_next_;
+      if (ad) {  // adaptive ranks: the neighbour's bonds change from step to step
+        int Dchk = 0;
+        exchange_dims(peer, dl, D, &Dchk, &Dr);
+        if (Dchk != D) throw ArgError("shard: the neighbour's junction bond differs from this rank's");
+      }
       if (xdim_ != D) throw ArgError("shard: joint matrix and block bond dimension differ");
       if (!b.envL_ok_[pl]) throw ArgError("shard: the block's left environment at its last site is missing");
       psi_r_.reserve((size_t)D * d1 * Dr);
@@ -676,6 +695,11 @@ class SiteShard {
       xfer_end();
     } else {
       D = b.dl_[0]; d1 = b.dd_[0]; Dr = b.dr_[0]; d0 = w0.d; dl = dl_prev_;
+      if (ad) {
+        int Dchk = 0;
+        exchange_dims(peer, D, Dr, &dl, &Dchk);
+        if (Dchk != D) throw ArgError("shard: the neighbour's junction bond differs from this rank's");
+      }
       if (b.center_ != 0) throw ArgError("shard: the block's first site must be the centre before a junction update");
       if (!b.envR_ok_[1]) throw ArgError("shard: the block's right environment at its first site is missing");
       psi_l_.reserve((size_t)dl * d0 * D);
@@ -714,29 +738,52 @@ class SiteShard {
     J.replace_site(1, dp(psi_r), MITDVP_GAUGE_PSI);
     J.split_center(false);
     J.absorb_bond(false);
-    J.site_exp(dt);
-    if (regularize_) regularize_center(J);
-    J.split_center(true);
-    J.bond_exp(dt);
-    J.kprev_set(1, J.kprev_get(0));
-    J.absorb_bond(true);
+    bool grown = false;
+    if (ad) {  // the serial adaptive step on the widened two-site superblock, as in junction_left; both ranks of the pair
+               // take the same decisions on identical data (every sharded contraction ends in a collective)
+      J.set_adaptive(true, b.ad_dmax_, b.ad_dd_, b.ad_p_);
+      J.adaptive_prepare();
+      J.build_superblock_full(true);
+      DevBuf spare = J.pool_get(J.V_.n / MAXK);
+      if (regularize_) J.ad_site_hook_ = [this, &J] { regularize_center(J); };
+      struct Unhook { Engine& e; ~Unhook() { e.ad_site_hook_ = nullptr; } } unhook{J};
+      grown = J.adaptive_site(0, dt, true, spare);
+      J.pool_put(std::move(spare));
+      J.ss_check();
+    }
+    if (!grown) {
+      J.site_exp(dt);
+      if (regularize_) regularize_center(J);
+      J.split_center(true);
+      J.bond_exp(dt);
+      J.kprev_set(1, J.kprev_get(0));
+      J.absorb_bond(true);
+    } else {
+      J.kprev_set(1, J.kprev_get(0));
+    }
     J.site_exp(dt);
     J.split_center(false);
     J.bond_exp(dt);
     if (p_svd_ >= 0.0) truncate_joint(J);
+    const int Dn = J.dr_[0];  // the junction's rank after the update (= D without adaptive ranks)
     HIP_CHECK(hipStreamSynchronize(J.st_));
-    HIP_CHECK(hipMemcpyAsync(Xj, J.sig_.p, (size_t)D * D * sizeof(zc), hipMemcpyDeviceToDevice, b.st_));
+    if (is_left) { X_.reserve((size_t)Dn * Dn); xdim_ = Dn; }
+    else xl_.reserve((size_t)Dn * Dn);
+    Xj = is_left ? X_.p : xl_.p;
+    HIP_CHECK(hipMemcpyAsync(Xj, J.sig_.p, (size_t)Dn * Dn * sizeof(zc), hipMemcpyDeviceToDevice, b.st_));
     HIP_CHECK(hipStreamSynchronize(b.st_));
     if (is_left) {
       b.kprev_set(n_ - 2, J.kprev_get(1));
-      b.replace_site(n_ - 1, dp(J.site_[0].p), MITDVP_GAUGE_A);
-      b.set_boundary_env(1, dp(J.envR_[1].p), D, w0.mr);
-      b.set_bond(n_, dp(X_.p), D);
+      if (Dn != D) b.reshape_site(n_ - 1, dp(J.site_[0].p), dl, d0, Dn, MITDVP_GAUGE_A);
+      else b.replace_site(n_ - 1, dp(J.site_[0].p), MITDVP_GAUGE_A);
+      b.set_boundary_env(1, dp(J.envR_[1].p), Dn, w0.mr);
+      b.set_bond(n_, dp(X_.p), Dn);
       b.absorb_bond(false);
     } else {
-      b.replace_site(0, dp(J.site_[1].p), MITDVP_GAUGE_B);
-      b.set_boundary_env(0, dp(J.envL_[1].p), D, w1.ml);
-      b.set_bond(0, dp(xl_.p), D);
+      if (Dn != D) b.reshape_site(0, dp(J.site_[1].p), Dn, d1, Dr, MITDVP_GAUGE_B);
+      else b.replace_site(0, dp(J.site_[1].p), MITDVP_GAUGE_B);
+      b.set_boundary_env(0, dp(J.envL_[1].p), Dn, w1.ml);
+      b.set_bond(0, dp(xl_.p), Dn);
       b.absorb_bond(true);
     }
   }

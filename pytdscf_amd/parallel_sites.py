@@ -29,8 +29,8 @@ setting) the path reproduces ``MPSCoefParallel`` to 1e-8 (``tests/test_gpu_site_
 ``adaptive={"Dmax", "dD", "p_proj"}`` (round 5): adaptive bond dimensions in the blocks AND across the junctions
 (``const.adaptive`` in ``propagate_along_sweep``, _mps_cls.py:863-987, and in ``propagate_joint_two_sites``,
 _mps_parallel.py:319-345, :371-374): the left rank of a junction widens the right site's tensor, chooses the junction's
-new rank and hands B, X' and the boundary block back at that rank; the shapes travel ahead of the tensors.  Single
-junction mode only.
+new rank and hands B, X' and the boundary block back at that rank; the shapes travel ahead of the tensors.  In the pair
+mode both ranks of the junction run that update on identical copies and take the same decisions.
 """
 
 from __future__ import annotations
@@ -174,9 +174,6 @@ class SiteShardedTDVP:
         self.adaptive = None
         if adaptive:
             self.adaptive = dict(Dmax=int(adaptive["Dmax"]), dD=int(adaptive["dD"]), p_proj=float(adaptive["p_proj"]))
-            if self.junction == "pair" and self._junction_explicit:
-                raise ValueError("adaptive ranks across junctions run in the single junction mode")
-            self.junction = "single"  # the pair mode shards the junction's bond over two ranks: fixed bonds only
         self._h = None
         self._cb = None
         import time as _time

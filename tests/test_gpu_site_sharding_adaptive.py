@@ -59,8 +59,8 @@ kin = [g[f"kin{{i}}"] for i in range(3)]
 mpo = O.merge_operator_terms([(pot, [0, 1, 2, 3]), (kin, [0, 1, 2])], dims=[8, 8, 8, 2])
 start = orc.canonicalize_site0(M.product_state_cores([g[f"weight{{i}}"] for i in range(4)], bond_dim=1))
 ad = dict(Dmax=int(g["Dmax"]), dD=int(g["dD"]), p_proj=float(g["p_proj"]))
-eng = SiteShardedTDVP(comm, mpo, cores=start, split=[(0, 1), (2, 3)], regularize=True, p_svd=float(g["p_svd"]), adaptive=ad)
-assert eng.junction == "single"
+eng = SiteShardedTDVP(comm, mpo, cores=start, split=[(0, 1), (2, 3)], regularize=True, p_svd=float(g["p_svd"]), adaptive=ad, junction={junction!r})
+assert eng.junction == {junction!r}
 ref_o = par.ParallelOracle(start, mpo, 2, ranges=[(0, 2), (2, 4)], regularize=True, p_svd=float(g["p_svd"]), adaptive=ad) if comm.rank == 0 else None
 dt = float(g["dt_au"])
 n = int(g["nstep"])
@@ -100,9 +100,12 @@ comm.close()
 
 
 @pytest.mark.gpu
-def test_adaptive_junction_against_the_reference_adaptive_run(tmp_path):
+@pytest.mark.parametrize("junction", ["single", "pair"])
+def test_adaptive_junction_against_the_reference_adaptive_run(junction, tmp_path):
+    """``junction``: the update on the left rank alone (the reference's arrangement) or run by both ranks of the junction
+    on identical copies (the default mode of the sharded sweep)."""
     script = tmp_path / "exc_ad.py"
-    script.write_text(textwrap.dedent(EXC_WORKER.format(root=ROOT)))
+    script.write_text(textwrap.dedent(EXC_WORKER.format(root=ROOT, junction=junction)))
     r = _launch(script, 2)
     print(json.dumps(r))
     assert r["dims"] == r["dims_ref"] == r["dims_oracle"], r              # (1,1,1) -> (8,7,2) within the first step
@@ -139,7 +142,7 @@ start = orc.canonicalize_site0([rng.standard_normal((dl, d, dr)) + 1j * rng.stan
 ad = dict(Dmax={Dmax}, dD={dD}, p_proj={p_proj})
 dt = {dt_fs} * 41.341373335
 opts = dict(regularize=True, p_svd={p_svd})
-eng = SiteShardedTDVP(comm, mpo, cores=start, adaptive=ad, **opts)
+eng = SiteShardedTDVP(comm, mpo, cores=start, adaptive=ad, junction={junction!r}, **opts)
 ref = par.ParallelOracle([c.copy() for c in start], mpo, comm.world, adaptive=ad, **opts) if comm.rank == 0 else None
 out = dict(dims=[], dims_oracle=[], infid=[], norm_gap=[], sv_gap=[], norm2=[], energy_gap=[])
 for k in range({nstep}):
@@ -183,11 +186,12 @@ comm.close()
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("junction", ["single", "pair"])
 @pytest.mark.parametrize(
     "world, L, seed, p_proj, p_svd, nstep",
     [(1, 8, 20261004, 1e-6, None, 2), (2, 8, 20261004, 1e-6, None, 2), (3, 9, 20261004, 1e-6, 1e-8, 2), (2, 8, 7, 3e-7, 1e-8, 1)],
 )
-def test_adaptive_sharded_sweep_against_its_oracle(world, L, seed, p_proj, p_svd, nstep, tmp_path):
+def test_adaptive_sharded_sweep_against_its_oracle(world, L, seed, p_proj, p_svd, nstep, junction, tmp_path):
     """A full-rank chain of bond dimension 3 with room to grow (Dmax = 6, dD = 3, dt = 0.02 fs).  Same ranks as the oracle
     at every bond after every step, same state (measured 1e-15), same joint spectra, same Krylov counts:
       * one rank: the shard's adaptive half-sweeps are the serial adaptive sweep;
@@ -205,8 +209,10 @@ def test_adaptive_sharded_sweep_against_its_oracle(world, L, seed, p_proj, p_svd
     to 5 in the oracle, metric 1.16e-6 against p_proj = 1e-6) -- a property of the reference's functional, not of
     either implementation."""
     script = tmp_path / "chain_ad.py"
+    if world == 1 and junction == "pair":
+        pytest.skip("one rank has no junction")
     script.write_text(textwrap.dedent(CHAIN_WORKER.format(root=ROOT, L=L, p_proj=p_proj, dt_fs=0.02, nstep=nstep, seed=seed, p_svd=p_svd,
-                                                          d=3, M=4, D0=3, Dmax=6, dD=3)))
+                                                          d=3, M=4, D0=3, Dmax=6, dD=3, junction=junction)))
     r = _launch(script, world)
     print(json.dumps(r))
     assert r["dims"] == r["dims_oracle"], r
@@ -219,7 +225,8 @@ def test_adaptive_sharded_sweep_against_its_oracle(world, L, seed, p_proj, p_svd
 
 
 @pytest.mark.gpu
-def test_adaptive_sharded_sweep_at_a_larger_shape(tmp_path):
+@pytest.mark.parametrize("junction", ["single", "pair"])
+def test_adaptive_sharded_sweep_at_a_larger_shape(junction, tmp_path):
     """d = 8, MPO bond 5, bonds 16 -> up to 19 with Dmax = 40, dD = 12 (two ranks, no truncation, one step): the general
     kernels (64 x 64 tiles, the blocked Householder QR with up to twelve completion columns, rectangular applies of the
     rank functional at 28 candidate ranks) instead of the small-size paths of the cases above.  The junction grows
@@ -227,7 +234,7 @@ def test_adaptive_sharded_sweep_at_a_larger_shape(tmp_path):
     in the oracle (and the reference's scheme) as here -- and rounding differences are amplified by ~1e4: bar 1e-7."""
     script = tmp_path / "chain_ad_big.py"
     script.write_text(textwrap.dedent(CHAIN_WORKER.format(root=ROOT, L=8, p_proj=7e-7, dt_fs=0.02, nstep=1, seed=5, p_svd=None,
-                                                          d=8, M=5, D0=16, Dmax=40, dD=12)))
+                                                          d=8, M=5, D0=16, Dmax=40, dD=12, junction=junction)))
     r = _launch(script, 2)
     print(json.dumps(r))
     assert r["dims"] == r["dims_oracle"] and r["dims"][0][3] > 16, r
