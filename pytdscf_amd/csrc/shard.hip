@@ -527,6 +527,37 @@ class SiteShard {
     J.pool_put(std::move(a2)); J.pool_put(std::move(b2));
   }
 
+  // Site L +dt/2 and the bond -dt/2 of a junction update on the two-site engine J (centre on site 0 on entry, on site 1
+  // on return).  With const.adaptive (_mps_parallel.py:319-345, :371-374) the two-site superblock [Psi, B] is widened
+  // (get_superblock_full), the junction's rank chosen by get_adaptive_rank_and_block, the left site propagated into the
+  // widened bond, regularised, split, and the bond matrix propagated in the blocks at the new rank: the serial adaptive
+  // step on two sites whose outer blocks are the two ranks' environments.  A junction already at its maximal rank takes
+  // the plain step.
+  void junction_first_half(Engine& J, Engine& b, double dt) {
+    bool grown = false;
+    if (b.adaptive_) {
+      J.set_adaptive(true, b.ad_dmax_, b.ad_dd_, b.ad_p_);
+      J.adaptive_prepare();
+      J.build_superblock_full(true);
+      DevBuf spare = J.pool_get(J.V_.n / MAXK);
+      if (regularize_) J.ad_site_hook_ = [this, &J] { regularize_center(J); };
+      struct Unhook { Engine& e; ~Unhook() { e.ad_site_hook_ = nullptr; } } unhook{J};
+      grown = J.adaptive_site(0, dt, true, spare);
+      J.pool_put(std::move(spare));
+      J.ss_check();
+    }
+    if (!grown) {
+      J.site_exp(dt);
+      if (regularize_) regularize_center(J);  // trans_next_psite_AsigmaB(regularize=True), :362-370
+      J.split_center(true);
+      J.bond_exp(dt);
+      J.kprev_set(1, J.kprev_get(0));
+      J.absorb_bond(true);
+    } else {
+      J.kprev_set(1, J.kprev_get(0));
+    }
+  }
+
   // The left rank of a junction (propagate_joint_two_sites, _mps_parallel.py:270-470): receives psi_R and the block
   // right of it, updates both sites (site L +dt/2, bond -dt/2, site R +dt/2, bond -dt/2), returns B, X' and the block
   // left of B; its own last site becomes A X' again (send_joint_sigvec_to_right, :541-597).
@@ -571,32 +602,7 @@ class SiteShard {
     J.replace_site(1, dp(psi_r_.p), MITDVP_GAUGE_PSI);
     J.split_center(false);  // psi_R = sigma B, block through B
     J.absorb_bond(false);
-    bool grown = false;
-    if (ad) {
-      // const.adaptive at the junction (_mps_parallel.py:319-345, :371-374): the two-site superblock [Psi, B] widened
-      // (get_superblock_full), the junction's rank chosen by get_adaptive_rank_and_block, the left site propagated into
-      // the widened bond, regularised, split, the bond matrix propagated in the blocks at the new rank: the serial
-      // adaptive step on two sites whose outer blocks are the two ranks' environments
-      J.set_adaptive(true, b.ad_dmax_, b.ad_dd_, b.ad_p_);
-      J.adaptive_prepare();
-      J.build_superblock_full(true);
-      DevBuf spare = J.pool_get(J.V_.n / MAXK);
-      if (regularize_) J.ad_site_hook_ = [this, &J] { regularize_center(J); };
-      struct Unhook { Engine& e; ~Unhook() { e.ad_site_hook_ = nullptr; } } unhook{J};
-      grown = J.adaptive_site(0, dt, true, spare);
-      J.pool_put(std::move(spare));
-      J.ss_check();
-    }
-    if (!grown) {
-      J.site_exp(dt);
-      if (regularize_) regularize_center(J);  // trans_next_psite_AsigmaB(regularize=True), :362-370
-      J.split_center(true);
-      J.bond_exp(dt);
-      J.kprev_set(1, J.kprev_get(0));
-      J.absorb_bond(true);
-    } else {
-      J.kprev_set(1, J.kprev_get(0));
-    }
+    junction_first_half(J, b, dt);
     J.site_exp(dt);
     J.split_center(false);
     J.bond_exp(dt);
@@ -738,29 +744,8 @@ class SiteShard {
     J.replace_site(1, dp(psi_r), MITDVP_GAUGE_PSI);
     J.split_center(false);
     J.absorb_bond(false);
-    bool grown = false;
-    if (ad) {  // the serial adaptive step on the widened two-site superblock, as in junction_left; both ranks of the pair
-               // take the same decisions on identical data (every sharded contraction ends in a collective)
-      J.set_adaptive(true, b.ad_dmax_, b.ad_dd_, b.ad_p_);
-      J.adaptive_prepare();
-      J.build_superblock_full(true);
-      DevBuf spare = J.pool_get(J.V_.n / MAXK);
-      if (regularize_) J.ad_site_hook_ = [this, &J] { regularize_center(J); };
-      struct Unhook { Engine& e; ~Unhook() { e.ad_site_hook_ = nullptr; } } unhook{J};
-      grown = J.adaptive_site(0, dt, true, spare);
-      J.pool_put(std::move(spare));
-      J.ss_check();
-    }
-    if (!grown) {
-      J.site_exp(dt);
-      if (regularize_) regularize_center(J);
-      J.split_center(true);
-      J.bond_exp(dt);
-      J.kprev_set(1, J.kprev_get(0));
-      J.absorb_bond(true);
-    } else {
-      J.kprev_set(1, J.kprev_get(0));
-    }
+    junction_first_half(J, b, dt);  // (pair mode: both ranks take the same decisions on identical data -- every sharded
+                                    // contraction ends in a collective)
     J.site_exp(dt);
     J.split_center(false);
     J.bond_exp(dt);
