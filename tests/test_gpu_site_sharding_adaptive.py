@@ -34,7 +34,7 @@ def _free_port():
     return p
 
 
-def _launch(script, world, timeout=150):
+def _launch(script, world, timeout=300):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                MITDVP_DIST_BACKEND="gloo")
     rcs, outs = run_ranks([[sys.executable, str(script)]] * world, [dict(env, RANK=str(r), LOCAL_RANK="0") for r in range(world)],
