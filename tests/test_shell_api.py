@@ -84,6 +84,67 @@ def test_parallel_split_indices_must_match_the_ranks(golden, monkeypatch):
         sim.propagate(maxstep=1, parallel_split_indices=[(0, 1), (2, 3)], restart=True)
 
 
+def test_sharded_adaptive_plumbing_of_the_shell(golden, tmp_path, monkeypatch):
+    """``propagate(parallel_split_indices=..., adaptive=True, ...)``: the adaptive settings reach the sharded engine
+    (const.adaptive / Dmax / dD / p_proj, _const_cls.py:212-216; p_svd and the junction regularisation as before), the
+    bond dimensions of ``bonddim.dat`` come from the shapes the ranks share after every step (properties.py:255-262), and
+    the serial engine's ``set_adaptive`` is not called on the sharded one.  Host logic only: the sharded engine and the
+    communicator are stand-ins."""
+    from pytdscf_amd import Simulator, api, dist, parallel_sites
+
+    seen = {}
+
+    class FakeDist:
+        @staticmethod
+        def broadcast_object_list(box, src=0):
+            return None
+
+    class FakeComm:
+        rank, world, dist = 0, 2, FakeDist()
+
+    class FakeShard:
+        def __init__(self, comm, mpo, **kw):
+            seen.update(kw, nsite=len(mpo))
+            self.rank, self.steps = 0, 0
+
+        def autocorr(self):
+            return 1.0 + 0.0j
+
+        def norm(self):
+            return 1.0
+
+        def expectation(self, op=None):
+            return 0.01 + 0.0j
+
+        def step(self, dt):
+            self.steps += 1
+
+        def bond_dims(self):
+            return [1, 1, 1] if self.steps == 0 else [8, 7, 2]
+
+        def gather(self):
+            return None
+
+        def close(self):
+            seen["closed"] = True
+
+    monkeypatch.setattr(dist, "world_comm", lambda site_sharding=False: FakeComm())
+    monkeypatch.setattr(parallel_sites, "SiteShardedTDVP", FakeShard)
+    monkeypatch.setattr(api.Simulator, "_gathered_wfunc", lambda self, eng, *a: None)
+    monkeypatch.chdir(tmp_path)
+    sim = Simulator("plumb", _exciton_model(golden("exciton.npz")), backend="hip")
+    ener, wf = sim.propagate(stepsize=0.05, maxstep=3, parallel_split_indices=[(0, 1), (2, 3)], adaptive=True, adaptive_Dmax=60,
+                             adaptive_dD=60, adaptive_p_proj=1e-5, adaptive_p_svd=1e-6)
+    assert seen["adaptive"] == dict(Dmax=60, dD=60, p_proj=1e-5) and seen["p_svd"] == 1e-6 and seen["regularize"] is True
+    assert seen["split"] == [(0, 1), (2, 3)] and seen["nsite"] == 4 and seen["closed"]
+    assert ener == pytest.approx(0.01) and wf is None
+    lines = open(tmp_path / "plumb_prop" / "bonddim.dat").read().splitlines()
+    assert [l.split()[1:] for l in lines[1:]] == [["1", "1", "1"], ["8", "7", "2"], ["8", "7", "2"]]
+    seen.clear()
+    sim.propagate(stepsize=0.05, maxstep=1, parallel_split_indices=[(0, 1), (2, 3)])
+    assert seen["adaptive"] is None
+
+
 @pytest.mark.gpu
 def test_exciton_script_on_gpu(golden, tmp_path, monkeypatch):
     """tests/test_exiciton_propagate.py of the reference, through the shell."""
